@@ -1,0 +1,152 @@
+"""ctypes binding of libhrp_hip.so (C ABI declared in include/hrp.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhrp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+HRP_F32, HRP_BF16 = 0, 1
+MAX_TAPS = 16
+EW_MAX_IN = 4
+EW_IDENTITY, EW_AFFINE, EW_BN_TRAIN = 0, 1, 2
+FK_MAX_JOINTS, FK_MAX_KP = 32, 24
+
+
+class HrpError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("res", C.c_void_p),
+                ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("stats", C.c_void_p),
+                ("dtype", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("x_pitch", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+                ("y_H", C.c_int32), ("y_W", C.c_int32), ("y_pitch", C.c_int32), ("res_pitch", C.c_int32),
+                ("out_stride", C.c_int32), ("out_off_y", C.c_int32), ("out_off_x", C.c_int32),
+                ("in_stride", C.c_int32), ("ntaps", C.c_int32),
+                ("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wtap", C.c_int32 * MAX_TAPS),
+                ("w_ntaps", C.c_int32), ("w_cout_pad", C.c_int32), ("relu", C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
+                ("dtype", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("x_pitch", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_pitch", C.c_int32),
+                ("in_stride", C.c_int32), ("ntaps", C.c_int32),
+                ("dy_t", C.c_int32 * MAX_TAPS), ("dx_t", C.c_int32 * MAX_TAPS),
+                ("dw_cin", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ntaps", C.c_int32)]
+
+
+class EwInput(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("pitch", C.c_int32), ("up", C.c_int32), ("mode", C.c_int32),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("stats", C.c_void_p),
+                ("count", C.c_float), ("eps", C.c_float)]
+
+
+class EwDesc(C.Structure):
+    _fields_ = [("inp", EwInput * EW_MAX_IN), ("nin", C.c_int32), ("out", C.c_void_p),
+                ("out_pitch", C.c_int32), ("dtype", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("relu", C.c_int32)]
+
+
+class EwBwdDesc(C.Structure):
+    _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("dout_pitch", C.c_int32), ("out_pitch", C.c_int32),
+                ("inp", EwInput), ("din", C.c_void_p), ("din_pitch", C.c_int32), ("sums", C.c_void_p),
+                ("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("relu", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class BnEntry(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("d", C.c_void_p),
+                ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("counter", C.c_void_p),
+                ("C", C.c_int32), ("count", C.c_float), ("momentum", C.c_float), ("eps", C.c_float),
+                ("accumulate", C.c_int32)]
+
+
+class FkChain(C.Structure):
+    _fields_ = [("njoints", C.c_int32), ("parent", C.c_int32 * FK_MAX_JOINTS), ("type", C.c_int32 * FK_MAX_JOINTS),
+                ("cfg", C.c_int32 * FK_MAX_JOINTS), ("mimic_mul", C.c_float * FK_MAX_JOINTS),
+                ("mimic_off", C.c_float * FK_MAX_JOINTS), ("origin", (C.c_float * 12) * FK_MAX_JOINTS),
+                ("axis", (C.c_float * 3) * FK_MAX_JOINTS), ("nkp", C.c_int32), ("kp_frame", C.c_int32 * FK_MAX_KP),
+                ("kp_offset", (C.c_float * 3) * FK_MAX_KP), ("dof", C.c_int32)]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+# name -> argtypes (every function returns int unless noted); mirrors include/hrp.h one to one
+PROTOTYPES = {
+    "hrp_version": [], "hrp_device_ok": [],
+    "hrp_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hrp_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hrp_nchw_grad_from_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hrp_pack_weights": [_P, _I, _I, _I, _P],
+    "hrp_conv2d_fwd": [C.POINTER(ConvDesc), _P],
+    "hrp_conv2d_bwd_weight": [C.POINTER(WgradDesc), _P],
+    "hrp_colsum": [_P, _I, _L, _I, _I, _P, _I, _P],
+    "hrp_ew_fwd": [C.POINTER(EwDesc), _P],
+    "hrp_ew_bwd_reduce": [C.POINTER(EwBwdDesc), _P],
+    "hrp_ew_bwd_apply": [C.POINTER(EwBwdDesc), _P],
+    "hrp_bn_running_update": [_P, _I, _P], "hrp_bn_fold": [_P, _I, _P], "hrp_bn_param_grad": [_P, _I, _P],
+    "hrp_avgpool_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "hrp_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hrp_softargmax3d_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "hrp_softargmax3d_bwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "hrp_pose_geometry_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    "hrp_pose_geometry_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "hrp_fk_project_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "hrp_fk_project_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hrp_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "hrp_scale_rows": [_P, _I, _I, _I, _P, _F, _P],
+    "hrp_mul_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],
+    "hrp_project_bwd": [_P, _P, _P, _I, _I, _P, _P],
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libhrp_hip.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise HrpError("building libhrp_hip.so failed:\n" + r.stdout[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HrpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, args in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.hrp_last_error.restype = C.c_char_p
+        L.hrp_last_error.argtypes = []
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HrpError(f"{what} failed ({rc}): {lib().hrp_last_error().decode()}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,368 @@
+// Tile convolution on MFMA for gfx950: one kernel family for conv k1/k3, stride 1/2, its data gradient
+// and nn.Linear (see hrp_conv_desc in include/hrp.h).
+//
+// Work decomposition
+//   workgroup (256 threads = 4 waves) -> output tile of BM = TI*TH*TW pixels x BN output channels
+//   K loop = input-channel chunks of 64 bytes (32 bf16 / 16 fp32) x taps x MFMA k-steps
+//   LDS   = input halo tile [pixel][64 B + 16 B pad]  (read once per chunk, reused by every tap)
+//         + weight slab    [tap][cout][64 B + 16 B pad] (TG taps at a time)
+//   MFMA  = 32x32x16 bf16 / 32x32x2 fp32, A = weights (rows = cout), B = pixels (cols = pixel):
+//           each lane ends up with 4 consecutive output channels of one pixel per accumulator quad,
+//           so the epilogue moves 8/16-byte pieces through LDS and leaves as 16-byte coalesced stores.
+//   epilogue = bias, per-channel affine (folded BN), residual add, ReLU, per-channel sum / sum-of-squares
+//           (train-mode BN statistics, one atomicAdd per channel per workgroup).
+//   block id -> XCD-contiguous remap so the cout blocks / neighbouring tiles that share an input tile hit
+//           the same XCD's L2.
+#include "hrp_common.h"
+
+namespace hrp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CHUNK_BYTES = 64;  // bytes of input channels per pixel staged per K chunk
+constexpr int PITCH = 80;        // LDS row pitch (64 B data + 16 B pad: odd multiple of 16 B)
+
+struct ConvTiling {
+  int TH, TW, TI;
+  int IHt, IWt;
+  int mindy, mindx;
+  int tiles_x, tiles_y, tiles_n;
+  int n_cout_blk;
+  int TG;
+  int in_pix;
+  int lds_w_off, lds_stats_off;
+  int nblocks;
+  int vec_ok;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  static constexpr int KB = 32;  // bytes of K per MFMA (16 bf16)
+  using Frag = bf16x8;
+  __device__ static __forceinline__ Frag ld(const char* p) { return *(const Frag*)p; }
+  __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  static constexpr int KB = 8;  // 2 fp32
+  using Frag = float;
+  __device__ static __forceinline__ Frag ld(const char* p) { return *(const float*)p; }
+  __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int CT, int PT, int WC, int WP>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, const ConvTiling t) {
+  static_assert(WC * WP == 4, "4 waves");
+  constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
+  constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
+  constexpr int KB = Mma<T>::KB;
+  constexpr int KSTEPS = CHUNK_BYTES / KB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_in = smem;
+  char* lds_w = smem + t.lds_w_off;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave % WC, wp = wave / WC;
+  const int l31 = lane & 31, khalf = lane >> 5;
+
+  int bid = blockIdx.x;
+  if ((t.nblocks & 7) == 0) bid = (bid & 7) * (t.nblocks >> 3) + (bid >> 3);
+  const int cb = bid % t.n_cout_blk;
+  int tile = bid / t.n_cout_blk;
+  const int tx_i = tile % t.tiles_x;
+  tile /= t.tiles_x;
+  const int ty_i = tile % t.tiles_y;
+  const int tn_i = tile / t.tiles_y;
+  const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
+  const int IS = d.in_stride;
+  const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
+  const int co0 = cb * BN;
+  const int thw = t.TH * t.TW;
+
+  int pixoff[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    int m = wp * (32 * PT) + pt * 32 + l31;
+    int ti = m / thw, rem = m - ti * thw;
+    int ty = rem / t.TW, tx = rem - ty * t.TW;
+    pixoff[pt] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * PITCH + khalf * (KB / 2);
+  }
+  const int wrow = (wc * 32 * CT + l31) * PITCH + khalf * (KB / 2);
+
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][p][i] = 0.f;
+
+  const int CKE = CHUNK_BYTES / SZ;  // channels per chunk
+  const int nchunks = (d.Cin + CKE - 1) / CKE;
+  const int ihw = t.IHt * t.IWt;
+  const char* xg = (const char*)d.x;
+  const char* wg = (const char*)d.w;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();  // everyone is done reading the previous chunk's tiles
+    const int c0 = chunk * CKE;
+    for (int v = tid; v < t.in_pix * 4; v += 256) {
+      int pix = v >> 2, vec = v & 3;
+      int ti = pix / ihw, rem = pix - ti * ihw;
+      int iy = rem / t.IWt, ix = rem - iy * t.IWt;
+      int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
+      int c = c0 + vec * VEC;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
+        size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
+        val = *(const uint4*)(xg + off * SZ);
+      }
+      *(uint4*)(lds_in + pix * PITCH + vec * 16) = val;
+    }
+    for (int tg0 = 0; tg0 < d.ntaps; tg0 += t.TG) {
+      if (tg0 > 0) __syncthreads();
+      const int tgn = min(t.TG, d.ntaps - tg0);
+      for (int v = tid; v < tgn * BN * 4; v += 256) {
+        int row = v >> 2, vec = v & 3;
+        int tl = row / BN, j = row - tl * BN;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (co0 + j < d.w_cout_pad) {
+          size_t roff = ((size_t)chunk * d.w_ntaps + d.wtap[tg0 + tl]) * d.w_cout_pad + co0 + j;
+          val = *(const uint4*)(wg + roff * CHUNK_BYTES + vec * 16);
+        }
+        *(uint4*)(lds_w + row * PITCH + vec * 16) = val;
+      }
+      __syncthreads();
+      for (int tl = 0; tl < tgn; ++tl) {
+        const int tap = tg0 + tl;
+        const int tapoff = ((d.dy[tap] - t.mindy) * t.IWt + (d.dx[tap] - t.mindx)) * PITCH;
+        const char* wbase = lds_w + tl * BN * PITCH + wrow;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+          typename Mma<T>::Frag a[CT], b[PT];
+#pragma unroll
+          for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(wbase + c * 32 * PITCH + kk * KB);
+#pragma unroll
+          for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in + pixoff[p] + tapoff + kk * KB);
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) Mma<T>::mma(a[c], b[p], acc[c][p]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: accumulators -> LDS tile [pixel][cout] (element type T) ----------------------
+  constexpr int OP = BN * SZ + 16;
+  char* lds_out = smem;
+  float* lds_stats = (float*)(smem + t.lds_stats_off);
+  if (d.stats) {
+    for (int i = tid; i < 2 * BN; i += 256) lds_stats[i] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cl = wc * 32 * CT + c * 32 + 8 * q + 4 * khalf;  // first of 4 consecutive local couts
+      float bia[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int co = co0 + cl + i;
+        if (co < d.Cout) {
+          if (d.bias) bia[i] = d.bias[co];
+          if (d.scale) { sc[i] = d.scale[co]; sh[i] = d.shift[co]; }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const int m = wp * (32 * PT) + p * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (acc[c][p][4 * q + i] + bia[i]) * sc[i] + sh[i];
+        char* dst = lds_out + m * OP + cl * SZ;
+        if constexpr (SZ == 4) {
+          *(uint4*)dst = Elem<float>::pack(v);
+        } else {
+          uint2 r;
+          r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(uint2*)dst = r;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- coalesced pass: residual, ReLU, statistics, global store -------------------------------
+  constexpr int NV = BN / VEC;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+  const int cv = tid % NV;  // 256 % NV == 0, so a thread keeps its channel group
+  const int co = co0 + cv * VEC;
+  char* yg = (char*)d.y;
+  const char* rg = (const char*)d.res;
+  if (co < d.Cout) {
+    const bool full = t.vec_ok && (co + VEC <= d.Cout);
+    for (int m = tid / NV; m < BM; m += 256 / NV) {
+      int ti = m / thw, rem = m - ti * thw;
+      int ty = rem / t.TW, tx = rem - ty * t.TW;
+      int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
+      if (n >= d.N || oy >= d.Ho || ox >= d.Wo) continue;
+      size_t opix = ((size_t)n * d.y_H + (oy * d.out_stride + d.out_off_y)) * d.y_W + (ox * d.out_stride + d.out_off_x);
+      float f[VEC];
+      Elem<T>::unpack(*(const uint4*)(lds_out + m * OP + cv * 16), f);
+      if (full) {
+        if (rg) {
+          float r[VEC];
+          Elem<T>::unpack(*(const uint4*)(rg + (opix * d.res_pitch + co) * SZ), r);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) f[i] += r[i];
+        }
+        if (d.relu) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+        }
+        uint4 packed = Elem<T>::pack(f);
+        *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = packed;
+        if (d.stats) {
+          float g[VEC];
+          Elem<T>::unpack(packed, g);  // statistics of the values as stored
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { s1[i] += g[i]; s2[i] += g[i] * g[i]; }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if (co + i < d.Cout) {
+            float val = f[i];
+            if (rg) val += Elem<T>::ld(rg, opix * d.res_pitch + co + i);
+            if (d.relu) val = fmaxf(val, 0.f);
+            Elem<T>::st(yg, opix * d.y_pitch + co + i, val);
+            if (d.stats) {
+              float g = Elem<T>::ld(yg, opix * d.y_pitch + co + i);
+              s1[i] += g; s2[i] += g * g;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (d.stats) {
+    if (co < d.Cout) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        atomicAdd(&lds_stats[cv * VEC + i], s1[i]);
+        atomicAdd(&lds_stats[BN + cv * VEC + i], s2[i]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BN; i += 256) {
+      if (co0 + i < d.Cout) {
+        atomicAdd(&d.stats[co0 + i], lds_stats[i]);
+        atomicAdd(&d.stats[d.Cout + co0 + i], lds_stats[BN + i]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Cfg { int CT, PT, WC, WP; };
+
+template <typename T, int CT, int PT, int WC, int WP>
+static int launch_cfg(const hrp_conv_desc& d, ConvTiling t, hipStream_t s) {
+  constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
+  constexpr int SZ = Elem<T>::SZ;
+  // tile geometry: TW x TH x TI = BM
+  int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
+  int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
+  int TI = BM / (TW * TH);
+  t.TW = TW; t.TH = TH; t.TI = TI;
+  int mindy = 1 << 30, maxdy = -(1 << 30), mindx = 1 << 30, maxdx = -(1 << 30);
+  for (int i = 0; i < d.ntaps; ++i) {
+    mindy = d.dy[i] < mindy ? d.dy[i] : mindy; maxdy = d.dy[i] > maxdy ? d.dy[i] : maxdy;
+    mindx = d.dx[i] < mindx ? d.dx[i] : mindx; maxdx = d.dx[i] > maxdx ? d.dx[i] : maxdx;
+  }
+  t.mindy = mindy; t.mindx = mindx;
+  t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
+  t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
+  t.in_pix = TI * t.IHt * t.IWt;
+  t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
+  t.n_cout_blk = cdiv(d.Cout, BN);
+  t.nblocks = t.tiles_x * t.tiles_y * t.tiles_n * t.n_cout_blk;
+  const int in_bytes = round_up(t.in_pix * PITCH, 16);
+  const int out_bytes = BM * (BN * SZ + 16);
+  const int budget = 72 * 1024;
+  int TG = (budget - in_bytes) / (BN * PITCH);
+  if (TG < 1) return -100;  // does not fit: caller tries a smaller pixel tile
+  if (TG > d.ntaps) TG = d.ntaps;
+  t.TG = TG;
+  t.lds_w_off = in_bytes;
+  int main_bytes = in_bytes + TG * BN * PITCH;
+  if (out_bytes > main_bytes) main_bytes = out_bytes;
+  t.lds_stats_off = round_up(main_bytes, 16);
+  int lds = t.lds_stats_off + 2 * BN * 4;
+  if (lds > 160 * 1024) return -100;
+  const bool aligned = ((uintptr_t)d.y % 16 == 0) && ((size_t)d.y_pitch * SZ % 16 == 0) &&
+                       (!d.res || (((uintptr_t)d.res % 16 == 0) && ((size_t)d.res_pitch * SZ % 16 == 0)));
+  t.vec_ok = aligned ? 1 : 0;
+  auto kern = conv_tile_kernel<T, CT, PT, WC, WP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(t.nblocks), dim3(256), lds, s, d, t);
+  return check_launch("conv_tile_kernel");
+}
+
+template <typename T>
+static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
+  ConvTiling t{};
+  const long pixels = (long)d.N * d.Ho * d.Wo;
+  int rc;
+  if (d.Cout <= 32) {
+    rc = (pixels >= 256 * 64) ? launch_cfg<T, 1, 2, 1, 4>(d, t, s) : launch_cfg<T, 1, 1, 1, 4>(d, t, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4>(d, t, s);
+  } else if (d.Cout <= 64) {
+    rc = (pixels >= 256 * 64) ? launch_cfg<T, 2, 2, 1, 4>(d, t, s) : launch_cfg<T, 2, 1, 1, 4>(d, t, s);
+    if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4>(d, t, s);
+  } else {
+    rc = (pixels >= 128 * 128) ? launch_cfg<T, 2, 2, 2, 2>(d, t, s) : launch_cfg<T, 2, 1, 2, 2>(d, t, s);
+    if (rc == -100) rc = launch_cfg<T, 2, 1, 2, 2>(d, t, s);
+  }
+  if (rc == -100) {
+    set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
+    return HRP_ERR_ARG;
+  }
+  return rc;
+}
+
+}  // namespace hrp
+
+extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
+  using namespace hrp;
+  HRP_REQUIRE(d && d->x && d->w && d->y, "conv: null pointer");
+  HRP_REQUIRE(d->ntaps >= 1 && d->ntaps <= HRP_MAX_TAPS, "conv: ntaps=%d", d->ntaps);
+  HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16, "conv: dtype=%d", d->dtype);
+  const int vec = d->dtype == HRP_F32 ? 4 : 8, sz = d->dtype == HRP_F32 ? 4 : 2;
+  HRP_REQUIRE(d->Cin % vec == 0 && d->x_pitch % vec == 0 && (uintptr_t)d->x % 16 == 0,
+              "conv: input channels / pitch must be multiples of %d elements (Cin=%d pitch=%d)", vec, d->Cin, d->x_pitch);
+  HRP_REQUIRE((uintptr_t)d->w % 16 == 0, "conv: packed weights must be 16-byte aligned");
+  HRP_REQUIRE(d->w_cout_pad % 32 == 0 && d->w_cout_pad >= d->Cout, "conv: w_cout_pad=%d Cout=%d", d->w_cout_pad, d->Cout);
+  HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
+  HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
+  HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
+  (void)sz;
+  if (d->dtype == HRP_F32) return launch_conv<float>(*d, (hipStream_t)stream);
+  return launch_conv<bf16_t>(*d, (hipStream_t)stream);
+}

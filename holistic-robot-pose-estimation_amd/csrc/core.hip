@@ -1,0 +1,298 @@
+// Library plumbing + the small HBM-bound kernels: layout change at the stem, weight packing,
+// column sums (bias gradients), batch-norm bookkeeping tables, global average pooling.
+#include "hrp_common.h"
+#include <string.h>
+
+namespace hrp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return HRP_ERR_LAUNCH;
+  }
+  return HRP_OK;
+}
+
+// ---- NCHW fp32 <-> NHWC T ----------------------------------------------------------------------
+// One workgroup handles 64 pixels x all channels through an LDS transpose so both sides are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                           int C, int HW, int pitch) {
+  // small-C path (stem: C = 3): thread per pixel, writes `pitch` channels (zero padded)
+  size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int n = blockIdx.y;
+  if (p >= (size_t)HW) return;
+  const float* s = src + (size_t)n * C * HW + p;
+  size_t o = ((size_t)n * HW + p) * pitch;
+  for (int c = 0; c < pitch; ++c) Elem<T>::st(dst, o + c, c < C ? s[(size_t)c * HW] : 0.f);
+}
+
+template <typename T, bool GRAD>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int pitch) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {  // r = pixel, tx = channel
+    int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? Elem<T>::ld(src, ((size_t)n * HW + p) * pitch + c) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {  // r = channel, tx = pixel
+    int c = c0 + r, p = p0 + tx;
+    if (p < HW && c < C) dst[((size_t)n * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry* __restrict__ table) {
+  const hrp_pack_entry e = table[blockIdx.y];
+  constexpr int CK = 64 / Elem<T>::SZ;
+  const int cout_pad = (e.Cout + 31) / 32 * 32, cin_pad = (e.Cin + 31) / 32 * 32;
+  if (e.dst) {
+    const int nch = (e.Cin + CK - 1) / CK;
+    const size_t total = (size_t)nch * e.ntaps * cout_pad * CK;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      int k = i % CK;
+      size_t r = i / CK;
+      int co = r % cout_pad; r /= cout_pad;
+      int tap = r % e.ntaps;
+      int ch = r / e.ntaps;
+      int ci = ch * CK + k;
+      float v = (co < e.Cout && ci < e.Cin) ? e.src[((size_t)co * e.Cin + ci) * e.ntaps + tap] : 0.f;
+      Elem<T>::st(e.dst, i, v);
+    }
+  }
+  if (e.dst_t) {
+    const int nch = (e.Cout + CK - 1) / CK;
+    const size_t total = (size_t)nch * e.ntaps * cin_pad * CK;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      int k = i % CK;
+      size_t r = i / CK;
+      int ci = r % cin_pad; r /= cin_pad;
+      int tap = r % e.ntaps;
+      int ch = r / e.ntaps;
+      int co = ch * CK + k;
+      float v = (co < e.Cout && ci < e.Cin) ? e.src[((size_t)co * e.Cin + ci) * e.ntaps + tap] : 0.f;
+      Elem<T>::st(e.dst_t, i, v);
+    }
+  }
+}
+
+// ---- column sums -----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, long rows, int C, int pitch,
+                                                     float* __restrict__ out) {
+  // thread (tx = channel within a 64-wide slab, ty = row phase); grid.x strides rows, grid.y = channel slab
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + tx;
+  float s = 0.f;
+  if (c < C)
+    for (long r = (long)blockIdx.x * 4 + ty; r < rows; r += (long)gridDim.x * 4) s += Elem<T>::ld(x, (size_t)r * pitch + c);
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) atomicAdd(&out[c], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
+// ---- batch-norm tables -----------------------------------------------------------------------------
+__global__ void bn_running_update_kernel(const hrp_bn_entry* __restrict__ table) {
+  const hrp_bn_entry e = table[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    float mean = e.stats[c] / e.count;
+    float var = fmaxf(e.stats[e.C + c] / e.count - mean * mean, 0.f);
+    float unbiased = e.count > 1.f ? var * (e.count / (e.count - 1.f)) : var;
+    e.a[c] = (1.f - e.momentum) * e.a[c] + e.momentum * mean;
+    e.b[c] = (1.f - e.momentum) * e.b[c] + e.momentum * unbiased;
+  }
+  if (threadIdx.x == 0 && e.counter) *e.counter += 1;
+}
+
+__global__ void bn_fold_kernel(const hrp_bn_entry* __restrict__ table) {
+  const hrp_bn_entry e = table[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    float sc = e.a[c] * rsqrtf(e.d[c] + e.eps);
+    e.out_scale[c] = sc;
+    e.out_shift[c] = e.b[c] - e.c[c] * sc;
+  }
+}
+
+// backward sums [2C] = (sum g, sum g*xhat) -> dbeta, dgamma
+__global__ void bn_param_grad_kernel(const hrp_bn_entry* __restrict__ table) {
+  const hrp_bn_entry e = table[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    float dbeta = e.stats[c], dgamma = e.stats[e.C + c];
+    if (e.accumulate) { e.a[c] += dgamma; e.b[c] += dbeta; }
+    else { e.a[c] = dgamma; e.b[c] = dbeta; }
+  }
+}
+
+// ---- global average pool ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const void* __restrict__ x, int HW, int C, int pitch,
+                                                          float* __restrict__ out, int out_pitch) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += Elem<T>::ld(x, ((size_t)n * HW + p) * pitch + c);
+  out[(size_t)n * out_pitch + c] = s / (float)HW;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, int dout_pitch, void* __restrict__ dx,
+                                                          int HW, int C, int pitch, int accumulate) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float g = dout[(size_t)n * dout_pitch + c] / (float)HW;
+  for (int p = 0; p < HW; ++p) {
+    size_t o = ((size_t)n * HW + p) * pitch + c;
+    Elem<T>::st(dx, o, accumulate ? Elem<T>::ld(dx, o) + g : g);
+  }
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, int sp, float* __restrict__ dst, int dp, int rows, int cols, int acc) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  int r = i / cols, c = i % cols;
+  float v = src[(size_t)r * sp + c];
+  float* d = dst + (size_t)r * dp + c;
+  *d = acc ? *d + v : v;
+}
+
+__global__ void scale_rows_kernel(float* __restrict__ x, int pitch, int rows, int cols, const float* __restrict__ rs, float s) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  int r = i / cols, c = i % cols;
+  x[(size_t)r * pitch + c] *= (rs ? rs[r] : 1.f) * s;
+}
+
+__global__ void mul_kernel(const float* __restrict__ x, int xp, const float* __restrict__ m, int mp, float* __restrict__ y, int yp,
+                           int rows, int cols, int acc) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  int r = i / cols, c = i % cols;
+  float v = x[(size_t)r * xp + c] * m[(size_t)r * mp + c];
+  float* d = y + (size_t)r * yp + c;
+  *d = acc ? *d + v : v;
+}
+
+}  // namespace hrp
+
+using namespace hrp;
+
+extern "C" int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,
+                           int accumulate, void* stream) {
+  HRP_REQUIRE(x && m && y && rows > 0 && cols > 0, "mul_f32: bad args");
+  hipLaunchKernelGGL(mul_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x, x_pitch, m, m_pitch, y, y_pitch,
+                     rows, cols, accumulate);
+  return check_launch("mul_f32");
+}
+
+extern "C" const char* hrp_last_error(void) { return hrp::g_err; }
+extern "C" int hrp_version(void) { return 100; }
+
+extern "C" int hrp_device_ok(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+extern "C" int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream) {
+  HRP_REQUIRE(src && dst && N > 0 && C > 0 && dst_pitch >= C, "nchw_to_nhwc: bad args");
+  dim3 grid(cdiv(H * W, 256), N);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch);
+  return check_launch("nchw_to_nhwc");
+}
+
+extern "C" int hrp_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream) {
+  HRP_REQUIRE(src && dst && N > 0 && C > 0 && src_pitch >= C, "nhwc_to_nchw: bad args");
+  dim3 grid(cdiv(H * W, 64), cdiv(C, 64), N);
+  if (dtype == HRP_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, src_pitch);
+  else hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, src_pitch);
+  return check_launch("nhwc_to_nchw");
+}
+
+extern "C" int hrp_nchw_grad_from_nhwc(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream) {
+  return hrp_nhwc_to_nchw(src, dst, dtype, N, C, H, W, src_pitch, stream);
+}
+
+extern "C" int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int max_elems, void* stream) {
+  HRP_REQUIRE(table_dev && count > 0, "pack_weights: empty table");
+  int bx = cdiv(max_elems, 256 * 8);
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  dim3 grid(bx, count);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+  else hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+  return check_launch("pack_weights");
+}
+
+extern "C" int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream) {
+  HRP_REQUIRE(x && out && rows > 0 && C > 0, "colsum: bad args");
+  if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream);
+  int gx = (int)((rows + 63) / 64);
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  dim3 grid(gx, cdiv(C, 64));
+  if (dtype == HRP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, pitch, out);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, pitch, out);
+  return check_launch("colsum");
+}
+
+extern "C" int hrp_bn_running_update(const hrp_bn_entry* table_dev, int count, void* stream) {
+  HRP_REQUIRE(table_dev && count > 0, "bn_running_update: empty table");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, table_dev);
+  return check_launch("bn_running_update");
+}
+extern "C" int hrp_bn_fold(const hrp_bn_entry* table_dev, int count, void* stream) {
+  HRP_REQUIRE(table_dev && count > 0, "bn_fold: empty table");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, table_dev);
+  return check_launch("bn_fold");
+}
+extern "C" int hrp_bn_param_grad(const hrp_bn_entry* table_dev, int count, void* stream) {
+  HRP_REQUIRE(table_dev && count > 0, "bn_param_grad: empty table");
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, table_dev);
+  return check_launch("bn_param_grad");
+}
+
+extern "C" int hrp_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, int pitch, float* out, int out_pitch, void* stream) {
+  HRP_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, "avgpool_fwd: bad args");
+  dim3 grid(cdiv(C, 256), N);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, pitch, out, out_pitch);
+  else hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, pitch, out, out_pitch);
+  return check_launch("avgpool_fwd");
+}
+extern "C" int hrp_avgpool_bwd(const float* dout, int dout_pitch, void* dx, int dtype, int N, int HW, int C, int pitch, int accumulate, void* stream) {
+  HRP_REQUIRE(dout && dx && N > 0 && HW > 0 && C > 0, "avgpool_bwd: bad args");
+  dim3 grid(cdiv(C, 256), N);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, dx, HW, C, pitch, accumulate);
+  else hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, dx, HW, C, pitch, accumulate);
+  return check_launch("avgpool_bwd");
+}
+
+extern "C" int hrp_copy_cols(const float* src, int src_pitch, float* dst, int dst_pitch, int rows, int cols, int accumulate, void* stream) {
+  HRP_REQUIRE(src && dst && rows > 0 && cols > 0, "copy_cols: bad args");
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, rows, cols, accumulate);
+  return check_launch("copy_cols");
+}
+extern "C" int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_scale, float s, void* stream) {
+  HRP_REQUIRE(x && rows > 0 && cols > 0, "scale_rows: bad args");
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x, pitch, rows, cols, row_scale, s);
+  return check_launch("scale_rows");
+}

@@ -1,0 +1,301 @@
+// Fused element-wise op of the HRNet graph and its backward (HBM-bound; 16-byte vector loads/stores).
+//
+//   out[n,y,x,c] = act( sum_j f_j( in_j[n, y/up_j, x/up_j, c] ) )
+//
+// covers BatchNorm (+ReLU) after a conv, the residual add of BasicBlock / Bottleneck, the whole
+// cross-resolution fuse of HighResolutionModule (BN of each incoming path + nearest upsample + sum +
+// ReLU in ONE pass; reference HRnet.py:256-263 materialises every term), and the cls-head adds.
+// Train-mode BN needs no separate finalize kernel: every thread derives scale/shift of its channels
+// from the (sum, sumsq) statistics the producing conv accumulated in its epilogue.
+#include "hrp_common.h"
+
+namespace hrp {
+
+template <typename T, int V>
+struct VecIO {
+  static_assert(V == 1 || V == Elem<T>::VEC, "vector width");
+  __device__ static __forceinline__ void ld(const void* p, size_t i, float* f) {
+    if constexpr (V == 1) f[0] = Elem<T>::ld(p, i);
+    else Elem<T>::unpack(*(const uint4*)((const char*)p + i * Elem<T>::SZ), f);
+  }
+  __device__ static __forceinline__ void st(void* p, size_t i, const float* f) {
+    if constexpr (V == 1) Elem<T>::st(p, i, f[0]);
+    else *(uint4*)((char*)p + i * Elem<T>::SZ) = Elem<T>::pack(f);
+  }
+};
+
+// scale/shift (and mean/invstd) of V channels starting at c for one input
+template <int V>
+__device__ __forceinline__ void channel_affine(const hrp_ew_input& in, int c, int C, float* sc, float* sh, float* mean, float* inv) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    sc[i] = 1.f; sh[i] = 0.f; mean[i] = 0.f; inv[i] = 1.f;
+    if (c + i >= C) continue;
+    if (in.mode == HRP_EW_AFFINE) {
+      sc[i] = in.a[c + i]; sh[i] = in.b[c + i];
+    } else if (in.mode == HRP_EW_BN_TRAIN) {
+      float m = in.stats[c + i] / in.count;
+      float var = fmaxf(in.stats[C + c + i] / in.count - m * m, 0.f);
+      float is = rsqrtf(var + in.eps);
+      mean[i] = m; inv[i] = is;
+      sc[i] = in.a[c + i] * is;
+      sh[i] = in.b[c + i] - m * sc[i];
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
+  const int cv = (blockIdx.y * tpr + threadIdx.x % tpr);
+  const int c = cv * V;
+  if (c >= d.C) return;
+  const int ppb = 256 / tpr;  // pixels per block-iteration
+  float sc[HRP_EW_MAX_IN][V], sh[HRP_EW_MAX_IN][V];
+  {
+    float m[V], iv[V];
+#pragma unroll
+    for (int j = 0; j < HRP_EW_MAX_IN; ++j)
+      if (j < d.nin) channel_affine<V>(d.in[j], c, d.C, sc[j], sh[j], m, iv);
+  }
+  const long npix = (long)d.N * d.H * d.W;
+  for (long p = (long)blockIdx.x * ppb + threadIdx.x / tpr; p < npix; p += (long)gridDim.x * ppb) {
+    int x = p % d.W;
+    long r = p / d.W;
+    int y = r % d.H;
+    int n = r / d.H;
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HRP_EW_MAX_IN; ++j) {
+      if (j >= d.nin) break;
+      const hrp_ew_input& in = d.in[j];
+      const int up = in.up;
+      size_t q = (((size_t)n * (d.H / up) + y / up) * (d.W / up) + x / up) * in.pitch + c;
+      float f[V];
+      VecIO<T, V>::ld(in.ptr, q, f);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] += f[i] * sc[j][i] + sh[j][i];
+    }
+    if (d.relu) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    }
+    VecIO<T, V>::st(d.out, (size_t)p * d.out_pitch + c, acc);
+  }
+}
+
+// pooled, masked output gradient at input pixel q = (n, qy, qx)
+template <typename T, int V>
+__device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, int n, int qy, int qx, int c, float* g) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) g[i] = 0.f;
+  const int up = d.in.up;
+  for (int dy = 0; dy < up; ++dy)
+    for (int dx = 0; dx < up; ++dx) {
+      size_t p = ((size_t)n * d.H + qy * up + dy) * d.W + qx * up + dx;
+      float go[V];
+      VecIO<T, V>::ld(d.dout, p * d.dout_pitch + c, go);
+      if (d.relu) {
+        float o[V];
+        VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
+#pragma unroll
+        for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] += go[i];
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_desc d, int tpr) {
+  __shared__ float red[2][256 * (V > 1 ? V : 1)];
+  const int lane_c = threadIdx.x % tpr;
+  const int cv = blockIdx.y * tpr + lane_c;
+  const int c = cv * V;
+  const int ppb = 256 / tpr;
+  const int up = d.in.up, Hq = d.H / up, Wq = d.W / up;
+  float s0[V], s1[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s0[i] = s1[i] = 0.f;
+  if (c < d.C) {
+    float sc[V], sh[V], mean[V], inv[V];
+    channel_affine<V>(d.in, c, d.C, sc, sh, mean, inv);
+    const long nq = (long)d.N * Hq * Wq;
+    for (long q = (long)blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += (long)gridDim.x * ppb) {
+      int qx = q % Wq;
+      long r = q / Wq;
+      int qy = r % Hq;
+      int n = r / Hq;
+      float g[V], xin[V];
+      pooled_grad<T, V>(d, n, qy, qx, c, g);
+      VecIO<T, V>::ld(d.in.ptr, (size_t)q * d.in.pitch + c, xin);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        s0[i] += g[i];
+        s1[i] += g[i] * (xin[i] - mean[i]) * inv[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    red[0][threadIdx.x * V + i] = s0[i];
+    red[1][threadIdx.x * V + i] = s1[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < tpr && c < d.C) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int k = 0; k < ppb; ++k) {
+        a0 += red[0][(k * tpr + lane_c) * V + i];
+        a1 += red[1][(k * tpr + lane_c) * V + i];
+      }
+      if (c + i < d.C) {
+        atomicAdd(&d.sums[c + i], a0);
+        atomicAdd(&d.sums[d.C + c + i], a1);
+      }
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
+  const int cv = blockIdx.y * tpr + threadIdx.x % tpr;
+  const int c = cv * V;
+  if (c >= d.C) return;
+  const int ppb = 256 / tpr;
+  const int up = d.in.up, Hq = d.H / up, Wq = d.W / up;
+  float sc[V], sh[V], mean[V], inv[V], k0[V], k1[V];
+  channel_affine<V>(d.in, c, d.C, sc, sh, mean, inv);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    k0[i] = k1[i] = 0.f;
+    if (d.in.mode == HRP_EW_BN_TRAIN && c + i < d.C) {
+      k0[i] = d.sums[c + i] / d.in.count;
+      k1[i] = d.sums[d.C + c + i] / d.in.count;
+    }
+  }
+  const long nq = (long)d.N * Hq * Wq;
+  for (long q = (long)blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += (long)gridDim.x * ppb) {
+    int qx = q % Wq;
+    long r = q / Wq;
+    int qy = r % Hq;
+    int n = r / Hq;
+    float g[V];
+    pooled_grad<T, V>(d, n, qy, qx, c, g);
+    if (d.in.mode == HRP_EW_BN_TRAIN) {
+      float xin[V];
+      VecIO<T, V>::ld(d.in.ptr, (size_t)q * d.in.pitch + c, xin);
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = sc[i] * (g[i] - k0[i] - (xin[i] - mean[i]) * inv[i] * k1[i]);
+    } else if (d.in.mode == HRP_EW_AFFINE) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] *= sc[i];
+    }
+    size_t o = (size_t)q * d.din_pitch + c;
+    if (d.accumulate) {
+      float old[V];
+      VecIO<T, V>::ld(d.din, o, old);
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] += old[i];
+    }
+    VecIO<T, V>::st(d.din, o, g);
+  }
+}
+
+static inline bool aligned16(const void* p, int pitch, int sz) {
+  return ((uintptr_t)p % 16 == 0) && (((size_t)pitch * sz) % 16 == 0);
+}
+
+struct EwGeom { int V, tpr, nslab, gx; };
+
+static EwGeom geom(int C, int vec, bool vec_ok, long npix) {
+  EwGeom g;
+  g.V = (vec_ok && C % vec == 0) ? vec : 1;
+  int nv = C / g.V;
+  int tpr = 1;
+  while (tpr < nv && tpr < 256) tpr <<= 1;
+  g.tpr = tpr;
+  g.nslab = cdiv(nv, tpr);
+  int ppb = 256 / tpr;
+  long blocks = (npix + ppb - 1) / ppb;
+  long cap = 256L * 8 / g.nslab;
+  if (cap < 1) cap = 1;
+  g.gx = (int)(blocks < cap ? blocks : cap);
+  if (g.gx < 1) g.gx = 1;
+  return g;
+}
+
+template <typename T>
+static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
+  constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
+  bool ok = aligned16(d.out, d.out_pitch, SZ);
+  for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W);
+  dim3 grid(g.gx, g.nslab);
+  if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
+  else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
+  return check_launch("ew_fwd");
+}
+
+template <typename T, bool APPLY>
+static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
+  constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
+  bool ok = aligned16(d.dout, d.dout_pitch, SZ) && aligned16(d.in.ptr ? d.in.ptr : d.dout, d.in.pitch ? d.in.pitch : d.dout_pitch, SZ);
+  if (d.relu) ok = ok && aligned16(d.out, d.out_pitch, SZ);
+  if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
+  const int up = d.in.up;
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up));
+  dim3 grid(g.gx, g.nslab);
+  if (APPLY) {
+    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr);
+    else hipLaunchKernelGGL((ew_bwd_apply_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr);
+  } else {
+    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr);
+    else hipLaunchKernelGGL((ew_bwd_reduce_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr);
+  }
+  return check_launch(APPLY ? "ew_bwd_apply" : "ew_bwd_reduce");
+}
+
+}  // namespace hrp
+
+using namespace hrp;
+
+extern "C" int hrp_ew_fwd(const hrp_ew_desc* d, void* stream) {
+  HRP_REQUIRE(d && d->out && d->nin >= 1 && d->nin <= HRP_EW_MAX_IN, "ew_fwd: bad descriptor");
+  HRP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0, "ew_fwd: empty");
+  for (int j = 0; j < d->nin; ++j) {
+    const hrp_ew_input& in = d->in[j];
+    HRP_REQUIRE(in.ptr && in.up >= 1 && d->H % in.up == 0 && d->W % in.up == 0, "ew_fwd: input %d geometry", j);
+    HRP_REQUIRE(in.mode == HRP_EW_IDENTITY || (in.a && in.b), "ew_fwd: input %d needs a/b", j);
+    HRP_REQUIRE(in.mode != HRP_EW_BN_TRAIN || (in.stats && in.count > 0.f), "ew_fwd: input %d needs stats", j);
+  }
+  if (d->dtype == HRP_F32) return ew_fwd_t<float>(*d, (hipStream_t)stream);
+  return ew_fwd_t<bf16_t>(*d, (hipStream_t)stream);
+}
+
+static int ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
+  HRP_REQUIRE(d && d->dout, "ew_bwd: bad descriptor");
+  HRP_REQUIRE(!d->relu || d->out, "ew_bwd: relu needs the forward output");
+  HRP_REQUIRE(d->in.up >= 1 && d->H % d->in.up == 0 && d->W % d->in.up == 0, "ew_bwd: geometry");
+  HRP_REQUIRE(d->in.mode == HRP_EW_IDENTITY || d->in.ptr, "ew_bwd: needs forward input values");
+  HRP_REQUIRE(d->in.mode != HRP_EW_BN_TRAIN || (d->sums && d->in.stats && d->in.a), "ew_bwd: bn needs sums/stats");
+  HRP_REQUIRE(!apply || d->din, "ew_bwd_apply: din");
+  HRP_REQUIRE(apply || d->sums, "ew_bwd_reduce: sums");
+  return HRP_OK;
+}
+
+extern "C" int hrp_ew_bwd_reduce(const hrp_ew_bwd_desc* d, void* stream) {
+  int rc = ew_bwd_check(d, false);
+  if (rc) return rc;
+  if (d->dtype == HRP_F32) return ew_bwd_t<float, false>(*d, (hipStream_t)stream);
+  return ew_bwd_t<bf16_t, false>(*d, (hipStream_t)stream);
+}
+
+extern "C" int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream) {
+  int rc = ew_bwd_check(d, true);
+  if (rc) return rc;
+  if (d->dtype == HRP_F32) return ew_bwd_t<float, true>(*d, (hipStream_t)stream);
+  return ew_bwd_t<bf16_t, true>(*d, (hipStream_t)stream);
+}

@@ -1,0 +1,521 @@
+// Pose heads: one-pass 3-D soft-argmax, camera geometry, forward kinematics + projection.
+#include "hrp_common.h"
+
+namespace hrp {
+
+// =================================================================================================
+// 3-D soft-argmax (reference lib/utils/integral.py:147-177): per (sample, joint) softmax over D*H*W
+// logits, then E[w], E[h], E[d].  The reference makes >= 5 passes over the [B, J*D, H, W] tensor;
+// here one workgroup streams the joint's logits ONCE with an online softmax carrying the three
+// weighted sums.  NHWC logits: the D depth bins of joint j are D contiguous channels of each pixel.
+// =================================================================================================
+struct SmState {
+  float m, s, sx, sy, sz;
+};
+__device__ __forceinline__ void sm_merge(SmState& a, const SmState& b) {
+  float m = fmaxf(a.m, b.m);
+  float fa = __expf(a.m - m), fb = __expf(b.m - m);
+  a.s = a.s * fa + b.s * fb;
+  a.sx = a.sx * fa + b.sx * fb;
+  a.sy = a.sy * fa + b.sy * fb;
+  a.sz = a.sz * fa + b.sz * fb;
+  a.m = m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softargmax_fwd_kernel(const void* __restrict__ logits, int J, int D, int H, int W, int pitch,
+                                                             int root, int fix_root, float* __restrict__ uvd, float* __restrict__ ms) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int j = blockIdx.x, b = blockIdx.y;
+  const int nv = D / VEC;          // vectors per pixel for this joint
+  const int ppi = 256 / nv;        // pixels per iteration
+  const int vi = threadIdx.x % nv, pl = threadIdx.x / nv;
+  SmState st{-INFINITY, 0.f, 0.f, 0.f, 0.f};
+  const int HW = H * W;
+  if (pl < ppi) {
+    for (int p = pl; p < HW; p += ppi) {
+      const int y = p / W, x = p - y * W;
+      float f[VEC];
+      Elem<T>::unpack(*(const uint4*)((const char*)logits + (((size_t)b * HW + p) * pitch + j * D + vi * VEC) * Elem<T>::SZ), f);
+      float mx = f[0];
+#pragma unroll
+      for (int i = 1; i < VEC; ++i) mx = fmaxf(mx, f[i]);
+      if (mx > st.m) {
+        float sc = __expf(st.m - mx);  // exp(-inf) = 0 on the first element
+        st.s *= sc; st.sx *= sc; st.sy *= sc; st.sz *= sc;
+        st.m = mx;
+      }
+      float es = 0.f, ez = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float e = __expf(f[i] - st.m);
+        es += e;
+        ez += e * (float)(vi * VEC + i);
+      }
+      st.s += es; st.sx += es * (float)x; st.sy += es * (float)y; st.sz += ez;
+    }
+  }
+  // wave reduce then block reduce
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    SmState ot;
+    ot.m = __shfl_xor(st.m, o, 64); ot.s = __shfl_xor(st.s, o, 64);
+    ot.sx = __shfl_xor(st.sx, o, 64); ot.sy = __shfl_xor(st.sy, o, 64); ot.sz = __shfl_xor(st.sz, o, 64);
+    if (ot.m > -INFINITY || st.m > -INFINITY) {
+      if (st.m == -INFINITY) st = ot;
+      else if (ot.m > -INFINITY) sm_merge(st, ot);
+    }
+  }
+  __shared__ SmState part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = st;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    SmState a = part[0];
+    for (int w = 1; w < 4; ++w) {
+      if (part[w].m == -INFINITY) continue;
+      if (a.m == -INFINITY) a = part[w];
+      else sm_merge(a, part[w]);
+    }
+    float inv = 1.f / a.s;
+    float* o = uvd + ((size_t)b * J + j) * 3;
+    o[0] = a.sx * inv / (float)W - 0.5f;
+    o[1] = a.sy * inv / (float)H - 0.5f;
+    o[2] = (fix_root && j == root) ? 0.f : a.sz * inv / (float)D - 0.5f;
+    ms[((size_t)b * J + j) * 2 + 0] = a.m;
+    ms[((size_t)b * J + j) * 2 + 1] = a.s;
+    // expected depth bin kept for the backward of the non-root joints only; root (fix_root) has no d-gradient
+  }
+}
+
+// d logit = p * ( gu (x - E[x]) / W + gv (y - E[y]) / H + gd (d - E[d]) / D )
+template <typename T>
+__global__ __launch_bounds__(256) void softargmax_bwd_kernel(const void* __restrict__ logits, int J, int D, int H, int W, int pitch,
+                                                             int root, int fix_root, const float* __restrict__ uvd,
+                                                             const float* __restrict__ ms, const float* __restrict__ duvd,
+                                                             void* __restrict__ dlogits, int dpitch) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int b = blockIdx.y;
+  const int C = J * D, nv = C / VEC;
+  const long total = (long)H * W * nv;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+    const int cv = v % nv;
+    const int p = v / nv;
+    const int y = p / W, x = p - y * W;
+    const int c = cv * VEC, j = c / D, d0 = c - j * D;
+    const float* g = duvd + ((size_t)b * J + j) * 3;
+    const float* o = uvd + ((size_t)b * J + j) * 3;
+    const float m = ms[((size_t)b * J + j) * 2], inv = 1.f / ms[((size_t)b * J + j) * 2 + 1];
+    const bool nod = fix_root && j == root;
+    const float gu = g[0] / (float)W, gv = g[1] / (float)H, gd = nod ? 0.f : g[2] / (float)D;
+    const float ex = (o[0] + 0.5f) * (float)W, ey = (o[1] + 0.5f) * (float)H, ed = (o[2] + 0.5f) * (float)D;
+    const float base = gu * ((float)x - ex) + gv * ((float)y - ey);
+    float f[VEC], r[VEC];
+    Elem<T>::unpack(*(const uint4*)((const char*)logits + (((size_t)b * H * W + p) * pitch + c) * Elem<T>::SZ), f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = __expf(f[i] - m) * inv * (base + gd * ((float)(d0 + i) - ed));
+    *(uint4*)((char*)dlogits + (((size_t)b * H * W + p) * dpitch + c) * Elem<T>::SZ) = Elem<T>::pack(r);
+  }
+}
+
+// =================================================================================================
+// Camera geometry of the heads (reference full_net.py:281-305, transforms.py:33-73, 133-162).
+// One thread per sample.
+// =================================================================================================
+struct InvK {
+  float a, b, c, d;  // [[a 0 b],[0 c d],[0 0 1]]
+};
+__device__ __forceinline__ InvK inv_intrinsics(const float* K) {
+  // fp64 divide stored to fp32, as transforms.py:150-154
+  double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  InvK r;
+  r.a = (float)(1.0 / fx); r.b = (float)(-cx / fx);
+  r.c = (float)(1.0 / fy); r.d = (float)(-cy / fy);
+  return r;
+}
+
+__global__ void pose_geometry_fwd_kernel(const float* __restrict__ gamma, const float* __restrict__ kval, const float* __restrict__ uvd,
+                                         const float* __restrict__ K, int B, int J, int root, float S, float DF,
+                                         float* __restrict__ depth, float* __restrict__ xyz, float* __restrict__ root_uv,
+                                         float* __restrict__ trans) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  InvK ik = inv_intrinsics(K + 9 * b);
+  float z = gamma[b] * kval[b] / 1000.0f;
+  depth[b] = z;
+  for (int j = 0; j < J; ++j) {
+    const float* o = uvd + ((size_t)b * J + j) * 3;
+    float U = (o[0] + 0.5f) * S, V = (o[1] + 0.5f) * S;
+    float za = o[2] * DF + z;
+    float* x = xyz + ((size_t)b * J + j) * 3;
+    x[0] = (ik.a * U + ik.b) * za;
+    x[1] = (ik.c * V + ik.d) * za;
+    x[2] = za;
+  }
+  const float* o = uvd + ((size_t)b * J + root) * 3;
+  float ru = (o[0] + 0.5f) * S, rv = (o[1] + 0.5f) * S;
+  root_uv[2 * b] = ru; root_uv[2 * b + 1] = rv;
+  trans[3 * b] = ik.a * (ru * z) + ik.b * z;
+  trans[3 * b + 1] = ik.c * (rv * z) + ik.d * z;
+  trans[3 * b + 2] = z;
+}
+
+__global__ void pose_geometry_bwd_kernel(const float* __restrict__ gamma, const float* __restrict__ kval, const float* __restrict__ uvd,
+                                         const float* __restrict__ K, int B, int J, int root, int fix_root, float S, float DF,
+                                         const float* __restrict__ d_depth, const float* __restrict__ d_xyz,
+                                         const float* __restrict__ d_root_uv, const float* __restrict__ d_trans,
+                                         float* __restrict__ d_gamma, float* __restrict__ d_uvd) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  InvK ik = inv_intrinsics(K + 9 * b);
+  float z = gamma[b] * kval[b] / 1000.0f;
+  float dz = d_depth ? d_depth[b] : 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float* o = uvd + ((size_t)b * J + j) * 3;
+    float U = (o[0] + 0.5f) * S, V = (o[1] + 0.5f) * S;
+    float za = o[2] * DF + z;
+    float r0 = ik.a * U + ik.b, r1 = ik.c * V + ik.d;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (d_xyz) { const float* g = d_xyz + ((size_t)b * J + j) * 3; g0 = g[0]; g1 = g[1]; g2 = g[2]; }
+    float dza = g0 * r0 + g1 * r1 + g2;
+    float* du = d_uvd + ((size_t)b * J + j) * 3;
+    du[0] = g0 * za * ik.a * S;
+    du[1] = g1 * za * ik.c * S;
+    du[2] = (fix_root && j == root) ? 0.f : dza * DF;
+    dz += dza;
+  }
+  const float* o = uvd + ((size_t)b * J + root) * 3;
+  float ru = (o[0] + 0.5f) * S, rv = (o[1] + 0.5f) * S;
+  float t0 = d_trans ? d_trans[3 * b] : 0.f, t1 = d_trans ? d_trans[3 * b + 1] : 0.f, t2 = d_trans ? d_trans[3 * b + 2] : 0.f;
+  float dru = t0 * ik.a * z + (d_root_uv ? d_root_uv[2 * b] : 0.f);
+  float drv = t1 * ik.c * z + (d_root_uv ? d_root_uv[2 * b + 1] : 0.f);
+  dz += t0 * (ik.a * ru + ik.b) + t1 * (ik.c * rv + ik.d) + t2;
+  float* du = d_uvd + ((size_t)b * J + root) * 3;
+  du[0] += dru * S;
+  du[1] += drv * S;
+  d_gamma[b] = dz * kval[b] / 1000.0f;
+}
+
+// =================================================================================================
+// Forward kinematics + projection, one wavefront per sample.
+//   forward : lane k computes keypoint k (walks its own base->link chain)
+//   backward: lane l carries the tangent of input parameter l (q_0..q_dof-1, rot6d_0..5, t_0..2)
+//             through the SAME templated code with dual numbers (forward-mode AD, exact), then dots
+//             its tangent outputs with the incoming gradients: one lane = one gradient entry.
+// Arithmetic follows lib/utils/urdfpytorch/urdf.py:2380-2390, 2427-2462, 3115-3140 (T = T_parent * origin *
+// Rot(axis, q), fp32), geometries.py:100-115 (rot6d), urdf_robot.py:169-199 (re-rooting; closed-form rigid
+// inverse instead of torch.linalg.inv) and transforms.py:7-21.
+// =================================================================================================
+struct Dual {
+  float v, d;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { float q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
+__device__ __forceinline__ Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ Dual operator-(float a, Dual b) { return {a - b.v, -b.d}; }
+__device__ __forceinline__ Dual dsqrt(Dual a) { float s = sqrtf(a.v); return {s, a.d / (2.f * s)}; }
+__device__ __forceinline__ float dsqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ Dual dsin(Dual a) { return {sinf(a.v), cosf(a.v) * a.d}; }
+__device__ __forceinline__ Dual dcos(Dual a) { return {cosf(a.v), -sinf(a.v) * a.d}; }
+__device__ __forceinline__ float dsin(float a) { return sinf(a); }
+__device__ __forceinline__ float dcos(float a) { return cosf(a); }
+template <class S> __device__ __forceinline__ S lift(float v);
+template <> __device__ __forceinline__ float lift<float>(float v) { return v; }
+template <> __device__ __forceinline__ Dual lift<Dual>(float v) { return {v, 0.f}; }
+
+template <class S>
+struct Rigid {  // 3x4 [R | t]
+  S r[3][3], t[3];
+};
+
+template <class S>
+__device__ __forceinline__ Rigid<S> rigid_identity() {
+  Rigid<S> T;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T.r[i][j] = lift<S>(i == j ? 1.f : 0.f);
+    T.t[i] = lift<S>(0.f);
+  }
+  return T;
+}
+
+template <class S>
+__device__ __forceinline__ Rigid<S> rigid_mul(const Rigid<S>& A, const Rigid<S>& B) {
+  Rigid<S> C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.r[i][j] = A.r[i][0] * B.r[0][j] + A.r[i][1] * B.r[1][j] + A.r[i][2] * B.r[2][j];
+    C.t[i] = A.r[i][0] * B.t[0] + A.r[i][1] * B.t[1] + A.r[i][2] * B.t[2] + A.t[i];
+  }
+  return C;
+}
+
+template <class S>
+__device__ __forceinline__ Rigid<S> rigid_inverse(const Rigid<S>& A) {
+  Rigid<S> C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.r[i][j] = A.r[j][i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) C.t[i] = lift<S>(0.f) - (C.r[i][0] * A.t[0] + C.r[i][1] * A.t[1] + C.r[i][2] * A.t[2]);
+  return C;
+}
+
+// child pose of joint j relative to its parent: origin * motion(q)
+template <class S>
+__device__ __forceinline__ Rigid<S> joint_pose(const hrp_fk_chain* ch, int j, const S* q) {
+  Rigid<S> O;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) O.r[i][k] = lift<S>(ch->origin[j][i * 4 + k]);
+    O.t[i] = lift<S>(ch->origin[j][i * 4 + 3]);
+  }
+  const int type = ch->type[j], cfg = ch->cfg[j];
+  if (type == 0 || cfg < 0) return O;
+  S qv = ch->mimic_mul[j] * q[cfg] + ch->mimic_off[j];
+  const float ax = ch->axis[j][0], ay = ch->axis[j][1], az = ch->axis[j][2];
+  Rigid<S> M = rigid_identity<S>();
+  if (type == 1) {
+    S s = dsin(qv), c = dcos(qv);
+    S omc = 1.f - c;
+    const float a[3] = {ax, ay, az};
+    const float sk[3][3] = {{0.f, -az, ay}, {az, 0.f, -ax}, {-ay, ax, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        S v = omc * (a[i] * a[k]) + s * sk[i][k];
+        if (i == k) v = c + v;
+        M.r[i][k] = v;
+      }
+  } else {
+    M.t[0] = qv * ax; M.t[1] = qv * ay; M.t[2] = qv * az;
+  }
+  return rigid_mul(O, M);
+}
+
+// pose of the child frame of joint `leaf` in the base frame (leaf = -1: identity)
+template <class S>
+__device__ __forceinline__ Rigid<S> frame_pose(const hrp_fk_chain* ch, int leaf, const S* q) {
+  Rigid<S> T = rigid_identity<S>();
+  unsigned mask = 0;
+  for (int j = leaf; j >= 0; j = ch->parent[j]) mask |= 1u << j;
+  for (int j = 0; j < ch->njoints; ++j)
+    if (mask & (1u << j)) T = rigid_mul(T, joint_pose<S>(ch, j, q));
+  return T;
+}
+
+template <class S>
+__device__ __forceinline__ Rigid<S> base_to_cam(const S* r6, const S* tr) {
+  // geometries.py:100-115
+  S ax = r6[0], ay = r6[1], az = r6[2], bx = r6[3], by = r6[4], bz = r6[5];
+  S n = dsqrt(ax * ax + ay * ay + az * az);
+  S x0 = ax / n, x1 = ay / n, x2 = az / n;
+  S z0 = x1 * bz - x2 * by, z1 = x2 * bx - x0 * bz, z2 = x0 * by - x1 * bx;
+  S zn = dsqrt(z0 * z0 + z1 * z1 + z2 * z2);
+  z0 = z0 / zn; z1 = z1 / zn; z2 = z2 / zn;
+  S y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+  Rigid<S> T;
+  T.r[0][0] = x0; T.r[0][1] = x1; T.r[0][2] = x2;
+  T.r[1][0] = y0; T.r[1][1] = y1; T.r[1][2] = y2;
+  T.r[2][0] = z0; T.r[2][1] = z1; T.r[2][2] = z2;
+  T.t[0] = tr[0]; T.t[1] = tr[1]; T.t[2] = tr[2];
+  return T;
+}
+
+// M = B2C (root == 0) or B2C * T_root^-1
+template <class S>
+__device__ __forceinline__ Rigid<S> camera_from_base(const hrp_fk_chain* ch, const S* q, const S* r6, const S* tr, int root) {
+  Rigid<S> M = base_to_cam<S>(r6, tr);
+  if (root > 0) M = rigid_mul(M, rigid_inverse(frame_pose<S>(ch, ch->kp_frame[root], q)));
+  return M;
+}
+
+template <class S>
+__device__ __forceinline__ void keypoint(const hrp_fk_chain* ch, const Rigid<S>& M, const S* q, int k, S* p) {
+  Rigid<S> P = rigid_mul(M, frame_pose<S>(ch, ch->kp_frame[k], q));
+  const float ox = ch->kp_offset[k][0], oy = ch->kp_offset[k][1], oz = ch->kp_offset[k][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = P.r[i][0] * ox + P.r[i][1] * oy + P.r[i][2] * oz + P.t[i];
+}
+
+template <class S>
+__device__ __forceinline__ void project(const float* K, const S* p, S* uv) {
+  S h0 = K[0] * p[0] + K[1] * p[1] + K[2] * p[2];
+  S h1 = K[3] * p[0] + K[4] * p[1] + K[5] * p[2];
+  S h2 = K[6] * p[0] + K[7] * p[1] + K[8] * p[2];
+  uv[0] = h0 / h2; uv[1] = h1 / h2;
+}
+
+__global__ __launch_bounds__(64) void fk_project_fwd_kernel(const hrp_fk_chain* __restrict__ ch, const float* __restrict__ q,
+                                                            const float* __restrict__ r6, const float* __restrict__ tr,
+                                                            const float* __restrict__ K, int root, float* __restrict__ xyz,
+                                                            float* __restrict__ uv, float* __restrict__ root_rot) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int dof = ch->dof, nkp = ch->nkp;
+  float ql[HRP_FK_MAX_JOINTS];
+  for (int i = 0; i < dof; ++i) ql[i] = q[(size_t)b * dof + i];
+  float rl[6], tl[3];
+  for (int i = 0; i < 6; ++i) rl[i] = r6[6 * b + i];
+  for (int i = 0; i < 3; ++i) tl[i] = tr[3 * b + i];
+  if (lane < nkp) {
+    Rigid<float> M = camera_from_base<float>(ch, ql, rl, tl, root);
+    float p[3];
+    keypoint<float>(ch, M, ql, lane, p);
+    float* o = xyz + ((size_t)b * nkp + lane) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    if (K && uv) {
+      float w[2];
+      project<float>(K + 9 * b, p, w);
+      uv[((size_t)b * nkp + lane) * 2] = w[0];
+      uv[((size_t)b * nkp + lane) * 2 + 1] = w[1];
+    }
+  }
+  if (root_rot && lane == 63) {
+    // urdf_robot.py:113-138: first two rows of (B2C * T_root).R
+    Rigid<float> P = base_to_cam<float>(rl, tl);
+    if (root > 0) P = rigid_mul(P, frame_pose<float>(ch, ch->kp_frame[root], ql));
+    for (int i = 0; i < 2; ++i)
+      for (int k = 0; k < 3; ++k) root_rot[6 * b + i * 3 + k] = P.r[i][k];
+  }
+}
+
+__global__ __launch_bounds__(64) void fk_project_bwd_kernel(const hrp_fk_chain* __restrict__ ch, const float* __restrict__ q,
+                                                            const float* __restrict__ r6, const float* __restrict__ tr,
+                                                            const float* __restrict__ K, int root, const float* __restrict__ d_xyz,
+                                                            const float* __restrict__ d_uv, float* __restrict__ d_q,
+                                                            float* __restrict__ d_r6, float* __restrict__ d_tr) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int dof = ch->dof, nkp = ch->nkp;
+  const int npar = dof + 9;
+  if (lane >= npar) return;
+  Dual ql[HRP_FK_MAX_JOINTS], rl[6], tl[3];
+  for (int i = 0; i < dof; ++i) ql[i] = {q[(size_t)b * dof + i], lane == i ? 1.f : 0.f};
+  for (int i = 0; i < 6; ++i) rl[i] = {r6[6 * b + i], lane == dof + i ? 1.f : 0.f};
+  for (int i = 0; i < 3; ++i) tl[i] = {tr[3 * b + i], lane == dof + 6 + i ? 1.f : 0.f};
+  Rigid<Dual> M = camera_from_base<Dual>(ch, ql, rl, tl, root);
+  float g = 0.f;
+  for (int k = 0; k < nkp; ++k) {
+    Dual p[3];
+    keypoint<Dual>(ch, M, ql, k, p);
+    if (d_xyz) {
+      const float* gx = d_xyz + ((size_t)b * nkp + k) * 3;
+      g += gx[0] * p[0].d + gx[1] * p[1].d + gx[2] * p[2].d;
+    }
+    if (d_uv && K) {
+      Dual w[2];
+      project<Dual>(K + 9 * b, p, w);
+      const float* gu = d_uv + ((size_t)b * nkp + k) * 2;
+      g += gu[0] * w[0].d + gu[1] * w[1].d;
+    }
+  }
+  if (lane < dof) d_q[(size_t)b * dof + lane] = g;
+  else if (lane < dof + 6) d_r6[6 * b + lane - dof] = g;
+  else d_tr[3 * b + lane - dof - 6] = g;
+}
+
+// standalone pinhole projection (transforms.py:17-21): one thread per point
+__global__ void project_fwd_kernel(const float* __restrict__ K, const float* __restrict__ pts, int B, int P, float* __restrict__ uv) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * P) return;
+  float w[2];
+  project<float>(K + 9 * (i / P), pts + 3 * (size_t)i, w);
+  uv[2 * (size_t)i] = w[0]; uv[2 * (size_t)i + 1] = w[1];
+}
+__global__ void project_bwd_kernel(const float* __restrict__ K, const float* __restrict__ pts, const float* __restrict__ duv, int B, int P,
+                                   float* __restrict__ dpts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * P) return;
+  const float* p = pts + 3 * (size_t)i;
+  for (int c = 0; c < 3; ++c) {
+    Dual d[3] = {{p[0], c == 0 ? 1.f : 0.f}, {p[1], c == 1 ? 1.f : 0.f}, {p[2], c == 2 ? 1.f : 0.f}};
+    Dual w[2];
+    project<Dual>(K + 9 * (i / P), d, w);
+    dpts[3 * (size_t)i + c] = duv[2 * (size_t)i] * w[0].d + duv[2 * (size_t)i + 1] * w[1].d;
+  }
+}
+
+}  // namespace hrp
+
+using namespace hrp;
+
+extern "C" int hrp_project_fwd(const float* K, const float* pts, int B, int P, float* uv, void* stream) {
+  HRP_REQUIRE(K && pts && uv && B > 0 && P > 0, "project_fwd: bad args");
+  hipLaunchKernelGGL(project_fwd_kernel, dim3(cdiv(B * P, 64)), dim3(64), 0, (hipStream_t)stream, K, pts, B, P, uv);
+  return check_launch("project_fwd");
+}
+extern "C" int hrp_project_bwd(const float* K, const float* pts, const float* duv, int B, int P, float* dpts, void* stream) {
+  HRP_REQUIRE(K && pts && duv && dpts && B > 0 && P > 0, "project_bwd: bad args");
+  hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(B * P, 64)), dim3(64), 0, (hipStream_t)stream, K, pts, duv, B, P, dpts);
+  return check_launch("project_bwd");
+}
+
+extern "C" int hrp_softargmax3d_fwd(const void* logits, int dtype, int B, int J, int D, int H, int W, int pitch,
+                                    int root, int fix_root, float* uvd, float* ms, void* stream) {
+  HRP_REQUIRE(logits && uvd && ms && B > 0 && J > 0, "softargmax_fwd: bad args");
+  const int vec = dtype == HRP_F32 ? 4 : 8;
+  HRP_REQUIRE(D % vec == 0 && D / vec <= 256 && 256 % (D / vec) == 0, "softargmax: D=%d unsupported", D);
+  HRP_REQUIRE(pitch % vec == 0 && (uintptr_t)logits % 16 == 0, "softargmax: alignment");
+  dim3 grid(J, B);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(softargmax_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logits, J, D, H, W, pitch, root, fix_root, uvd, ms);
+  else hipLaunchKernelGGL(softargmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logits, J, D, H, W, pitch, root, fix_root, uvd, ms);
+  return check_launch("softargmax_fwd");
+}
+
+extern "C" int hrp_softargmax3d_bwd(const void* logits, int dtype, int B, int J, int D, int H, int W, int pitch,
+                                    int root, int fix_root, const float* uvd, const float* ms, const float* duvd,
+                                    void* dlogits, int dpitch, void* stream) {
+  HRP_REQUIRE(logits && uvd && ms && duvd && dlogits, "softargmax_bwd: bad args");
+  const int vec = dtype == HRP_F32 ? 4 : 8;
+  HRP_REQUIRE(D % vec == 0 && pitch % vec == 0 && dpitch % vec == 0, "softargmax_bwd: alignment");
+  long total = (long)H * W * (J * D / vec);
+  int gx = (int)((total + 255) / 256);
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, B);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(softargmax_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logits, J, D, H, W, pitch, root, fix_root, uvd, ms, duvd, dlogits, dpitch);
+  else hipLaunchKernelGGL(softargmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logits, J, D, H, W, pitch, root, fix_root, uvd, ms, duvd, dlogits, dpitch);
+  return check_launch("softargmax_bwd");
+}
+
+extern "C" int hrp_pose_geometry_fwd(const float* gamma, const float* k_value, const float* uvd, const float* K,
+                                     int B, int J, int root, float image_size, float depth_factor,
+                                     float* depth, float* xyz, float* root_uv, float* trans, void* stream) {
+  HRP_REQUIRE(gamma && k_value && uvd && K && depth && xyz && root_uv && trans && B > 0, "pose_geometry_fwd: bad args");
+  hipLaunchKernelGGL(pose_geometry_fwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, gamma, k_value, uvd, K, B, J, root,
+                     image_size, depth_factor, depth, xyz, root_uv, trans);
+  return check_launch("pose_geometry_fwd");
+}
+
+extern "C" int hrp_pose_geometry_bwd(const float* gamma, const float* k_value, const float* uvd, const float* K,
+                                     int B, int J, int root, float image_size, float depth_factor,
+                                     const float* d_depth, const float* d_xyz, const float* d_root_uv, const float* d_trans,
+                                     float* d_gamma, float* d_uvd, void* stream) {
+  HRP_REQUIRE(gamma && k_value && uvd && K && d_gamma && d_uvd && B > 0, "pose_geometry_bwd: bad args");
+  hipLaunchKernelGGL(pose_geometry_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, gamma, k_value, uvd, K, B, J, root, 0,
+                     image_size, depth_factor, d_depth, d_xyz, d_root_uv, d_trans, d_gamma, d_uvd);
+  return check_launch("pose_geometry_bwd");
+}
+
+extern "C" int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
+                                  const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream) {
+  HRP_REQUIRE(chain_dev && q && rot6d && trans && xyz && B > 0, "fk_project_fwd: bad args");
+  hipLaunchKernelGGL(fk_project_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, K, root, xyz, uv, root_rot6d);
+  return check_launch("fk_project_fwd");
+}
+
+extern "C" int hrp_fk_project_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
+                                  const float* K, int B, int root, const float* d_xyz, const float* d_uv,
+                                  float* d_q, float* d_rot6d, float* d_trans, void* stream) {
+  HRP_REQUIRE(chain_dev && q && rot6d && trans && d_q && d_rot6d && d_trans && B > 0, "fk_project_bwd: bad args");
+  hipLaunchKernelGGL(fk_project_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, K, root, d_xyz, d_uv, d_q, d_rot6d, d_trans);
+  return check_launch("fk_project_bwd");
+}

@@ -1,0 +1,89 @@
+// Shared device/host helpers for libhrp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/hrp.h"
+
+namespace hrp {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define HRP_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      hrp::set_error(__VA_ARGS__);    \
+      return HRP_ERR_ARG;             \
+    }                                 \
+  } while (0)
+
+// ---- element types ---------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int SZ = 4;
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
+  __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+  __device__ static __forceinline__ void unpack(const uint4& r, float* f) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y);
+    f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int SZ = 2;
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const void* p, size_t i) { return bf2f(((const uint16_t*)p)[i]); }
+  __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
+  __device__ static __forceinline__ void unpack(const uint4& r, float* f) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    return r;
+  }
+};
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+}  // namespace hrp

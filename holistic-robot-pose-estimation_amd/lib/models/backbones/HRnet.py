@@ -1,0 +1,399 @@
+"""HRNet backbone on the hrpe_amd plan runtime (drop-in for reference lib/models/backbones/HRnet.py).
+
+Same public names, constructor arguments, return values and state-dict keys as the reference:
+``BasicBlock`` (HRnet.py:28-57), ``Bottleneck`` (:60-98), ``HighResolutionModule`` (:101-265),
+``PoseHighResolutionNet`` (:274-603), ``load_hrnet_cfg`` (:606-610), ``get_hrnet`` (:613-623).
+Nothing here computes with torch ops: every module describes itself to a PlanBuilder (``emit``) and the
+plan executes hand-written HIP kernels (conv on MFMA, one-pass BN/add/upsample/ReLU fusion).
+"""
+import logging
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from hrpe_amd.plan import Term
+from hrpe_amd.runtime import PlannedModule, SingleTensorModule
+from .configs import HRNET_CONFIGS, AttrDict
+
+BN_MOMENTUM = 0.1  # reference HRnet.py:18
+logger = logging.getLogger(__name__)
+
+
+# ---- parameter containers ----------------------------------------------------------------------------
+class Conv2d(SingleTensorModule):
+    """Holds [Cout, Cin, k, k] weight (+bias); k in {1, 3}, padding k//2, stride in {1, 2}."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True):
+        super().__init__()
+        assert kernel_size in (1, 3) and stride in (1, 2)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        bound = 1.0 / math.sqrt(in_channels * kernel_size * kernel_size)
+        nn.init.uniform_(self.weight, -bound, bound)
+        if bias:
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def emit(self, pb, x, want_stats=False):
+        return pb.conv(x, self.weight, self.bias, stride=self.stride, want_stats=want_stats)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}"
+
+
+class BatchNorm2d(PlannedModule):
+    def __init__(self, num_features, momentum=0.1, eps=1e-5):
+        super().__init__()
+        self.num_features, self.momentum, self.eps = num_features, momentum, eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):
+        raise NotImplementedError("BatchNorm2d is always fused with its producing conv in a plan")
+
+
+def conv_bn(pb, x, conv, bn):
+    """conv output (raw) as a BN term; the conv epilogue gathers batch statistics in train mode."""
+    return Term(conv.emit(pb, x, want_stats=pb.plan.training), bn)
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return Conv2d(in_planes, out_planes, 3, stride=stride, bias=False)
+
+
+class _Downsample(nn.Sequential):
+    """conv1x1 + BN on the residual path (keys ``downsample.0`` / ``downsample.1``)."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__(Conv2d(cin, cout, 1, stride=stride, bias=False), BatchNorm2d(cout, momentum=BN_MOMENTUM))
+
+
+class BasicBlock(SingleTensorModule):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.downsample = downsample
+        self.stride = stride
+
+    def emit(self, pb, x):
+        h = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
+        skip = Term(x) if self.downsample is None else conv_bn(pb, x, self.downsample[0], self.downsample[1])
+        return pb.act([conv_bn(pb, h, self.conv2, self.bn2), skip], relu=True)
+
+
+class Bottleneck(SingleTensorModule):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv2 = Conv2d(planes, planes, 3, stride=stride, bias=False)
+        self.bn2 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv3 = Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = BatchNorm2d(planes * self.expansion, momentum=BN_MOMENTUM)
+        self.downsample = downsample
+        self.stride = stride
+
+    def emit(self, pb, x):
+        h = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
+        h = pb.act([conv_bn(pb, h, self.conv2, self.bn2)], relu=True)
+        skip = Term(x) if self.downsample is None else conv_bn(pb, x, self.downsample[0], self.downsample[1])
+        return pb.act([conv_bn(pb, h, self.conv3, self.bn3), skip], relu=True)
+
+
+blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
+
+
+def _block_stack(block, inplanes, planes, count, stride=1):
+    """`count` blocks; the first gets a 1x1 projection when shape changes (HRnet.py:139-175, 431-465)."""
+    ds = None
+    if stride != 1 or inplanes != planes * block.expansion:
+        ds = _Downsample(inplanes, planes * block.expansion, stride)
+    mods = [block(inplanes, planes, stride, ds)]
+    mods += [block(planes * block.expansion, planes) for _ in range(1, count)]
+    return nn.Sequential(*mods)
+
+
+def _emit_seq(pb, seq, x):
+    for m in seq:
+        x = m.emit(pb, x)
+    return x
+
+
+class HighResolutionModule(PlannedModule):
+    """Parallel branches + all-to-all cross-resolution fuse (reference HRnet.py:101-265)."""
+
+    def __init__(self, num_branches, blocks, num_blocks, num_inchannels, num_channels, fuse_method,
+                 multi_scale_output=True):
+        super().__init__()
+        for name, lst in (("NUM_BLOCKS", num_blocks), ("NUM_CHANNELS", num_channels),
+                          ("NUM_INCHANNELS", num_inchannels)):
+            if num_branches != len(lst):
+                msg = "NUM_BRANCHES({}) <> {}({})".format(num_branches, name, len(lst))
+                logger.error(msg)
+                raise ValueError(msg)
+        self.num_inchannels = num_inchannels
+        self.fuse_method = fuse_method
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        branches = []
+        for b in range(num_branches):
+            branches.append(_block_stack(blocks, num_inchannels[b], num_channels[b], num_blocks[b]))
+            self.num_inchannels[b] = num_channels[b] * blocks.expansion
+        self.branches = nn.ModuleList(branches)
+        self.fuse_layers = self._make_fuse_layers()
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        ch = self.num_inchannels
+        rows = []
+        for i in range(self.num_branches if self.multi_scale_output else 1):
+            row = []
+            for j in range(self.num_branches):
+                if j > i:      # lower resolution -> 1x1 conv + BN, upsampled in the fuse kernel
+                    row.append(nn.Sequential(Conv2d(ch[j], ch[i], 1, bias=False), BatchNorm2d(ch[i])))
+                elif j == i:
+                    row.append(None)
+                else:          # higher resolution -> (i-j) stride-2 3x3 convs
+                    steps = []
+                    for k in range(i - j):
+                        cout = ch[i] if k == i - j - 1 else ch[j]
+                        steps.append(nn.Sequential(Conv2d(ch[j], cout, 3, stride=2, bias=False), BatchNorm2d(cout)))
+                    row.append(nn.Sequential(*steps))
+            rows.append(nn.ModuleList(row))
+        return nn.ModuleList(rows)
+
+    def get_num_inchannels(self):
+        return self.num_inchannels
+
+    def emit(self, pb, xs):
+        xs = [_emit_seq(pb, self.branches[b], xs[b]) for b in range(self.num_branches)]
+        if self.num_branches == 1:
+            return xs
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            terms = []
+            for j in range(self.num_branches):
+                if j == i:
+                    terms.append(Term(xs[j]))
+                elif j > i:
+                    t = conv_bn(pb, xs[j], row[j][0], row[j][1])
+                    t.up = 2 ** (j - i)
+                    terms.append(t)
+                else:
+                    h = xs[j]
+                    steps = list(row[j])
+                    for st in steps[:-1]:
+                        h = pb.act([conv_bn(pb, h, st[0], st[1])], relu=True)
+                    terms.append(conv_bn(pb, h, steps[-1][0], steps[-1][1]))
+            outs.append(pb.act(terms, relu=True))
+        return outs
+
+    def forward(self, x):
+        outs = self._run(*x)
+        return list(outs)
+
+    def _build(self, pb, *xs):
+        names, hs, imgs = [], [], {}
+        for i, x in enumerate(xs):
+            N, Cc, H, W = x.shape
+            t = pb.image_input(f"x{i}", N, Cc, H, W)
+            t.requires_grad = pb.plan.need_grad and x.requires_grad
+            names.append(f"x{i}")
+            hs.append(t)
+            imgs[f"x{i}"] = t
+        ys = self.emit(pb, hs)
+        outs = []
+        for y in ys:
+            holder = pb.nchw_output(y)
+            holder["handle"] = y
+            outs.append(("nchw", holder, None))
+        return names, outs, imgs
+
+
+class PoseHighResolutionNet(PlannedModule):
+    """HRNet trunk with optional heat-map conv and 2048-d classification-head feature
+    (reference HRnet.py:274-570)."""
+
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        extra = cfg["MODEL"]["EXTRA"]
+        self.generate_feat = kwargs["generate_feat"]
+        self.generate_hm = kwargs.get("generate_hm", True)
+        self.conv1 = Conv2d(3, 64, 3, stride=2, bias=False)
+        self.bn1 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.conv2 = Conv2d(64, 64, 3, stride=2, bias=False)
+        self.bn2 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.layer1 = _block_stack(Bottleneck, 64, 64, 4)
+        pre = [256]
+        for idx, name in enumerate(("STAGE2", "STAGE3", "STAGE4")):
+            scfg = extra[name]
+            setattr(self, name.lower() + "_cfg", scfg)
+            block = blocks_dict[scfg["BLOCK"]]
+            chans = [c * block.expansion for c in scfg["NUM_CHANNELS"]]
+            setattr(self, f"transition{idx + 1}", self._make_transition_layer(pre, chans))
+            mso = True if name != "STAGE4" else self.generate_feat
+            stage, pre = self._make_stage(scfg, chans, multi_scale_output=mso)
+            setattr(self, name.lower(), stage)
+        if self.generate_feat:
+            self.incre_modules, self.downsamp_modules, self.final_feat_layer = self._make_cls_head(pre)
+        if self.generate_hm:
+            k = extra["FINAL_CONV_KERNEL"]
+            self.final_layer = Conv2d(pre[0], cfg["MODEL"]["NUM_JOINTS"] * cfg["MODEL"]["DEPTH_DIM"], k, bias=True)
+        self.pretrained_layers = extra["PRETRAINED_LAYERS"]
+
+    # -- construction helpers (key layout of HRnet.py:341-429) -----------------------------------------
+    def _make_cls_head(self, pre_stage_channels):
+        head_channels = [32, 64, 128, 256]
+        incre = nn.ModuleList([_block_stack(Bottleneck, c, head_channels[i], 1)
+                               for i, c in enumerate(pre_stage_channels)])
+        down = []
+        for i in range(len(pre_stage_channels) - 1):
+            cin, cout = head_channels[i] * 4, head_channels[i + 1] * 4
+            down.append(nn.Sequential(Conv2d(cin, cout, 3, stride=2, bias=True),
+                                      BatchNorm2d(cout, momentum=BN_MOMENTUM)))
+        final = nn.Sequential(Conv2d(head_channels[3] * 4, 2048, 1, bias=True),
+                              BatchNorm2d(2048, momentum=BN_MOMENTUM))
+        return incre, nn.ModuleList(down), final
+
+    def _make_transition_layer(self, pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    layers.append(nn.Sequential(Conv2d(pre[i], cur[i], 3, bias=False), BatchNorm2d(cur[i])))
+                else:
+                    layers.append(None)
+            else:
+                steps = []
+                for j in range(i + 1 - len(pre)):
+                    cout = cur[i] if j == i - len(pre) else pre[-1]
+                    steps.append(nn.Sequential(Conv2d(pre[-1], cout, 3, stride=2, bias=False), BatchNorm2d(cout)))
+                layers.append(nn.Sequential(*steps))
+        return nn.ModuleList(layers)
+
+    def _make_stage(self, layer_config, num_inchannels, multi_scale_output=True):
+        block = blocks_dict[layer_config["BLOCK"]]
+        n = layer_config["NUM_MODULES"]
+        mods = []
+        for i in range(n):
+            mso = multi_scale_output or i != n - 1
+            mods.append(HighResolutionModule(layer_config["NUM_BRANCHES"], block, layer_config["NUM_BLOCKS"],
+                                             num_inchannels, layer_config["NUM_CHANNELS"],
+                                             layer_config["FUSE_METHOD"], mso))
+            num_inchannels = mods[-1].get_num_inchannels()
+        return nn.Sequential(*mods), num_inchannels
+
+    # -- plan description ---------------------------------------------------------------------------------
+    def emit_trunk(self, pb, x):
+        x = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
+        x = pb.act([conv_bn(pb, x, self.conv2, self.bn2)], relu=True)
+        x = _emit_seq(pb, self.layer1, x)
+        def transition(tr, src):
+            steps = [tr] if isinstance(tr[0], Conv2d) else list(tr)
+            for st in steps:
+                src = pb.act([conv_bn(pb, src, st[0], st[1])], relu=True)
+            return src
+
+        ys = [x if tr is None else transition(tr, x) for tr in self.transition1]
+        for stage, trans in ((self.stage2, self.transition2), (self.stage3, self.transition3), (self.stage4, None)):
+            for m in stage:
+                ys = m.emit(pb, ys)
+            if trans is not None:
+                # a new branch always starts from the LAST (lowest-resolution) output, HRnet.py:516-529
+                ys = [ys[i] if tr is None else transition(tr, ys[-1]) for i, tr in enumerate(trans)]
+        return ys
+
+    def emit_heads(self, pb, ys, feat_out=None):
+        """-> (heat-map tensor or None, fp32 feature tensor or None)."""
+        heat = feat = None
+        if self.generate_hm:
+            heat = self.final_layer.emit(pb, ys[0])
+        if self.generate_feat:
+            y = self.incre_modules[0][0].emit(pb, ys[0])
+            for i, dm in enumerate(self.downsamp_modules):
+                d = pb.act([conv_bn(pb, y, dm[0], dm[1])], relu=True)
+                inc = self.incre_modules[i + 1][0].emit(pb, ys[i + 1])
+                y = pb.act([Term(inc), Term(d)], relu=False)
+            y = pb.act([conv_bn(pb, y, self.final_feat_layer[0], self.final_feat_layer[1])], relu=True)
+            feat = pb.avgpool(y, out=feat_out)
+        return heat, feat
+
+    def emit(self, pb, x, feat_out=None):
+        return self.emit_heads(pb, self.emit_trunk(pb, x), feat_out=feat_out)
+
+    def _build(self, pb, x):
+        N, Cc, H, W = x.shape
+        t = pb.image_input("x", N, Cc, H, W)
+        t.requires_grad = pb.plan.need_grad and x.requires_grad
+        heat, feat = self.emit(pb, t)
+        outs = []
+        if heat is not None:
+            holder = pb.nchw_output(heat)
+            holder["handle"] = heat
+            outs.append(("nchw", holder, None))
+        if feat is not None:
+            outs.append(("dense", feat, (N, feat.C)))
+        return ["x"], outs, {"x": t}
+
+    def forward(self, x):
+        outs = self._run(x)
+        if self.generate_hm and self.generate_feat:
+            return outs[0], outs[1]
+        return outs[0]
+
+    def init_weights(self, pretrained=""):
+        logger.info("=> init weights from normal distribution")
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if os.path.isfile(pretrained):
+            print(f"Loading hrnet pretrained weights (ImageNet) from {pretrained}")
+            state = torch.load(pretrained, map_location="cpu")
+            keep = {k: v for k, v in state.items()
+                    if k.split(".")[0] in self.pretrained_layers or self.pretrained_layers[0] == "*"}
+            self.load_state_dict(keep, strict=False)
+        elif pretrained:
+            logger.error("=> please download pre-trained models first!")
+            raise ValueError("{} is not exist!".format(pretrained))
+
+
+def load_hrnet_cfg(file_name):
+    """YAML file -> attribute dict; falls back to the built-in W32/W48 tables when the file is absent."""
+    if os.path.isfile(file_name):
+        import yaml
+        with open(file_name) as f:
+            return AttrDict(yaml.load(f, Loader=yaml.FullLoader))
+    key = os.path.splitext(os.path.basename(file_name))[0]
+    if key not in HRNET_CONFIGS:
+        raise FileNotFoundError(file_name)
+    return AttrDict(HRNET_CONFIGS[key])
+
+
+def get_hrnet(type_name, num_joints, depth_dim, pretrain=True, **kwargs):
+    cfg = load_hrnet_cfg(f"./lib/models/backbones/configs/hrnet_w{type_name}.yaml")
+    cfg["MODEL"]["NUM_JOINTS"] = num_joints
+    cfg["MODEL"]["DEPTH_DIM"] = depth_dim
+    model = PoseHighResolutionNet(cfg, **kwargs)
+    if pretrain:
+        pre = cfg["MODEL"]["PRETRAINED"]
+        model.init_weights(pretrained=pre if os.path.isfile(pre) else "")
+    return model

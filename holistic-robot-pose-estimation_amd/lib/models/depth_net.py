@@ -1,0 +1,53 @@
+"""DepthNet (RootNet) on the plan runtime - drop-in for reference lib/models/depth_net.py:11-168.
+
+``RootNet('hrnet32').forward(x, k_value)`` -> depth [B, 1] in the reference's unit (gamma * k_value, mm).
+State-dict keys: ``backbone.*`` + ``depth_layer.{weight,bias}`` as in the reference."""
+import torch.nn as nn
+
+from hrpe_amd.runtime import PlannedModule
+from .backbones.HRnet import Conv2d, get_hrnet
+
+
+class RootNet(PlannedModule):
+    def __init__(self, backbone, pred_xy=False, use_offset=False, add_fc=False, input_shape=(256, 256), **kwargs):
+        super().__init__()
+        self.backbone_name = backbone
+        if backbone in ["hrnet", "hrnet32"]:
+            self.backbone = get_hrnet(type_name=32, num_joints=7, depth_dim=1, pretrain=True,
+                                      generate_feat=True, generate_hm=False)
+            self.inplanes = 2048
+        elif backbone in ["resnet34", "resnet50", "resnet"]:
+            raise NotImplementedError("ResNet root backbones are not built yet (HRNet-W32 is the shipped DepthNet, "
+                                      "configs/panda/depthnet.yaml:17)")
+        else:
+            raise NotImplementedError
+        if pred_xy or use_offset or add_fc:
+            raise NotImplementedError("pred_xy / use_offset / add_fc heads are off in every shipped config and not built")
+        self.pred_xy, self.add_fc, self.use_offset = pred_xy, add_fc, use_offset
+        self.input_shape = input_shape
+        self.output_shape = (input_shape[0] // 4, input_shape[1] // 4)
+        self.outplanes = 256
+        self.depth_layer = Conv2d(self.inplanes, 1, 1, bias=True)
+
+    def _build(self, pb, x, k_value):
+        N, Cc, H, W = x.shape
+        t = pb.image_input("x", N, Cc, H, W)
+        kv = pb.vector_input("k_value", N, 1, dense=True)
+        _, feat = self.backbone.emit(pb, t)
+        gamma = self.depth_layer.emit(pb, feat)          # 1x1 conv on [N,2048,1,1] == linear (depth_net.py:121-123)
+        depth = pb.row_scale(gamma, kv)                  # depth = gamma * k_value (depth_net.py:125)
+        return ["x", "k_value"], [("dense", depth, (N, 1))], {"x": t}
+
+    def forward(self, x, k_value):
+        return self._run(x, k_value.reshape(-1, 1))[0]
+
+    def init_weights(self):
+        nn.init.normal_(self.depth_layer.weight, std=0.001)
+        nn.init.constant_(self.depth_layer.bias, 0)
+        print("Initialized depth layer of RootNet.")
+
+
+def get_rootnet(backbone, pred_xy=False, use_offset=False, add_fc=False, input_shape=(256, 256), **kwargs):
+    model = RootNet(backbone, pred_xy, use_offset, add_fc, input_shape=(256, 256), **kwargs)
+    model.init_weights()
+    return model

@@ -1,0 +1,210 @@
+"""Kinematics-only robot model on the HIP FK kernel (drop-in for the FK part of reference
+lib/utils/urdf_robot.py:22-199; the rendering half of that file is out of scope).
+
+``URDFRobot(robot_type)`` parses the URDF once on the host into a flat chain descriptor
+(``hrp_fk_chain`` in include/hrp.h) and every ``get_keypoints*`` call is ONE launch of the
+wavefront-per-sample FK kernel (csrc/heads.hip) instead of ~50 small torch matmuls per call
+(reference lib/utils/urdfpytorch/urdf.py:3115-3140).
+"""
+import ctypes as C
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import torch
+
+from hrpe_amd import _native as nv
+from hrpe_amd.lib.dataset.const import JOINT_NAMES, LINK_NAMES
+
+_ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "assets")
+
+
+def _default_urdf(robot_type):
+    # reference location first (lib/config.py:33), then the kinematics-only file shipped with this package
+    cands = {"panda": ["data/deps/panda-description/panda.urdf", os.path.join(_ASSETS, "panda_kinematics.urdf")],
+             "kuka": ["data/deps/kuka-description/iiwa_description/urdf/iiwa7.urdf"]}
+    for c in cands.get(robot_type, []):
+        if os.path.isfile(c):
+            return c
+    raise FileNotFoundError(f"no URDF for robot '{robot_type}' (looked in {cands.get(robot_type)})")
+
+
+def _rpy(r, p, y):
+    cr, cp, cy, sr, sp, sy = np.cos(r), np.cos(p), np.cos(y), np.sin(r), np.sin(p), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - cr * sy, sy * sr + cy * cr * sp],
+                     [cp * sy, cy * cr + sy * sp * sr, cr * sy * sp - cy * sr],
+                     [-sp, cp * sr, cp * cr]], dtype=np.float64)
+
+
+def parse_chain(urdf_path, link_names, offsets=None):
+    """URDF -> (ctypes hrp_fk_chain, actuated joint names in configuration-column order)."""
+    root = ET.parse(urdf_path).getroot()
+    joints = []
+    for n in root.findall("joint"):
+        T = np.eye(4)
+        o = n.find("origin")
+        if o is not None:
+            if "xyz" in o.attrib:
+                T[:3, 3] = [float(v) for v in o.attrib["xyz"].split()]
+            if "rpy" in o.attrib:
+                T[:3, :3] = _rpy(*[float(v) for v in o.attrib["rpy"].split()])
+        ax = n.find("axis")
+        mim = n.find("mimic")
+        joints.append(dict(name=n.attrib["name"], type=n.attrib["type"], parent=n.find("parent").attrib["link"],
+                           child=n.find("child").attrib["link"], origin=T,
+                           axis=np.array([float(v) for v in ax.attrib["xyz"].split()]) if ax is not None else np.array([1.0, 0, 0]),
+                           mimic=None if mim is None else (mim.attrib["joint"], float(mim.attrib.get("multiplier", 1.0)),
+                                                           float(mim.attrib.get("offset", 0.0)))))
+    by_child = {j["child"]: j for j in joints}
+
+    def depth(link):
+        d = 0
+        while link in by_child:
+            link = by_child[link]["parent"]
+            d += 1
+        return d
+
+    order = sorted(range(len(joints)), key=lambda i: depth(joints[i]["child"]))  # parents before children
+    joints = [joints[i] for i in order]
+    index = {j["child"]: i for i, j in enumerate(joints)}
+    # configuration columns: non-fixed, non-mimic joints by ascending distance from the base
+    # (reference urdf.py:3795-3813, 3933-3934)
+    act = [j for j in joints if j["type"] != "fixed" and j["mimic"] is None]
+    cfg_of = {j["name"]: i for i, j in enumerate(act)}
+    if len(joints) > nv.FK_MAX_JOINTS or len(link_names) > nv.FK_MAX_KP:
+        raise ValueError("robot too large for hrp_fk_chain")
+    ch = nv.FkChain()
+    ch.njoints = len(joints)
+    for i, j in enumerate(joints):
+        ch.parent[i] = index.get(j["parent"], -1)
+        ch.type[i] = {"fixed": 0, "revolute": 1, "continuous": 1, "prismatic": 2}[j["type"]]
+        ch.mimic_mul[i], ch.mimic_off[i] = 1.0, 0.0
+        if j["type"] == "fixed":
+            ch.cfg[i] = -1
+        elif j["mimic"] is not None:
+            src, mul, off = j["mimic"]
+            ch.cfg[i] = cfg_of.get(src, -1)
+            ch.mimic_mul[i], ch.mimic_off[i] = mul, off
+        else:
+            ch.cfg[i] = cfg_of[j["name"]]
+        for r in range(3):
+            for c in range(4):
+                ch.origin[i][r * 4 + c] = float(j["origin"][r, c])
+        a = j["axis"] / np.linalg.norm(j["axis"])
+        for r in range(3):
+            ch.axis[i][r] = float(a[r])
+    ch.nkp = len(link_names)
+    for k, ln in enumerate(link_names):
+        ch.kp_frame[k] = index.get(ln, -1)
+        for r in range(3):
+            ch.kp_offset[k][r] = float(offsets[k][r]) if offsets is not None else 0.0
+    ch.dof = len(act)
+    return ch, [j["name"] for j in act]
+
+
+class _FKFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, robot, q, rot, trans, K, root, want):
+        B = q.shape[0]
+        dev = q.device
+        chain = robot.chain_on(dev)
+        q, rot, trans = [t.contiguous().float() for t in (q, rot, trans)]
+        Kc = K.contiguous().float() if K is not None else None
+        nkp = robot.nkp
+        xyz = torch.empty(B, nkp, 3, device=dev)
+        uv = torch.empty(B, nkp, 2, device=dev) if Kc is not None else None
+        rr = torch.empty(B, 6, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        nv.call("hrp_fk_project_fwd", chain.data_ptr(), q.data_ptr(), rot.data_ptr(), trans.data_ptr(),
+                Kc.data_ptr() if Kc is not None else None, B, root, xyz.data_ptr(),
+                uv.data_ptr() if uv is not None else None, rr.data_ptr(), s)
+        ctx.save_for_backward(q, rot, trans, Kc if Kc is not None else torch.empty(0, device=dev))
+        ctx.robot, ctx.root, ctx.hasK = robot, root, Kc is not None
+        outs = {"xyz": xyz, "uv": uv, "rot": rr}
+        ctx.want = want
+        if "rot" in want:
+            ctx.mark_non_differentiable(rr)
+        return tuple(outs[w] for w in want)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        q, rot, trans, Kc = ctx.saved_tensors
+        B, dev = q.shape[0], q.device
+        g = dict(zip(ctx.want, grads))
+        gx = g.get("xyz")
+        gu = g.get("uv")
+        gx = gx.contiguous().float() if gx is not None else None
+        gu = gu.contiguous().float() if gu is not None else None
+        dq, dr, dt = torch.empty_like(q), torch.empty_like(rot), torch.empty_like(trans)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        nv.call("hrp_fk_project_bwd", ctx.robot.chain_on(dev).data_ptr(), q.data_ptr(), rot.data_ptr(), trans.data_ptr(),
+                Kc.data_ptr() if ctx.hasK else None, B, ctx.root, gx.data_ptr() if gx is not None else None,
+                gu.data_ptr() if gu is not None else None, dq.data_ptr(), dr.data_ptr(), dt.data_ptr(), s)
+        return None, dq, dr, dt, None, None, None
+
+
+class URDFRobot:
+    def __init__(self, robot_type, urdf_path=None):
+        if robot_type not in LINK_NAMES:
+            raise NotImplementedError(f"robot '{robot_type}' has no keypoint table in this build")
+        self.robot_type = robot_type
+        self.urdf_path = urdf_path or _default_urdf(robot_type)
+        self.link_names = LINK_NAMES[robot_type]
+        self.actuated_joint_names = JOINT_NAMES[robot_type]
+        self.global_scale = 1.0
+        # panda / kuka keypoints sit at the link origins (reference urdf_robot.py:53-56)
+        self.offsets = torch.zeros(1, len(self.link_names), 3, 1)
+        self.chain, names = parse_chain(self.urdf_path, self.link_names)
+        if names != list(self.actuated_joint_names):
+            raise ValueError(f"URDF actuated joints {names} differ from JOINT_NAMES {self.actuated_joint_names}")
+        self.dof = self.chain.dof
+        self.nkp = len(self.link_names)
+        self._dev = {}
+
+    def chain_on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            if device.type != "cuda":
+                raise nv.HrpError("URDFRobot kinematics run on the GPU only (no CPU path)")
+            self._dev[key] = torch.frombuffer(bytearray(bytes(self.chain)), dtype=torch.uint8).to(device)
+        return self._dev[key]
+
+    def _identity_cam(self, q):
+        B = q.shape[0]
+        rot = torch.tensor([1.0, 0, 0, 0, 1, 0], device=q.device).repeat(B, 1)
+        return rot, torch.zeros(B, 3, device=q.device)
+
+    def get_keypoints(self, jointcfgs, b2c_rot, b2c_trans):
+        if b2c_rot.shape[1] != 6:
+            raise NotImplementedError("only the 6-D rotation representation is supported")
+        return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, None, 0, ("xyz",))[0]
+
+    def get_keypoints_root(self, jointcfgs, b2c_rot, b2c_trans, root=0):
+        if root == 0:
+            return self.get_keypoints(jointcfgs, b2c_rot, b2c_trans)
+        assert 0 < root < len(self.link_names)
+        if b2c_rot.shape[1] != 6:
+            raise NotImplementedError("only the 6-D rotation representation is supported")
+        return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, None, root, ("xyz",))[0]
+
+    def get_keypoints_and_projection(self, jointcfgs, b2c_rot, b2c_trans, K, root=0):
+        """Fused extra: camera-frame keypoints AND their pixel projection in one launch."""
+        return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, K, root, ("xyz", "uv"))
+
+    def get_rotation_at_specific_root(self, jointcfgs, b2c_rot, b2c_trans, root=0):
+        if root == 0:
+            return b2c_rot
+        assert root < len(self.link_names), (root, len(self.link_names))
+        with torch.no_grad():
+            return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, None, root, ("rot",))[0]
+
+    def get_keypoints_only_fk(self, jointcfgs):
+        rot, tr = self._identity_cam(jointcfgs)
+        return _FKFn.apply(self, jointcfgs, rot, tr, None, 0, ("xyz",))[0]
+
+    def get_keypoints_only_fk_at_specific_root(self, jointcfgs, root=0):
+        if root == 0:
+            return self.get_keypoints_only_fk(jointcfgs)
+        assert 0 < root < len(self.link_names)
+        rot, tr = self._identity_cam(jointcfgs)
+        return _FKFn.apply(self, jointcfgs, rot, tr, None, root, ("xyz",))[0]

@@ -1,0 +1,760 @@
+"""Static op plan: the host-side replacement for eager per-layer dispatch.
+
+A model's ``emit(pb, ...)`` methods describe the network ONCE per (batch size, dtype, mode) as a list
+of kernel launches on pre-allocated NHWC buffers; running the plan is a straight walk over that list
+(ctypes calls into libhrp_hip.so on the current HIP stream), so a whole forward+backward is
+hipGraph-capturable and carries no per-step Python graph building, no autograd tape and no allocator
+traffic.  The backward list is generated at build time from the forward list (reverse order, static
+decision of "first writer overwrites / later writers accumulate" for every gradient buffer).
+
+PyTorch is used for device memory (torch.zeros buffers), the stream handle and the public
+``torch.autograd.Function`` boundary only.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as nv
+
+BN_EPS = 1e-5
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _dt(dtype):
+    return nv.HRP_F32 if dtype == torch.float32 else nv.HRP_BF16
+
+
+class TensorH:
+    """NHWC activation handle: logical shape (N,H,W,C), channel pitch, backing buffer (+ gradient)."""
+
+    def __init__(self, plan, N, H, W, Cc, dtype, buf=None, offset=0, pitch=None, base=None):
+        self.plan, self.N, self.H, self.W, self.C, self.dtype = plan, N, H, W, Cc, dtype
+        self.pitch = pitch if pitch is not None else _rup(Cc, 8)
+        self.offset = offset  # element offset into buf (column slices)
+        self.base = base      # parent handle when this is a slice
+        if buf is None:
+            buf = torch.zeros(N * H * W * self.pitch, dtype=dtype, device=plan.device)
+            plan.keep.append(buf)
+        self.buf = buf
+        self._grad = None
+        self.grad_written = False
+        self.requires_grad = False
+        self.stats = None      # (arena offset) of forward sum/sumsq when produced by a conv in train mode
+        self.producer = None
+
+    @property
+    def esz(self):
+        return self.buf.element_size()
+
+    def ptr(self):
+        return self.buf.data_ptr() + self.offset * self.esz
+
+    def grad_buf(self):
+        root = self.base if self.base is not None else self
+        if root._grad is None:
+            root._grad = torch.zeros_like(root.buf)
+            self.plan.keep.append(root._grad)
+        return root._grad
+
+    def gptr(self):
+        return self.grad_buf().data_ptr() + self.offset * self.esz
+
+    def take_grad_slot(self):
+        """-> accumulate flag for a producer of this tensor's gradient."""
+        acc = self.grad_written
+        self.grad_written = True
+        return 1 if acc else 0
+
+    def view4(self):
+        return self.buf.view(self.N, self.H, self.W, self.pitch)[..., :self.C]
+
+
+class Term:
+    """One summand of an element-wise op: tensor, optional BatchNorm module, upsample factor."""
+
+    def __init__(self, t, bn=None, up=1):
+        self.t, self.bn, self.up = t, bn, up
+
+
+class ParamW:
+    """Packed copies of one conv / linear weight."""
+
+    def __init__(self, param, cout, cin, ntaps):
+        self.param, self.cout, self.cin, self.ntaps = param, cout, cin, ntaps
+        self.fwd_off = self.bwd_off = None
+        self.grad_written = False
+
+
+class Plan:
+    def __init__(self, device, dtype, training, need_grad):
+        self.device, self.dtype, self.training, self.need_grad = device, dtype, training, need_grad
+        self.keep = []
+        self.prep, self.fwd, self.post_fwd, self.bwd = [], [], [], []
+        self.weights = {}          # id(param) -> ParamW
+        self.weight_list = []
+        self.bn_train = []         # (bn module, stats offset, count)
+        self.bn_fold = {}          # id(bn) -> (scale tensor, shift tensor)
+        self.bn_bwd = []           # (bn module, bwd sums offset)
+        self.stats_floats = 0
+        self.bsums_floats = 0
+        self.param_grads = {}      # id(param) -> (param, grad tensor)
+        self.inputs, self.outputs = {}, {}
+        self.dyn = {}              # name -> current external tensor (bound per call)
+        self.built = False
+        self._versions = None
+        self._late = []
+        self.out_handles = []      # TensorH whose gradient is seeded from outside
+
+    # ---- build-time helpers -------------------------------------------------------------------
+    def new(self, N, H, W, Cc, dtype=None, pitch=None):
+        return TensorH(self, N, H, W, Cc, dtype or self.dtype, pitch=pitch)
+
+    def weight(self, param, cout, cin, ntaps):
+        w = self.weights.get(id(param))
+        if w is None:
+            w = ParamW(param, cout, cin, ntaps)
+            self.weights[id(param)] = w
+            self.weight_list.append(w)
+        return w
+
+    def grad_of_param(self, p):
+        e = self.param_grads.get(id(p))
+        if e is None:
+            e = (p, torch.zeros_like(p, dtype=torch.float32))
+            self.param_grads[id(p)] = e
+            self.keep.append(e[1])
+        return e[1]
+
+    def alloc_stats(self, Cc):
+        off = self.stats_floats
+        self.stats_floats += 2 * Cc
+        return off
+
+    def alloc_bsums(self, Cc):
+        off = self.bsums_floats
+        self.bsums_floats += 2 * Cc
+        return off
+
+    # ---- finalisation -----------------------------------------------------------------------------
+    def finalize(self):
+        dev = self.device
+        self.stats = torch.zeros(max(self.stats_floats, 2), dtype=torch.float32, device=dev)
+        self.bsums = torch.zeros(max(self.bsums_floats, 2), dtype=torch.float32, device=dev)
+        # packed weights: separate arenas per element type
+        self._pack_tables = []
+        for dtype in (torch.float32, torch.bfloat16):
+            ws = [w for w in self.weight_list if w.dtype == dtype]
+            if not ws:
+                continue
+            esz = 4 if dtype == torch.float32 else 2
+            ck = 64 // esz
+            total, maxel = 0, 0
+            for w in ws:
+                nf = math.ceil(w.cin_used / ck) * w.ntaps * _rup(w.cout, 32) * ck
+                w.fwd_off = total
+                total += _rup(nf, 64)
+                maxel = max(maxel, nf)
+                if w.need_t:
+                    nb = math.ceil(w.cout / ck) * w.ntaps * _rup(w.cin_used, 32) * ck
+                    w.bwd_off = total
+                    total += _rup(nb, 64)
+                    maxel = max(maxel, nb)
+            arena = torch.zeros(total, dtype=dtype, device=dev)
+            self.keep.append(arena)
+            tab = (nv.PackEntry * len(ws))()
+            for i, w in enumerate(ws):
+                w.arena = arena
+                tab[i].src = w.param.data_ptr()
+                tab[i].dst = arena.data_ptr() + w.fwd_off * esz
+                tab[i].dst_t = (arena.data_ptr() + w.bwd_off * esz) if w.need_t else None
+                tab[i].Cout, tab[i].Cin, tab[i].ntaps = w.cout, w.cin, w.ntaps
+            tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+            self.keep.append(tdev)
+            self._pack_tables.append((tdev, len(ws), _dt(dtype), maxel))
+        # resolve deferred pointers
+        for fn in self._late:
+            fn()
+        self._late = []
+        self._bn_tables()
+        self.built = True
+
+    def late(self, fn):
+        """Defer pointer patching until the arenas exist (finalize)."""
+        self._late.append(fn)
+
+    def _table(self, entries):
+        tab = (nv.BnEntry * len(entries))()
+        for i, e in enumerate(entries):
+            for k, v in e.items():
+                setattr(tab[i], k, v)
+        tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+        self.keep.append(tdev)
+        return tdev, len(entries)
+
+    def _bn_tables(self):
+        self._run_tab = self._fold_tab = self._pgrad_tab = None
+        if self.bn_train:
+            ents = []
+            for bn, off, count in self.bn_train:
+                ents.append(dict(stats=self.stats.data_ptr() + 4 * off, a=bn.running_mean.data_ptr(),
+                                 b=bn.running_var.data_ptr(), counter=bn.num_batches_tracked.data_ptr(),
+                                 C=bn.num_features, count=float(count), momentum=bn.momentum, eps=bn.eps))
+            self._run_tab = self._table(ents)
+        if self.bn_fold:
+            ents = []
+            for bn, sc, sh in self.bn_fold.values():
+                ents.append(dict(a=bn.weight.data_ptr(), b=bn.bias.data_ptr(), c=bn.running_mean.data_ptr(),
+                                 d=bn.running_var.data_ptr(), out_scale=sc.data_ptr(), out_shift=sh.data_ptr(),
+                                 C=bn.num_features, eps=bn.eps))
+            self._fold_tab = self._table(ents)
+        if self.bn_bwd:
+            ents = []
+            for bn, off in self.bn_bwd:
+                ents.append(dict(stats=self.bsums.data_ptr() + 4 * off, a=self.grad_of_param(bn.weight).data_ptr(),
+                                 b=self.grad_of_param(bn.bias).data_ptr(), C=bn.num_features, accumulate=0))
+            self._pgrad_tab = self._table(ents)
+
+    # ---- execution ----------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def params_dirty(self):
+        v = tuple(w.param._version for w in self.weight_list) + \
+            tuple(t._version for bn, _, _ in self.bn_fold.values() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        if v != self._versions:
+            self._versions = v
+            return True
+        return False
+
+    def run_prep(self, force=False):
+        if not (force or self.params_dirty()):
+            return
+        s = self._stream()
+        for tdev, n, dt, maxel in self._pack_tables:
+            nv.call("hrp_pack_weights", tdev.data_ptr(), n, dt, maxel, s)
+        if self._fold_tab:
+            nv.call("hrp_bn_fold", self._fold_tab[0].data_ptr(), self._fold_tab[1], s)
+
+    def run_forward(self):
+        s = self._stream()
+        if self.stats_floats:
+            self.stats.zero_()
+        for op in self.fwd:
+            op(s)
+        if self._run_tab:
+            nv.call("hrp_bn_running_update", self._run_tab[0].data_ptr(), self._run_tab[1], s)
+
+    def run_backward(self):
+        s = self._stream()
+        if self.bsums_floats:
+            self.bsums.zero_()
+        for op in self.bwd:
+            op(s)
+        if self._pgrad_tab:
+            nv.call("hrp_bn_param_grad", self._pgrad_tab[0].data_ptr(), self._pgrad_tab[1], s)
+
+    def publish_param_grads(self):
+        """Hand the plan-owned gradient buffers to the parameters (torch semantics: .grad holds this
+        backward's gradient; an already-present foreign .grad tensor is accumulated into)."""
+        for p, g in self.param_grads.values():
+            if p.grad is None or p.grad is g:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+
+
+# =====================================================================================================
+# Plan builder: the vocabulary modules use in emit()
+# =====================================================================================================
+_TAPS3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+
+
+class PlanBuilder:
+    def __init__(self, plan):
+        self.plan = plan
+        self.bwd_stack = []   # emitters of backward ops, in forward order (run reversed at the end)
+        self.fuse_inference = (not plan.training) and (not plan.need_grad)
+
+    # ---- inputs / outputs ---------------------------------------------------------------------------
+    def image_input(self, name, N, Cc, H, W):
+        """NCHW fp32 external tensor -> NHWC plan tensor (channel-padded to 8)."""
+        p = self.plan
+        t = p.new(N, H, W, Cc)
+        dt = _dt(t.dtype)
+
+        def op(s):
+            x = p.dyn[name]
+            nv.call("hrp_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
+        p.fwd.append(op)
+        t.external = name
+        return t
+
+    def constant(self, N, Cc, value):
+        t = self.plan.new(N, 1, 1, Cc, torch.float32, pitch=Cc)
+        t.buf.fill_(value)
+        return t
+
+    def vector_input(self, name, N, Cc, dense=False):
+        """fp32 [N, C] external tensor copied into a static buffer."""
+        p = self.plan
+        t = p.new(N, 1, 1, Cc, torch.float32, pitch=Cc if dense else None)
+
+        def op(s):
+            x = p.dyn[name]
+            nv.call("hrp_copy_cols", x.data_ptr(), Cc, t.ptr(), t.pitch, N, Cc, 0, s)
+        p.fwd.append(op)
+        return t
+
+    def nchw_output(self, t):
+        """NHWC plan tensor -> fresh NCHW fp32 torch tensor (public API boundary)."""
+        dt = _dt(t.dtype)
+        holder = {}
+        p = self.plan
+
+        def op(s):
+            out = torch.empty(t.N, t.C, t.H, t.W, dtype=torch.float32, device=p.device)
+            nv.call("hrp_nhwc_to_nchw", t.ptr(), out.data_ptr(), dt, t.N, t.C, t.H, t.W, t.pitch, s)
+            holder["out"] = out
+        p.fwd.append(op)
+        return holder
+
+    # ---- convolution ----------------------------------------------------------------------------------
+    def _conv_desc(self, x, w, y, stride, ksize, dtype):
+        d = nv.ConvDesc()
+        d.x, d.y = x.ptr(), y.ptr()
+        d.dtype = _dt(dtype)
+        d.N, d.H, d.W, d.Cin, d.x_pitch = x.N, x.H, x.W, _rup(x.C, 8 if dtype == torch.bfloat16 else 4), x.pitch
+        d.Ho, d.Wo, d.Cout = y.H, y.W, y.C
+        d.y_H, d.y_W, d.y_pitch, d.res_pitch = y.H, y.W, y.pitch, y.pitch
+        d.out_stride, d.out_off_y, d.out_off_x = 1, 0, 0
+        d.in_stride = stride
+        taps = _TAPS3 if ksize == 3 else [(0, 0)]
+        d.ntaps = len(taps)
+        for i, (a, b) in enumerate(taps):
+            d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+        d.w_ntaps = len(taps)
+        d.w_cout_pad = _rup(y.C, 32)
+        return d
+
+    def conv(self, x, weight, bias=None, stride=1, want_stats=False, out=None, residual=None, relu=False):
+        """y = conv(x) (+bias) (+residual) (ReLU).  weight: torch parameter [Cout, Cin, k, k] or [Cout, Cin]."""
+        p = self.plan
+        cout, cin = weight.shape[0], weight.shape[1]
+        ksize = weight.shape[2] if weight.dim() == 4 else 1
+        ntaps = ksize * ksize
+        dtype = x.dtype
+        w = p.weight(weight, cout, cin, ntaps)
+        w.dtype = dtype
+        w.cin_used = cin
+        w.need_t = getattr(w, "need_t", False) or (p.need_grad and x.requires_grad)
+        Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
+        Wo = (x.W + 2 * (ksize // 2) - ksize) // stride + 1
+        y = out if out is not None else p.new(x.N, Ho, Wo, cout, dtype)
+        y.requires_grad = p.need_grad
+        d = self._conv_desc(x, w, y, stride, ksize, dtype)
+        if bias is not None:
+            d.bias = bias.data_ptr()
+        if residual is not None:
+            d.res, d.res_pitch = residual.ptr(), residual.pitch
+        d.relu = 1 if relu else 0
+        if want_stats:
+            y.stats = p.alloc_stats(cout)
+        esz = 4 if dtype == torch.float32 else 2
+
+        def late():
+            d.w = w.arena.data_ptr() + w.fwd_off * esz
+            if y.stats is not None:
+                d.stats = p.stats.data_ptr() + 4 * y.stats
+        p.late(late)
+        p.fwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+        y.producer = ("conv", d)
+        if p.need_grad:
+            self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu))
+        return y
+
+    def _conv_bwd(self, x, w, y, bias, stride, ksize, dtype, residual, relu):
+        p = self.plan
+        assert not relu, "ReLU fused in a conv epilogue is inference-only"
+        if not y.grad_written:
+            return  # nobody consumed this output
+        esz = 4 if dtype == torch.float32 else 2
+        vec = 8 if dtype == torch.bfloat16 else 4
+        taps = _TAPS3 if ksize == 3 else [(0, 0)]
+        # residual: d_res += dY (fp32 heads only)
+        if residual is not None and residual.requires_grad:
+            assert dtype == torch.float32
+            acc = residual.take_grad_slot()
+            p.bwd.append(lambda s: nv.call("hrp_copy_cols", y.gptr(), y.pitch, residual.gptr(), residual.pitch,
+                                           y.N * y.H * y.W, y.C, acc, s))
+        # bias gradient
+        if bias is not None and bias.requires_grad:
+            gb = p.grad_of_param(bias)
+            p.bwd.append(lambda s: nv.call("hrp_colsum", y.gptr(), _dt(dtype), y.N * y.H * y.W, y.C, y.pitch,
+                                           gb.data_ptr(), 0, s))
+        # weight gradient
+        if w.param.requires_grad:
+            g = nv.WgradDesc()
+            g.x, g.dy, g.dw = x.ptr(), y.gptr(), p.grad_of_param(w.param).data_ptr()
+            g.dtype = _dt(dtype)
+            g.N, g.H, g.W, g.Cin, g.x_pitch = x.N, x.H, x.W, _rup(x.C, vec), x.pitch
+            g.Ho, g.Wo, g.Cout, g.dy_pitch = y.H, y.W, y.C, y.pitch
+            g.in_stride, g.ntaps = stride, len(taps)
+            for i, (a, b) in enumerate(taps):
+                g.dy_t[i], g.dx_t[i] = a, b
+            g.dw_cin = w.cin
+            g.accumulate = 1 if w.grad_written else 0
+            w.grad_written = True
+            p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
+        # data gradient
+        if x.requires_grad:
+            acc = x.take_grad_slot()
+            classes = [(0, 0)] if stride == 1 else [(0, 0), (0, 1), (1, 0), (1, 1)]
+            for (py, px) in classes:
+                d = nv.ConvDesc()
+                d.x, d.y = y.gptr(), x.gptr()
+                d.dtype = _dt(dtype)
+                d.N, d.H, d.W, d.Cin, d.x_pitch = y.N, y.H, y.W, _rup(y.C, vec), y.pitch
+                d.Cout = x.C
+                d.y_H, d.y_W, d.y_pitch = x.H, x.W, x.pitch
+                d.in_stride = 1
+                if stride == 1:
+                    d.Ho, d.Wo = x.H, x.W
+                    d.out_stride, d.out_off_y, d.out_off_x = 1, 0, 0
+                    tl = [(-a, -b, i) for i, (a, b) in enumerate(taps)]
+                else:
+                    assert ksize == 3 and stride == 2
+                    d.Ho, d.Wo = (x.H - py + 1) // 2, (x.W - px + 1) // 2
+                    d.out_stride, d.out_off_y, d.out_off_x = 2, py, px
+                    # forward: iy = 2*oy + ky - 1  ->  iy = 2a+py: py=0: ky=1, oy=a ; py=1: (ky=0, oy=a+1), (ky=2, oy=a)
+                    ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]
+                    xs = [(1, 0)] if px == 0 else [(0, 1), (2, 0)]
+                    tl = [(oy, ox, ky * 3 + kx) for (ky, oy) in ys for (kx, ox) in xs]
+                d.ntaps = len(tl)
+                for i, (a, b, t) in enumerate(tl):
+                    d.dy[i], d.dx[i], d.wtap[i] = a, b, t
+                d.w_ntaps = len(taps)
+                d.w_cout_pad = _rup(x.C, 32)
+                p.late(lambda d=d: setattr(d, "w", w.arena.data_ptr() + w.bwd_off * esz))
+                if acc:
+                    d.res, d.res_pitch = x.gptr(), x.pitch
+                if d.Ho > 0 and d.Wo > 0:
+                    p.bwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+
+    # ---- element-wise ---------------------------------------------------------------------------------
+    def _fold(self, bn):
+        p = self.plan
+        e = p.bn_fold.get(id(bn))
+        if e is None:
+            sc = torch.zeros(bn.num_features, dtype=torch.float32, device=p.device)
+            sh = torch.zeros(bn.num_features, dtype=torch.float32, device=p.device)
+            e = (bn, sc, sh)
+            p.bn_fold[id(bn)] = e
+        return e[1], e[2]
+
+    def act(self, terms, relu):
+        """out = act(sum_j BN_j(t_j) upsampled).  In inference plans a single conv+BN(+identity residual)
+        is folded into the producing conv's epilogue instead."""
+        p = self.plan
+        t0 = terms[0]
+        ref = max((tm.t for tm in terms), key=lambda t: t.H)  # output geometry = largest input x its up
+        H = max(tm.t.H * tm.up for tm in terms)
+        W = max(tm.t.W * tm.up for tm in terms)
+        Cc, N, dtype = t0.t.C, t0.t.N, t0.t.dtype
+        if self.fuse_inference and t0.bn is not None and t0.up == 1 and t0.t.producer is not None \
+                and t0.t.producer[0] == "conv" and not getattr(t0.t, "consumed", False) \
+                and len(terms) <= 2 and all(tm.bn is None and tm.up == 1 for tm in terms[1:]):
+            d = t0.t.producer[1]
+            sc, sh = self._fold(t0.bn)
+            d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+            if len(terms) == 2:
+                d.res, d.res_pitch = terms[1].t.ptr(), terms[1].t.pitch
+            d.relu = 1 if relu else 0
+            t0.t.consumed = True
+            t0.t.producer = None
+            return t0.t
+        out = p.new(N, H, W, Cc, dtype)
+        out.requires_grad = p.need_grad and any(tm.t.requires_grad for tm in terms)
+        d = nv.EwDesc()
+        d.nin = len(terms)
+        d.out, d.out_pitch, d.dtype = out.ptr(), out.pitch, _dt(dtype)
+        d.N, d.H, d.W, d.C, d.relu = N, H, W, Cc, 1 if relu else 0
+        ins = []
+        for j, tm in enumerate(terms):
+            e = d.inp[j]
+            e.ptr, e.pitch, e.up = tm.t.ptr(), tm.t.pitch, tm.up
+            assert tm.t.H * tm.up == H and tm.t.W * tm.up == W and tm.t.C == Cc
+            if tm.bn is None:
+                e.mode = nv.EW_IDENTITY
+            elif p.training:
+                assert tm.t.stats is not None, "train-mode BN needs conv statistics"
+                e.mode = nv.EW_BN_TRAIN
+                e.a, e.b = tm.bn.weight.data_ptr(), tm.bn.bias.data_ptr()
+                e.count, e.eps = float(tm.t.N * tm.t.H * tm.t.W), tm.bn.eps
+                p.bn_train.append((tm.bn, tm.t.stats, tm.t.N * tm.t.H * tm.t.W))
+                off = tm.t.stats
+                p.late(lambda e=e, off=off: setattr(e, "stats", p.stats.data_ptr() + 4 * off))
+            else:
+                sc, sh = self._fold(tm.bn)
+                e.mode = nv.EW_AFFINE
+                e.a, e.b = sc.data_ptr(), sh.data_ptr()
+            ins.append(e)
+        p.fwd.append(lambda s, d=d: nv.call("hrp_ew_fwd", C.byref(d), s))
+        if p.need_grad:
+            self.bwd_stack.append(lambda: self._act_bwd(terms, out, relu, d))
+        return out
+
+    def _act_bwd(self, terms, out, relu, fd):
+        p = self.plan
+        if not out.grad_written:
+            return
+        for j, tm in enumerate(terms):
+            if not tm.t.requires_grad:
+                continue
+            if tm.bn is not None and not p.training:
+                raise NotImplementedError("gradients through eval-mode BatchNorm are not supported yet")
+            b = nv.EwBwdDesc()
+            b.dout, b.out = out.gptr(), out.ptr()
+            b.dout_pitch, b.out_pitch = out.pitch, out.pitch
+            src = fd.inp[j]
+            for f, _ in nv.EwInput._fields_:
+                setattr(b.inp, f, getattr(src, f))
+            b.dtype, b.N, b.H, b.W, b.C, b.relu = fd.dtype, fd.N, fd.H, fd.W, fd.C, fd.relu
+            b.din, b.din_pitch = tm.t.gptr(), tm.t.pitch
+            b.accumulate = tm.t.take_grad_slot()
+            if tm.bn is not None:
+                off = p.alloc_bsums(fd.C)
+                p.bn_bwd.append((tm.bn, off))
+                p.late(lambda b=b, off=off: setattr(b, "sums", p.bsums.data_ptr() + 4 * off))
+                p.bwd.append(lambda s, b=b: nv.call("hrp_ew_bwd_reduce", C.byref(b), s))
+            p.bwd.append(lambda s, b=b: nv.call("hrp_ew_bwd_apply", C.byref(b), s))
+
+    # ---- pooling / heads -----------------------------------------------------------------------------
+    def avgpool(self, x, out=None):
+        """Global average pool -> fp32 [N, C] (optionally into a column slice of `out`)."""
+        p = self.plan
+        y = out if out is not None else p.new(x.N, 1, 1, x.C, torch.float32)
+        y.requires_grad = p.need_grad and x.requires_grad
+        p.fwd.append(lambda s: nv.call("hrp_avgpool_fwd", x.ptr(), _dt(x.dtype), x.N, x.H * x.W, x.C, x.pitch,
+                                       y.ptr(), y.pitch, s))
+        if p.need_grad:
+            def bw():
+                if not y.grad_written or not x.requires_grad:
+                    return
+                acc = x.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_avgpool_bwd", y.gptr(), y.pitch, x.gptr(), _dt(x.dtype), x.N,
+                                               x.H * x.W, x.C, x.pitch, acc, s))
+            self.bwd_stack.append(bw)
+        return y
+
+    def copy_cols(self, src, dst):
+        """dst[:, :src.C] = src (fp32), gradient flows back additively."""
+        p = self.plan
+        rows = src.N * src.H * src.W
+        dst.requires_grad = dst.requires_grad or src.requires_grad
+        p.fwd.append(lambda s: nv.call("hrp_copy_cols", src.ptr(), src.pitch, dst.ptr(), dst.pitch, rows, src.C, 0, s))
+        if p.need_grad:
+            def bw():
+                if not dst.grad_written or not src.requires_grad:
+                    return
+                acc = src.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_copy_cols", dst.gptr(), dst.pitch, src.gptr(), src.pitch, rows,
+                                               src.C, acc, s))
+            self.bwd_stack.append(bw)
+
+    def finish(self):
+        """Emit the backward list (reverse forward order) and resolve pointers."""
+        p = self.plan
+        for emit in reversed(self.bwd_stack):
+            emit()
+        p.finalize()
+
+    # ---- outputs ----------------------------------------------------------------------------------------
+    def output(self, t):
+        """Mark a tensor as a plan output whose gradient is provided by the caller."""
+        p = self.plan
+        if p.need_grad and t.requires_grad:
+            t.grad_written = True
+            t.grad_buf()
+        p.out_handles.append(t)
+        return t
+
+    # ---- heads ------------------------------------------------------------------------------------------
+    def softargmax(self, heat, J, D, root, fix_root):
+        """3-D soft-argmax of NHWC logits [N,H,W,J*D] -> uvd fp32 [N, J*3] (dense)."""
+        p = self.plan
+        N, H, W = heat.N, heat.H, heat.W
+        uvd = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
+        ms = p.new(N, 1, 1, J * 2, torch.float32, pitch=J * 2)
+        uvd.requires_grad = p.need_grad and heat.requires_grad
+        dt = _dt(heat.dtype)
+        p.fwd.append(lambda s: nv.call("hrp_softargmax3d_fwd", heat.ptr(), dt, N, J, D, H, W, heat.pitch, root,
+                                       1 if fix_root else 0, uvd.ptr(), ms.ptr(), s))
+        if p.need_grad:
+            def bw():
+                if not uvd.grad_written or not heat.requires_grad:
+                    return
+                assert not heat.grad_written, "heat-map gradient has a single producer"
+                heat.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_softargmax3d_bwd", heat.ptr(), dt, N, J, D, H, W, heat.pitch, root,
+                                               1 if fix_root else 0, uvd.ptr(), ms.ptr(), uvd.gptr(), heat.gptr(),
+                                               heat.pitch, s))
+            self.bwd_stack.append(bw)
+        return uvd
+
+    def pose_geometry(self, gamma, kval, uvd, Kmat, J, root, image_size, depth_factor):
+        """depth = gamma*k/1000; xyz_int = uvd_to_xyz; root_uv; trans = uvz2xyz (all fp32, dense)."""
+        p = self.plan
+        N = gamma.N
+        depth = p.new(N, 1, 1, 1, torch.float32, pitch=1)
+        xyz = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
+        ruv = p.new(N, 1, 1, 2, torch.float32, pitch=2)
+        trans = p.new(N, 1, 1, 3, torch.float32, pitch=3)
+        rg = p.need_grad and (gamma.requires_grad or uvd.requires_grad)
+        for t in (depth, xyz, ruv, trans):
+            t.requires_grad = rg
+        assert gamma.pitch == 1 and kval.pitch == 1 and Kmat.pitch == 9
+        p.fwd.append(lambda s: nv.call("hrp_pose_geometry_fwd", gamma.ptr(), kval.ptr(), uvd.ptr(), Kmat.ptr(), N, J, root,
+                                       float(image_size), float(depth_factor), depth.ptr(), xyz.ptr(), ruv.ptr(),
+                                       trans.ptr(), s))
+        if p.need_grad:
+            def bw():
+                if not rg:
+                    return
+                gp = [t.gptr() if t.grad_written else None for t in (depth, xyz, ruv, trans)]
+                if not any(gp):
+                    return
+                dg = p.new(N, 1, 1, 1, torch.float32, pitch=1)
+                du = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
+                p.bwd.append(lambda s: nv.call("hrp_pose_geometry_bwd", gamma.ptr(), kval.ptr(), uvd.ptr(), Kmat.ptr(), N, J,
+                                               root, float(image_size), float(depth_factor), gp[0], gp[1], gp[2], gp[3],
+                                               dg.ptr(), du.ptr(), s))
+                for src, dst in ((dg, gamma), (du, uvd)):
+                    if dst.requires_grad:
+                        acc = dst.take_grad_slot()
+                        p.bwd.append(lambda s, src=src, dst=dst, acc=acc: nv.call(
+                            "hrp_copy_cols", src.ptr(), src.pitch, dst.gptr(), dst.pitch, N, src.C, acc, s))
+            self.bwd_stack.append(bw)
+        return depth, xyz, ruv, trans
+
+    def fk(self, chain_dev, dof, nkp, q, rot, trans, root, Kmat=None, want_uv=False, want_root_rot=False):
+        """Forward kinematics (+projection): q [N,dof], rot6d [N,6], trans [N,3] dense fp32."""
+        p = self.plan
+        N = q.N
+        assert q.pitch == dof and rot.pitch == 6 and trans.pitch == 3
+        xyz = p.new(N, 1, 1, nkp * 3, torch.float32, pitch=nkp * 3)
+        uv = p.new(N, 1, 1, nkp * 2, torch.float32, pitch=nkp * 2) if want_uv else None
+        rr = p.new(N, 1, 1, 6, torch.float32, pitch=6) if want_root_rot else None
+        rg = p.need_grad and (q.requires_grad or rot.requires_grad or trans.requires_grad)
+        xyz.requires_grad = rg
+        if uv is not None:
+            uv.requires_grad = rg
+        kp = Kmat.ptr() if Kmat is not None else None
+        p.fwd.append(lambda s: nv.call("hrp_fk_project_fwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), trans.ptr(), kp, N, root,
+                                       xyz.ptr(), uv.ptr() if uv is not None else None,
+                                       rr.ptr() if rr is not None else None, s))
+        if p.need_grad:
+            def bw():
+                gx = xyz.gptr() if xyz.grad_written else None
+                gu = uv.gptr() if (uv is not None and uv.grad_written) else None
+                if not rg or (gx is None and gu is None):
+                    return
+                dq = p.new(N, 1, 1, dof, torch.float32, pitch=dof)
+                dr = p.new(N, 1, 1, 6, torch.float32, pitch=6)
+                dtv = p.new(N, 1, 1, 3, torch.float32, pitch=3)
+                p.bwd.append(lambda s: nv.call("hrp_fk_project_bwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), trans.ptr(), kp, N,
+                                               root, gx, gu, dq.ptr(), dr.ptr(), dtv.ptr(), s))
+                for src, dst in ((dq, q), (dr, rot), (dtv, trans)):
+                    if dst.requires_grad:
+                        acc = dst.take_grad_slot()
+                        p.bwd.append(lambda s, src=src, dst=dst, acc=acc: nv.call(
+                            "hrp_copy_cols", src.ptr(), src.pitch, dst.gptr(), dst.pitch, N, src.C, acc, s))
+            self.bwd_stack.append(bw)
+        return xyz, uv, rr
+
+    def dropout(self, x, prob):
+        """Inverted dropout on an fp32 [N, C] tensor (mask drawn by torch's generator each run)."""
+        p = self.plan
+        if not p.training or prob <= 0.0:
+            return x
+        rows, cols = x.N, x.C
+        mask = torch.zeros(rows, cols, dtype=torch.float32, device=p.device)
+        p.keep.append(mask)
+        y = p.new(x.N, 1, 1, x.C, torch.float32, pitch=x.pitch)
+        y.requires_grad = x.requires_grad
+        keep = 1.0 - prob
+
+        def fw(s):
+            mask.bernoulli_(keep).mul_(1.0 / keep)
+            nv.call("hrp_mul_f32", x.ptr(), x.pitch, mask.data_ptr(), cols, y.ptr(), y.pitch, rows, cols, 0, s)
+        p.fwd.append(fw)
+        if p.need_grad:
+            def bw():
+                if not y.grad_written or not x.requires_grad:
+                    return
+                acc = x.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), y.pitch, mask.data_ptr(), cols, x.gptr(), x.pitch,
+                                               rows, cols, acc, s))
+            self.bwd_stack.append(bw)
+        return y
+
+    def cat_cols(self, parts, width=None):
+        """fp32 [N, sum C_i] = concatenation of [N, C_i] tensors; gradient splits back additively."""
+        p = self.plan
+        N = parts[0].N
+        total = sum(t.C for t in parts)
+        out = p.new(N, 1, 1, width or total, torch.float32)
+        out.requires_grad = p.need_grad and any(t.requires_grad for t in parts)
+        offs, c = [], 0
+        for t in parts:
+            offs.append(c)
+            c += t.C
+        for t, o in zip(parts, offs):
+            p.fwd.append(lambda s, t=t, o=o: nv.call("hrp_copy_cols", t.ptr(), t.pitch, out.ptr() + 4 * o, out.pitch, N, t.C, 0, s))
+        if p.need_grad:
+            def bw():
+                if not out.grad_written:
+                    return
+                for t, o in zip(parts, offs):
+                    if t.requires_grad:
+                        acc = t.take_grad_slot()
+                        p.bwd.append(lambda s, t=t, o=o, acc=acc: nv.call(
+                            "hrp_copy_cols", out.gptr() + 4 * o, out.pitch, t.gptr(), t.pitch, N, t.C, acc, s))
+            self.bwd_stack.append(bw)
+        return out
+
+    def broadcast_row(self, src_tensor, N, Cc):
+        """[1, C] torch buffer -> [N, C] plan tensor (no gradient)."""
+        p = self.plan
+        out = p.new(N, 1, 1, Cc, torch.float32)
+        p.fwd.append(lambda s: nv.call("hrp_copy_cols", src_tensor.data_ptr(), 0, out.ptr(), out.pitch, N, Cc, 0, s))
+        return out
+
+    def dense(self, x):
+        """fp32 copy with pitch == C (layout the head kernels expect)."""
+        p = self.plan
+        if x.pitch == x.C:
+            return x
+        out = p.new(x.N, 1, 1, x.C, torch.float32, pitch=x.C)
+        out.requires_grad = x.requires_grad
+        self.copy_cols(x, out)
+        return out
+
+    def row_scale(self, x, kvec, scale=1.0):
+        """y[n, :] = x[n, :] * k[n] * scale  (fp32, C == 1 use: depth = gamma * k_value)."""
+        p = self.plan
+        assert x.C == 1 and kvec.pitch == 1
+        y = p.new(x.N, 1, 1, 1, torch.float32, pitch=1)
+        y.requires_grad = x.requires_grad
+        p.fwd.append(lambda s: nv.call("hrp_mul_f32", x.ptr(), x.pitch, kvec.ptr(), 1, y.ptr(), 1, x.N, 1, 0, s))
+        if p.need_grad:
+            def bw():
+                if not y.grad_written or not x.requires_grad:
+                    return
+                acc = x.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), 1, kvec.ptr(), 1, x.gptr(), x.pitch, x.N, 1, acc, s))
+            self.bwd_stack.append(bw)
+        return y

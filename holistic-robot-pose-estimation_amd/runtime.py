@@ -1,0 +1,167 @@
+"""Glue between torch.nn.Module / autograd and the static plans (plan.py).
+
+A ``PlannedModule`` keeps one plan per (input shapes, compute dtype, train/eval, grad mode).  Its
+``forward`` binds the caller's tensors, runs the plan's forward list and returns fresh torch tensors;
+when gradients are required the call is wrapped in ONE ``torch.autograd.Function`` whose backward runs
+the plan's backward list and publishes parameter gradients into ``param.grad``.
+"""
+import torch
+import torch.nn as nn
+
+from . import _native as nv
+from .plan import Plan, PlanBuilder, _dt
+
+
+def require_gpu(device):
+    if device.type != "cuda":
+        raise nv.HrpError("hrpe_amd runs on an MI355X (gfx950) only: tensors must live on a HIP device; "
+                          "there is no CPU path")
+    nv.lib()
+
+
+class Runner:
+    """A built plan plus its external inputs/outputs."""
+
+    def __init__(self, plan, in_names, outs, img_inputs):
+        self.plan, self.in_names, self.outs, self.img_inputs = plan, in_names, outs, img_inputs
+
+    def forward(self, tensors):
+        p = self.plan
+        for n, t in zip(self.in_names, tensors):
+            p.dyn[n] = t
+        p.run_prep()
+        p.run_forward()
+        res = []
+        for kind, h, shape in self.outs:
+            if kind == "nchw":
+                res.append(h["out"])
+            else:
+                res.append(h.buf.view(-1)[: h.N * h.pitch].view(h.N, h.pitch)[:, : h.C].reshape(shape).clone())
+        return tuple(res)
+
+    def backward(self, grads):
+        p = self.plan
+        s = torch.cuda.current_stream(p.device).cuda_stream
+        for (kind, h, shape), g in zip(self.outs, grads):
+            t = h["handle"] if kind == "nchw" else h
+            if not (t.requires_grad and t.grad_written):
+                continue
+            gb = t.grad_buf()
+            if g is None:
+                gb.zero_()
+            elif kind == "nchw":
+                g = g.contiguous().float()
+                nv.call("hrp_nchw_to_nhwc", g.data_ptr(), t.gptr(), _dt(t.dtype), t.N, t.C, t.H, t.W, t.pitch, s)
+            else:
+                gb.view(t.N, t.pitch)[:, : t.C].copy_(g.reshape(t.N, t.C))
+        p.run_backward()
+        p.publish_param_grads()
+        gin = []
+        for n in self.in_names:
+            t = self.img_inputs.get(n)
+            if t is not None and t.requires_grad and t.grad_written:
+                out = torch.empty(t.N, t.C, t.H, t.W, dtype=torch.float32, device=p.device)
+                nv.call("hrp_nhwc_to_nchw", t.gptr(), out.data_ptr(), _dt(t.dtype), t.N, t.C, t.H, t.W, t.pitch, s)
+                gin.append(out)
+            else:
+                gin.append(None)
+        return gin
+
+
+class _PlanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, anchor, *tensors):
+        ctx.runner = runner
+        ctx.n = len(tensors)
+        outs = runner.forward(tensors)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gin = ctx.runner.backward(grads)
+        return (None, None) + tuple(gin)
+
+
+class PlannedModule(nn.Module):
+    """Base of every hrpe_amd module: owns plans, never computes with torch ops."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_plans", {})
+        object.__setattr__(self, "_compute_dtype", torch.float32)
+
+    # compute dtype of the convolution trunk (heads stay fp32)
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        for m in self.modules():
+            if isinstance(m, PlannedModule):
+                object.__setattr__(m, "_compute_dtype", dtype)
+                m._plans.clear()
+        return self
+
+    @property
+    def compute_dtype(self):
+        return self._compute_dtype
+
+    def invalidate_plans(self):
+        for m in self.modules():
+            if isinstance(m, PlannedModule):
+                m._plans.clear()
+
+    def _apply(self, fn, *a, **k):
+        # parameters moved / cast: cached plans hold stale pointers
+        r = super()._apply(fn, *a, **k)
+        self.invalidate_plans()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        for m in self.modules():
+            if isinstance(m, PlannedModule):
+                for pl in m._plans.values():
+                    pl.plan._versions = None
+        return r
+
+    # subclasses implement: _signature(*inputs) -> hashable ; _build(pb, *inputs) -> (in_names, outs, img_inputs)
+    def _run(self, *tensors):
+        dev = tensors[0].device
+        require_gpu(dev)
+        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                 or any(t.requires_grad for t in tensors))
+        key = (tuple(tuple(t.shape) for t in tensors), self._compute_dtype, self.training, need_grad,
+               tuple(bool(t.requires_grad) for t in tensors) if need_grad else ())
+        runner = self._plans.get(key)
+        if runner is None:
+            plan = Plan(dev, self._compute_dtype, self.training, need_grad)
+            pb = PlanBuilder(plan)
+            in_names, outs, img_inputs = self._build(pb, *tensors)
+            for kind, h, shape in outs:
+                t = h["handle"] if kind == "nchw" else h
+                pb.output(t)
+            pb.finish()
+            runner = Runner(plan, in_names, outs, img_inputs)
+            self._plans[key] = runner
+        tensors = tuple(t.contiguous().float() if t.dtype != torch.float32 or not t.is_contiguous() else t
+                        for t in tensors)
+        if need_grad:
+            anchor = next((p for p in self.parameters() if p.requires_grad), None)
+            if anchor is None:
+                anchor = tensors[0]
+            return _PlanFn.apply(runner, anchor, *tensors)
+        return runner.forward(tensors)
+
+
+class SingleTensorModule(PlannedModule):
+    """Modules mapping one NCHW tensor to one NCHW tensor through ``emit(pb, x)`` (blocks, stages)."""
+
+    def forward(self, x):
+        return self._run(x)[0]
+
+    def _build(self, pb, x):
+        N, Cc, H, W = x.shape
+        t = pb.image_input("x", N, Cc, H, W)
+        t.requires_grad = pb.plan.need_grad and x.requires_grad
+        y = self.emit(pb, t)
+        holder = pb.nchw_output(y)
+        holder["handle"] = y
+        return ["x"], [("nchw", holder, None)], {"x": t}

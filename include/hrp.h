@@ -1,0 +1,246 @@
+/*
+ * hrp.h - C ABI of libhrp_hip.so: the MI355X (gfx950) kernels behind the HoRoPose image->pose path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / POD descriptors (no torch, no C++
+ * types), launches asynchronously on the caller's hipStream_t (passed as void*), returns 0 on success
+ * or a negative hrp_status (text via hrp_last_error()).  The caller owns every buffer (device pointers,
+ * e.g. tensor.data_ptr()); the library allocates nothing and keeps no state, so all calls are
+ * hipGraph-capturable.
+ *
+ * Tensor layout: activations are NHWC ("pixel-major": N, H, W, C with C contiguous), element type
+ * hrp_dtype (fp32 for parity runs, bf16 for speed); per-channel parameters and statistics are fp32.
+ * Convolution weights are consumed in the packed layout written by hrp_pack_weights.
+ *
+ * Reference interface each entry replaces (file:line in Oliverbansk/Holistic-Robot-Pose-Estimation;
+ * the reference reaches these through PyTorch ATen/cuDNN calls, it has no native code of its own):
+ *   hrp_conv2d_fwd            nn.Conv2d forward       lib/models/backbones/HRnet.py:22-25, 65-71, 284-288,
+ *                                                     200-204, 218-233, 331-337, 364-368, 377-383;
+ *                             nn.Linear forward       lib/models/full_net.py:95-97, 129-131; depth_layer :159-165
+ *   hrp_conv2d_bwd_data/_bwd_weight / hrp_colsum      autograd of the above (loss.backward(), scripts/train_full.py:61)
+ *   hrp_ew_fwd                BatchNorm2d + ReLU + residual add + nn.Upsample(nearest) + fuse sum
+ *                                                     HRnet.py:45-55, 82-96, 197-208, 256-263, 539-540
+ *   hrp_ew_bwd_reduce/_apply  autograd of the above
+ *   hrp_bn_running_update     BatchNorm2d running statistics (momentum 0.1, HRnet.py:18)
+ *   hrp_bn_fold               BatchNorm2d eval mode folded to scale/shift
+ *   hrp_avgpool_fwd/_bwd      F.avg_pool2d over the whole map      HRnet.py:547-548
+ *   hrp_nchw_to_nhwc          x.to(torch.float) + layout change at the stem   lib/models/full_net.py:242-243
+ *   hrp_softargmax3d_fwd/_bwd HeatmapIntegralPose (hrnet branch)   lib/utils/integral.py:147-177
+ *   hrp_pose_geometry_fwd/_bwd uvd_to_xyz, uvz2xyz_singlepoint, depth = gamma*k/1000
+ *                                                     lib/utils/transforms.py:33-73, 133-162; full_net.py:281-305
+ *   hrp_fk_project_fwd/_bwd   URDFRobot.get_keypoints[_root] + point_projection_from_3d_tensor
+ *                                                     lib/utils/urdf_robot.py:82-111, 169-199;
+ *                                                     lib/utils/urdfpytorch/urdf.py:3115-3140, 2344-2462;
+ *                                                     lib/utils/geometries.py:100-115; lib/utils/transforms.py:17-21
+ */
+#ifndef HRP_H
+#define HRP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { HRP_F32 = 0, HRP_BF16 = 1 } hrp_dtype;
+
+typedef enum {
+  HRP_OK = 0,
+  HRP_ERR_ARG = -1,     /* bad descriptor (shape / alignment / unsupported combination) */
+  HRP_ERR_LAUNCH = -2,  /* HIP reported an error at launch */
+  HRP_ERR_NODEV = -3    /* no usable gfx950 device */
+} hrp_status;
+
+#define HRP_MAX_TAPS 16
+
+/* One convolution "problem": out[n, oy, ox, co] = sum_t sum_ci in[n, oy*IS+dy[t], ox*IS+dx[t], ci] * W[t][co][ci].
+ * Covers conv k1/k3 stride 1/2 forward, its data gradient (stride 1: mirrored taps, stride 2: one call per
+ * output parity class with out_stride = 2), and nn.Linear (H = W = 1). */
+typedef struct hrp_conv_desc {
+  const void* x;       /* input  [N, H, W, x_pitch], first Cin channels used                     */
+  const void* w;       /* packed weights, see hrp_pack_weights: [chunk][tap][Cout_pad][CK]        */
+  void* y;             /* output [N, y_H, y_W, y_pitch]                                           */
+  const void* res;     /* optional residual added in the epilogue, geometry of y (res_pitch)      */
+  const float* bias;   /* optional [Cout]                                                         */
+  const float* scale;  /* optional per-channel affine applied after bias: v*scale+shift           */
+  const float* shift;
+  float* stats;        /* optional [2*Cout]: += sum(y), sum(y*y) over all output pixels           */
+  int32_t dtype;       /* hrp_dtype of x, w, y, res                                               */
+  int32_t N, H, W, Cin, x_pitch;
+  int32_t Ho, Wo, Cout; /* logical output grid walked by the kernel                               */
+  int32_t y_H, y_W, y_pitch, res_pitch;
+  int32_t out_stride, out_off_y, out_off_x; /* (oy,ox) is stored at (oy*out_stride+off_y, ox*...+off_x) */
+  int32_t in_stride;   /* IS */
+  int32_t ntaps;
+  int32_t dy[HRP_MAX_TAPS], dx[HRP_MAX_TAPS];
+  int32_t wtap[HRP_MAX_TAPS]; /* tap slot of the packed weights used by tap t                     */
+  int32_t w_ntaps;     /* tap slots per chunk in the packed weights                               */
+  int32_t w_cout_pad;  /* Cout rounded up to 32 (row count per tap in the packed weights)         */
+  int32_t relu;
+} hrp_conv_desc;
+
+/* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],
+ * written in fp32 straight into the PyTorch-shaped gradient tensor [Cout][Cin_w][ntaps] (Cin_w >= Cin real). */
+typedef struct hrp_wgrad_desc {
+  const void* x;       /* forward input  [N, H, W, x_pitch] */
+  const void* dy;      /* output grad    [N, Ho, Wo, dy_pitch] */
+  float* dw;           /* fp32 [Cout][dw_cin][ntaps] */
+  int32_t dtype;
+  int32_t N, H, W, Cin, x_pitch;
+  int32_t Ho, Wo, Cout, dy_pitch;
+  int32_t in_stride, ntaps;
+  int32_t dy_t[HRP_MAX_TAPS], dx_t[HRP_MAX_TAPS];
+  int32_t dw_cin;      /* row length (in taps groups) of dw: element (co,ci,t) at (co*dw_cin+ci)*ntaps+t */
+  int32_t accumulate;  /* 0: dw is zeroed by the call first, 1: add to existing */
+} hrp_wgrad_desc;
+
+/* Weight packing table entry (one launch packs every conv / linear weight of a network).
+ * src: fp32 [Cout][Cin][ntaps] (PyTorch [Cout][Cin][KH][KW]).  CK = 64 bytes / sizeof(elem).
+ * dst   (forward):       [ceil(Cin/CK)][tap][Cout_pad][CK],  value W[co][chunk*CK+k][tap]
+ * dst_t (data gradient): [ceil(Cout/CK)][tap][Cin_pad][CK],  value W[chunk*CK+k][ci][tap]
+ * Cout_pad / Cin_pad = round_up(.., 32); everything outside the real extents is zero. */
+typedef struct hrp_pack_entry {
+  const float* src;
+  void* dst;           /* forward packing or NULL */
+  void* dst_t;         /* transposed (data-gradient) packing or NULL */
+  int32_t Cout, Cin, ntaps;
+} hrp_pack_entry;
+
+#define HRP_EW_MAX_IN 4
+/* inputs of the fused element-wise op: out = act( sum_j f_j(in_j[up_j(p)]) ),
+ * f_j = identity | per-channel affine | train-mode batch-norm from (sum, sumsq) statistics */
+typedef enum { HRP_EW_IDENTITY = 0, HRP_EW_AFFINE = 1, HRP_EW_BN_TRAIN = 2 } hrp_ew_mode;
+
+typedef struct hrp_ew_input {
+  const void* ptr;     /* [N, H/up, W/up, pitch] */
+  int32_t pitch;
+  int32_t up;          /* nearest-neighbour upsample factor (1, 2, 4, 8) */
+  int32_t mode;        /* hrp_ew_mode */
+  const float* a;      /* AFFINE: scale[C]; BN_TRAIN: gamma[C] */
+  const float* b;      /* AFFINE: shift[C]; BN_TRAIN: beta[C]  */
+  const float* stats;  /* BN_TRAIN: [2C] sum, sumsq of this input over its own pixels */
+  float count;         /* BN_TRAIN: number of pixels the statistics were taken over */
+  float eps;
+} hrp_ew_input;
+
+typedef struct hrp_ew_desc {
+  hrp_ew_input in[HRP_EW_MAX_IN];
+  int32_t nin;
+  void* out;           /* [N, H, W, out_pitch] */
+  int32_t out_pitch;
+  int32_t dtype;
+  int32_t N, H, W, C;
+  int32_t relu;
+} hrp_ew_desc;
+
+/* Backward of one input j of an ew op.  g = dOut * (out > 0 if relu), pooled (summed) over the
+ * up x up footprint.  reduce: sums[0:C] += sum g, sums[C:2C] += sum g * xhat (BN/affine inputs).
+ * apply: din = identity: g | affine: a*g | bn_train: a*invstd*(g - sums0/count - xhat*sums1/count). */
+typedef struct hrp_ew_bwd_desc {
+  const void* dout;    /* [N, H, W, dout_pitch] */
+  const void* out;     /* forward output (relu mask), may be NULL when relu == 0 */
+  int32_t dout_pitch, out_pitch;
+  hrp_ew_input in;     /* the forward input this call differentiates (ptr = forward input values) */
+  void* din;           /* [N, H/up, W/up, din_pitch]; apply only */
+  int32_t din_pitch;
+  float* sums;         /* [2C] */
+  int32_t dtype;
+  int32_t N, H, W, C;  /* geometry of out */
+  int32_t relu;
+  int32_t accumulate;  /* apply: din += */
+} hrp_ew_bwd_desc;
+
+/* Table entry for the one-launch batch-norm bookkeeping kernels. */
+typedef struct hrp_bn_entry {
+  const float* stats;  /* forward [2C] sums (running_update) or backward sums (param_grad) */
+  float* a;            /* running_update: running_mean | fold: gamma | param_grad: dgamma */
+  float* b;            /* running_update: running_var  | fold: beta  | param_grad: dbeta  */
+  const float* c;      /* fold: running_mean */
+  const float* d;      /* fold: running_var  */
+  float* out_scale;    /* fold */
+  float* out_shift;    /* fold */
+  int64_t* counter;    /* running_update: num_batches_tracked (may be NULL) */
+  int32_t C;
+  float count, momentum, eps;
+  int32_t accumulate;  /* param_grad: += */
+} hrp_bn_entry;
+
+/* Kinematic chain descriptor for hrp_fk_project_* (built by the host from a URDF). */
+#define HRP_FK_MAX_JOINTS 32
+#define HRP_FK_MAX_KP 24
+typedef struct hrp_fk_chain {
+  int32_t njoints;                       /* joints in base->leaf order                          */
+  int32_t parent[HRP_FK_MAX_JOINTS];     /* index of the parent joint's child frame, -1 = base */
+  int32_t type[HRP_FK_MAX_JOINTS];       /* 0 fixed, 1 revolute/continuous, 2 prismatic        */
+  int32_t cfg[HRP_FK_MAX_JOINTS];        /* column of q driving the joint, -1 none             */
+  float mimic_mul[HRP_FK_MAX_JOINTS], mimic_off[HRP_FK_MAX_JOINTS];
+  float origin[HRP_FK_MAX_JOINTS][12];   /* rows of the 3x4 origin transform                   */
+  float axis[HRP_FK_MAX_JOINTS][3];      /* unit axis                                          */
+  int32_t nkp;
+  int32_t kp_frame[HRP_FK_MAX_KP];       /* joint index whose child frame carries the keypoint, -1 = base */
+  float kp_offset[HRP_FK_MAX_KP][3];
+  int32_t dof;
+} hrp_fk_chain;
+
+const char* hrp_last_error(void);
+int hrp_version(void);
+int hrp_device_ok(void);  /* 1 when the current HIP device is gfx950 */
+
+int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream);
+int hrp_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream);
+int hrp_nchw_grad_from_nhwc(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream);
+int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int max_elems, void* stream);
+
+int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream);
+int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream);
+/* out[c] (+)= sum over rows of x[rows, pitch] (bias gradients) */
+int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream);
+
+int hrp_ew_fwd(const hrp_ew_desc* d, void* stream);
+int hrp_ew_bwd_reduce(const hrp_ew_bwd_desc* d, void* stream);
+int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream);
+
+int hrp_bn_running_update(const hrp_bn_entry* table_dev, int count, void* stream);
+int hrp_bn_fold(const hrp_bn_entry* table_dev, int count, void* stream);
+int hrp_bn_param_grad(const hrp_bn_entry* table_dev, int count, void* stream);
+
+int hrp_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, int pitch, float* out, int out_pitch, void* stream);
+int hrp_avgpool_bwd(const float* dout, int dout_pitch, void* dx, int dtype, int N, int HW, int C, int pitch, int accumulate, void* stream);
+
+/* logits [B, H, W, J*D] (channel = j*D + d) -> uvd [B, J, 3] in [-0.5, 0.5); ms = saved (max, sum) [B, J, 2] */
+int hrp_softargmax3d_fwd(const void* logits, int dtype, int B, int J, int D, int H, int W, int pitch,
+                         int root, int fix_root, float* uvd, float* ms, void* stream);
+int hrp_softargmax3d_bwd(const void* logits, int dtype, int B, int J, int D, int H, int W, int pitch,
+                         int root, int fix_root, const float* uvd, const float* ms, const float* duvd,
+                         void* dlogits, int dpitch, void* stream);
+
+/* gamma [B], k_value [B], uvd [B,J,3], K [B,9] -> depth [B] (m), xyz_int [B,J,3], root_uv [B,2], trans [B,3] */
+int hrp_pose_geometry_fwd(const float* gamma, const float* k_value, const float* uvd, const float* K,
+                          int B, int J, int root, float image_size, float depth_factor,
+                          float* depth, float* xyz, float* root_uv, float* trans, void* stream);
+int hrp_pose_geometry_bwd(const float* gamma, const float* k_value, const float* uvd, const float* K,
+                          int B, int J, int root, float image_size, float depth_factor,
+                          const float* d_depth, const float* d_xyz, const float* d_root_uv, const float* d_trans,
+                          float* d_gamma, float* d_uvd, void* stream);
+
+/* q [B,dof], rot6d [B,6], trans [B,3], K [B,9] (may be NULL -> no uv) -> xyz [B,nkp,3], uv [B,nkp,2].
+ * root > 0 re-roots the chain at keypoint `root` (urdf_robot.py:194-198). One wavefront per sample. */
+int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
+                       const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream);
+int hrp_fk_project_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
+                       const float* K, int B, int root, const float* d_xyz, const float* d_uv,
+                       float* d_q, float* d_rot6d, float* d_trans, void* stream);
+
+/* small fp32 helpers used by the regression heads */
+int hrp_copy_cols(const float* src, int src_pitch, float* dst, int dst_pitch, int rows, int cols, int accumulate, void* stream);
+int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_scale, float s, void* stream);
+/* y (+)= x * m element-wise on [rows, cols] fp32 (dropout masks of the regression heads, full_net.py:98-99) */
+int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,
+                int accumulate, void* stream);
+/* point_projection_from_3d_tensor (lib/utils/transforms.py:17-21): K [B,9], pts [B,P,3] -> uv [B,P,2] */
+int hrp_project_fwd(const float* K, const float* pts, int B, int P, float* uv, void* stream);
+int hrp_project_bwd(const float* K, const float* pts, const float* duv, int B, int P, float* dpts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRP_H */

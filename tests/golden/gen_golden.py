@@ -1,0 +1,351 @@
+"""Generate the committed golden fixtures by running the REFERENCE itself on CPU.
+
+Run by hand in the build container (needs /root/reference):  ``python tests/golden/gen_golden.py``
+Writes small ``.npz`` files next to this script.  Weights come from ``synth.synth_state_dict`` and
+images from seeded numpy streams, so only small inputs/outputs are stored.
+
+Fixtures (reference call site that produced each):
+  golden_fk.npz          URDFRobot.get_keypoints / get_keypoints_root / get_rotation_at_specific_root
+                         (lib/utils/urdf_robot.py:82-199), point_projection_from_3d_tensor
+                         (lib/utils/transforms.py:17-21), autograd grads; q=0 limb lengths.
+  golden_integral.npz    HeatmapIntegralPose.forward, hrnet branch (lib/utils/integral.py:97-186).
+  golden_hrnet_eval.npz  PoseHighResolutionNet.forward eval, hm+feat (HRnet.py:499-570) + stage taps.
+  golden_depthnet.npz    RootNet('hrnet32') eval forward, and train-mode L1 loss + grads
+                         (lib/models/depth_net.py:92-137, scripts/train_depthnet.py:231-250).
+  golden_full_eval.npz   RootNetwithRegInt.forward eval 8-tuple (lib/models/full_net.py:239-397).
+  golden_full_train.npz  lib/core/function.py farward_loss(train=True): loss terms + grads + BN
+                         running stats after one step.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+rh.setup()
+import torch  # noqa: E402
+from synth import synth_inputs, synth_state_dict  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+from lib.dataset.const import INITIAL_JOINT_ANGLE, JOINT_BOUNDS, JOINT_NAMES  # noqa: E402
+from lib.models.backbones.HRnet import get_hrnet  # noqa: E402
+from lib.models.depth_net import get_rootnet  # noqa: E402
+from lib.models.full_net import RootNetwithRegInt  # noqa: E402
+from lib.utils.geometries import rotmat_to_rot6d  # noqa: E402
+from lib.utils.integral import HeatmapIntegralPose  # noqa: E402
+from lib.utils.transforms import point_projection_from_3d_tensor  # noqa: E402
+from lib.utils.urdf_robot import URDFRobot  # noqa: E402
+
+
+def sample_indices(n, count, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return np.sort(g.choice(n, size=min(count, n), replace=False))
+
+
+def summary(t, seed):
+    """mean, abs-mean and 256 sampled elements of a tensor (fixture stays small)."""
+    f = t.detach().reshape(-1).double()
+    idx = sample_indices(f.numel(), 256, seed)
+    return np.array([f.mean().item(), f.abs().mean().item()]), idx, f[idx].float().numpy()
+
+
+def random_rotations(g, n):
+    q = g.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)
+    return R.reshape(n, 3, 3).astype(np.float32)
+
+
+def gen_fk():
+    robot = URDFRobot("panda")
+    g = np.random.Generator(np.random.PCG64(1234))
+    n = 256
+    b = np.array(JOINT_BOUNDS["panda"], dtype=np.float64)
+    q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((n, 8))).astype(np.float32)
+    rot6d = (random_rotations(g, n)[:, :2, :].reshape(n, 6)
+             * g.uniform(0.5, 2.0, (n, 1)) + g.normal(0, 0.05, (n, 6))).astype(np.float32)
+    t = np.stack([g.uniform(-.3, .3, n), g.uniform(-.3, .3, n), g.uniform(.6, 2.0, n)], 1).astype(np.float32)
+    s = g.uniform(0.8, 2.5, n)
+    K = np.zeros((n, 3, 3), np.float32)
+    K[:, 0, 0] = 320 * s
+    K[:, 1, 1] = 300 * s
+    K[:, 0, 2] = 128 + g.uniform(-20, 20, n)
+    K[:, 1, 2] = 128 + g.uniform(-20, 20, n)
+    K[:, 2, 2] = 1
+    out = dict(q=q, rot6d=rot6d, t=t, K=K)
+    wx = g.normal(size=(n, 7, 3)).astype(np.float32)
+    wu = g.normal(size=(n, 7, 2)).astype(np.float32) * 1e-2
+    out["w_xyz"], out["w_uv"] = wx, wu
+    for root in (0, 3):
+        tq, tr, tt = [torch.tensor(a, requires_grad=True) for a in (q, rot6d, t)]
+        xyz = robot.get_keypoints_root(tq, tr, tt, root=root)
+        uv = point_projection_from_3d_tensor(torch.tensor(K), xyz)
+        L = (xyz * torch.tensor(wx)).sum() + (uv * torch.tensor(wu)).sum()
+        L.backward()
+        out[f"xyz_root{root}"] = xyz.detach().numpy()
+        out[f"uv_root{root}"] = uv.detach().numpy()
+        out[f"gq_root{root}"] = tq.grad.numpy()
+        out[f"grot_root{root}"] = tr.grad.numpy()
+        out[f"gt_root{root}"] = tt.grad.numpy()
+        with torch.no_grad():
+            out[f"rootrot_root{root}"] = robot.get_rotation_at_specific_root(
+                torch.tensor(q), torch.tensor(rot6d), torch.tensor(t), root=root).numpy()
+    with torch.no_grad():
+        out["fk_only"] = robot.get_keypoints_only_fk(torch.tensor(q)).numpy()
+        out["fk_q0"] = robot.get_keypoints_only_fk(torch.zeros(1, 8)).numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_fk.npz"), **out)
+    print("fk ok", out["xyz_root3"][0, :2])
+
+
+def gen_integral():
+    g = np.random.Generator(np.random.PCG64(4321))
+    B = 2
+    # logits: smooth bumps + noise so that the expectation is informative
+    out = torch.as_tensor(g.normal(0, 2.0, (B, 7 * 64, 64, 64)).astype(np.float32))
+    out[:, ::5] += 3.0
+    _, _, kv, K = synth_inputs(B, seed=99)
+    z = torch.tensor([[0.9], [1.4]])
+    layer = HeatmapIntegralPose(backbone="hrnet32", num_joints=7, depth_dim=64, height_dim=64,
+                                width_dim=64, norm_type="softmax", image_size=256.0,
+                                bbox_3d_shape=[1300, 1300, 1300], rootid=3, fixroot=True)
+    root_trans = torch.zeros(B, 3)
+    root_trans[:, 2:3] = z
+    xin = out.clone().requires_grad_(True)
+    uvd, xyz = layer(xin, root_trans=root_trans, K=K)
+    w = torch.as_tensor(g.normal(size=(B, 7, 3)).astype(np.float32))
+    (uvd * w).sum().backward()
+    gsum, gidx, gval = summary(xin.grad, 5)
+    np.savez_compressed(os.path.join(HERE, "golden_integral.npz"), seed=4321, K=K.numpy(),
+                        z_root=z.numpy(), uvd=uvd.detach().numpy(), xyz=xyz.detach().numpy(),
+                        w=w.numpy(), g_summary=gsum, g_idx=gidx, g_val=gval)
+    print("integral ok", uvd[0, 0])
+
+
+def gen_hrnet_eval():
+    m = get_hrnet(type_name=32, num_joints=7, depth_dim=64, pretrain=False, generate_feat=True,
+                  generate_hm=True)
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m.eval()
+    x, _, _, _ = synth_inputs(2)
+    taps = {}
+    hooks = []
+    for name in ["layer1", "stage2", "stage3", "stage4", "final_feat_layer"]:
+        hooks.append(getattr(m, name).register_forward_hook(
+            lambda mod, i, o, name=name: taps.__setitem__(name, o)))
+    hooks.append(m.bn2.register_forward_hook(lambda mod, i, o: taps.__setitem__("stem_bn2", o)))
+    with torch.no_grad():
+        heat, feat = m(x)
+    out = dict(feat=feat.numpy())
+    s, idx, val = summary(heat, 11)
+    out.update(heat_summary=s, heat_idx=idx, heat_val=val)
+    flat = {"stem": torch.relu(taps["stem_bn2"]), "layer1": taps["layer1"],
+            "head_map": taps["final_feat_layer"]}
+    for st in ("stage2", "stage3", "stage4"):
+        for b, t in enumerate(taps[st]):
+            flat[f"{st}_{b}"] = t
+    for k, t in flat.items():
+        s, idx, val = summary(t, 17)
+        out[f"tap_{k}_summary"], out[f"tap_{k}_idx"], out[f"tap_{k}_val"] = s, idx, val
+    np.savez_compressed(os.path.join(HERE, "golden_hrnet_eval.npz"), **out)
+    print("hrnet eval ok", feat[0, :4])
+
+
+PICK_GRADS_DEPTHNET = [
+    "backbone.conv1.weight", "backbone.bn1.weight", "backbone.layer1.0.conv2.weight",
+    "backbone.layer1.0.downsample.0.weight", "backbone.transition1.1.0.0.weight",
+    "backbone.stage2.0.branches.0.0.conv1.weight", "backbone.stage2.0.fuse_layers.0.1.0.weight",
+    "backbone.stage2.0.fuse_layers.1.0.0.0.weight", "backbone.stage3.1.branches.1.2.conv2.weight",
+    "backbone.stage3.2.branches.2.3.bn2.bias", "backbone.stage4.0.fuse_layers.3.0.1.0.weight",
+    "backbone.stage4.2.branches.3.1.conv1.weight", "backbone.stage4.2.fuse_layers.0.3.1.weight",
+    "backbone.incre_modules.2.0.conv3.weight", "backbone.downsamp_modules.1.0.weight",
+    "backbone.downsamp_modules.1.0.bias", "backbone.final_feat_layer.0.weight",
+    "backbone.final_feat_layer.1.weight", "depth_layer.weight", "depth_layer.bias",
+]
+
+
+def grad_fixture(model, names, out, tag):
+    params = dict(model.named_parameters())
+    for i, n in enumerate(names):
+        g = params[n].grad
+        s, idx, val = summary(g, 100 + i)
+        out[f"{tag}grad:{n}:summary"], out[f"{tag}grad:{n}:idx"], out[f"{tag}grad:{n}:val"] = s, idx, val
+
+
+def gen_depthnet():
+    m = get_rootnet("hrnet32")
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    x, _, kv, _ = synth_inputs(2)
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        out["depth_eval"] = m(x, kv).numpy()
+    # one train_depthnet step: pred/1000 vs gt, L1 (train_depthnet.py:231-250)
+    m.train()
+    gt = torch.tensor([[1.1], [0.7]])
+    pred = m(x, kv) / 1000.0
+    loss = torch.nn.L1Loss()(pred, gt)
+    loss.backward()
+    out["depth_train"] = pred.detach().numpy()
+    out["loss"] = np.array(loss.item())
+    out["gt_depth"] = gt.numpy()
+    grad_fixture(m, PICK_GRADS_DEPTHNET, out, "")
+    sd = m.state_dict()
+    for n in ["backbone.bn1.running_mean", "backbone.bn1.running_var",
+              "backbone.stage4.2.branches.3.3.bn2.running_var",
+              "backbone.final_feat_layer.1.running_mean"]:
+        out["buf:" + n] = sd[n][:64].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_depthnet.npz"), **out)
+    print("depthnet ok", out["depth_eval"].ravel(), out["loss"])
+
+
+def build_full():
+    args = rh.default_args()
+    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE,
+            "cam_params": np.eye(4, dtype=float), "init_pose_from_mean": True}
+    full = RootNetwithRegInt(init, args)
+    full.load_state_dict(synth_state_dict(full.state_dict()))
+    return full, args
+
+
+NAMES8 = ["pose", "rot", "trans", "root_uv", "depth", "uvd", "xyz_int", "xyz_fk"]
+
+
+def gen_full_eval():
+    full, _ = build_full()
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval.npz"),
+                        **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval ok", o[0][0, :3])
+
+
+def make_batch(B, robot, seed=2024):
+    """A DreamDataset-shaped batch (lib/dataset/dream.py:393-413) from synthetic poses."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    img_reg = g.integers(0, 256, (B, 3, 256, 256)).astype(np.float32)
+    img_root = g.integers(0, 256, (B, 3, 256, 256)).astype(np.float32)
+    b = np.array(JOINT_BOUNDS["panda"], dtype=np.float64)
+    q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((B, 8))).astype(np.float32)
+    R = random_rotations(g, B)
+    t = np.stack([g.uniform(-.3, .3, B), g.uniform(-.3, .3, B), g.uniform(.8, 2.0, B)], 1).astype(np.float32)
+    TCO = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    TCO[:, :3, :3] = R
+    TCO[:, :3, 3] = t
+    s = g.uniform(0.8, 2.5, B).astype(np.float32)
+    K = np.zeros((B, 3, 3), np.float32)
+    K[:, 0, 0] = K[:, 1, 1] = 320 * s
+    K[:, 0, 2] = K[:, 1, 2] = 128
+    K[:, 2, 2] = 1
+    side = g.uniform(80, 240, B).astype(np.float32)
+    bbox = np.stack([128 - side / 2, 128 - side / 2 * 0.8, 128 + side / 2, 128 + side / 2 * 0.8], 1).astype(np.float32)
+    rot6d = rotmat_to_rot6d(torch.tensor(R))
+    with torch.no_grad():
+        kp3d = robot.get_keypoints(torch.tensor(q), rot6d, torch.tensor(t))
+        kp2d = point_projection_from_3d_tensor(torch.tensor(K), kp3d)
+    mask = np.ones((B, 7), np.float32)
+    mask[0, 5] = 0.0
+    jointpose = {n: [float(q[i, j]) for i in range(B)] for j, n in enumerate(JOINT_NAMES["panda"])}
+    batch = {
+        "root": {"images": torch.tensor(img_root), "K": torch.tensor(K),
+                 "bbox_strict_bounded": torch.tensor(bbox), "bbox_gt2d_extended": torch.tensor(bbox)},
+        "other": {"images": torch.tensor(img_reg), "K": torch.tensor(K), "keypoints_2d": kp2d,
+                  "valid_mask_crop": torch.tensor(mask), "keypoints_3d": kp3d},
+        "TCO": torch.tensor(TCO), "K_original": torch.tensor(K), "jointpose": jointpose,
+        "keypoints_2d_original": kp2d.clone(), "valid_mask": torch.tensor(mask),
+    }
+    small = dict(q=q, R=R, t=t, K=K, bbox=bbox, kp3d=kp3d.numpy(), kp2d=kp2d.numpy(), mask=mask)
+    return batch, small
+
+
+PICK_GRADS_FULL = [
+    "reg_backbone.conv1.weight", "reg_backbone.final_layer.weight", "reg_backbone.final_layer.bias",
+    "reg_backbone.stage3.0.branches.0.1.conv1.weight", "reg_backbone.stage4.1.fuse_layers.2.0.0.0.weight",
+    "reg_backbone.stage4.2.fuse_layers.0.1.0.weight", "reg_backbone.incre_modules.0.0.conv1.weight",
+    "rootnet_backbone.conv1.weight", "rootnet_backbone.stage2.0.branches.1.3.bn2.weight",
+    "rootnet_backbone.final_feat_layer.0.weight", "fc_pose_1.weight", "fc_pose_2.bias",
+    "decpose.weight", "fc_rot_1.weight", "decrot.bias", "depth_layer.weight", "depth_layer.bias",
+]
+
+
+def import_reference_step_function():
+    """lib/core/function.py pulls in cv2 / kornia / torchnet / tensorboard and BPnP.py:2 runs a CUDA
+    op at import; none of that is on the synthetic-data path, so those modules are replaced by
+    shells.  ``cast`` is the reference's own two-liner (lib/utils/utils.py:18-29: ``obj.to(device)``)."""
+    bp = types.ModuleType("lib.utils.BPnP")
+    bp.BPnP_m3d = None
+    sys.modules["lib.utils.BPnP"] = bp
+    mt = types.ModuleType("lib.utils.metrics")
+    mt.compute_metrics_batch = mt.summary_add_pck = None
+    sys.modules["lib.utils.metrics"] = mt
+    ut = types.ModuleType("lib.utils.utils")
+    ut.cast = lambda obj, device, dtype=None: obj.to(device)
+    sys.modules["lib.utils.utils"] = ut
+    tn = types.ModuleType("torchnet")
+    tm = types.ModuleType("torchnet.meter")
+    tm.AverageValueMeter = object
+    sys.modules["torchnet"], sys.modules["torchnet.meter"] = tn, tm
+    from lib.core import function
+    return function
+
+
+def gen_full_train():
+    function = import_reference_step_function()
+    full, margs = build_full()
+    B = 2
+    batch, small = make_batch(B, full.robot)
+    args = rh._AttrDict(dict(margs))
+    args.update(urdf_robot_name="panda", use_origin_bbox=False, use_extended_bbox=True,
+                train_ds_names="dream/synthetic/panda_synth_train_dr", use_joint_valid_mask=False,
+                known_joint=False, joint_individual_weights=None, image_size=256.0, fix_mask=False,
+                pose_loss_func="mse", rot_loss_func="mse", trans_loss_func="l2norm",
+                depth_loss_func="l1", uv_loss_func="l2norm", kp2d_loss_func="l2norm",
+                kp3d_loss_func="l2norm", kp2d_int_loss_func="l2norm", kp3d_int_loss_func="l2norm",
+                align_3d_loss_func="l2norm", pose_loss_weight=1.0, rot_loss_weight=1.0,
+                trans_loss_weight=1.0, depth_loss_weight=10.0, uv_loss_weight=1.0,
+                kp2d_loss_weight=10.0, kp3d_loss_weight=10.0, kp2d_int_loss_weight=10.0,
+                kp3d_int_loss_weight=10.0, align_3d_loss_weight=0.0)
+    loss, terms = function.farward_loss(args, batch, full, full.robot, "cpu", [0], train=True)
+    loss.backward()
+    out = {"loss": np.array(loss.item())}
+    for k, v in terms.items():
+        out["term:" + k] = np.array(v.item())
+    out.update({"in:" + k: v for k, v in small.items()})
+    grad_fixture(full, PICK_GRADS_FULL, out, "")
+    sd = full.state_dict()
+    for n in ["reg_backbone.bn1.running_mean", "rootnet_backbone.stage4.2.branches.3.3.bn2.running_var"]:
+        out["buf:" + n] = sd[n][:64].numpy()
+    # the forward outputs of the same train-mode call, for localisation of a mismatch
+    full.zero_grad()
+    sd0 = synth_state_dict(full.state_dict())
+    full.load_state_dict(sd0)
+    full.train()
+    x_reg = batch["other"]["images"].float() / 255.
+    x_root = batch["root"]["images"].float() / 255.
+    fx = small["K"][:, 0, 0]
+    area = np.maximum(np.abs(small["bbox"][:, 2] - small["bbox"][:, 0]),
+                      np.abs(small["bbox"][:, 3] - small["bbox"][:, 1])) ** 2
+    kv = torch.tensor(np.sqrt(fx * fx * 1000.0 * 1000.0 / area).astype(np.float32))
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, torch.tensor(small["K"]))
+    for n, t in zip(NAMES8, o):
+        out["fwd:" + n] = t.numpy()
+    out["k_values"] = kv.numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_full_train.npz"), **out)
+    print("full train ok", out["loss"], {k: float(v) for k, v in terms.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["fk", "integral", "hrnet_eval", "depthnet", "full_eval", "full_train"]
+    for w in which:
+        globals()["gen_" + w]()

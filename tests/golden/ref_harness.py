@@ -1,0 +1,152 @@
+"""Import the reference HoRoPose code on CPU, in THIS container only, to produce golden vectors.
+
+Used by ``gen_golden.py`` (run by hand where ``/root/reference`` exists).  Nothing in the
+``-m gpu`` tests, ``smoke()`` or ``bench.py`` imports this file: the GPU box has no reference tree.
+
+What it does:
+  * scratch cwd with ``lib -> /root/reference/lib`` and a writable ``data/`` holding the
+    kinematics-only Panda URDF this repo authors (assets/panda_kinematics.urdf);
+  * ``sys.modules`` stubs for the third-party packages that are absent here and carry no
+    hot-path arithmetic (URDF XML parsing goes to xml.etree, the rest are empty shells);
+  * ``torch.Tensor.cuda`` -> identity (the reference hard-codes ``.cuda()``);
+  * no pretrained files: HRNet ``PRETRAINED`` blanked, ``ResNet.init_weights`` no-op.
+"""
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+REFERENCE_ROOT = os.environ.get("HRP_REFERENCE_ROOT", "/root/reference")
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PANDA_URDF = os.path.join(REPO_ROOT, "holistic-robot-pose-estimation_amd", "assets",
+                          "panda_kinematics.urdf")
+
+
+class _AttrDict(dict):
+    """easydict stand-in: nested attribute access."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {}, **kw)
+        for k, v in d.items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, _AttrDict):
+            v = _AttrDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _install_stubs():
+    import xml.etree.ElementTree as ET
+
+    _stub("easydict", EasyDict=_AttrDict)
+
+    class _Parser:
+        def __init__(self, **kw):
+            pass
+
+    def _parse(path, parser=None):
+        return ET.parse(path)
+
+    etree = _stub("lxml.etree", XMLParser=_Parser, parse=_parse, Element=ET.Element,
+                  tostring=ET.tostring, fromstring=ET.fromstring, ElementTree=ET.ElementTree,
+                  SubElement=ET.SubElement)
+    _stub("lxml", etree=etree)
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    _stub("trimesh", Trimesh=_Any, Scene=_Any, load=lambda *a, **k: None)
+    _stub("pyrender")
+    names = ["RasterizationSettings", "MeshRenderer", "MeshRasterizer", "BlendParams",
+             "SoftSilhouetteShader", "HardPhongShader", "PointLights", "TexturesVertex",
+             "PerspectiveCameras", "Textures"]
+    _stub("pytorch3d")
+    _stub("pytorch3d.io", load_obj=lambda *a, **k: None)
+    _stub("pytorch3d.structures", Meshes=_Any)
+    _stub("pytorch3d.renderer", **{n: _Any for n in names})
+
+    class _ERobot:
+        def __init__(self, *a, **k):
+            pass
+
+        def URDF_read(self, f):
+            return [], "panda", "", f
+
+    _stub("roboticstoolbox")
+    _stub("roboticstoolbox.robot")
+    _stub("roboticstoolbox.robot.ERobot", ERobot=_ERobot)
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", ColorJitter=_Any, Compose=_Any)
+    tv.ops = _stub("torchvision.ops")
+    tv.models = _stub("torchvision.models")
+    tv.transforms.functional = _stub("torchvision.transforms.functional")
+
+
+_SCRATCH = None
+
+
+def setup():
+    """Prepare scratch cwd, stubs and patches; return the scratch path."""
+    global _SCRATCH
+    if _SCRATCH is not None:
+        return _SCRATCH
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    import torch
+
+    scratch = tempfile.mkdtemp(prefix="hrp_ref_")
+    os.symlink(os.path.join(REFERENCE_ROOT, "lib"), os.path.join(scratch, "lib"))
+    dep = os.path.join(scratch, "data", "deps", "panda-description")
+    os.makedirs(os.path.join(dep, "patched_urdf"))
+    shutil.copy(PANDA_URDF, os.path.join(dep, "panda.urdf"))
+    shutil.copy(PANDA_URDF, os.path.join(dep, "patched_urdf", "panda.urdf"))
+    os.chdir(scratch)
+    sys.path.insert(0, scratch)
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    from lib.models.backbones import HRnet, Resnet
+
+    _orig = HRnet.load_hrnet_cfg
+
+    def _load(file_name):
+        cfg = _orig(file_name)
+        cfg["MODEL"]["PRETRAINED"] = ""
+        return cfg
+
+    HRnet.load_hrnet_cfg = _load
+    Resnet.ResNet.init_weights = lambda self, *a, **k: None
+    _SCRATCH = scratch
+    return scratch
+
+
+def default_args(**over):
+    """The model-relevant keys of lib/core/config.py:8-133 with configs/panda/full.yaml values."""
+    a = _AttrDict(backbone_name="hrnet32", rootnet_backbone_name="hrnet32", other_image_size=256.0,
+                  use_rpmg=False, n_iter=4, p_dropout=0.0, reg_joint_map=False, joint_conv_dim=[],
+                  rotation_dim=6, direct_reg_rot=False, rot_iterative_matmul=False, fix_root=True,
+                  bbox_3d_shape=[1300, 1300, 1300], reference_keypoint_id=3, add_fc=False,
+                  multi_kp=False, kps_need_depth=None, pretrained_rootnet=None)
+    a.update(over)
+    return a

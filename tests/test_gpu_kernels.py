@@ -1,0 +1,275 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against the CPU oracle / plain torch fp32.
+
+Tolerances: fp32 path - summation-order differences only (1e-4 relative to the tensor's scale);
+bf16 path - operands rounded to 8 mantissa bits, fp32 accumulation (3e-2 relative to the scale).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, PANDA_URDF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 4e-2
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, H, W, N, bias
+    (3, 64, 3, 2, 64, 64, 2, False),       # stem conv1 (3 input channels, padded to 8)
+    (64, 64, 3, 2, 32, 32, 2, False),      # stem conv2
+    (32, 32, 3, 1, 64, 64, 2, False),      # branch 0 BasicBlock conv
+    (64, 64, 3, 1, 32, 32, 2, False),
+    (128, 128, 3, 1, 16, 16, 2, False),
+    (256, 256, 3, 1, 8, 8, 2, False),
+    (256, 32, 3, 1, 16, 16, 1, False),     # transition1.0
+    (32, 64, 3, 2, 32, 32, 2, False),      # fuse down path
+    (128, 32, 1, 1, 16, 16, 2, False),     # fuse up path 1x1
+    (32, 448, 1, 1, 16, 16, 1, True),      # final_layer (heat-map conv, bias)
+    (128, 256, 3, 2, 16, 16, 2, True),     # cls-head downsample (bias)
+    (256, 512, 1, 1, 8, 8, 2, True),       # final_feat_layer-like
+    (64, 256, 1, 1, 20, 12, 1, False),     # layer1 1x1, ragged spatial size
+    (32, 32, 3, 1, 13, 9, 3, False),       # ragged everything
+    (64, 64, 3, 2, 13, 9, 3, False),       # ragged stride 2 (odd sizes)
+    (32, 32, 3, 1, 1, 1, 5, False),        # degenerate 1x1 image
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, dtype):
+    from hrpe_amd.lib.models.backbones.HRnet import Conv2d
+    cin, cout, k, stride, H, W, N, bias = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    conv = Conv2d(cin, cout, k, stride=stride, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / np.sqrt(cin * k * k))
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = torch.randn(N, cin, H, W, generator=g)
+    # CPU reference (plain torch fp32)
+    wr = conv.weight.detach().clone().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True) if bias else None
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    # HIP
+    conv = conv.to(DEV).set_compute_dtype(dtype)
+    xd = x.to(DEV).requires_grad_(True)
+    y = conv(xd)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < tol(dtype), f"fwd {rel_err(y, yr)}"
+    (y * gy.to(DEV)).sum().backward()
+    assert rel_err(xd.grad, xr.grad) < tol(dtype), f"dgrad {rel_err(xd.grad, xr.grad)}"
+    assert rel_err(conv.weight.grad, wr.grad) < tol(dtype), f"wgrad {rel_err(conv.weight.grad, wr.grad)}"
+    if bias:
+        assert rel_err(conv.bias.grad, br.grad) < tol(dtype), f"bias grad {rel_err(conv.bias.grad, br.grad)}"
+
+
+def _load_into(module, sd_cpu):
+    module.load_state_dict({k: v.clone() for k, v in sd_cpu.items()})
+    return module
+
+
+def _rand_sd(module, seed):
+    from synth import synth_state_dict
+    sd = synth_state_dict({f"s{seed}." + k: v for k, v in module.state_dict().items()})
+    return {k.split(".", 1)[1]: v for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("kind", ["basic", "bottleneck", "bottleneck_ds"])
+def test_residual_blocks(kind, training, dtype):
+    """BasicBlock / Bottleneck (reference HRnet.py:28-98) forward + backward, eval (folded BN, fused
+    epilogue) and train (batch statistics, running-stat update)."""
+    from hrpe_amd.lib.models.backbones import HRnet as H
+    from oracle import hrnet as O
+    if kind == "basic":
+        m, cin = H.BasicBlock(32, 32), 32
+        ofn = O._basic_block
+    elif kind == "bottleneck":
+        m, cin = H.Bottleneck(128, 32), 128
+        ofn = O._bottleneck
+    else:
+        m, cin = H.Bottleneck(64, 32, downsample=H._Downsample(64, 128, 1)), 64
+        ofn = O._bottleneck
+    sd = _rand_sd(m, 3)
+    _load_into(m, sd)
+    x = torch.randn(3, cin, 20, 12, generator=torch.Generator().manual_seed(5))
+    # oracle
+    osd = {"b." + k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ctx = O._Ctx(osd, "", training)
+    yr = ofn(ctx, "b", xr)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(6))
+    m = m.to(DEV).set_compute_dtype(dtype)
+    m.train(training)
+    if not training:
+        with torch.no_grad():
+            y = m(x.to(DEV))
+        assert rel_err(y, yr) < tol(dtype), f"eval fwd {rel_err(y, yr)}"
+        return
+    (yr * gy).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    y = m(xd)
+    assert rel_err(y, yr) < tol(dtype), f"train fwd {rel_err(y, yr)}"
+    (y * gy.to(DEV)).sum().backward()
+    t = tol(dtype) * (5 if dtype == torch.float32 else 2)
+    assert rel_err(xd.grad, xr.grad) < t, f"dx {rel_err(xd.grad, xr.grad)}"
+    params = dict(m.named_parameters())
+    for k, v in osd.items():
+        name = k[2:]
+        if v.grad is not None:
+            assert rel_err(params[name].grad, v.grad) < t, f"grad {name} {rel_err(params[name].grad, v.grad)}"
+    bufs = dict(m.named_buffers())
+    for k, v in osd.items():
+        if "running" in k:
+            assert rel_err(bufs[k[2:]], v) < tol(dtype), f"buffer {k}"
+        if k.endswith("num_batches_tracked"):
+            assert int(bufs[k[2:]].item()) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+def test_hr_module_fuse(training, dtype):
+    """HighResolutionModule with 3 branches: branch blocks + the all-to-all fuse (1x1 conv + BN + nearest
+    upsample, chains of stride-2 convs, sum, ReLU; reference HRnet.py:187-265)."""
+    from hrpe_amd.lib.models.backbones import HRnet as H
+    from oracle import hrnet as O
+    m = H.HighResolutionModule(3, H.BasicBlock, [4, 4, 4], [32, 64, 128], [32, 64, 128], "SUM", True)
+    sd = _rand_sd(m, 9)
+    _load_into(m, sd)
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(2, 32, 16, 16, generator=g), torch.randn(2, 64, 8, 8, generator=g), torch.randn(2, 128, 4, 4, generator=g)]
+    osd = {"m." + k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    yr = O._hr_module(O._Ctx(osd, "", training), "m", xr)
+    m = m.to(DEV).set_compute_dtype(dtype)
+    m.train(training)
+    if not training:
+        with torch.no_grad():
+            ys = m([x.to(DEV) for x in xs])
+        for a, b in zip(ys, yr):
+            assert rel_err(a, b) < tol(dtype) * 2
+        return
+    gys = [torch.randn(y.shape, generator=g) for y in yr]
+    sum((y * gy).sum() for y, gy in zip(yr, gys)).backward()
+    xd = [x.to(DEV).requires_grad_(True) for x in xs]
+    ys = m(xd)
+    for a, b in zip(ys, yr):
+        assert rel_err(a, b) < tol(dtype) * 2, f"fwd {rel_err(a, b)}"
+    sum((y * gy.to(DEV)).sum() for y, gy in zip(ys, gys)).backward()
+    t = tol(dtype) * (10 if dtype == torch.float32 else 3)
+    for a, b in zip(xd, xr):
+        assert rel_err(a.grad, b.grad) < t, f"dx {rel_err(a.grad, b.grad)}"
+    params = dict(m.named_parameters())
+    worst = max(rel_err(params[k[2:]].grad, v.grad) for k, v in osd.items() if v.grad is not None)
+    assert worst < t, f"param grads {worst}"
+
+
+def test_softargmax_golden_and_backward():
+    """One-pass 3-D soft-argmax against the reference fixture (HeatmapIntegralPose, integral.py:147-186)."""
+    from hrpe_amd.lib.utils.integral import HeatmapIntegralPose
+    g = np.load(os.path.join(GOLDEN, "golden_integral.npz"))
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    out = torch.as_tensor(rng.normal(0, 2.0, (2, 7 * 64, 64, 64)).astype(np.float32))
+    out[:, ::5] += 3.0
+    layer = HeatmapIntegralPose(backbone="hrnet32", num_joints=7, depth_dim=64, height_dim=64, width_dim=64,
+                                norm_type="softmax", image_size=256.0, bbox_3d_shape=[1300, 1300, 1300], rootid=3,
+                                fixroot=True)
+    root_trans = torch.zeros(2, 3)
+    root_trans[:, 2:3] = torch.tensor(g["z_root"])
+    xin = out.to(DEV).requires_grad_(True)
+    uvd, xyz = layer(xin, root_trans=root_trans.to(DEV), K=torch.tensor(g["K"]).to(DEV))
+    np.testing.assert_allclose(uvd.detach().cpu().numpy(), g["uvd"], atol=2e-6)
+    np.testing.assert_allclose(xyz.detach().cpu().numpy(), g["xyz"], atol=5e-6)
+    (uvd * torch.tensor(g["w"]).to(DEV)).sum().backward()
+    f = xin.grad.detach().cpu().reshape(-1).double()
+    np.testing.assert_allclose(f.abs().mean().item(), g["g_summary"][1], rtol=1e-4)
+    np.testing.assert_allclose(f[g["g_idx"]].float().numpy(), g["g_val"], rtol=2e-4, atol=1e-11)
+
+
+def test_softargmax_bf16_and_peaked():
+    """bf16 logits, and a near one-hot heat-map (online-softmax rescale branch with a huge late maximum)."""
+    from hrpe_amd.lib.utils.integral import HeatmapIntegralPose
+    from oracle import heads
+    layer = HeatmapIntegralPose(backbone="hrnet32", num_joints=7, depth_dim=64, height_dim=64, width_dim=64,
+                                norm_type="softmax", image_size=256.0, bbox_3d_shape=[1300, 1300, 1300], rootid=3,
+                                fixroot=True)
+    g = torch.Generator().manual_seed(3)
+    out = torch.randn(1, 448, 64, 64, generator=g)
+    out[0, 64 * 2 + 17, 40, 63] = 80.0      # joint 2: spike at the very end of the scan order
+    out[0, 64 * 5 + 3, 0, 0] = -90.0
+    K = torch.tensor([[[400.0, 0, 128], [0, 380, 120], [0, 0, 1]]])
+    z = torch.tensor([[1.2]])
+    uvd_ref = heads.soft_argmax_uvd(out)
+    rt = torch.zeros(1, 3)
+    rt[:, 2:3] = z
+    uvd, _ = layer(out.to(DEV), root_trans=rt.to(DEV), K=K.to(DEV))
+    np.testing.assert_allclose(uvd.cpu().numpy(), uvd_ref.numpy(), atol=2e-6)
+    layer.set_compute_dtype(torch.bfloat16)
+    outb = out.bfloat16().float()
+    uvd_ref = heads.soft_argmax_uvd(outb)
+    uvd, _ = layer(outb.to(DEV), root_trans=rt.to(DEV), K=K.to(DEV))
+    np.testing.assert_allclose(uvd.cpu().numpy(), uvd_ref.numpy(), atol=2e-6)
+
+
+def test_fk_golden():
+    """FK kernel against the reference fixture: keypoints, projection, gradients, root rotation, q=0 limbs."""
+    from hrpe_amd.lib.utils.transforms import point_projection_from_3d_tensor
+    from hrpe_amd.lib.utils.urdf_robot import URDFRobot
+    g = np.load(os.path.join(GOLDEN, "golden_fk.npz"))
+    robot = URDFRobot("panda", urdf_path=PANDA_URDF)
+    q, r, t, K = [torch.tensor(g[k]).to(DEV) for k in ("q", "rot6d", "t", "K")]
+    p0 = robot.get_keypoints_only_fk(torch.zeros(1, 8, device=DEV))[0].cpu()
+    np.testing.assert_allclose(torch.norm(p0[1:] - p0[:-1], dim=1).numpy(),
+                               [0.3330, 0.3160, 0.0825, 0.39276, 0.0880, 0.1070], atol=2e-5)
+    np.testing.assert_allclose(robot.get_keypoints_only_fk(q).cpu().numpy(), g["fk_only"], atol=2e-6)
+    for root in (0, 3):
+        tq, tr, tt = [x.clone().requires_grad_(True) for x in (q, r, t)]
+        xyz = robot.get_keypoints_root(tq, tr, tt, root=root)
+        uv = point_projection_from_3d_tensor(K, xyz)
+        np.testing.assert_allclose(xyz.detach().cpu().numpy(), g[f"xyz_root{root}"], atol=3e-6)
+        # north-star gate: projected keypoints within 1e-3 px of the reference
+        assert np.abs(uv.detach().cpu().numpy() - g[f"uv_root{root}"]).max() < 1e-3
+        ((xyz * torch.tensor(g["w_xyz"]).to(DEV)).sum() + (uv * torch.tensor(g["w_uv"]).to(DEV)).sum()).backward()
+        for name, x in (("gq", tq), ("grot", tr), ("gt", tt)):
+            ref = g[f"{name}_root{root}"]
+            np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=3e-4 * max(1.0, np.abs(ref).max()), rtol=2e-3)
+        rr = robot.get_rotation_at_specific_root(q, r, t, root=root)
+        np.testing.assert_allclose(rr.cpu().numpy(), g[f"rootrot_root{root}"], atol=3e-6)
+        xyz2, uv2 = robot.get_keypoints_and_projection(q, r, t, K, root=root)
+        assert np.abs(uv2.cpu().numpy() - g[f"uv_root{root}"]).max() < 1e-3
+
+
+def test_c_abi_rejects_bad_descriptors():
+    """Error behaviour of the C ABI: bad arguments return HRP_ERR_ARG with a message, nothing launches."""
+    import ctypes as C
+    from hrpe_amd import _native as nv
+    d = nv.ConvDesc()
+    rc = nv.lib().hrp_conv2d_fwd(C.byref(d), None)
+    assert rc == -1 and b"null" in nv.lib().hrp_last_error()
+    x = torch.zeros(64, device=DEV)
+    d.x = d.w = d.y = x.data_ptr()
+    d.ntaps = 99
+    assert nv.lib().hrp_conv2d_fwd(C.byref(d), None) == -1
+    assert nv.lib().hrp_device_ok() == 1

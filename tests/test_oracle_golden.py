@@ -1,0 +1,186 @@
+"""CPU: the oracle (oracle/*.py) against every golden fixture produced by the reference itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PANDA_URDF
+from oracle import fk, heads, hrnet
+from synth import synth_inputs, synth_state_dict
+
+torch.set_num_threads(8)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def check_summary(t, g, key, rtol, atol):
+    f = t.detach().reshape(-1).double()
+    s = g[key + "summary"] if (key + "summary") in g else g[key + "_summary"]
+    idx = g[key + "idx"] if (key + "idx") in g else g[key + "_idx"]
+    val = g[key + "val"] if (key + "val") in g else g[key + "_val"]
+    np.testing.assert_allclose(f.abs().mean().item(), s[1], rtol=rtol)
+    np.testing.assert_allclose(f[idx].float().numpy(), val, rtol=rtol, atol=atol)
+
+
+def hrnet_shapes(prefix="", hm=True, feat=True, depth_dim=64):
+    """State-dict key -> shape of the reference HRNet-W32 (built from the product module tree)."""
+    from hrpe_amd.lib.models.backbones.HRnet import get_hrnet
+    m = get_hrnet(32, 7, depth_dim, pretrain=False, generate_feat=feat, generate_hm=hm)
+    return {prefix + k: v for k, v in m.state_dict().items()}
+
+
+@pytest.fixture(scope="module")
+def robot():
+    return fk.Robot(PANDA_URDF)
+
+
+def test_fk_known_answer_limb_lengths(robot):
+    """Weights-free known answer: FK at q=0 reproduces PANDA_LIMB_LENGTH (reference const.py:100-107)."""
+    p = robot.get_keypoints_only_fk(torch.zeros(1, 8))[0]
+    d = torch.norm(p[1:] - p[:-1], dim=1).numpy()
+    np.testing.assert_allclose(d, [0.3330, 0.3160, 0.0825, 0.39276, 0.0880, 0.1070], atol=2e-5)
+
+
+def test_fk_golden(robot):
+    g = load("golden_fk.npz")
+    q, r, t, K = [torch.tensor(g[k]) for k in ("q", "rot6d", "t", "K")]
+    np.testing.assert_allclose(robot.get_keypoints_only_fk(q).numpy(), g["fk_only"], atol=1e-6)
+    np.testing.assert_allclose(robot.get_keypoints_only_fk(torch.zeros(1, 8)).numpy(), g["fk_q0"], atol=1e-7)
+    for root in (0, 3):
+        tq, tr, tt = [x.clone().requires_grad_(True) for x in (q, r, t)]
+        xyz = robot.get_keypoints_root(tq, tr, tt, root=root)
+        uv = fk.project(K, xyz)
+        np.testing.assert_allclose(xyz.detach().numpy(), g[f"xyz_root{root}"], atol=2e-6)
+        np.testing.assert_allclose(uv.detach().numpy(), g[f"uv_root{root}"], atol=2e-3, rtol=1e-5)
+        ((xyz * torch.tensor(g["w_xyz"])).sum() + (uv * torch.tensor(g["w_uv"])).sum()).backward()
+        for name, x in (("gq", tq), ("grot", tr), ("gt", tt)):
+            ref = g[f"{name}_root{root}"]
+            np.testing.assert_allclose(x.grad.numpy(), ref, atol=2e-4 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+        rr = robot.get_rotation_at_specific_root(q, r, t, root=root)
+        np.testing.assert_allclose(rr.numpy(), g[f"rootrot_root{root}"], atol=2e-6)
+
+
+def test_integral_golden():
+    g = load("golden_integral.npz")
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    out = torch.as_tensor(rng.normal(0, 2.0, (2, 7 * 64, 64, 64)).astype(np.float32))
+    out[:, ::5] += 3.0
+    out.requires_grad_(True)
+    uvd = heads.soft_argmax_uvd(out)
+    xyz = heads.uvd_to_xyz(uvd, torch.tensor(g["K"]), torch.tensor(g["z_root"]))
+    np.testing.assert_allclose(uvd.detach().numpy(), g["uvd"], atol=1e-6)
+    np.testing.assert_allclose(xyz.detach().numpy(), g["xyz"], atol=1e-6)
+    (uvd * torch.tensor(g["w"])).sum().backward()
+    check_summary(out.grad, g, "g_", rtol=1e-4, atol=1e-12)
+
+
+def test_hrnet_eval_golden():
+    g = load("golden_hrnet_eval.npz")
+    sd = synth_state_dict(hrnet_shapes())
+    x, _, _, _ = synth_inputs(2)
+    taps = {}
+    with torch.no_grad():
+        heat, feat = hrnet.hrnet_w32_forward(sd, x, taps=taps)
+    np.testing.assert_allclose(feat.numpy(), g["feat"], atol=1e-6)
+    check_summary(heat, g, "heat_", rtol=1e-6, atol=1e-6)
+    flat = {"stem": taps["stem"], "layer1": taps["layer1"], "head_map": taps["head_map"]}
+    for st in ("stage2", "stage3", "stage4"):
+        for b, t in enumerate(taps[st]):
+            flat[f"{st}_{b}"] = t
+    for k, t in flat.items():
+        check_summary(t, g, f"tap_{k}_", rtol=1e-6, atol=1e-6)
+
+
+def depthnet_sd():
+    shapes = hrnet_shapes("backbone.", hm=False, feat=True)
+    shapes["depth_layer.weight"] = torch.empty(1, 2048, 1, 1)
+    shapes["depth_layer.bias"] = torch.empty(1)
+    return synth_state_dict(shapes)
+
+
+def test_depthnet_golden():
+    g = load("golden_depthnet.npz")
+    sd = depthnet_sd()
+    x, _, kv, _ = synth_inputs(2)
+    with torch.no_grad():
+        d = heads.rootnet_forward(sd, x, kv)
+    np.testing.assert_allclose(d.numpy(), g["depth_eval"], rtol=1e-6)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    pred = heads.rootnet_forward(sd, x, kv, training=True) / 1000.0
+    loss = torch.nn.functional.l1_loss(pred, torch.tensor(g["gt_depth"]))
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().numpy(), g["depth_train"], rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            check_summary(sd[name].grad, g, f"grad:{name}:", rtol=2e-3, atol=1e-9)
+        if key.startswith("buf:"):
+            np.testing.assert_allclose(sd[key[4:]][:64].detach().numpy(), g[key], rtol=1e-5, atol=1e-7)
+
+
+def full_sd():
+    shapes = {}
+    shapes.update(hrnet_shapes("reg_backbone.", hm=True, feat=True))
+    shapes.update(hrnet_shapes("rootnet_backbone.", hm=False, feat=True))
+    for n, (o, i) in {"fc_pose_1": (1024, 2056), "fc_pose_2": (1024, 1024), "decpose": (8, 1024),
+                      "fc_rot_1": (1024, 2054), "fc_rot_2": (1024, 1024), "decrot": (6, 1024)}.items():
+        shapes[n + ".weight"] = torch.empty(o, i)
+        shapes[n + ".bias"] = torch.empty(o)
+    shapes["depth_layer.weight"] = torch.empty(1, 2048, 1, 1)
+    shapes["depth_layer.bias"] = torch.empty(1)
+    # reference const.py:168-178 mean pose / identity camera rotation (full_net.py:179-192)
+    shapes["init_pose"] = torch.tensor([[0.0, 0.0, 0.0, -1.52715, 0.0, 1.8675, 0.0, 0.02]])
+    shapes["init_rot"] = torch.tensor([[1.0, 0.0, 0.0, 0.0, 1.0, 0.0]])
+    return synth_state_dict(shapes)
+
+
+NAMES8 = ["pose", "rot", "trans", "root_uv", "depth", "uvd", "xyz_int", "xyz_fk"]
+
+
+def test_full_eval_golden(robot):
+    g = load("golden_full_eval.npz")
+    sd = full_sd()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K)
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
+def test_full_train_golden(robot):
+    """One reference training step (lib/core/function.py farward_loss, train=True): loss terms,
+    gradients and BN running stats."""
+    g = load("golden_full_train.npz")
+    sd = full_sd()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
+            v.requires_grad_(True)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.
+    x_root = torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.
+    K = torch.tensor(g["in:K"])
+    kv = torch.tensor(g["k_values"])
+    q, R, t = torch.tensor(g["in:q"]), torch.tensor(g["in:R"]), torch.tensor(g["in:t"])
+    kp3d, kp2d, mask = torch.tensor(g["in:kp3d"]), torch.tensor(g["in:kp2d"]), torch.tensor(g["in:mask"])
+    gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, fk.rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    pred = heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=True)
+    for n, p in zip(NAMES8, pred):
+        np.testing.assert_allclose(p.detach().numpy(), g["fwd:" + n], rtol=2e-4, atol=2e-5, err_msg=n)
+    loss, terms = heads.full_loss(pred, gt, K)
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g["term:" + k], rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    loss.backward()
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            check_summary(sd[name].grad, g, f"grad:{name}:", rtol=5e-3, atol=1e-8)
+        if key.startswith("buf:"):
+            np.testing.assert_allclose(sd[key[4:]][:64].detach().numpy(), g[key], rtol=1e-5, atol=1e-7)

@@ -148,5 +148,16 @@ def check(rc, what=""):
         raise HrpError(f"{what} failed ({rc}): {lib().hrp_last_error().decode()}")
 
 
+_profile_hook = None  # set by bench.py's instrumented pass: fn(name, args, launch) -> None
+
+
+def set_profile_hook(fn):
+    global _profile_hook
+    _profile_hook = fn
+
+
 def call(name, *args):
+    if _profile_hook is not None:
+        _profile_hook(name, args, lambda: check(getattr(lib(), name)(*args), name))
+        return
     check(getattr(lib(), name)(*args), name)

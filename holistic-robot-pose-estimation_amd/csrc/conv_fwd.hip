@@ -24,7 +24,7 @@ constexpr int CHUNK_BYTES = 64;  // bytes of input channels per pixel staged per
 constexpr int PITCH = 80;        // LDS row pitch (64 B data + 16 B pad: odd multiple of 16 B)
 
 struct ConvTiling {
-  int TH, TW, TI;
+  int TH, TW, TI;   // TI = images per tile actually staged (TI*TH*TW <= BM; the rest of the tile is idle)
   int IHt, IWt;
   int mindy, mindx;
   int tiles_x, tiles_y, tiles_n;
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     int m = wp * (32 * PT) + pt * 32 + l31;
     int ti = m / thw, rem = m - ti * thw;
     int ty = rem / t.TW, tx = rem - ty * t.TW;
+    if (ti >= t.TI) ti = t.TI - 1;  // idle slot of a partially filled tile: read something valid, never stored
     pixoff[pt] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * PITCH + khalf * (KB / 2);
   }
   const int wrow = (wc * 32 * CT + l31) * PITCH + khalf * (KB / 2);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       int ti = m / thw, rem = m - ti * thw;
       int ty = rem / t.TW, tx = rem - ty * t.TW;
       int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
-      if (n >= d.N || oy >= d.Ho || ox >= d.Wo) continue;
+      if (ti >= t.TI || n >= d.N || oy >= d.Ho || ox >= d.Wo) continue;
       size_t opix = ((size_t)n * d.y_H + (oy * d.out_stride + d.out_off_y)) * d.y_W + (ox * d.out_stride + d.out_off_x);
       float f[VEC];
       Elem<T>::unpack(*(const uint4*)(lds_out + m * OP + cv * 16), f);
@@ -286,7 +287,8 @@ static int launch_cfg(const hrp_conv_desc& d, ConvTiling t, hipStream_t s) {
   int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
   int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
   int TI = BM / (TW * TH);
-  t.TW = TW; t.TH = TH; t.TI = TI;
+  if (TI > d.N) TI = d.N;
+  t.TW = TW; t.TH = TH;
   int mindy = 1 << 30, maxdy = -(1 << 30), mindx = 1 << 30, maxdx = -(1 << 30);
   for (int i = 0; i < d.ntaps; ++i) {
     mindy = d.dy[i] < mindy ? d.dy[i] : mindy; maxdy = d.dy[i] > maxdy ? d.dy[i] : maxdy;
@@ -295,13 +297,20 @@ static int launch_cfg(const hrp_conv_desc& d, ConvTiling t, hipStream_t s) {
   t.mindy = mindy; t.mindx = mindx;
   t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
   t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
+  const int budget = 72 * 1024;
+  {  // shrink the number of images per tile until the halo tile + one tap of weights fit
+    int per_img = t.IHt * t.IWt * PITCH;
+    int maxti = (budget - BN * PITCH) / per_img;
+    if (maxti < 1) return -100;
+    if (TI > maxti) TI = maxti;
+  }
+  t.TI = TI;
   t.in_pix = TI * t.IHt * t.IWt;
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.n_cout_blk = cdiv(d.Cout, BN);
   t.nblocks = t.tiles_x * t.tiles_y * t.tiles_n * t.n_cout_blk;
   const int in_bytes = round_up(t.in_pix * PITCH, 16);
   const int out_bytes = BM * (BN * SZ + 16);
-  const int budget = 72 * 1024;
   int TG = (budget - in_bytes) / (BN * PITCH);
   if (TG < 1) return -100;  // does not fit: caller tries a smaller pixel tile
   if (TG > d.ntaps) TG = d.ntaps;

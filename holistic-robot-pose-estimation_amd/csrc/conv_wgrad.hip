@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
   for (int m = tid; m < t.BM; m += 256) {
     int ti = m / thw, rem = m - ti * thw;
     int ty = rem / t.TW, tx = rem - ty * t.TW;
+    if (ti >= t.TI) ti = t.TI - 1;  // idle slot (its dY row is zero)
     xtab[m] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * P;
   }
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
       int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
       int c = co0 + vec * VEC;
       uint4 val = make_uint4(0, 0, 0, 0);
-      if (n < d.N && oy < d.Ho && ox < d.Wo && c < d.Cout) {
+      if (ti < t.TI && n < d.N && oy < d.Ho && ox < d.Wo && c < d.Cout) {
         size_t off = (((size_t)n * d.Ho + oy) * d.Wo + ox) * (size_t)d.dy_pitch + c;
         val = *(const uint4*)(dyg + off * SZ);
       }
@@ -184,9 +185,16 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
     int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
     int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
     int TI = BM / (TW * TH);
-    t.TW = TW; t.TH = TH; t.TI = TI; t.BM = BM;
+    if (TI > d.N) TI = d.N;
+    t.TW = TW; t.TH = TH; t.BM = BM;
     t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
     t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
+    {
+      int maxti = (budget - BM * P - BM * 4) / (t.IHt * t.IWt * P);
+      if (maxti < 1) maxti = 1;
+      if (TI > maxti) TI = maxti;
+    }
+    t.TI = TI;
     t.in_pix = TI * t.IHt * t.IWt;
     t.lds_dy_off = round_up(t.in_pix * P, 16);
     t.lds_tab_off = t.lds_dy_off + BM * P;

@@ -108,6 +108,8 @@ class Plan:
         self._versions = None
         self._late = []
         self.out_handles = []      # TensorH whose gradient is seeded from outside
+        self.grad_arena = None
+        self._grad_views = {}
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -121,10 +123,24 @@ class Plan:
             self.weight_list.append(w)
         return w
 
+    def preallocate_param_grads(self, params):
+        """One flat fp32 arena for every parameter gradient (what the data-parallel all-reduce walks in
+        large buckets); .grad tensors are views into it."""
+        params = [p for p in params if p.requires_grad]
+        total = sum(_rup(p.numel(), 4) for p in params)
+        self.grad_arena = torch.zeros(max(total, 4), dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            self._grad_views[id(p)] = self.grad_arena[off:off + p.numel()].view(p.shape)
+            off += _rup(p.numel(), 4)
+
     def grad_of_param(self, p):
         e = self.param_grads.get(id(p))
         if e is None:
-            e = (p, torch.zeros_like(p, dtype=torch.float32))
+            g = self._grad_views.get(id(p))
+            if g is None:
+                g = torch.zeros_like(p, dtype=torch.float32)
+            e = (p, g)
             self.param_grads[id(p)] = e
             self.keep.append(e[1])
         return e[1]
@@ -522,6 +538,8 @@ class PlanBuilder:
             src = fd.inp[j]
             for f, _ in nv.EwInput._fields_:
                 setattr(b.inp, f, getattr(src, f))
+            # the statistics pointer of the forward descriptor is patched at finalize: copy it then
+            p.late(lambda b=b, src=src: setattr(b.inp, "stats", src.stats))
             b.dtype, b.N, b.H, b.W, b.C, b.relu = fd.dtype, fd.N, fd.H, fd.W, fd.C, fd.relu
             b.din, b.din_pitch = tm.t.gptr(), tm.t.pitch
             b.accumulate = tm.t.take_grad_slot()

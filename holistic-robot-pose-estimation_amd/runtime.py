@@ -103,6 +103,10 @@ class PlannedModule(nn.Module):
     def compute_dtype(self):
         return self._compute_dtype
 
+    def flat_grads(self):
+        """Flat fp32 gradient arena of the training plan(s) (views of it are the parameters' .grad)."""
+        return [r.plan.grad_arena for r in self._plans.values() if r.plan.grad_arena is not None]
+
     def invalidate_plans(self):
         for m in self.modules():
             if isinstance(m, PlannedModule):
@@ -133,6 +137,8 @@ class PlannedModule(nn.Module):
         runner = self._plans.get(key)
         if runner is None:
             plan = Plan(dev, self._compute_dtype, self.training, need_grad)
+            if need_grad:
+                plan.preallocate_param_grads(list(self.parameters()))
             pb = PlanBuilder(plan)
             in_names, outs, img_inputs = self._build(pb, *tensors)
             for kind, h, shape in outs:

@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Benchmark of the HoRoPose image->pose hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one training step of the reference's full network (RootNetwithRegInt with HRNet-W32 as the
+regression AND the root/depth backbone, configs[2] of BASELINE.json) on one synthetic batch of 64
+256x256 images per GPU: forward, loss of lib/core/function.py:191-322, backward, gradient all-reduce
+(N > 1), clip_grad_norm_(5.0) and the Adam update (scripts/train_full.py:53-67).  The convolution trunk
+runs in bf16 on MFMA, heads in fp32.  The whole step is captured once in a HIP graph and replayed.
+
+Prints ONE JSON line (rank 0): images/sec over all GPUs, the roofline entry of the dominant kernel
+family (durations measured with HIP events on the launch stream in an instrumented pass of the same step)
+and a CPU baseline of the same step timed with the oracle on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import hrpe_amd  # noqa: E402,F401
+from hrpe_amd import _native as nv  # noqa: E402
+from hrpe_amd.lib.core.function import compute_k_values, full_loss  # noqa: E402
+from hrpe_amd.lib.dataset.const import INITIAL_JOINT_ANGLE, JOINT_BOUNDS  # noqa: E402
+from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d  # noqa: E402
+from hrpe_amd.parallel import GradAllReducer, broadcast_module, init_distributed  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+# algorithmic forward FLOP per image (2*MAC over conv/linear), SURVEY.md 6: HRNet-W32 hm+feat 23.416 G,
+# DepthNet trunk 23.299 G, heads 0.05 G; fwd+bwd = 3x
+FWD_GFLOP_PER_IMAGE = {"full": 23.416 + 23.299 + 0.05, "depthnet": 23.299}
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+
+
+def model_args(p_dropout):
+    return Args(backbone_name="hrnet32", rootnet_backbone_name="hrnet32", other_image_size=256.0, use_rpmg=False,
+                n_iter=4, p_dropout=p_dropout, reg_joint_map=False, joint_conv_dim=[], rotation_dim=6,
+                direct_reg_rot=False, rot_iterative_matmul=False, fix_root=True, bbox_3d_shape=[1300, 1300, 1300],
+                reference_keypoint_id=3, add_fc=False, multi_kp=False, kps_need_depth=None, pretrained_rootnet=None)
+
+
+def random_rotations(g, n):
+    q = g.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)
+    return R.reshape(n, 3, 3).astype(np.float32)
+
+
+def synthetic_batch(B, seed):
+    """Panda-DR-shaped synthetic batch: images U[0,1), crop intrinsics, boxes, poses."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    d = {}
+    d["x_reg"] = g.random((B, 3, 256, 256), dtype=np.float32)
+    d["x_root"] = g.random((B, 3, 256, 256), dtype=np.float32)
+    s = g.uniform(0.8, 2.5, B).astype(np.float32)
+    K = np.zeros((B, 3, 3), np.float32)
+    K[:, 0, 0] = K[:, 1, 1] = 320.0 * s
+    K[:, 0, 2] = K[:, 1, 2] = 128.0
+    K[:, 2, 2] = 1.0
+    side = g.uniform(80.0, 240.0, B).astype(np.float32)
+    d["K"] = K
+    d["bbox"] = np.stack([128 - side / 2, 128 - side / 2, 128 + side / 2, 128 + side / 2], 1).astype(np.float32)
+    b = np.array(JOINT_BOUNDS["panda"])
+    d["q"] = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((B, 8))).astype(np.float32)
+    d["R"] = random_rotations(g, B)
+    d["t"] = np.stack([g.uniform(-.3, .3, B), g.uniform(-.3, .3, B), g.uniform(.6, 2.0, B)], 1).astype(np.float32)
+    return d
+
+
+def build_model(p_dropout):
+    from hrpe_amd.lib.models.full_net import RootNetwithRegInt
+    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE, "cam_params": np.eye(4),
+            "init_pose_from_mean": True}
+    torch.manual_seed(808)  # reference seed, scripts/train_full.py:18
+    m = RootNetwithRegInt(init, model_args(p_dropout))
+    # random init of this architecture, scaled so that activations stay O(1) (the reference's own
+    # N(0, sqrt(2/n)) conv init on top of BN would do as well; values do not change the work done)
+    return m
+
+
+def cpu_baseline(B, threads):
+    """The same training step (forward, loss, backward) on the host with the CPU oracle (fp32)."""
+    from oracle import fk as ofk, heads as oheads
+    torch.set_num_threads(threads)
+    m = build_model(0.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
+            v.requires_grad_(True)
+    robot = ofk.Robot(os.path.join(ROOT, "holistic-robot-pose-estimation_amd", "assets", "panda_kinematics.urdf"))
+    d = {k: torch.tensor(v) for k, v in synthetic_batch(B, 1).items()}
+    K = d["K"]
+    kv = torch.sqrt(K[:, 0, 0] * K[:, 1, 1] * 1e6 / (d["bbox"][:, 2] - d["bbox"][:, 0]) ** 2)
+    rot6 = ofk.rotmat_to_rot6d(d["R"])
+    with torch.no_grad():
+        kp3d = robot.get_keypoints(d["q"], rot6, d["t"])
+        kp2d = ofk.project(K, kp3d)
+        gt = dict(pose=d["q"], root_rot=robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
+                  root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7))
+    t0 = time.time()
+    pred = oheads.full_forward(sd, robot, d["x_reg"], d["x_root"], kv, K, training=True)
+    loss, _ = oheads.full_loss(pred, gt, K)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch fp32 CPU restatement) full-network forward+loss+backward, B={B}, 1 step, {dt:.1f} s"}
+
+
+def conv_flops(name, args):
+    """Algorithmic FLOP of one launch from its descriptor (real channel counts)."""
+    if name == "hrp_conv2d_fwd":
+        d = args[0]._obj
+        return 2.0 * d.N * d.Ho * d.Wo * d.Cout * min(d.Cin, 10 ** 9) * d.ntaps
+    if name == "hrp_conv2d_bwd_weight":
+        d = args[0]._obj
+        return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps
+    return 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--p-dropout", type=float, default=0.5, help="lib/core/config.py:70 default")
+    a = ap.parse_args()
+
+    rank, world, local = init_distributed()
+    if world != a.gpus and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if not nv.lib().hrp_device_ok():
+        raise SystemExit("libhrp_hip.so is built for gfx950 only")
+    B = a.batch
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    model = build_model(a.p_dropout).to(dev).set_compute_dtype(dtype).train()
+    broadcast_module(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, capturable=not a.no_graph)   # scripts/train_full.py:42
+    reducer = GradAllReducer(bucket_mb=64)
+
+    d = {k: torch.tensor(v).to(dev) for k, v in synthetic_batch(B, 808 + rank).items()}
+    K = d["K"]
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], d["bbox"])
+    rot6 = rotmat_to_rot6d(d["R"])
+    with torch.no_grad():
+        kp3d, kp2d = model.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
+        gt = dict(pose=d["q"], root_rot=model.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
+                  root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d,
+                  mask=torch.ones(B, 7, device=dev))
+    loss_holder = {}
+
+    def fwd_bwd():
+        pred = model(d["x_reg"], d["x_root"], kv, K)
+        loss, _ = full_loss(pred, gt, K)
+        loss.backward()
+        loss_holder["loss"] = loss.detach()
+
+    def update():
+        torch.nn.utils.clip_grad_norm_(params, 5.0)   # configs/panda/full.yaml:39
+        opt.step()
+
+    def step_eager():
+        fwd_bwd()
+        reducer(model.flat_grads())
+        update()
+
+    # first step eagerly: builds the plan, allocates gradients / optimizer state
+    step_eager()
+    torch.cuda.synchronize(dev)
+
+    use_graph = not a.no_graph
+    if use_graph:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step_eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if world == 1:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+                update()
+
+            def step():
+                g1.replay()
+        else:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+            with torch.cuda.graph(g2):
+                update()
+
+            def step():
+                g1.replay()
+                reducer(model.flat_grads())
+                g2.replay()
+    else:
+        step = step_eager
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = float(loss_holder["loss"].item())
+
+    if rank != 0:
+        return
+    ms_per_step = dt / a.steps * 1e3
+    value = B * world * a.steps / dt
+
+    # ---- instrumented pass: HIP events around every C-ABI launch on the launch stream --------------
+    records = []
+
+    def hook(name, args, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        records.append((name, conv_flops(name, args), e0, e1))
+
+    nv.set_profile_hook(hook)
+    fwd_bwd()
+    nv.set_profile_hook(None)
+    torch.cuda.synchronize(dev)
+    fam = {}
+    for name, fl, e0, e1 in records:
+        f = fam.setdefault(name, [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += e0.elapsed_time(e1)
+        f[2] += fl
+    kernels = {n: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
+               for n, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}
+    dom = max(fam.items(), key=lambda kv: kv[1][1])
+    peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+    ach = dom[1][2] / (dom[1][1] * 1e-3) / 1e12 if dom[1][2] else 0.0
+    roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches": dom[1][0],
+                "avg_launch_us": round(dom[1][1] / dom[1][0] * 1e3, 2)}
+    step_tflops = 3 * FWD_GFLOP_PER_IMAGE["full"] * 1e9 * B / (ms_per_step * 1e-3) / 1e12
+    out = {
+        "metric": "images/sec/GPU fwd+bwd HRNet-W32 256x256 bs=64; 1/2/4/8-GPU scaling",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "full network (HRNet-W32 reg backbone + HRNet-W32 DepthNet + heads + FK loss) "
+                               "fwd+loss+bwd+clip+Adam, BASELINE.json configs[2]",
+                   "global_batch": B * world, "per_gpu_batch": B, "image": "3x256x256",
+                   "hrnet_w32_passes_per_image": 2, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                   "p_dropout": a.p_dropout},
+        "hrnet_w32_passes_per_sec": round(2 * value, 2),
+        "step_model_tflops": round(step_tflops, 2),
+        "step_frac_of_mfma_peak": round(step_tflops / peak, 4),
+        "roofline": roofline,
+        "kernels": kernels,
+        "loss": final_loss,
+    }
+    if not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, os.cpu_count() or 1)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

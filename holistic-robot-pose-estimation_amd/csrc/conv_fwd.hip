@@ -9,6 +9,8 @@
 //   MFMA  = 32x32x16 bf16 / 32x32x2 fp32, A = weights (rows = cout), B = pixels (cols = pixel):
 //           each lane ends up with 4 consecutive output channels of one pixel per accumulator quad,
 //           so the epilogue moves 8/16-byte pieces through LDS and leaves as 16-byte coalesced stores.
+//   staging = 16-byte global loads issued 4 deep per thread before the LDS writes (independent loads in
+//           flight instead of one load->store round trip per iteration); index math by multiply-high.
 //   epilogue = bias, per-channel affine (folded BN), residual add, ReLU, per-channel sum / sum-of-squares
 //           (train-mode BN statistics, one atomicAdd per channel per workgroup).
 //   block id -> XCD-contiguous remap so the cout blocks / neighbouring tiles that share an input tile hit
@@ -22,6 +24,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CHUNK_BYTES = 64;  // bytes of input channels per pixel staged per K chunk
 constexpr int PITCH = 80;        // LDS row pitch (64 B data + 16 B pad: odd multiple of 16 B)
+constexpr int STAGE_U = 4;       // independent 16-byte loads in flight per thread while staging
 
 struct ConvTiling {
   int TH, TW, TI;   // TI = images per tile actually staged (TI*TH*TW <= BM; the rest of the tile is idle)
@@ -34,6 +37,7 @@ struct ConvTiling {
   int lds_w_off, lds_stats_off;
   int nblocks;
   int vec_ok;
+  FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_ncb, fd_tx, fd_ty;
 };
 
 template <typename T>
@@ -74,12 +78,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 
   int bid = blockIdx.x;
   if ((t.nblocks & 7) == 0) bid = (bid & 7) * (t.nblocks >> 3) + (bid >> 3);
-  const int cb = bid % t.n_cout_blk;
-  int tile = bid / t.n_cout_blk;
-  const int tx_i = tile % t.tiles_x;
-  tile /= t.tiles_x;
-  const int ty_i = tile % t.tiles_y;
-  const int tn_i = tile / t.tiles_y;
+  int tile = fdiv(bid, t.fd_ncb);
+  const int cb = bid - tile * t.n_cout_blk;
+  int q = fdiv(tile, t.fd_tx);
+  const int tx_i = tile - q * t.tiles_x;
+  const int tn_i = fdiv(q, t.fd_ty);
+  const int ty_i = q - tn_i * t.tiles_y;
   const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
   const int IS = d.in_stride;
   const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     int m = wp * (32 * PT) + pt * 32 + l31;
-    int ti = m / thw, rem = m - ti * thw;
-    int ty = rem / t.TW, tx = rem - ty * t.TW;
+    int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+    int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
     if (ti >= t.TI) ti = t.TI - 1;  // idle slot of a partially filled tile: read something valid, never stored
     pixoff[pt] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * PITCH + khalf * (KB / 2);
   }
@@ -110,35 +114,61 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   const int ihw = t.IHt * t.IWt;
   const char* xg = (const char*)d.x;
   const char* wg = (const char*)d.w;
+  const int in_vecs = t.in_pix * 4;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     __syncthreads();  // everyone is done reading the previous chunk's tiles
     const int c0 = chunk * CKE;
-    for (int v = tid; v < t.in_pix * 4; v += 256) {
-      int pix = v >> 2, vec = v & 3;
-      int ti = pix / ihw, rem = pix - ti * ihw;
-      int iy = rem / t.IWt, ix = rem - iy * t.IWt;
-      int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
-      int c = c0 + vec * VEC;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
-        size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
-        val = *(const uint4*)(xg + off * SZ);
+    for (int v0 = tid; v0 < in_vecs; v0 += 256 * STAGE_U) {
+      uint4 val[STAGE_U];
+      int dst[STAGE_U];
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u) {
+        const int v = v0 + u * 256;
+        val[u] = make_uint4(0, 0, 0, 0);
+        dst[u] = -1;
+        if (v < in_vecs) {
+          int pix = v >> 2, vec = v & 3;
+          int ti = fdiv(pix, t.fd_ihw), rem = pix - ti * ihw;
+          int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+          int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
+          int c = c0 + vec * VEC;
+          dst[u] = pix * PITCH + vec * 16;
+          if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
+            size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
+            val[u] = *(const uint4*)(xg + off * SZ);
+          }
+        }
       }
-      *(uint4*)(lds_in + pix * PITCH + vec * 16) = val;
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u)
+        if (dst[u] >= 0) *(uint4*)(lds_in + dst[u]) = val[u];
     }
     for (int tg0 = 0; tg0 < d.ntaps; tg0 += t.TG) {
       if (tg0 > 0) __syncthreads();
       const int tgn = min(t.TG, d.ntaps - tg0);
-      for (int v = tid; v < tgn * BN * 4; v += 256) {
-        int row = v >> 2, vec = v & 3;
-        int tl = row / BN, j = row - tl * BN;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (co0 + j < d.w_cout_pad) {
-          size_t roff = ((size_t)chunk * d.w_ntaps + d.wtap[tg0 + tl]) * d.w_cout_pad + co0 + j;
-          val = *(const uint4*)(wg + roff * CHUNK_BYTES + vec * 16);
+      const int w_vecs = tgn * BN * 4;
+      for (int v0 = tid; v0 < w_vecs; v0 += 256 * STAGE_U) {
+        uint4 val[STAGE_U];
+        int dst[STAGE_U];
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u) {
+          const int v = v0 + u * 256;
+          val[u] = make_uint4(0, 0, 0, 0);
+          dst[u] = -1;
+          if (v < w_vecs) {
+            int row = v >> 2, vec = v & 3;
+            int tl = row / BN, j = row - tl * BN;
+            dst[u] = row * PITCH + vec * 16;
+            if (co0 + j < d.w_cout_pad) {
+              size_t roff = ((size_t)chunk * d.w_ntaps + d.wtap[tg0 + tl]) * d.w_cout_pad + co0 + j;
+              val[u] = *(const uint4*)(wg + roff * CHUNK_BYTES + vec * 16);
+            }
+          }
         }
-        *(uint4*)(lds_w + row * PITCH + vec * 16) = val;
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u)
+          if (dst[u] >= 0) *(uint4*)(lds_w + dst[u]) = val[u];
       }
       __syncthreads();
       for (int tl = 0; tl < tgn; ++tl) {
@@ -172,8 +202,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cl = wc * 32 * CT + c * 32 + 8 * q + 4 * khalf;  // first of 4 consecutive local couts
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int cl = wc * 32 * CT + c * 32 + 8 * q4 + 4 * khalf;  // first of 4 consecutive local couts
       float bia[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -188,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
         const int m = wp * (32 * PT) + p * 32 + l31;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (acc[c][p][4 * q + i] + bia[i]) * sc[i] + sh[i];
+        for (int i = 0; i < 4; ++i) v[i] = (acc[c][p][4 * q4 + i] + bia[i]) * sc[i] + sh[i];
         char* dst = lds_out + m * OP + cl * SZ;
         if constexpr (SZ == 4) {
           *(uint4*)dst = Elem<float>::pack(v);
@@ -215,8 +245,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   if (co < d.Cout) {
     const bool full = t.vec_ok && (co + VEC <= d.Cout);
     for (int m = tid / NV; m < BM; m += 256 / NV) {
-      int ti = m / thw, rem = m - ti * thw;
-      int ty = rem / t.TW, tx = rem - ty * t.TW;
+      int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+      int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
       int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
       if (ti >= t.TI || n >= d.N || oy >= d.Ho || ox >= d.Wo) continue;
       size_t opix = ((size_t)n * d.y_H + (oy * d.out_stride + d.out_off_y)) * d.y_W + (ox * d.out_stride + d.out_off_x);
@@ -277,13 +307,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 }
 
 // ---------------------------------------------------------------------------------------------
-struct Cfg { int CT, PT, WC, WP; };
-
 template <typename T, int CT, int PT, int WC, int WP>
-static int launch_cfg(const hrp_conv_desc& d, ConvTiling t, hipStream_t s) {
+static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
   constexpr int SZ = Elem<T>::SZ;
-  // tile geometry: TW x TH x TI = BM
+  ConvTiling t{};
+  // tile geometry: TW x TH x TI <= BM
   int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
   int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
   int TI = BM / (TW * TH);
@@ -324,6 +353,9 @@ static int launch_cfg(const hrp_conv_desc& d, ConvTiling t, hipStream_t s) {
   const bool aligned = ((uintptr_t)d.y % 16 == 0) && ((size_t)d.y_pitch * SZ % 16 == 0) &&
                        (!d.res || (((uintptr_t)d.res % 16 == 0) && ((size_t)d.res_pitch * SZ % 16 == 0)));
   t.vec_ok = aligned ? 1 : 0;
+  t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
+  t.fd_thw = make_fastdiv(TH * TW); t.fd_tw = make_fastdiv(TW);
+  t.fd_ncb = make_fastdiv(t.n_cout_blk); t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y);
   auto kern = conv_tile_kernel<T, CT, PT, WC, WP>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -334,20 +366,27 @@ static int launch_cfg(const hrp_conv_desc& d, ConvTiling t, hipStream_t s) {
   return check_launch("conv_tile_kernel");
 }
 
+// Tile choice: BN covers Cout up to 128; BM as large as possible while the launch still has >= ~1.5
+// workgroups per CU (the small high-channel branches are otherwise left with 64..128 workgroups on 256 CUs).
 template <typename T>
 static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
-  ConvTiling t{};
   const long pixels = (long)d.N * d.Ho * d.Wo;
-  int rc;
+  const long want = 384;
+  int rc = -100;
   if (d.Cout <= 32) {
-    rc = (pixels >= 256 * 64) ? launch_cfg<T, 1, 2, 1, 4>(d, t, s) : launch_cfg<T, 1, 1, 1, 4>(d, t, s);
-    if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4>(d, t, s);
+    if (pixels / 256 >= want) rc = launch_cfg<T, 1, 2, 1, 4>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4>(d, s);
   } else if (d.Cout <= 64) {
-    rc = (pixels >= 256 * 64) ? launch_cfg<T, 2, 2, 1, 4>(d, t, s) : launch_cfg<T, 2, 1, 1, 4>(d, t, s);
-    if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4>(d, t, s);
+    if (pixels / 256 >= want) rc = launch_cfg<T, 2, 2, 1, 4>(d, s);
+    if (rc == -100 && pixels / 128 >= want) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
   } else {
-    rc = (pixels >= 128 * 128) ? launch_cfg<T, 2, 2, 2, 2>(d, t, s) : launch_cfg<T, 2, 1, 2, 2>(d, t, s);
-    if (rc == -100) rc = launch_cfg<T, 2, 1, 2, 2>(d, t, s);
+    const long nb = (d.Cout + 127) / 128;
+    if (pixels / 128 * nb >= want) rc = launch_cfg<T, 2, 2, 2, 2>(d, s);
+    if (rc == -100 && pixels / 64 * nb >= want) rc = launch_cfg<T, 2, 1, 2, 2>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 2, 1, 2, 2>(d, s);
   }
   if (rc == -100) {
     set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
@@ -363,7 +402,7 @@ extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   HRP_REQUIRE(d && d->x && d->w && d->y, "conv: null pointer");
   HRP_REQUIRE(d->ntaps >= 1 && d->ntaps <= HRP_MAX_TAPS, "conv: ntaps=%d", d->ntaps);
   HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16, "conv: dtype=%d", d->dtype);
-  const int vec = d->dtype == HRP_F32 ? 4 : 8, sz = d->dtype == HRP_F32 ? 4 : 2;
+  const int vec = d->dtype == HRP_F32 ? 4 : 8;
   HRP_REQUIRE(d->Cin % vec == 0 && d->x_pitch % vec == 0 && (uintptr_t)d->x % 16 == 0,
               "conv: input channels / pitch must be multiples of %d elements (Cin=%d pitch=%d)", vec, d->Cin, d->x_pitch);
   HRP_REQUIRE((uintptr_t)d->w % 16 == 0, "conv: packed weights must be 16-byte aligned");
@@ -371,7 +410,6 @@ extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
   HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
   HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
-  (void)sz;
   if (d->dtype == HRP_F32) return launch_conv<float>(*d, (hipStream_t)stream);
   return launch_conv<bf16_t>(*d, (hipStream_t)stream);
 }

@@ -8,16 +8,22 @@
 // shifted offset.  The 4 waves split the tile's pixels (split-K inside the workgroup), partial sums are
 // combined through LDS and leave as fp32 atomics straight into the PyTorch-shaped gradient tensor.
 //
-// Operand gather: the reduction index is the pixel, but NHWC keeps channels contiguous, so the 8
-// k-values a lane needs for the bf16 MFMA are 8 different pixels.  v1 gathers them with 16-bit LDS
-// reads (fp32 needs one 32-bit read per operand and is unaffected).
+// Operand gather: the reduction index is the pixel, but NHWC keeps channels contiguous, so the 8 k-values
+// a lane needs for the bf16 MFMA belong to 8 different pixels.  gfx950's LDS transpose read
+// (ds_read_b64_tr_b16) does exactly that re-layout: within a 16-lane group source lane 4j+t supplies 4
+// contiguous channels (8 bytes) of pixel j and destination lane i receives channel i of pixels 0..3
+// (mapping measured with tools/probe_tr.hip: result[i][j] = src[4j + (i >> 2)][i & 3]).  Two such reads
+// build one 8-deep MFMA operand; every source lane carries its own pixel address, so tap shifts and
+// stride-2 sampling cost nothing extra.  fp32 needs one 32-bit read per operand.
 #include "hrp_common.h"
 
 namespace hrp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short short8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WSTAGE_U = 4;
 
 struct WgradTiling {
   int TH, TW, TI, BM;
@@ -26,19 +32,17 @@ struct WgradTiling {
   int n_cob, n_cib, G;
   int in_pix;
   int lds_dy_off, lds_tab_off, lds_red_off;
+  FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_tx, fd_ty, fd_cib;
 };
 
 template <typename T>
 struct WG;
 template <>
 struct WG<bf16_t> {
-  static constexpr int K = 16, KH = 8;
+  static constexpr int K = 16;
   using Frag = bf16x8;
-  __device__ static __forceinline__ Frag gather(const char* base, const int* off) {
-    short8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = *(const short*)(base + off[j]);
-    return __builtin_bit_cast(Frag, r);
+  __device__ static __forceinline__ bf16x4 tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
   }
   __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -46,9 +50,8 @@ struct WG<bf16_t> {
 };
 template <>
 struct WG<float> {
-  static constexpr int K = 2, KH = 1;
+  static constexpr int K = 2;
   using Frag = float;
-  __device__ static __forceinline__ Frag gather(const char* base, const int* off) { return *(const float*)(base + off[0]); }
   __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
   constexpr int ROWB = 32 * SZ;     // bytes of 32 channels
   constexpr int P = ROWB + 16;      // LDS pixel pitch
   constexpr int NVEC = ROWB / 16;   // 16-byte vectors per pixel row
-  constexpr int K = WG<T>::K, KH = WG<T>::KH;
+  constexpr int K = WG<T>::K;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_x = smem;
   char* lds_dy = smem + t.lds_dy_off;
@@ -70,15 +73,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int blk = blockIdx.y;
-  const int cob = blk / t.n_cib, cib = blk % t.n_cib;
+  const int cob = fdiv(blk, t.fd_cib), cib = blk - cob * t.n_cib;
   const int co0 = cob * 32, ci0 = cib * 32;
   const int IS = d.in_stride;
   const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
 
   // pixel -> X-tile byte offset table
   for (int m = tid; m < t.BM; m += 256) {
-    int ti = m / thw, rem = m - ti * thw;
-    int ty = rem / t.TW, tx = rem - ty * t.TW;
+    int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+    int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
     if (ti >= t.TI) ti = t.TI - 1;  // idle slot (its dY row is zero)
     xtab[m] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * P;
   }
@@ -92,56 +95,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
   const char* xg = (const char*)d.x;
   const char* dyg = (const char*)d.dy;
   const int ppw = t.BM / 4;  // pixels per wave
+  const int x_vecs = t.in_pix * NVEC, dy_vecs = t.BM * NVEC;
+
+  int tapoff[NT];
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) tapoff[tp] = ((d.dy_t[tp] - t.mindy) * t.IWt + (d.dx_t[tp] - t.mindx)) * P;
+
+  // transpose-read lane roles (bf16): source lane s = lane & 15 -> pixel (s >> 2) of the 4-pixel block,
+  // channels rbase + 4 (s & 3) .. +3; rbase = 16 for the odd 16-lane groups
+  const int tr_pix = (lane & 15) >> 2;
+  const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * SZ;
 
   for (int tile = blockIdx.x; tile < t.ntiles; tile += t.G) {
-    int tt = tile;
-    const int tx_i = tt % t.tiles_x; tt /= t.tiles_x;
-    const int ty_i = tt % t.tiles_y;
-    const int tn_i = tt / t.tiles_y;
+    int q = fdiv(tile, t.fd_tx);
+    const int tx_i = tile - q * t.tiles_x;
+    const int tn_i = fdiv(q, t.fd_ty);
+    const int ty_i = q - tn_i * t.tiles_y;
     const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
     const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
     __syncthreads();
-    for (int v = tid; v < t.in_pix * NVEC; v += 256) {
-      int pix = v / NVEC, vec = v - pix * NVEC;
-      int ti = pix / ihw, rem = pix - ti * ihw;
-      int iy = rem / t.IWt, ix = rem - iy * t.IWt;
-      int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
-      int c = ci0 + vec * VEC;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
-        size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
-        val = *(const uint4*)(xg + off * SZ);
+    for (int v0 = tid; v0 < x_vecs; v0 += 256 * WSTAGE_U) {
+      uint4 val[WSTAGE_U];
+      int dst[WSTAGE_U];
+#pragma unroll
+      for (int u = 0; u < WSTAGE_U; ++u) {
+        const int v = v0 + u * 256;
+        val[u] = make_uint4(0, 0, 0, 0);
+        dst[u] = -1;
+        if (v < x_vecs) {
+          int pix = v / NVEC, vec = v - pix * NVEC;
+          int ti = fdiv(pix, t.fd_ihw), rem = pix - ti * ihw;
+          int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+          int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
+          int c = ci0 + vec * VEC;
+          dst[u] = pix * P + vec * 16;
+          if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
+            size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
+            val[u] = *(const uint4*)(xg + off * SZ);
+          }
+        }
       }
-      *(uint4*)(lds_x + pix * P + vec * 16) = val;
+#pragma unroll
+      for (int u = 0; u < WSTAGE_U; ++u)
+        if (dst[u] >= 0) *(uint4*)(lds_x + dst[u]) = val[u];
     }
-    for (int v = tid; v < t.BM * NVEC; v += 256) {
-      int m = v / NVEC, vec = v - m * NVEC;
-      int ti = m / thw, rem = m - ti * thw;
-      int ty = rem / t.TW, tx = rem - ty * t.TW;
-      int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
-      int c = co0 + vec * VEC;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (ti < t.TI && n < d.N && oy < d.Ho && ox < d.Wo && c < d.Cout) {
-        size_t off = (((size_t)n * d.Ho + oy) * d.Wo + ox) * (size_t)d.dy_pitch + c;
-        val = *(const uint4*)(dyg + off * SZ);
+    for (int v0 = tid; v0 < dy_vecs; v0 += 256 * WSTAGE_U) {
+      uint4 val[WSTAGE_U];
+      int dst[WSTAGE_U];
+#pragma unroll
+      for (int u = 0; u < WSTAGE_U; ++u) {
+        const int v = v0 + u * 256;
+        val[u] = make_uint4(0, 0, 0, 0);
+        dst[u] = -1;
+        if (v < dy_vecs) {
+          int m = v / NVEC, vec = v - m * NVEC;
+          int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+          int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+          int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
+          int c = co0 + vec * VEC;
+          dst[u] = m * P + vec * 16;
+          if (ti < t.TI && n < d.N && oy < d.Ho && ox < d.Wo && c < d.Cout) {
+            size_t off = (((size_t)n * d.Ho + oy) * d.Wo + ox) * (size_t)d.dy_pitch + c;
+            val[u] = *(const uint4*)(dyg + off * SZ);
+          }
+        }
       }
-      *(uint4*)(lds_dy + m * P + vec * 16) = val;
+#pragma unroll
+      for (int u = 0; u < WSTAGE_U; ++u)
+        if (dst[u] >= 0) *(uint4*)(lds_dy + dst[u]) = val[u];
     }
     __syncthreads();
     for (int kb = 0; kb < ppw; kb += K) {
-      const int m0 = wave * ppw + kb + khalf * KH;
-      int offa[KH], offx[KH];
+      if constexpr (SZ == 2) {
+        // k-slot (khalf, q4, j) <-> pixel  wave*ppw + kb + 8*khalf + 4*q4 + j
+        const int m0 = wave * ppw + kb + 8 * khalf + tr_pix;
+        const int x0 = xtab[m0] + tr_coff, x1 = xtab[m0 + 4] + tr_coff;
+        const char* pa = lds_dy + m0 * P + tr_coff;
+        bf16x4 a0 = WG<T>::tr(pa), a1 = WG<T>::tr(pa + 4 * P);
+        bf16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int j = 0; j < KH; ++j) {
-        offa[j] = (m0 + j) * P + l31 * SZ;
-        offx[j] = xtab[m0 + j] + l31 * SZ;
-      }
-      typename WG<T>::Frag a = WG<T>::gather(lds_dy, offa);
+        for (int tp = 0; tp < NT; ++tp) {
+          bf16x4 b0 = WG<T>::tr(lds_x + x0 + tapoff[tp]), b1 = WG<T>::tr(lds_x + x1 + tapoff[tp]);
+          bf16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+          WG<T>::mma(a, b, acc[tp]);
+        }
+      } else {
+        const int m0 = wave * ppw + kb + khalf;
+        const float a = *(const float*)(lds_dy + m0 * P + l31 * 4);
+        const int xo = xtab[m0] + l31 * 4;
 #pragma unroll
-      for (int tp = 0; tp < NT; ++tp) {
-        const int tapoff = ((d.dy_t[tp] - t.mindy) * t.IWt + (d.dx_t[tp] - t.mindx)) * P;
-        typename WG<T>::Frag b = WG<T>::gather(lds_x + tapoff, offx);
-        WG<T>::mma(a, b, acc[tp]);
+        for (int tp = 0; tp < NT; ++tp) {
+          const float b = *(const float*)(lds_x + xo + tapoff[tp]);
+          WG<T>::mma(a, b, acc[tp]);
+        }
       }
     }
   }
@@ -213,10 +259,15 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
   t.ntiles = t.tiles_x * t.tiles_y * t.tiles_n;
   t.n_cob = cdiv(d.Cout, 32); t.n_cib = cdiv(d.Cin, 32);
   int pairs = t.n_cob * t.n_cib;
-  int G = 2048 / pairs;
+  // workgroups per (cout, cin) block: enough to fill the chip (~1024 in total), few enough that the
+  // final fp32 atomics (NT*1024 per workgroup) stay a small fraction of the work
+  int G = 1024 / pairs;
   if (G < 1) G = 1;
   if (G > t.ntiles) G = t.ntiles;
   t.G = G;
+  t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
+  t.fd_thw = make_fastdiv(t.TH * t.TW); t.fd_tw = make_fastdiv(t.TW);
+  t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y); t.fd_cib = make_fastdiv(t.n_cib);
   if (!d.accumulate) (void)hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
   auto kern = conv_wgrad_kernel<T, NT>;
   static bool attr_set = false;

@@ -137,25 +137,41 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < V; ++i) {
-    red[0][threadIdx.x * V + i] = s0[i];
-    red[1][threadIdx.x * V + i] = s1[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < tpr && c < d.C) {
+  // lanes lane_c, lane_c + tpr, ... of a wave hold the same channels: butterfly over the pixel lanes first
+  if (tpr < 64) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      float a0 = 0.f, a1 = 0.f;
-      for (int k = 0; k < ppb; ++k) {
-        a0 += red[0][(k * tpr + lane_c) * V + i];
-        a1 += red[1][(k * tpr + lane_c) * V + i];
-      }
-      if (c + i < d.C) {
-        atomicAdd(&d.sums[c + i], a0);
-        atomicAdd(&d.sums[d.C + c + i], a1);
+      for (int o = 32; o >= tpr; o >>= 1) {
+        s0[i] += __shfl_xor(s0[i], o, 64);
+        s1[i] += __shfl_xor(s1[i], o, 64);
       }
     }
+  }
+  // one partial per wave (tpr < 64) or per thread (tpr >= 64, then ppb = 256 / tpr threads share a channel)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nparts = tpr < 64 ? 4 : ppb;                 // partials per channel group in LDS
+  const int part = tpr < 64 ? wave : threadIdx.x / tpr;  // which partial this thread writes
+  const bool writer = tpr < 64 ? (lane < tpr) : true;
+  if (writer) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      red[0][(part * tpr + lane_c) * V + i] = s0[i];
+      red[1][(part * tpr + lane_c) * V + i] = s1[i];
+    }
+  }
+  __syncthreads();
+  // thread (lane_c, i) -> one channel: tpr * V threads finish the sum and issue the atomics
+  for (int e = threadIdx.x; e < tpr * V; e += 256) {
+    const int lc = e / V, i = e - lc * V;
+    const int ch = (blockIdx.y * tpr + lc) * V + i;
+    if (ch >= d.C) continue;
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = 0; k < nparts; ++k) {
+      a0 += red[0][(k * tpr + lc) * V + i];
+      a1 += red[1][(k * tpr + lc) * V + i];
+    }
+    atomicAdd(&d.sums[ch], a0);
+    atomicAdd(&d.sums[d.C + ch], a1);
   }
 }
 

@@ -83,6 +83,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// division by a launch-invariant divisor: q = umulhi(v, m) is exact while v * d < 2^32 (m = 2^32/d + 1)
+struct FastDiv {
+  uint32_t m, d;
+};
+static inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = (uint32_t)d;
+  f.m = d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int v, const FastDiv& f) { return f.m ? (int)__umulhi((uint32_t)v, f.m) : v; }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

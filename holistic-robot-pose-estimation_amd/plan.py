@@ -266,6 +266,8 @@ class Plan:
 
     def run_backward(self):
         s = self._stream()
+        if self.grad_arena is not None:
+            self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
         if self.bsums_floats:
             self.bsums.zero_()
         for op in self.bwd:
@@ -410,7 +412,7 @@ class PlanBuilder:
         if bias is not None and bias.requires_grad:
             gb = p.grad_of_param(bias)
             p.bwd.append(lambda s: nv.call("hrp_colsum", y.gptr(), _dt(dtype), y.N * y.H * y.W, y.C, y.pitch,
-                                           gb.data_ptr(), 0, s))
+                                           gb.data_ptr(), 1 if p.grad_arena is not None else 0, s))
         # weight gradient
         if w.param.requires_grad:
             g = nv.WgradDesc()
@@ -422,7 +424,7 @@ class PlanBuilder:
             for i, (a, b) in enumerate(taps):
                 g.dy_t[i], g.dx_t[i] = a, b
             g.dw_cin = w.cin
-            g.accumulate = 1 if w.grad_written else 0
+            g.accumulate = 1 if (w.grad_written or p.grad_arena is not None) else 0
             w.grad_written = True
             p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
         # data gradient

@@ -29,7 +29,9 @@ class Runner:
         p = self.plan
         for n, t in zip(self.in_names, tensors):
             p.dyn[n] = t
-        p.run_prep()
+        # training plans repack the weights on every step (they change every step, and a captured HIP graph
+        # must contain the pack launch); inference plans repack only when a parameter version changed
+        p.run_prep(force=p.need_grad)
         p.run_forward()
         res = []
         for kind, h, shape in self.outs:

@@ -41,7 +41,8 @@ class WgradDesc(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_pitch", C.c_int32),
                 ("in_stride", C.c_int32), ("ntaps", C.c_int32),
                 ("dy_t", C.c_int32 * MAX_TAPS), ("dx_t", C.c_int32 * MAX_TAPS),
-                ("dw_cin", C.c_int32), ("accumulate", C.c_int32)]
+                ("dw_cin", C.c_int32), ("accumulate", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class PackEntry(C.Structure):
@@ -139,6 +140,8 @@ def lib():
             fn.restype = C.c_int
         L.hrp_last_error.restype = C.c_char_p
         L.hrp_last_error.argtypes = []
+        L.hrp_wgrad_workspace_bytes.restype = C.c_int64
+        L.hrp_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         _lib = L
     return _lib
 

@@ -3,16 +3,19 @@
 //
 // Work decomposition
 //   workgroup (256 threads = 4 waves) -> output tile of BM = TI*TH*TW pixels x BN output channels
-//   K loop = input-channel chunks of 64 bytes (32 bf16 / 16 fp32) x taps x MFMA k-steps
-//   LDS   = input halo tile [pixel][64 B + 16 B pad]  (read once per chunk, reused by every tap)
-//         + weight slab    [tap][cout][64 B + 16 B pad] (TG taps at a time)
+//   K loop = input-channel chunks of 32 bytes (16 bf16 / 8 fp32) x taps x MFMA k-steps
+//   LDS   = two stage buffers, each: input halo tile [pixel][32 B] (read once per chunk, reused by every
+//           tap) + weight slab [tap][cout][32 B]
+//   staging = direct-to-LDS DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip):
+//           chunk c+1 is in flight while chunk c is multiplied; one barrier per chunk.  The DMA writes
+//           lane-linear, so the 16-byte XOR swizzle that keeps ds_read_b128 conflict-free is applied on the
+//           per-lane SOURCE address (row r keeps its two 16-byte halves swapped when bit 3 of r is set) and
+//           again on the read.  Out-of-image pixels (zero padding) read a 64-byte zero page instead.
 //   MFMA  = 32x32x16 bf16 / 32x32x2 fp32, A = weights (rows = cout), B = pixels (cols = pixel):
 //           each lane ends up with 4 consecutive output channels of one pixel per accumulator quad,
 //           so the epilogue moves 8/16-byte pieces through LDS and leaves as 16-byte coalesced stores.
-//   staging = 16-byte global loads issued 4 deep per thread before the LDS writes (independent loads in
-//           flight instead of one load->store round trip per iteration); index math by multiply-high.
 //   epilogue = bias, per-channel affine (folded BN), residual add, ReLU, per-channel sum / sum-of-squares
-//           (train-mode BN statistics, one atomicAdd per channel per workgroup).
+//           (train-mode BN statistics, one atomicAdd per channel per workgroup into one of 8 slots).
 //   block id -> XCD-contiguous remap so the cout blocks / neighbouring tiles that share an input tile hit
 //           the same XCD's L2.
 #include "hrp_common.h"
@@ -22,9 +25,9 @@ namespace hrp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int CHUNK_BYTES = 64;  // bytes of input channels per pixel staged per K chunk
-constexpr int PITCH = 80;        // LDS row pitch (64 B data + 16 B pad: odd multiple of 16 B)
-constexpr int STAGE_U = 4;       // independent 16-byte loads in flight per thread while staging
+constexpr int ROW = 32;  // bytes of input channels per pixel / weight row staged per K chunk
+
+__device__ uint4 g_zero_page[4];  // 64 zero bytes: DMA source of padding pixels / rows beyond the tensor
 
 struct ConvTiling {
   int TH, TW, TI;   // TI = images per tile actually staged (TI*TH*TW <= BM; the rest of the tile is idle)
@@ -32,47 +35,59 @@ struct ConvTiling {
   int mindy, mindx;
   int tiles_x, tiles_y, tiles_n;
   int n_cout_blk;
-  int TG;
-  int in_pix;
-  int lds_w_off, lds_stats_off;
+  int in_rows;              // TI*IHt*IWt
+  int in_pieces, w_pieces;  // 1 KiB DMA pieces per stage
+  int buf_bytes;            // one stage buffer
+  int lds_stats_off;
   int nblocks;
   int vec_ok;
   FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_ncb, fd_tx, fd_ty;
 };
 
+// byte offset of (row r, 16-byte half h) inside a staged region
+__device__ __forceinline__ int row_addr(int r, int h) { return r * ROW + ((h ^ ((r >> 3) & 1)) << 4); }
+
 template <typename T>
 struct Mma;
 template <>
 struct Mma<bf16_t> {
-  static constexpr int KB = 32;  // bytes of K per MFMA (16 bf16)
   using Frag = bf16x8;
-  __device__ static __forceinline__ Frag ld(const char* p) { return *(const Frag*)p; }
+  // one k-step per 32-byte row: lanes 0-31 take the first 16 bytes (k 0..7), lanes 32-63 the second
+  static constexpr int KSTEPS = 1;
+  __device__ static __forceinline__ Frag ld(const char* base, int r, int kk, int khalf) {
+    return *(const Frag*)(base + row_addr(r, khalf));
+  }
   __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
 template <>
 struct Mma<float> {
-  static constexpr int KB = 8;  // 2 fp32
   using Frag = float;
-  __device__ static __forceinline__ Frag ld(const char* p) { return *(const float*)p; }
+  static constexpr int KSTEPS = 4;  // 8 fp32 per row, 2 per MFMA
+  __device__ static __forceinline__ Frag ld(const char* base, int r, int kk, int khalf) {
+    return *(const float*)(base + row_addr(r, kk >> 1) + (kk & 1) * 8 + khalf * 4);
+  }
   __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
 };
+
+__device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <typename T, int CT, int PT, int WC, int WP>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, const ConvTiling t) {
   static_assert(WC * WP == 4, "4 waves");
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
-  constexpr int KB = Mma<T>::KB;
-  constexpr int KSTEPS = CHUNK_BYTES / KB;
+  constexpr int CKE = ROW / SZ;  // channels per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_in = smem;
-  char* lds_w = smem + t.lds_w_off;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % WC, wp = wave / WC;
   const int l31 = lane & 31, khalf = lane >> 5;
 
@@ -89,17 +104,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
   const int co0 = cb * BN;
   const int thw = t.TH * t.TW;
+  const int ihw = t.IHt * t.IWt;
 
-  int pixoff[PT];
+  int pixrow[PT];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     int m = wp * (32 * PT) + pt * 32 + l31;
     int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
     int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
     if (ti >= t.TI) ti = t.TI - 1;  // idle slot of a partially filled tile: read something valid, never stored
-    pixoff[pt] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * PITCH + khalf * (KB / 2);
+    pixrow[pt] = (ti * t.IHt + ty * IS) * t.IWt + tx * IS;
   }
-  const int wrow = (wc * 32 * CT + l31) * PITCH + khalf * (KB / 2);
+  const int wrow0 = wc * 32 * CT + l31;
 
   f32x16 acc[CT][PT];
 #pragma unroll
@@ -109,84 +125,68 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[c][p][i] = 0.f;
 
-  const int CKE = CHUNK_BYTES / SZ;  // channels per chunk
   const int nchunks = (d.Cin + CKE - 1) / CKE;
-  const int ihw = t.IHt * t.IWt;
   const char* xg = (const char*)d.x;
   const char* wg = (const char*)d.w;
-  const int in_vecs = t.in_pix * 4;
+  const char* zero = (const char*)g_zero_page;
+  const int w_rows = d.ntaps * BN;
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();  // everyone is done reading the previous chunk's tiles
+  // ---- DMA issue of one chunk into a stage buffer (each wave takes every 4th 1 KiB piece) ------------
+  auto issue = [&](int chunk, char* buf) {
     const int c0 = chunk * CKE;
-    for (int v0 = tid; v0 < in_vecs; v0 += 256 * STAGE_U) {
-      uint4 val[STAGE_U];
-      int dst[STAGE_U];
-#pragma unroll
-      for (int u = 0; u < STAGE_U; ++u) {
-        const int v = v0 + u * 256;
-        val[u] = make_uint4(0, 0, 0, 0);
-        dst[u] = -1;
-        if (v < in_vecs) {
-          int pix = v >> 2, vec = v & 3;
-          int ti = fdiv(pix, t.fd_ihw), rem = pix - ti * ihw;
-          int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
-          int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
-          int c = c0 + vec * VEC;
-          dst[u] = pix * PITCH + vec * 16;
-          if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
-            size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
-            val[u] = *(const uint4*)(xg + off * SZ);
-          }
-        }
+    for (int p = wave; p < t.in_pieces; p += 4) {
+      const int s = p * 64 + lane;                 // 16-byte slot of the input region
+      const int r = s >> 1;                        // tile pixel row
+      const int h = (s & 1) ^ ((r >> 3) & 1);      // logical half stored in this slot
+      const char* src = zero;
+      if (r < t.in_rows) {
+        int ti = fdiv(r, t.fd_ihw), rem = r - ti * ihw;
+        int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+        int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
+        int c = c0 + h * VEC;
+        if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin)
+          src = xg + ((((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c) * SZ;
       }
-#pragma unroll
-      for (int u = 0; u < STAGE_U; ++u)
-        if (dst[u] >= 0) *(uint4*)(lds_in + dst[u]) = val[u];
+      dma16(src, buf + p * 1024);
     }
-    for (int tg0 = 0; tg0 < d.ntaps; tg0 += t.TG) {
-      if (tg0 > 0) __syncthreads();
-      const int tgn = min(t.TG, d.ntaps - tg0);
-      const int w_vecs = tgn * BN * 4;
-      for (int v0 = tid; v0 < w_vecs; v0 += 256 * STAGE_U) {
-        uint4 val[STAGE_U];
-        int dst[STAGE_U];
-#pragma unroll
-        for (int u = 0; u < STAGE_U; ++u) {
-          const int v = v0 + u * 256;
-          val[u] = make_uint4(0, 0, 0, 0);
-          dst[u] = -1;
-          if (v < w_vecs) {
-            int row = v >> 2, vec = v & 3;
-            int tl = row / BN, j = row - tl * BN;
-            dst[u] = row * PITCH + vec * 16;
-            if (co0 + j < d.w_cout_pad) {
-              size_t roff = ((size_t)chunk * d.w_ntaps + d.wtap[tg0 + tl]) * d.w_cout_pad + co0 + j;
-              val[u] = *(const uint4*)(wg + roff * CHUNK_BYTES + vec * 16);
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < STAGE_U; ++u)
-          if (dst[u] >= 0) *(uint4*)(lds_w + dst[u]) = val[u];
+    char* wbuf = buf + t.in_pieces * 1024;
+    for (int p = wave; p < t.w_pieces; p += 4) {
+      const int s = p * 64 + lane;
+      const int r = s >> 1;                        // tap-major weight row: tl * BN + j
+      const int h = (s & 1) ^ ((r >> 3) & 1);
+      const char* src = zero;
+      if (r < w_rows) {
+        const int tl = (p * 32) / BN;              // a piece is 32 rows and BN is a multiple of 32: one tap
+        const int j = r - tl * BN;
+        if (co0 + j < d.w_cout_pad)
+          src = wg + (((size_t)chunk * d.w_ntaps + d.wtap[tl]) * d.w_cout_pad + co0 + j) * ROW + h * 16;
       }
-      __syncthreads();
-      for (int tl = 0; tl < tgn; ++tl) {
-        const int tap = tg0 + tl;
-        const int tapoff = ((d.dy[tap] - t.mindy) * t.IWt + (d.dx[tap] - t.mindx)) * PITCH;
-        const char* wbase = lds_w + tl * BN * PITCH + wrow;
+      dma16(src, wbuf + p * 1024);
+    }
+  };
+
+  issue(0, smem);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of `chunk` have landed
+    __syncthreads();                                   // everyone's have, and chunk-1 has been consumed
+    char* buf = smem + (chunk & 1) * t.buf_bytes;
+    if (chunk + 1 < nchunks) issue(chunk + 1, smem + ((chunk + 1) & 1) * t.buf_bytes);
+    const char* lds_in = buf;
+    const char* lds_w = buf + t.in_pieces * 1024;
+    for (int tap = 0; tap < d.ntaps; ++tap) {
+      const int taprow = (d.dy[tap] - t.mindy) * t.IWt + (d.dx[tap] - t.mindx);
+      const int wr = tap * BN + wrow0;
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-          typename Mma<T>::Frag a[CT], b[PT];
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) {
+        typename Mma<T>::Frag a[CT], b[PT];
 #pragma unroll
-          for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(wbase + c * 32 * PITCH + kk * KB);
+        for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
 #pragma unroll
-          for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in + pixoff[p] + tapoff + kk * KB);
+        for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow, kk, khalf);
 #pragma unroll
-          for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int p = 0; p < PT; ++p) Mma<T>::mma(a[c], b[p], acc[c][p]);
-        }
+          for (int p = 0; p < PT; ++p) Mma<T>::mma(a[c], b[p], acc[c][p]);
       }
     }
   }
@@ -299,8 +299,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     __syncthreads();
     for (int i = tid; i < BN; i += 256) {
       if (co0 + i < d.Cout) {
-        atomicAdd(&d.stats[co0 + i], lds_stats[i]);
-        atomicAdd(&d.stats[d.Cout + co0 + i], lds_stats[BN + i]);
+        float* slot = d.stats + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.Cout;
+        atomicAdd(&slot[co0 + i], lds_stats[i]);
+        atomicAdd(&slot[d.Cout + co0 + i], lds_stats[BN + i]);
       }
     }
   }
@@ -326,26 +327,23 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.mindy = mindy; t.mindx = mindx;
   t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
   t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
-  const int budget = 72 * 1024;
-  {  // shrink the number of images per tile until the halo tile + one tap of weights fit
-    int per_img = t.IHt * t.IWt * PITCH;
-    int maxti = (budget - BN * PITCH) / per_img;
+  const int budget = 76 * 1024;  // two workgroups per CU
+  t.w_pieces = cdiv(d.ntaps * BN * ROW, 1024);
+  {  // shrink the number of images per tile until two stage buffers fit
+    int per_img = t.IHt * t.IWt * ROW;
+    int maxti = (budget / 2 - t.w_pieces * 1024 - 1024) / per_img;
     if (maxti < 1) return -100;
     if (TI > maxti) TI = maxti;
   }
   t.TI = TI;
-  t.in_pix = TI * t.IHt * t.IWt;
+  t.in_rows = TI * t.IHt * t.IWt;
+  t.in_pieces = cdiv(t.in_rows * ROW, 1024);
+  t.buf_bytes = (t.in_pieces + t.w_pieces) * 1024;
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.n_cout_blk = cdiv(d.Cout, BN);
   t.nblocks = t.tiles_x * t.tiles_y * t.tiles_n * t.n_cout_blk;
-  const int in_bytes = round_up(t.in_pix * PITCH, 16);
   const int out_bytes = BM * (BN * SZ + 16);
-  int TG = (budget - in_bytes) / (BN * PITCH);
-  if (TG < 1) return -100;  // does not fit: caller tries a smaller pixel tile
-  if (TG > d.ntaps) TG = d.ntaps;
-  t.TG = TG;
-  t.lds_w_off = in_bytes;
-  int main_bytes = in_bytes + TG * BN * PITCH;
+  int main_bytes = 2 * t.buf_bytes;
   if (out_bytes > main_bytes) main_bytes = out_bytes;
   t.lds_stats_off = round_up(main_bytes, 16);
   int lds = t.lds_stats_off + 2 * BN * 4;
@@ -366,27 +364,23 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   return check_launch("conv_tile_kernel");
 }
 
-// Tile choice: BN covers Cout up to 128; BM as large as possible while the launch still has >= ~1.5
-// workgroups per CU (the small high-channel branches are otherwise left with 64..128 workgroups on 256 CUs).
+// Tile choice.  Weight bytes streamed per workgroup are fixed by BN x K, so the pixel tile should be as
+// large as the launch allows while still giving every CU a workgroup (>= 256 blocks); BN = 64 at most so
+// that two stage buffers of a 3x3 conv stay under ~60 KB.
 template <typename T>
 static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
   const long pixels = (long)d.N * d.Ho * d.Wo;
-  const long want = 384;
+  const long want = 256;
   int rc = -100;
   if (d.Cout <= 32) {
     if (pixels / 256 >= want) rc = launch_cfg<T, 1, 2, 1, 4>(d, s);
     if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4>(d, s);
-  } else if (d.Cout <= 64) {
-    if (pixels / 256 >= want) rc = launch_cfg<T, 2, 2, 1, 4>(d, s);
-    if (rc == -100 && pixels / 128 >= want) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
+  } else {
+    const long nb = (d.Cout + 63) / 64;
+    if (pixels / 256 * nb >= want) rc = launch_cfg<T, 2, 2, 1, 4>(d, s);
+    if (rc == -100 && pixels / 128 * nb >= want) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
     if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2>(d, s);
     if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
-  } else {
-    const long nb = (d.Cout + 127) / 128;
-    if (pixels / 128 * nb >= want) rc = launch_cfg<T, 2, 2, 2, 2>(d, s);
-    if (rc == -100 && pixels / 64 * nb >= want) rc = launch_cfg<T, 2, 1, 2, 2>(d, s);
-    if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2>(d, s);
-    if (rc == -100) rc = launch_cfg<T, 2, 1, 2, 2>(d, s);
   }
   if (rc == -100) {
     set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);

@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WSTAGE_U = 4;
+constexpr int WSTAGE_U = 8;
 
 struct WgradTiling {
   int TH, TW, TI, BM;
@@ -32,6 +32,7 @@ struct WgradTiling {
   int n_cob, n_cib, G;
   int in_pix;
   int lds_dy_off, lds_tab_off, lds_red_off;
+  int use_ws, lds_bytes;
   FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_tx, fd_ty, fd_cib;
 };
 
@@ -207,18 +208,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
     }
     __syncthreads();
   }
-  for (int i = tid; i < NT * 1024; i += 256) {
+  if (t.use_ws) {
+    // partial slab [g][block][NT*1024], coalesced; a second launch folds the G slabs into dW
+    float* ws = (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NT * 1024);
+    for (int i = tid; i < NT * 1024; i += 256) ws[i] = red[i];
+  } else {
+    for (int i = tid; i < NT * 1024; i += 256) {
+      int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
+      int co = co0 + row, cin = ci0 + ci;
+      if (co < d.Cout && cin < d.dw_cin) atomicAdd(&d.dw[((size_t)co * d.dw_cin + cin) * d.ntaps + tp], red[i]);
+    }
+  }
+}
+
+// dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci]
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc d, int G, int pairs, int n_cib) {
+  const int blk = blockIdx.y;
+  const int cob = blk / n_cib, cib = blk - cob * n_cib;
+  // block = 64 consecutive elements x 4 slab phases; lanes read 256 contiguous bytes of a slab, 8 loads
+  // in flight per thread
+  __shared__ float part[4][64];
+  const float* ws = (const float*)d.workspace + (size_t)blk * (NT * 1024);
+  const size_t gstride = (size_t)pairs * (NT * 1024);
+  const int e = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  float s = 0.f;
+  int g = ph;
+  for (; g + 28 < G; g += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + 4 * u) * gstride + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; g < G; g += 4) s += ws[(size_t)g * gstride + i];
+  part[ph][e] = s;
+  __syncthreads();
+  if (ph == 0) {
+    s = part[0][e] + part[1][e] + part[2][e] + part[3][e];
     int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
-    int co = co0 + row, cin = ci0 + ci;
-    if (co < d.Cout && cin < d.dw_cin) atomicAdd(&d.dw[((size_t)co * d.dw_cin + cin) * d.ntaps + tp], red[i]);
+    int co = cob * 32 + row, cin = cib * 32 + ci;
+    if (co < d.Cout && cin < d.dw_cin) {
+      float* o = &d.dw[((size_t)co * d.dw_cin + cin) * d.ntaps + tp];
+      *o = d.accumulate ? *o + s : s;
+    }
   }
 }
 
 template <typename T, int NT>
-static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
+static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   constexpr int SZ = Elem<T>::SZ;
   constexpr int P = 32 * SZ + 16;
-  WgradTiling t{};
   int mindy = 1 << 30, maxdy = -(1 << 30), mindx = 1 << 30, maxdx = -(1 << 30);
   for (int i = 0; i < d.ntaps; ++i) {
     mindy = d.dy_t[i] < mindy ? d.dy_t[i] : mindy; maxdy = d.dy_t[i] > maxdy ? d.dy_t[i] : maxdy;
@@ -255,28 +296,50 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
       return HRP_ERR_ARG;
     }
   }
+  t.lds_bytes = lds;
   t.tiles_x = cdiv(d.Wo, t.TW); t.tiles_y = cdiv(d.Ho, t.TH); t.tiles_n = cdiv(d.N, t.TI);
   t.ntiles = t.tiles_x * t.tiles_y * t.tiles_n;
   t.n_cob = cdiv(d.Cout, 32); t.n_cib = cdiv(d.Cin, 32);
   int pairs = t.n_cob * t.n_cib;
-  // workgroups per (cout, cin) block: enough to fill the chip (~1024 in total), few enough that the
-  // final fp32 atomics (NT*1024 per workgroup) stay a small fraction of the work
-  int G = 1024 / pairs;
+  // workgroups per (cout, cin) block: ~2 per CU over the whole launch; each walks ntiles / G pixel tiles
+  int G = 256 / pairs;
   if (G < 1) G = 1;
   if (G > t.ntiles) G = t.ntiles;
   t.G = G;
   t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
   t.fd_thw = make_fastdiv(t.TH * t.TW); t.fd_tw = make_fastdiv(t.TW);
   t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y); t.fd_cib = make_fastdiv(t.n_cib);
-  if (!d.accumulate) (void)hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
+  return HRP_OK;
+}
+
+template <typename T, int NT>
+static int64_t wgrad_ws_bytes(const hrp_wgrad_desc& d) {
+  WgradTiling t{};
+  if (wgrad_tiling<T, NT>(d, t) != HRP_OK) return 0;
+  return (int64_t)t.G * t.n_cob * t.n_cib * NT * 1024 * 4;
+}
+
+template <typename T, int NT>
+static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
+  WgradTiling t{};
+  int rc = wgrad_tiling<T, NT>(d, t);
+  if (rc != HRP_OK) return rc;
+  const int pairs = t.n_cob * t.n_cib;
+  const int64_t need = (int64_t)t.G * pairs * NT * 1024 * 4;
+  t.use_ws = (d.workspace && d.workspace_bytes >= need) ? 1 : 0;
+  if (!t.use_ws && !d.accumulate)
+    (void)hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
   auto kern = conv_wgrad_kernel<T, NT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(G, pairs), dim3(256), lds, s, d, t);
-  return check_launch("conv_wgrad_kernel");
+  hipLaunchKernelGGL(kern, dim3(t.G, pairs), dim3(256), t.lds_bytes, s, d, t);
+  rc = check_launch("conv_wgrad_kernel");
+  if (rc != HRP_OK || !t.use_ws) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel<NT>, dim3(NT * 1024 / 64, pairs), dim3(256), 0, s, d, t.G, pairs, t.n_cib);
+  return check_launch("wgrad_reduce_kernel");
 }
 
 }  // namespace hrp
@@ -301,4 +364,17 @@ extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
   if (d->ntaps == 1) return launch_wgrad<bf16_t, 1>(*d, s);
   if (d->ntaps == 4) return launch_wgrad<bf16_t, 4>(*d, s);
   return launch_wgrad<bf16_t, 9>(*d, s);
+}
+
+extern "C" int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d) {
+  using namespace hrp;
+  if (!d) return 0;
+  if (d->dtype == HRP_F32) {
+    if (d->ntaps == 1) return wgrad_ws_bytes<float, 1>(*d);
+    if (d->ntaps == 4) return wgrad_ws_bytes<float, 4>(*d);
+    return wgrad_ws_bytes<float, 9>(*d);
+  }
+  if (d->ntaps == 1) return wgrad_ws_bytes<bf16_t, 1>(*d);
+  if (d->ntaps == 4) return wgrad_ws_bytes<bf16_t, 4>(*d);
+  return wgrad_ws_bytes<bf16_t, 9>(*d);
 }

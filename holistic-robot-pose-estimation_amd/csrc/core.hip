@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry* __restrict__ table) {
   const hrp_pack_entry e = table[blockIdx.y];
-  constexpr int CK = 64 / Elem<T>::SZ;
+  constexpr int CK = 32 / Elem<T>::SZ;  // one 32-byte K chunk of the conv kernels (csrc/conv_fwd.hip ROW)
   const int cout_pad = (e.Cout + 31) / 32 * 32, cin_pad = (e.Cin + 31) / 32 * 32;
   if (e.dst) {
     const int nch = (e.Cin + CK - 1) / CK;
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
 __global__ void bn_running_update_kernel(const hrp_bn_entry* __restrict__ table) {
   const hrp_bn_entry e = table[blockIdx.x];
   for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
-    float mean = e.stats[c] / e.count;
-    float var = fmaxf(e.stats[e.C + c] / e.count - mean * mean, 0.f);
+    float mean = slot_sum(e.stats, c, 2 * e.C) / e.count;
+    float var = fmaxf(slot_sum(e.stats, e.C + c, 2 * e.C) / e.count - mean * mean, 0.f);
     float unbiased = e.count > 1.f ? var * (e.count / (e.count - 1.f)) : var;
     e.a[c] = (1.f - e.momentum) * e.a[c] + e.momentum * mean;
     e.b[c] = (1.f - e.momentum) * e.b[c] + e.momentum * unbiased;
@@ -132,7 +132,7 @@ __global__ void bn_fold_kernel(const hrp_bn_entry* __restrict__ table) {
 __global__ void bn_param_grad_kernel(const hrp_bn_entry* __restrict__ table) {
   const hrp_bn_entry e = table[blockIdx.x];
   for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
-    float dbeta = e.stats[c], dgamma = e.stats[e.C + c];
+    float dbeta = slot_sum(e.stats, c, 2 * e.C), dgamma = slot_sum(e.stats, e.C + c, 2 * e.C);
     if (e.accumulate) { e.a[c] += dgamma; e.b[c] += dbeta; }
     else { e.a[c] = dgamma; e.b[c] = dbeta; }
   }

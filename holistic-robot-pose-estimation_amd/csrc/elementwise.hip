@@ -5,8 +5,8 @@
 // covers BatchNorm (+ReLU) after a conv, the residual add of BasicBlock / Bottleneck, the whole
 // cross-resolution fuse of HighResolutionModule (BN of each incoming path + nearest upsample + sum +
 // ReLU in ONE pass; reference HRnet.py:256-263 materialises every term), and the cls-head adds.
-// Train-mode BN needs no separate finalize kernel: every thread derives scale/shift of its channels
-// from the (sum, sumsq) statistics the producing conv accumulated in its epilogue.
+// Train-mode BN needs no separate finalize kernel: each workgroup derives scale/shift of its channel slab
+// once (into LDS) from the (sum, sumsq) statistic slots the producing conv accumulated in its epilogue.
 #include "hrp_common.h"
 
 namespace hrp {
@@ -24,39 +24,68 @@ struct VecIO {
   }
 };
 
-// scale/shift (and mean/invstd) of V channels starting at c for one input
+constexpr int TAB_CH = 512;  // channels per block whose constants are shared through LDS
+
+// scale / shift / mean / invstd of ONE channel of an input
+__device__ __forceinline__ void channel_consts(const hrp_ew_input& in, int c, int C, float& sc, float& sh, float& mean, float& inv) {
+  sc = 1.f; sh = 0.f; mean = 0.f; inv = 1.f;
+  if (c >= C) return;
+  if (in.mode == HRP_EW_AFFINE) {
+    sc = in.a[c]; sh = in.b[c];
+  } else if (in.mode == HRP_EW_BN_TRAIN) {
+    float m = slot_sum(in.stats, c, 2 * C) / in.count;
+    float var = fmaxf(slot_sum(in.stats, C + c, 2 * C) / in.count - m * m, 0.f);
+    float is = rsqrtf(var + in.eps);
+    mean = m; inv = is;
+    sc = in.a[c] * is;
+    sh = in.b[c] - m * sc;
+  }
+}
+
+// Fill tab[f][e] (f = 0 scale, 1 shift, 2 mean, 3 invstd) for the block's channels cbase .. cbase+nch-1.
+// nch <= TAB_CH: computed once per block; otherwise every thread computes its own V channels.
 template <int V>
-__device__ __forceinline__ void channel_affine(const hrp_ew_input& in, int c, int C, float* sc, float* sh, float* mean, float* inv) {
+__device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int cbase, int nch, int c, float (*tab)[TAB_CH],
+                                            float* sc, float* sh, float* mean, float* inv) {
+  if (nch <= TAB_CH) {
+    for (int e = threadIdx.x; e < nch; e += 256)
+      channel_consts(in, cbase + e, C, tab[0][e], tab[1][e], tab[2][e], tab[3][e]);
+    __syncthreads();
+    const int e0 = c - cbase;
 #pragma unroll
-  for (int i = 0; i < V; ++i) {
-    sc[i] = 1.f; sh[i] = 0.f; mean[i] = 0.f; inv[i] = 1.f;
-    if (c + i >= C) continue;
-    if (in.mode == HRP_EW_AFFINE) {
-      sc[i] = in.a[c + i]; sh[i] = in.b[c + i];
-    } else if (in.mode == HRP_EW_BN_TRAIN) {
-      float m = in.stats[c + i] / in.count;
-      float var = fmaxf(in.stats[C + c + i] / in.count - m * m, 0.f);
-      float is = rsqrtf(var + in.eps);
-      mean[i] = m; inv[i] = is;
-      sc[i] = in.a[c + i] * is;
-      sh[i] = in.b[c + i] - m * sc[i];
+    for (int i = 0; i < V; ++i) {
+      const int e = min(e0 + i, TAB_CH - 1);
+      sc[i] = tab[0][e]; sh[i] = tab[1][e]; mean[i] = tab[2][e]; inv[i] = tab[3][e];
     }
+    __syncthreads();  // the table may be reused for the next input
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) channel_consts(in, c + i, C, sc[i], sh[i], mean[i], inv[i]);
   }
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
+  __shared__ float tab[4][TAB_CH];
   const int cv = (blockIdx.y * tpr + threadIdx.x % tpr);
   const int c = cv * V;
-  if (c >= d.C) return;
+  const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;  // pixels per block-iteration
   float sc[HRP_EW_MAX_IN][V], sh[HRP_EW_MAX_IN][V];
   {
     float m[V], iv[V];
 #pragma unroll
     for (int j = 0; j < HRP_EW_MAX_IN; ++j)
-      if (j < d.nin) channel_affine<V>(d.in[j], c, d.C, sc[j], sh[j], m, iv);
+      if (j < d.nin) {
+        if (d.in[j].mode == HRP_EW_IDENTITY) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) { sc[j][i] = 1.f; sh[j][i] = 0.f; }
+        } else {
+          load_consts<V>(d.in[j], d.C, cbase, nch, c, tab, sc[j], sh[j], m, iv);
+        }
+      }
   }
+  if (c >= d.C) return;
   const long npix = (long)d.N * d.H * d.W;
   for (long p = (long)blockIdx.x * ppb + threadIdx.x / tpr; p < npix; p += (long)gridDim.x * ppb) {
     int x = p % d.W;
@@ -110,17 +139,19 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, int n, int
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_desc d, int tpr) {
   __shared__ float red[2][256 * (V > 1 ? V : 1)];
+  __shared__ float tab[4][TAB_CH];
   const int lane_c = threadIdx.x % tpr;
   const int cv = blockIdx.y * tpr + lane_c;
   const int c = cv * V;
+  const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;
   const int up = d.in.up, Hq = d.H / up, Wq = d.W / up;
   float s0[V], s1[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) s0[i] = s1[i] = 0.f;
+  float sc[V], sh[V], mean[V], inv[V];
+  load_consts<V>(d.in, d.C, cbase, nch, c, tab, sc, sh, mean, inv);
   if (c < d.C) {
-    float sc[V], sh[V], mean[V], inv[V];
-    channel_affine<V>(d.in, c, d.C, sc, sh, mean, inv);
     const long nq = (long)d.N * Hq * Wq;
     for (long q = (long)blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += (long)gridDim.x * ppb) {
       int qx = q % Wq;
@@ -170,28 +201,48 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
       a0 += red[0][(k * tpr + lc) * V + i];
       a1 += red[1][(k * tpr + lc) * V + i];
     }
-    atomicAdd(&d.sums[ch], a0);
-    atomicAdd(&d.sums[d.C + ch], a1);
+    float* slot = d.sums + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.C;
+    atomicAdd(&slot[ch], a0);
+    atomicAdd(&slot[d.C + ch], a1);
   }
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
+  __shared__ float tab[4][TAB_CH];
+  __shared__ float ktab[2][TAB_CH];
   const int cv = blockIdx.y * tpr + threadIdx.x % tpr;
   const int c = cv * V;
-  if (c >= d.C) return;
+  const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;
   const int up = d.in.up, Hq = d.H / up, Wq = d.W / up;
   float sc[V], sh[V], mean[V], inv[V], k0[V], k1[V];
-  channel_affine<V>(d.in, c, d.C, sc, sh, mean, inv);
 #pragma unroll
-  for (int i = 0; i < V; ++i) {
-    k0[i] = k1[i] = 0.f;
-    if (d.in.mode == HRP_EW_BN_TRAIN && c + i < d.C) {
-      k0[i] = d.sums[c + i] / d.in.count;
-      k1[i] = d.sums[d.C + c + i] / d.in.count;
+  for (int i = 0; i < V; ++i) { sc[i] = 1.f; sh[i] = 0.f; mean[i] = 0.f; inv[i] = 1.f; k0[i] = k1[i] = 0.f; }
+  if (d.in.mode != HRP_EW_IDENTITY) load_consts<V>(d.in, d.C, cbase, nch, c, tab, sc, sh, mean, inv);
+  if (d.in.mode == HRP_EW_BN_TRAIN) {
+    if (nch <= TAB_CH) {
+      for (int e = threadIdx.x; e < nch; e += 256) {
+        const int ch = cbase + e;
+        ktab[0][e] = ch < d.C ? slot_sum(d.sums, ch, 2 * d.C) / d.in.count : 0.f;
+        ktab[1][e] = ch < d.C ? slot_sum(d.sums, d.C + ch, 2 * d.C) / d.in.count : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int e = min(c - cbase + i, TAB_CH - 1);
+        k0[i] = ktab[0][e]; k1[i] = ktab[1][e];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        if (c + i < d.C) {
+          k0[i] = slot_sum(d.sums, c + i, 2 * d.C) / d.in.count;
+          k1[i] = slot_sum(d.sums, d.C + c + i, 2 * d.C) / d.in.count;
+        }
     }
   }
+  if (c >= d.C) return;
   const long nq = (long)d.N * Hq * Wq;
   for (long q = (long)blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += (long)gridDim.x * ppb) {
     int qx = q % Wq;
@@ -226,7 +277,9 @@ static inline bool aligned16(const void* p, int pitch, int sz) {
 
 struct EwGeom { int V, tpr, nslab, gx; };
 
-static EwGeom geom(int C, int vec, bool vec_ok, long npix) {
+// maxblocks: 4 workgroups per CU for the streaming kernels; the reduce kernel uses fewer, each block ends
+// with 2 * channels atomics
+static EwGeom geom(int C, int vec, bool vec_ok, long npix, int maxblocks) {
   EwGeom g;
   g.V = (vec_ok && C % vec == 0) ? vec : 1;
   int nv = C / g.V;
@@ -236,7 +289,7 @@ static EwGeom geom(int C, int vec, bool vec_ok, long npix) {
   g.nslab = cdiv(nv, tpr);
   int ppb = 256 / tpr;
   long blocks = (npix + ppb - 1) / ppb;
-  long cap = 256L * 8 / g.nslab;
+  long cap = maxblocks / g.nslab;
   if (cap < 1) cap = 1;
   g.gx = (int)(blocks < cap ? blocks : cap);
   if (g.gx < 1) g.gx = 1;
@@ -248,7 +301,7 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
   bool ok = aligned16(d.out, d.out_pitch, SZ);
   for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W);
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, 1024);
   dim3 grid(g.gx, g.nslab);
   if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
   else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
@@ -262,7 +315,7 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   if (d.relu) ok = ok && aligned16(d.out, d.out_pitch, SZ);
   if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
   const int up = d.in.up;
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up));
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : 512);
   dim3 grid(g.gx, g.nslab);
   if (APPLY) {
     if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr);
@@ -298,7 +351,7 @@ static int ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
   HRP_REQUIRE(d->in.mode == HRP_EW_IDENTITY || d->in.ptr, "ew_bwd: needs forward input values");
   HRP_REQUIRE(d->in.mode != HRP_EW_BN_TRAIN || (d->sums && d->in.stats && d->in.a), "ew_bwd: bn needs sums/stats");
   HRP_REQUIRE(!apply || d->din, "ew_bwd_apply: din");
-  HRP_REQUIRE(apply || d->sums, "ew_bwd_reduce: sums");
+  HRP_REQUIRE(apply || (d->sums && d->in.ptr), "ew_bwd_reduce: sums / input values");
   return HRP_OK;
 }
 

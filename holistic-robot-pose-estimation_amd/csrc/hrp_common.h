@@ -71,6 +71,14 @@ struct Elem<bf16_t> {
   }
 };
 
+// sum of the HRP_STAT_SLOTS replicas of statistic element i (buffer laid out [slot][n])
+__device__ __forceinline__ float slot_sum(const float* p, int i, int n) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < HRP_STAT_SLOTS; ++k) s += p[k * n + i];
+  return s;
+}
+
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

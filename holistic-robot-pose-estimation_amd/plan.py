@@ -18,6 +18,7 @@ import torch
 from . import _native as nv
 
 BN_EPS = 1e-5
+STAT_SLOTS = 8   # HRP_STAT_SLOTS in include/hrp.h
 
 
 def _rup(a, b):
@@ -110,6 +111,8 @@ class Plan:
         self.out_handles = []      # TensorH whose gradient is seeded from outside
         self.grad_arena = None
         self._grad_views = {}
+        self.wgrad_ws_bytes = 0    # scratch shared by all weight-gradient launches (stream ordered)
+        self.wgrad_ws = None
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -147,12 +150,12 @@ class Plan:
 
     def alloc_stats(self, Cc):
         off = self.stats_floats
-        self.stats_floats += 2 * Cc
+        self.stats_floats += 2 * Cc * STAT_SLOTS
         return off
 
     def alloc_bsums(self, Cc):
         off = self.bsums_floats
-        self.bsums_floats += 2 * Cc
+        self.bsums_floats += 2 * Cc * STAT_SLOTS
         return off
 
     # ---- finalisation -----------------------------------------------------------------------------
@@ -167,7 +170,7 @@ class Plan:
             if not ws:
                 continue
             esz = 4 if dtype == torch.float32 else 2
-            ck = 64 // esz
+            ck = 32 // esz   # channels per 32-byte K chunk (csrc/conv_fwd.hip ROW, core.hip pack kernel)
             total, maxel = 0, 0
             for w in ws:
                 nf = math.ceil(w.cin_used / ck) * w.ntaps * _rup(w.cout, 32) * ck
@@ -191,6 +194,7 @@ class Plan:
             tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
             self.keep.append(tdev)
             self._pack_tables.append((tdev, len(ws), _dt(dtype), maxel))
+        self.wgrad_ws = torch.zeros(max(self.wgrad_ws_bytes // 4, 4), dtype=torch.float32, device=dev)
         # resolve deferred pointers
         for fn in self._late:
             fn()
@@ -426,6 +430,9 @@ class PlanBuilder:
             g.dw_cin = w.cin
             g.accumulate = 1 if (w.grad_written or p.grad_arena is not None) else 0
             w.grad_written = True
+            p.wgrad_ws_bytes = max(p.wgrad_ws_bytes, int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
+            p.late(lambda g=g: (setattr(g, "workspace", p.wgrad_ws.data_ptr()),
+                                setattr(g, "workspace_bytes", p.wgrad_ws.numel() * 4)))
             p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
         # data gradient
         if x.requires_grad:

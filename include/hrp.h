@@ -52,6 +52,12 @@ typedef enum {
 
 #define HRP_MAX_TAPS 16
 
+/* Per-channel statistics (BN forward sum/sumsq, BN backward sums) are accumulated with fp32 atomics.
+ * Same-address atomics serialise (~20 ns each on MI355X), so every statistics buffer has HRP_STAT_SLOTS
+ * replicas laid out [slot][2*C]; a workgroup adds into slot (blockIdx & (SLOTS-1)) and readers sum the
+ * slots.  The caller zeroes all slots before the producing launch. */
+#define HRP_STAT_SLOTS 8
+
 /* One convolution "problem": out[n, oy, ox, co] = sum_t sum_ci in[n, oy*IS+dy[t], ox*IS+dx[t], ci] * W[t][co][ci].
  * Covers conv k1/k3 stride 1/2 forward, its data gradient (stride 1: mirrored taps, stride 2: one call per
  * output parity class with out_stride = 2), and nn.Linear (H = W = 1). */
@@ -63,7 +69,7 @@ typedef struct hrp_conv_desc {
   const float* bias;   /* optional [Cout]                                                         */
   const float* scale;  /* optional per-channel affine applied after bias: v*scale+shift           */
   const float* shift;
-  float* stats;        /* optional [2*Cout]: += sum(y), sum(y*y) over all output pixels           */
+  float* stats;        /* optional [HRP_STAT_SLOTS][2*Cout]: += sum(y), sum(y*y) over output pixels */
   int32_t dtype;       /* hrp_dtype of x, w, y, res                                               */
   int32_t N, H, W, Cin, x_pitch;
   int32_t Ho, Wo, Cout; /* logical output grid walked by the kernel                               */
@@ -90,11 +96,14 @@ typedef struct hrp_wgrad_desc {
   int32_t in_stride, ntaps;
   int32_t dy_t[HRP_MAX_TAPS], dx_t[HRP_MAX_TAPS];
   int32_t dw_cin;      /* row length (in taps groups) of dw: element (co,ci,t) at (co*dw_cin+ci)*ntaps+t */
-  int32_t accumulate;  /* 0: dw is zeroed by the call first, 1: add to existing */
+  int32_t accumulate;  /* 0: dw is overwritten, 1: add to existing */
+  void* workspace;     /* optional scratch of hrp_wgrad_workspace_bytes(): partial sums are written there
+                          and reduced by a second launch instead of fp32 atomics into dw */
+  int64_t workspace_bytes;
 } hrp_wgrad_desc;
 
 /* Weight packing table entry (one launch packs every conv / linear weight of a network).
- * src: fp32 [Cout][Cin][ntaps] (PyTorch [Cout][Cin][KH][KW]).  CK = 64 bytes / sizeof(elem).
+ * src: fp32 [Cout][Cin][ntaps] (PyTorch [Cout][Cin][KH][KW]).  CK = 32 bytes / sizeof(elem).
  * dst   (forward):       [ceil(Cin/CK)][tap][Cout_pad][CK],  value W[co][chunk*CK+k][tap]
  * dst_t (data gradient): [ceil(Cout/CK)][tap][Cin_pad][CK],  value W[chunk*CK+k][ci][tap]
  * Cout_pad / Cin_pad = round_up(.., 32); everything outside the real extents is zero. */
@@ -117,7 +126,7 @@ typedef struct hrp_ew_input {
   int32_t mode;        /* hrp_ew_mode */
   const float* a;      /* AFFINE: scale[C]; BN_TRAIN: gamma[C] */
   const float* b;      /* AFFINE: shift[C]; BN_TRAIN: beta[C]  */
-  const float* stats;  /* BN_TRAIN: [2C] sum, sumsq of this input over its own pixels */
+  const float* stats;  /* BN_TRAIN: [HRP_STAT_SLOTS][2C] sum, sumsq of this input over its own pixels */
   float count;         /* BN_TRAIN: number of pixels the statistics were taken over */
   float eps;
 } hrp_ew_input;
@@ -142,7 +151,7 @@ typedef struct hrp_ew_bwd_desc {
   hrp_ew_input in;     /* the forward input this call differentiates (ptr = forward input values) */
   void* din;           /* [N, H/up, W/up, din_pitch]; apply only */
   int32_t din_pitch;
-  float* sums;         /* [2C] */
+  float* sums;         /* [HRP_STAT_SLOTS][2C] */
   int32_t dtype;
   int32_t N, H, W, C;  /* geometry of out */
   int32_t relu;
@@ -151,7 +160,7 @@ typedef struct hrp_ew_bwd_desc {
 
 /* Table entry for the one-launch batch-norm bookkeeping kernels. */
 typedef struct hrp_bn_entry {
-  const float* stats;  /* forward [2C] sums (running_update) or backward sums (param_grad) */
+  const float* stats;  /* [HRP_STAT_SLOTS][2C] forward sums (running_update) or backward sums (param_grad) */
   float* a;            /* running_update: running_mean | fold: gamma | param_grad: dgamma */
   float* b;            /* running_update: running_var  | fold: beta  | param_grad: dbeta  */
   const float* c;      /* fold: running_mean */
@@ -192,6 +201,8 @@ int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int 
 
 int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream);
 int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream);
+/* scratch bytes hrp_conv2d_bwd_weight wants for this problem (0 is never returned for a valid problem) */
+int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d);
 /* out[c] (+)= sum over rows of x[rows, pitch] (bias gradients) */
 int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream);
 

@@ -196,9 +196,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   constexpr int OP = BN * SZ + 16;
   char* lds_out = smem;
   float* lds_stats = (float*)(smem + t.lds_stats_off);
-  if (d.stats) {
-    for (int i = tid; i < 2 * BN; i += 256) lds_stats[i] = 0.f;
-  }
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
 #pragma unroll
@@ -224,8 +221,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
           *(uint4*)dst = Elem<float>::pack(v);
         } else {
           uint2 r;
-          r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          r.x = pack_bf2(v[0], v[1]);
+          r.y = pack_bf2(v[2], v[3]);
           *(uint2*)dst = r;
         }
       }
@@ -250,9 +247,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
       if (ti >= t.TI || n >= d.N || oy >= d.Ho || ox >= d.Wo) continue;
       size_t opix = ((size_t)n * d.y_H + (oy * d.out_stride + d.out_off_y)) * d.y_W + (ox * d.out_stride + d.out_off_x);
+      const uint4 raw = *(const uint4*)(lds_out + m * OP + cv * 16);
       float f[VEC];
-      Elem<T>::unpack(*(const uint4*)(lds_out + m * OP + cv * 16), f);
-      if (full) {
+      Elem<T>::unpack(raw, f);
+      if (full && !rg && !d.relu) {
+        // plain conv output (the train-mode case): the LDS image is already the stored value
+        *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = raw;
+        if (d.stats) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+        }
+      } else if (full) {
         if (rg) {
           float r[VEC];
           Elem<T>::unpack(*(const uint4*)(rg + (opix * d.res_pitch + co) * SZ), r);
@@ -289,19 +294,31 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     }
   }
   if (d.stats) {
-    if (co < d.Cout) {
+    // lanes cv, cv + NV, ... of a wave own the same channels: butterfly over them, then one partial per
+    // wave in LDS ([wave][2][BN]), then one global atomic per channel per workgroup
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+      for (int o = 32; o >= NV; o >>= 1) {
+        s1[i] += __shfl_xor(s1[i], o, 64);
+        s2[i] += __shfl_xor(s2[i], o, 64);
+      }
+    }
+    if (lane < NV) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        atomicAdd(&lds_stats[cv * VEC + i], s1[i]);
-        atomicAdd(&lds_stats[BN + cv * VEC + i], s2[i]);
+        lds_stats[(wave * 2 + 0) * BN + lane * VEC + i] = s1[i];
+        lds_stats[(wave * 2 + 1) * BN + lane * VEC + i] = s2[i];
       }
     }
     __syncthreads();
-    for (int i = tid; i < BN; i += 256) {
-      if (co0 + i < d.Cout) {
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, ch = i - which * BN;
+      if (co0 + ch < d.Cout) {
+        float v = lds_stats[(0 * 2 + which) * BN + ch] + lds_stats[(1 * 2 + which) * BN + ch] +
+                  lds_stats[(2 * 2 + which) * BN + ch] + lds_stats[(3 * 2 + which) * BN + ch];
         float* slot = d.stats + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.Cout;
-        atomicAdd(&slot[co0 + i], lds_stats[i]);
-        atomicAdd(&slot[d.Cout + co0 + i], lds_stats[BN + i]);
+        atomicAdd(&slot[which * d.Cout + co0 + ch], v);
       }
     }
   }
@@ -346,7 +363,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   int main_bytes = 2 * t.buf_bytes;
   if (out_bytes > main_bytes) main_bytes = out_bytes;
   t.lds_stats_off = round_up(main_bytes, 16);
-  int lds = t.lds_stats_off + 2 * BN * 4;
+  int lds = t.lds_stats_off + 8 * BN * 4;  // [wave][sum, sumsq][BN] partials
   if (lds > 160 * 1024) return -100;
   const bool aligned = ((uintptr_t)d.y % 16 == 0) && ((size_t)d.y_pitch * SZ % 16 == 0) &&
                        (!d.res || (((uintptr_t)d.res % 16 == 0) && ((size_t)d.res_pitch * SZ % 16 == 0)));

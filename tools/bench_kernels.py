@@ -80,6 +80,11 @@ def conv_case(N, H, W, cin, cout, k, stride, dtype, stats):
     if stats:
         d.stats = st.data_ptr()
     us = timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d), None))
+    if os.environ.get("HRP_DBG"):
+        for flag, name in ((256, "no-mfma"), (2048, "no-store"), (2048 + 256, "no-mfma-store"), (256 + 512, "dma only"), (1024+256+512, "empty")):
+            d.relu = flag
+            print(f"      {name:12s}: {timeit(lambda: nv.call('hrp_conv2d_fwd', C.byref(d), None)):8.1f} us")
+        d.relu = 0
     fl = 2.0 * N * Ho * Wo * cout * cin * len(taps)
     by = (x.numel() + y.numel()) * esz
     print(f"conv  N={N} {cin:4d}->{cout:4d} k{k} s{stride} @{H:3d}x{W:<3d} stats={int(stats)}: {us:8.1f} us  "

@@ -248,19 +248,47 @@ def main():
     value = B * world * a.steps / dt
 
     # ---- instrumented pass: HIP events around every C-ABI launch on the launch stream --------------
-    records = []
+    records, records_shape = [], []
+
+    def shape_key(name, args):
+        try:
+            dd = args[0]._obj
+        except AttributeError:
+            return ""
+        if name == "hrp_conv2d_fwd":
+            return f"{dd.Cin}->{dd.Cout} taps{dd.ntaps} s{dd.in_stride}/{dd.out_stride} @{dd.Ho}x{dd.Wo}"
+        if name == "hrp_conv2d_bwd_weight":
+            return f"{dd.Cin}->{dd.Cout} taps{dd.ntaps} s{dd.in_stride} @{dd.Ho}x{dd.Wo}"
+        if name == "hrp_ew_fwd":
+            return f"C{dd.C} @{dd.H}x{dd.W} nin{dd.nin}"
+        if name.startswith("hrp_ew_bwd"):
+            return f"C{dd.C} @{dd.H}x{dd.W} up{dd.inp.up} mode{dd.inp.mode}"
+        return ""
 
     def hook(name, args, launch):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        records.append((name, conv_flops(name, args), e0, e1))
+        fl = conv_flops(name, args)
+        records.append((name, fl, e0, e1))
+        if os.environ.get("HRP_BENCH_SHAPES"):
+            records_shape.append((name, fl, e0, e1, shape_key(name, args)))
 
     nv.set_profile_hook(hook)
     fwd_bwd()
     nv.set_profile_hook(None)
     torch.cuda.synchronize(dev)
+    if os.environ.get("HRP_BENCH_SHAPES"):   # development aid: time per (kernel, shape) class to stderr
+        shp = {}
+        for name, fl, e0, e1, key in records_shape:
+            v = shp.setdefault((name, key), [0, 0.0, 0.0])
+            v[0] += 1
+            v[1] += e0.elapsed_time(e1)
+            v[2] += fl
+        for (name, key), v in sorted(shp.items(), key=lambda kv: -kv[1][1])[:40]:
+            tf = f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s" if v[2] else ""
+            print(f"{name:24s} {key:44s} n={v[0]:4d} {v[1]:8.3f} ms  avg {v[1] / v[0] * 1e3:7.1f} us {tf}", file=sys.stderr)
     fam = {}
     for name, fl, e0, e1 in records:
         f = fam.setdefault(name, [0, 0.0, 0.0])

@@ -37,7 +37,8 @@ struct ConvTiling {
   int n_cout_blk;
   int in_rows;              // TI*IHt*IWt
   int in_pieces, w_pieces;  // 1 KiB DMA pieces per stage
-  int buf_bytes;            // one stage buffer
+  int buf_bytes;            // one 32-byte-chunk buffer (input rows + weight rows)
+  int G;                    // chunks per pipeline stage
   int lds_stats_off;
   int nblocks;
   int vec_ok;
@@ -78,7 +79,7 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int CT, int PT, int WC, int WP>
+template <typename T, int CT, int PT, int WC, int WP, int NT>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, const ConvTiling t) {
   static_assert(WC * WP == 4, "4 waves");
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
@@ -129,64 +130,105 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   const char* xg = (const char*)d.x;
   const char* wg = (const char*)d.w;
   const char* zero = (const char*)g_zero_page;
-  const int w_rows = d.ntaps * BN;
+  constexpr int w_rows = NT * BN;
+  // tap offsets (in tile rows) live in registers: with NT known the tap loop unrolls completely and the
+  // compiler can run the LDS reads of tap t+1 under the MFMAs of tap t
+  int taprow[NT];
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) taprow[tp] = (d.dy[tp] - t.mindy) * t.IWt + (d.dx[tp] - t.mindx);
 
-  // ---- DMA issue of one chunk into a stage buffer (each wave takes every 4th 1 KiB piece) ------------
-  auto issue = [&](int chunk, char* buf) {
-    const int c0 = chunk * CKE;
-    for (int p = wave; p < t.in_pieces; p += 4) {
+  // ---- DMA plan of this wave: per-lane source offsets of its 1 KiB pieces, computed ONCE -----------------
+  // (the per-chunk issue is then one add + one global_load_lds per piece; doing the pixel decode per chunk
+  // made deep-K layers issue-bound: 16 chunks x ~6 pieces x ~40 VALU instructions per wave)
+  constexpr int MAXP_IN = 10;                    // input pieces per wave (tile <= 40 KiB per chunk)
+  constexpr int W_PIECES = NT * BN / 32;         // weight pieces per chunk (BN % 32 == 0)
+  constexpr int MAXP_W = (W_PIECES + 3) / 4;
+  int in_off[MAXP_IN];                           // byte offset into x for chunk 0, half h; -1 = zero page
+  int in_h[MAXP_IN];
+#pragma unroll
+  for (int i = 0; i < MAXP_IN; ++i) {
+    in_off[i] = -1; in_h[i] = 0;
+    const int p = wave + 4 * i;
+    if (p < t.in_pieces) {
       const int s = p * 64 + lane;                 // 16-byte slot of the input region
       const int r = s >> 1;                        // tile pixel row
       const int h = (s & 1) ^ ((r >> 3) & 1);      // logical half stored in this slot
-      const char* src = zero;
+      in_h[i] = h;
       if (r < t.in_rows) {
         int ti = fdiv(r, t.fd_ihw), rem = r - ti * ihw;
         int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
         int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
-        int c = c0 + h * VEC;
-        if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin)
-          src = xg + ((((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c) * SZ;
+        if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W)
+          in_off[i] = (int)(((((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + h * VEC) * SZ);
       }
-      dma16(src, buf + p * 1024);
     }
-    char* wbuf = buf + t.in_pieces * 1024;
-    for (int p = wave; p < t.w_pieces; p += 4) {
+  }
+  int w_off[MAXP_W];                             // byte offset into the packed weights for chunk 0; -1 = zero
+#pragma unroll
+  for (int i = 0; i < MAXP_W; ++i) {
+    w_off[i] = -1;
+    const int p = wave + 4 * i;
+    if (p < W_PIECES) {
       const int s = p * 64 + lane;
       const int r = s >> 1;                        // tap-major weight row: tl * BN + j
       const int h = (s & 1) ^ ((r >> 3) & 1);
-      const char* src = zero;
-      if (r < w_rows) {
-        const int tl = (p * 32) / BN;              // a piece is 32 rows and BN is a multiple of 32: one tap
-        const int j = r - tl * BN;
-        if (co0 + j < d.w_cout_pad)
-          src = wg + (((size_t)chunk * d.w_ntaps + d.wtap[tl]) * d.w_cout_pad + co0 + j) * ROW + h * 16;
+      const int tl = (p * 32) / BN;                // a piece is 32 rows and BN is a multiple of 32: one tap
+      const int j = r - tl * BN;
+      if (co0 + j < d.w_cout_pad) w_off[i] = (int)(((size_t)d.wtap[tl] * d.w_cout_pad + co0 + j) * ROW + h * 16);
+    }
+  }
+  const int w_chunk_stride = d.w_ntaps * d.w_cout_pad * ROW;  // bytes between consecutive chunks of the packing
+
+  auto issue = [&](int chunk, char* buf) {
+    const int c0 = chunk * CKE;
+#pragma unroll
+    for (int i = 0; i < MAXP_IN; ++i) {
+      const int p = wave + 4 * i;
+      if (p < t.in_pieces) {
+        const bool ok = in_off[i] >= 0 && (c0 + in_h[i] * VEC < d.Cin);
+        dma16(ok ? xg + (size_t)in_off[i] + (size_t)chunk * ROW : zero, buf + p * 1024);
       }
-      dma16(src, wbuf + p * 1024);
+    }
+    char* wbuf = buf + t.in_pieces * 1024;
+#pragma unroll
+    for (int i = 0; i < MAXP_W; ++i) {
+      const int p = wave + 4 * i;
+      if (p < W_PIECES) dma16(w_off[i] >= 0 ? wg + (size_t)w_off[i] + (size_t)chunk * w_chunk_stride : zero, wbuf + p * 1024);
     }
   };
 
-  issue(0, smem);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of `chunk` have landed
-    __syncthreads();                                   // everyone's have, and chunk-1 has been consumed
-    char* buf = smem + (chunk & 1) * t.buf_bytes;
-    if (chunk + 1 < nchunks) issue(chunk + 1, smem + ((chunk + 1) & 1) * t.buf_bytes);
-    const char* lds_in = buf;
-    const char* lds_w = buf + t.in_pieces * 1024;
-    for (int tap = 0; tap < d.ntaps; ++tap) {
-      const int taprow = (d.dy[tap] - t.mindy) * t.IWt + (d.dx[tap] - t.mindx);
-      const int wr = tap * BN + wrow0;
+  // A stage = G consecutive 32-byte chunks (G sub-buffers): the DMA latency of a stage is paid once per G
+  // chunks of MFMA work instead of once per chunk (deep-K layers have 16 chunks of only 9 MFMAs per wave).
+  const int G = t.G, stage_bytes = G * t.buf_bytes;
+  const int nstages = (nchunks + G - 1) / G;
+  auto issue_stage = [&](int st, char* base) {
+    for (int g = 0; g < G; ++g)
+      if (st * G + g < nchunks) issue(st * G + g, base + g * t.buf_bytes);
+  };
+  issue_stage(0, smem);
+  for (int st = 0; st < nstages; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of stage `st` have landed
+    __syncthreads();                                   // everyone's have, and stage st-1 has been consumed
+    char* sbuf = smem + (st & 1) * stage_bytes;
+    if (st + 1 < nstages) issue_stage(st + 1, smem + ((st + 1) & 1) * stage_bytes);
+    for (int g = 0; g < G && st * G + g < nchunks; ++g) {
+      const char* lds_in = sbuf + g * t.buf_bytes;
+      const char* lds_w = lds_in + t.in_pieces * 1024;
 #pragma unroll
-      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) {
-        typename Mma<T>::Frag a[CT], b[PT];
+      for (int tap = 0; tap < NT; ++tap) {
+        const int wr = tap * BN + wrow0;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
+        for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) {
+          typename Mma<T>::Frag a[CT], b[PT];
 #pragma unroll
-        for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow, kk, khalf);
+          for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+          for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow[tap], kk, khalf);
 #pragma unroll
-          for (int p = 0; p < PT; ++p) Mma<T>::mma(a[c], b[p], acc[c][p]);
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) Mma<T>::mma(a[c], b[p], acc[c][p]);
+        }
       }
     }
   }
@@ -325,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CT, int PT, int WC, int WP>
+template <typename T, int CT, int PT, int WC, int WP, int NT>
 static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
   constexpr int SZ = Elem<T>::SZ;
@@ -345,7 +387,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
   t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
   const int budget = 76 * 1024;  // two workgroups per CU
-  t.w_pieces = cdiv(d.ntaps * BN * ROW, 1024);
+  t.w_pieces = NT * BN / 32;
   {  // shrink the number of images per tile until two stage buffers fit
     int per_img = t.IHt * t.IWt * ROW;
     int maxti = (budget / 2 - t.w_pieces * 1024 - 1024) / per_img;
@@ -355,12 +397,22 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.TI = TI;
   t.in_rows = TI * t.IHt * t.IWt;
   t.in_pieces = cdiv(t.in_rows * ROW, 1024);
+  if (t.in_pieces > 40) return -100;  // MAXP_IN pieces per wave
   t.buf_bytes = (t.in_pieces + t.w_pieces) * 1024;
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.n_cout_blk = cdiv(d.Cout, BN);
   t.nblocks = t.tiles_x * t.tiles_y * t.tiles_n * t.n_cout_blk;
   const int out_bytes = BM * (BN * SZ + 16);
-  int main_bytes = 2 * t.buf_bytes;
+  {  // chunks per stage: as many as two stages of LDS allow (all of LDS when the launch has at most one
+     // workgroup per CU anyway, half of it otherwise), up to 4
+    const int nsub = cdiv(d.Cin * SZ, ROW);
+    int G = (t.nblocks <= 256 ? 144 * 1024 : budget) / (2 * t.buf_bytes);
+    if (G < 1) G = 1;
+    if (G > 16) G = 16;
+    if (G > nsub) G = nsub;
+    t.G = G;
+  }
+  int main_bytes = 2 * t.G * t.buf_bytes;
   if (out_bytes > main_bytes) main_bytes = out_bytes;
   t.lds_stats_off = round_up(main_bytes, 16);
   int lds = t.lds_stats_off + 8 * BN * 4;  // [wave][sum, sumsq][BN] partials
@@ -371,7 +423,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
   t.fd_thw = make_fastdiv(TH * TW); t.fd_tw = make_fastdiv(TW);
   t.fd_ncb = make_fastdiv(t.n_cout_blk); t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y);
-  auto kern = conv_tile_kernel<T, CT, PT, WC, WP>;
+  auto kern = conv_tile_kernel<T, CT, PT, WC, WP, NT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -384,26 +436,39 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
 // Tile choice.  Weight bytes streamed per workgroup are fixed by BN x K, so the pixel tile should be as
 // large as the launch allows while still giving every CU a workgroup (>= 256 blocks); BN = 64 at most so
 // that two stage buffers of a 3x3 conv stay under ~60 KB.
-template <typename T>
-static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
+template <typename T, int NT>
+static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
   const long pixels = (long)d.N * d.Ho * d.Wo;
   const long want = 256;
   int rc = -100;
   if (d.Cout <= 32) {
-    if (pixels / 256 >= want) rc = launch_cfg<T, 1, 2, 1, 4>(d, s);
-    if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4>(d, s);
+    if (pixels / 256 >= want) rc = launch_cfg<T, 1, 2, 1, 4, NT>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4, NT>(d, s);
   } else {
     const long nb = (d.Cout + 63) / 64;
-    if (pixels / 256 * nb >= want) rc = launch_cfg<T, 2, 2, 1, 4>(d, s);
-    if (rc == -100 && pixels / 128 * nb >= want) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
-    if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2>(d, s);
-    if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4>(d, s);
+    if (pixels / 256 * nb >= want) rc = launch_cfg<T, 2, 2, 1, 4, NT>(d, s);
+    if (rc == -100 && pixels / 128 * nb >= want) rc = launch_cfg<T, 2, 1, 1, 4, NT>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2, NT>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4, NT>(d, s);
   }
   if (rc == -100) {
     set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
     return HRP_ERR_ARG;
   }
   return rc;
+}
+
+template <typename T>
+static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
+  switch (d.ntaps) {
+    case 1: return launch_conv_nt<T, 1>(d, s);
+    case 2: return launch_conv_nt<T, 2>(d, s);
+    case 4: return launch_conv_nt<T, 4>(d, s);
+    case 9: return launch_conv_nt<T, 9>(d, s);
+    default:
+      set_error("conv: ntaps=%d is not one of the built tap counts (1, 2, 4, 9)", d.ntaps);
+      return HRP_ERR_ARG;
+  }
 }
 
 }  // namespace hrp

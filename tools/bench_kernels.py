@@ -80,6 +80,14 @@ def conv_case(N, H, W, cin, cout, k, stride, dtype, stats):
     if stats:
         d.stats = st.data_ptr()
     us = timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d), None))
+    if os.environ.get("HRP_CYC"):
+        dbg = torch.zeros(4, device=DEV)
+        d.bias, d.relu = dbg.data_ptr(), 4096
+        nv.call("hrp_conv2d_fwd", C.byref(d), None)
+        torch.cuda.synchronize()
+        v = dbg.cpu().tolist()
+        print(f"      cycles/WG: first-stage wait {v[0]/v[3]:.0f}  main loop {v[1]/v[3]:.0f}  epilogue {v[2]/v[3]:.0f}  (WGs {v[3]:.0f})")
+        d.bias, d.relu = None, 0
     if os.environ.get("HRP_DBG"):
         for flag, name in ((256, "no-mfma"), (2048, "no-store"), (2048 + 256, "no-mfma-store"), (256 + 512, "dma only"), (1024+256+512, "empty")):
             d.relu = flag

@@ -141,9 +141,18 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--p-dropout", type=float, default=0.5, help="lib/core/config.py:70 default")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    if a.cpu_baseline_only:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        print(json.dumps(cpu_baseline(a.cpu_batch, max(1, min(cores, 64)))))
+        return
 
     rank, world, local = init_distributed()
     if world != a.gpus and rank == 0 and world > 1:
@@ -322,10 +331,16 @@ def main():
         "loss": final_loss,
     }
     if not a.no_cpu_baseline:
+        # separate process (own thread pool, hard time limit): the baseline must never take the GPU number
+        # down with it
+        import subprocess
         try:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, os.cpu_count() or 1)
-        except Exception as e:  # the baseline must never take the GPU number down with it
-            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch",
+                                str(a.cpu_batch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                               timeout=240)
+            out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "images/sec", "error": repr(e)[:200]}
     print(json.dumps(out))
 
 

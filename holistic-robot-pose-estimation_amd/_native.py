@@ -133,6 +133,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HrpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # PyTorch ships its own libamdhip64; it must be the HIP runtime already in the process when our
+        # library is dlopen'ed, otherwise two runtimes coexist and stream / device handles do not match
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, args in PROTOTYPES.items():
             fn = getattr(L, name)

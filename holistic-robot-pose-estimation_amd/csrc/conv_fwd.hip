@@ -19,6 +19,7 @@
 //   block id -> XCD-contiguous remap so the cout blocks / neighbouring tiles that share an input tile hit
 //           the same XCD's L2.
 #include "hrp_common.h"
+#include <stdlib.h>
 
 namespace hrp {
 
@@ -439,7 +440,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
 template <typename T, int NT>
 static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
   const long pixels = (long)d.N * d.Ho * d.Wo;
-  const long want = 256;
+  static const long want = getenv("HRP_CONV_WANT") ? atol(getenv("HRP_CONV_WANT")) : 256;
   int rc = -100;
   if (d.Cout <= 32) {
     if (pixels / 256 >= want) rc = launch_cfg<T, 1, 2, 1, 4, NT>(d, s);

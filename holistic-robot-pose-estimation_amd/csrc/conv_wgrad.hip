@@ -6,7 +6,8 @@
 // 32-cout x 32-cin block for ALL taps and walks a strided share of the pixel tiles; per tile it stages
 // the dY tile and the X halo tile (32 channels each) in LDS once and every tap re-reads the X tile at a
 // shifted offset.  The 4 waves split the tile's pixels (split-K inside the workgroup), partial sums are
-// combined through LDS and leave as fp32 atomics straight into the PyTorch-shaped gradient tensor.
+// combined through LDS and leave as one partial slab per workgroup (folded into the PyTorch-shaped gradient
+// by wgrad_reduce_kernel) or, without a workspace, as fp32 atomics.
 //
 // Operand gather: the reduction index is the pixel, but NHWC keeps channels contiguous, so the 8 k-values
 // a lane needs for the bf16 MFMA belong to 8 different pixels.  gfx950's LDS transpose read
@@ -16,6 +17,14 @@
 // build one 8-deep MFMA operand; every source lane carries its own pixel address, so tap shifts and
 // stride-2 sampling cost nothing extra.  fp32 needs one 32-bit read per operand.
 #include "hrp_common.h"
+
+// -DHRP_TIMELINE (tools/bench_kernels.py timeline, never in the shipped library): wave 0 of every workgroup
+// stamps the 100 MHz wall clock at phase boundaries into the last MiB of the workspace.
+#ifdef HRP_TIMELINE
+#define HRP_STAMP(i) do { if (tid == 0) tl[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HRP_STAMP(i) do { } while (0)
+#endif
 
 namespace hrp {
 
@@ -31,7 +40,8 @@ struct WgradTiling {
   int tiles_x, tiles_y, tiles_n, ntiles;
   int n_cob, n_cib, G;
   int in_pix;
-  int lds_dy_off, lds_tab_off, lds_red_off;
+  int x_pieces, dy_pieces, buf_bytes;   // 1 KiB DMA pieces of the X halo tile / dY tile; one stage buffer
+  int lds_tab_off, lds_red_off;
   int use_ws, lds_bytes;
   FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_tx, fd_ty, fd_cib;
 };
@@ -58,33 +68,50 @@ struct WG<float> {
   }
 };
 
-template <typename T, int NT>
+__device__ uint4 g_wg_zero_page[4];  // 64 zero bytes: DMA source of padding / out-of-range rows
+
+// 64 lanes x 16 bytes global -> LDS (lane-linear at lds_wave_base).  Written as inline assembly on purpose:
+// behind the builtin the compiler's wait-count pass cannot tell the DMA destination from the buffer the
+// transpose reads are working on and drains the DMA (s_waitcnt vmcnt(0)) before every LDS read, which
+// serialises the prefetch with the MFMAs.  The kernel waits explicitly (vmcnt(0) + barrier) per tile.
+__device__ __forceinline__ void wg_dma16(const char* src, char* lds_wave_base) {
+  const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(src), "s"(lds) : "memory");   // m0 is scratch for the compiler too: it never keeps a value there
+}
+
+template <typename T, int NT, int NKS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d, const WgradTiling t) {
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
-  constexpr int ROWB = 32 * SZ;     // bytes of 32 channels
-  constexpr int P = ROWB + 16;      // LDS pixel pitch
-  constexpr int NVEC = ROWB / 16;   // 16-byte vectors per pixel row
+  constexpr int P = 32 * SZ;        // LDS pixel row: 32 channels, unpadded (DMA writes lane-linear)
+  constexpr int NVEC = P / 16;      // 16-byte slots per pixel row
   constexpr int K = WG<T>::K;
+  constexpr int MAXP_X = 12, MAXP_DY = 8;   // 1 KiB DMA pieces per wave (host keeps tiles below 48 / 32 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_x = smem;
-  char* lds_dy = smem + t.lds_dy_off;
   int* xtab = (int*)(smem + t.lds_tab_off);
-  float* red = (float*)(smem + t.lds_red_off);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
   const int blk = blockIdx.y;
   const int cob = fdiv(blk, t.fd_cib), cib = blk - cob * t.n_cib;
   const int co0 = cob * 32, ci0 = cib * 32;
   const int IS = d.in_stride;
   const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
+#ifdef HRP_TIMELINE
+  unsigned long long* tl = (unsigned long long*)((char*)d.workspace + d.workspace_bytes - (1 << 20)) +
+                           ((size_t)blockIdx.x * gridDim.y + blk) * 16;
+#endif
+  HRP_STAMP(0);
 
-  // pixel -> X-tile byte offset table
-  for (int m = tid; m < t.BM; m += 256) {
-    int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-    int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
-    if (ti >= t.TI) ti = t.TI - 1;  // idle slot (its dY row is zero)
-    xtab[m] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * P;
+  // pixel -> X-tile byte offset table (fp32 path; bf16 keeps its operand offsets in registers)
+  if constexpr (SZ == 4) {
+    for (int m = tid; m < t.BM; m += 256) {
+      int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+      int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+      if (ti >= t.TI) ti = t.TI - 1;  // idle slot (its dY row is zero)
+      xtab[m] = ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * P;
+    }
   }
 
   f32x16 acc[NT];
@@ -95,129 +122,228 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
 
   const char* xg = (const char*)d.x;
   const char* dyg = (const char*)d.dy;
+  const char* zero = (const char*)g_wg_zero_page;
   const int ppw = t.BM / 4;  // pixels per wave
-  const int x_vecs = t.in_pix * NVEC, dy_vecs = t.BM * NVEC;
 
   int tapoff[NT];
 #pragma unroll
   for (int tp = 0; tp < NT; ++tp) tapoff[tp] = ((d.dy_t[tp] - t.mindy) * t.IWt + (d.dx_t[tp] - t.mindx)) * P;
 
-  // transpose-read lane roles (bf16): source lane s = lane & 15 -> pixel (s >> 2) of the 4-pixel block,
-  // channels rbase + 4 (s & 3) .. +3; rbase = 16 for the odd 16-lane groups
-  const int tr_pix = (lane & 15) >> 2;
-  const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * SZ;
+  // ---- DMA plan (tile independent part) ---------------------------------------------------------------
+  // Per 1 KiB piece a lane keeps the byte offset of its 16-byte slot relative to the tile origin and a
+  // validity code: bit 0/1 = outside the image in the first / last tile row, bit 2/3 = same for tile
+  // columns, bit 4 = beyond the batch in the last image group, bit 5 = never fetched (tile padding,
+  // channel tail).  A tile's class mask selects the bits that apply to it, so issuing a piece is one AND,
+  // one select and one 64-bit add (the host checks that only border tiles can leave the image).
+  const int x_pieces = t.x_pieces, dy_pieces = t.dy_pieces;
+  int xrel[MAXP_X], xcode[MAXP_X], dyrel[MAXP_DY], dycode[MAXP_DY];
+  {
+    const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
+    const int iy_last = y_last * IS + t.mindy, ix_last = x_last * IS + t.mindx;
+#pragma unroll
+    for (int i = 0; i < MAXP_X; ++i) {
+      xcode[i] = 32; xrel[i] = 0;
+      if (wave + 4 * i >= x_pieces) continue;
+      const int sl = (wave + 4 * i) * 64 + lane, pix = sl / NVEC, vec = sl - pix * NVEC;
+      const int ti = fdiv(pix, t.fd_ihw), rem = pix - ti * ihw;
+      const int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+      const int c = ci0 + vec * VEC;
+      int code = (pix >= t.in_pix || c >= d.Cin) ? 32 : 0;
+      code |= (iy + t.mindy < 0) ? 1 : 0;
+      code |= (iy + iy_last >= d.H) ? 2 : 0;
+      code |= (ix + t.mindx < 0) ? 4 : 0;
+      code |= (ix + ix_last >= d.W) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      xcode[i] = code;
+      xrel[i] = (((ti * d.H + iy) * d.W + ix) * d.x_pitch + c) * SZ;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP_DY; ++i) {
+      dycode[i] = 32; dyrel[i] = 0;
+      if (wave + 4 * i >= dy_pieces) continue;
+      const int sl = (wave + 4 * i) * 64 + lane, m = sl / NVEC, vec = sl - m * NVEC;
+      const int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+      const int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+      const int c = co0 + vec * VEC;
+      int code = (m >= t.BM || ti >= t.TI || c >= d.Cout) ? 32 : 0;
+      code |= (ty + y_last >= d.Ho) ? 2 : 0;
+      code |= (tx + x_last >= d.Wo) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      dycode[i] = code;
+      dyrel[i] = (((ti * d.Ho + ty) * d.Wo + tx) * d.dy_pitch + c) * SZ;
+    }
+  }
 
-  for (int tile = blockIdx.x; tile < t.ntiles; tile += t.G) {
+  struct TileCtx { const char* xbase; const char* dybase; char* buf; int cls; };
+  auto tile_ctx = [&](int tile, char* buf) {
     int q = fdiv(tile, t.fd_tx);
     const int tx_i = tile - q * t.tiles_x;
     const int tn_i = fdiv(q, t.fd_ty);
     const int ty_i = q - tn_i * t.tiles_y;
     const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
     const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
-    __syncthreads();
-    for (int v0 = tid; v0 < x_vecs; v0 += 256 * WSTAGE_U) {
-      uint4 val[WSTAGE_U];
-      int dst[WSTAGE_U];
-#pragma unroll
-      for (int u = 0; u < WSTAGE_U; ++u) {
-        const int v = v0 + u * 256;
-        val[u] = make_uint4(0, 0, 0, 0);
-        dst[u] = -1;
-        if (v < x_vecs) {
-          int pix = v / NVEC, vec = v - pix * NVEC;
-          int ti = fdiv(pix, t.fd_ihw), rem = pix - ti * ihw;
-          int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
-          int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
-          int c = ci0 + vec * VEC;
-          dst[u] = pix * P + vec * 16;
-          if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && c < d.Cin) {
-            size_t off = (((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + c;
-            val[u] = *(const uint4*)(xg + off * SZ);
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < WSTAGE_U; ++u)
-        if (dst[u] >= 0) *(uint4*)(lds_x + dst[u]) = val[u];
+    TileCtx c;
+    c.cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
+            (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
+    // tile origins (the X origin may lie before the tensor: only valid lanes dereference it)
+    c.xbase = xg + (((long long)n0 * d.H + iy0) * d.W + ix0) * (long long)d.x_pitch * SZ;
+    c.dybase = dyg + (((long long)n0 * d.Ho + oy0) * d.Wo + ox0) * (long long)d.dy_pitch * SZ;
+    c.buf = buf;
+    return c;
+  };
+  // DMA slot = one 1 KiB piece of this wave: slots 0 .. MAXP_X-1 belong to the X tile, the rest to dY
+  auto issue_slot = [&](const TileCtx& c, int slot) {   // slot is a constant after unrolling
+    if (slot < MAXP_X) {
+      const int p = wave + 4 * slot;
+      if (p < x_pieces) wg_dma16((xcode[slot] & c.cls) ? zero : c.xbase + (unsigned)xrel[slot], c.buf + p * 1024);
+    } else if (slot < MAXP_X + MAXP_DY) {
+      const int i = slot - MAXP_X, p = wave + 4 * i;
+      if (p < dy_pieces)
+        wg_dma16((dycode[i] & c.cls) ? zero : c.dybase + (unsigned)dyrel[i], c.buf + (x_pieces + p) * 1024);
     }
-    for (int v0 = tid; v0 < dy_vecs; v0 += 256 * WSTAGE_U) {
-      uint4 val[WSTAGE_U];
-      int dst[WSTAGE_U];
+  };
+  auto issue = [&](int tile, char* buf) {
+    const TileCtx c = tile_ctx(tile, buf);
 #pragma unroll
-      for (int u = 0; u < WSTAGE_U; ++u) {
-        const int v = v0 + u * 256;
-        val[u] = make_uint4(0, 0, 0, 0);
-        dst[u] = -1;
-        if (v < dy_vecs) {
-          int m = v / NVEC, vec = v - m * NVEC;
-          int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-          int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
-          int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
-          int c = co0 + vec * VEC;
-          dst[u] = m * P + vec * 16;
-          if (ti < t.TI && n < d.N && oy < d.Ho && ox < d.Wo && c < d.Cout) {
-            size_t off = (((size_t)n * d.Ho + oy) * d.Wo + ox) * (size_t)d.dy_pitch + c;
-            val[u] = *(const uint4*)(dyg + off * SZ);
-          }
-        }
-      }
+    for (int slot = 0; slot < MAXP_X + MAXP_DY; ++slot) issue_slot(c, slot);
+  };
+
+  // transpose-read lane roles (bf16): source lane s = lane & 15 -> pixel (s >> 2) of the 4-pixel block,
+  // channels rbase + 4 (s & 3) .. +3; rbase = 16 for the odd 16-lane groups
+  const int tr_pix = (lane & 15) >> 2;
+  const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * SZ;
+
+  // bf16: the LDS offsets of a lane's operands do not depend on the tile -> registers, NKS k-steps of 16 pixels
+  constexpr int NKS_ = NKS > 0 ? NKS : 1;
+  int xo0[NKS_], xo1[NKS_], ao[NKS_];
+  if constexpr (SZ == 2) {
+    auto xoff = [&](int m) {
+      int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+      int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+      if (ti >= t.TI) ti = t.TI - 1;
+      return ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * P + tr_coff;
+    };
 #pragma unroll
-      for (int u = 0; u < WSTAGE_U; ++u)
-        if (dst[u] >= 0) *(uint4*)(lds_dy + dst[u]) = val[u];
+    for (int ks = 0; ks < NKS_; ++ks) {
+      // k-slot (khalf, q4, j) <-> pixel  wave*ppw + 16 ks + 8*khalf + 4*q4 + j
+      const int m0 = wave * ppw + ks * 16 + 8 * khalf + tr_pix;
+      xo0[ks] = xoff(m0); xo1[ks] = xoff(m0 + 4);
+      ao[ks] = m0 * P + tr_coff;
     }
+  }
+
+  // tile loop, double buffered: the DMA of tile i+1 runs under the MFMAs of tile i.  Inside a tile the
+  // operand reads of k-step s+1 are issued between the MFMAs of k-step s (one wave per SIMD: nobody else
+  // hides the LDS latency).
+  int it = 0;
+  HRP_STAMP(1);
+  if ((int)blockIdx.x < t.ntiles) issue(blockIdx.x, smem);
+  HRP_STAMP(2);
+  for (int tile = blockIdx.x; tile < t.ntiles; tile += t.G, ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kb = 0; kb < ppw; kb += K) {
-      if constexpr (SZ == 2) {
-        // k-slot (khalf, q4, j) <-> pixel  wave*ppw + kb + 8*khalf + 4*q4 + j
-        const int m0 = wave * ppw + kb + 8 * khalf + tr_pix;
-        const int x0 = xtab[m0] + tr_coff, x1 = xtab[m0 + 4] + tr_coff;
-        const char* pa = lds_dy + m0 * P + tr_coff;
-        bf16x4 a0 = WG<T>::tr(pa), a1 = WG<T>::tr(pa + 4 * P);
-        bf16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if (it < 4) HRP_STAMP(3 + 2 * it);
+    const char* lds_x = smem + (it & 1) * t.buf_bytes;
+    const char* lds_dy = lds_x + x_pieces * 1024;
+    const bool more = tile + t.G < t.ntiles;
+    if constexpr (SZ == 2) {
+      // the next tile's DMA pieces are issued between the MFMAs (SPP slots per MFMA) so that a full memory
+      // queue stalls the wave while the matrix pipe still has work
+      constexpr int SPP = (MAXP_X + MAXP_DY + NKS_ * NT - 1) / (NKS_ * NT);
+      TileCtx nx{};
+      if (more) nx = tile_ctx(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
+      bf16x8 a[2], b[2][NT];
+      auto load_a = [&](int ks, bf16x8& f) {
+        bf16x4 lo = WG<T>::tr(lds_dy + ao[ks]), hi = WG<T>::tr(lds_dy + ao[ks] + 4 * P);
+        f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      auto load_b = [&](int ks, int tp, bf16x8& f) {
+        bf16x4 lo = WG<T>::tr(lds_x + xo0[ks] + tapoff[tp]), hi = WG<T>::tr(lds_x + xo1[ks] + tapoff[tp]);
+        f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      load_a(0, a[0]);
+#pragma unroll
+      for (int tp = 0; tp < NT; ++tp) load_b(0, tp, b[0][tp]);
+#pragma unroll
+      for (int ks = 0; ks < NKS_; ++ks) {
+        const int c = ks & 1, n = c ^ 1;
+        if (ks + 1 < NKS_) load_a(ks + 1, a[n]);
 #pragma unroll
         for (int tp = 0; tp < NT; ++tp) {
-          bf16x4 b0 = WG<T>::tr(lds_x + x0 + tapoff[tp]), b1 = WG<T>::tr(lds_x + x1 + tapoff[tp]);
-          bf16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-          WG<T>::mma(a, b, acc[tp]);
+          if (ks + 1 < NKS_) load_b(ks + 1, tp, b[n][tp]);
+          WG<T>::mma(a[c], b[c][tp], acc[tp]);
+          if (more) {
+#pragma unroll
+            for (int u = 0; u < SPP; ++u) issue_slot(nx, (ks * NT + tp) * SPP + u);
+          }
         }
-      } else {
+        // keep the prefetch in this k-step: without the fence the scheduler sinks the reads next to their MFMA
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      if (more) issue(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
+      auto load = [&](int kb, float& a, float (&b)[NT]) {
         const int m0 = wave * ppw + kb + khalf;
-        const float a = *(const float*)(lds_dy + m0 * P + l31 * 4);
+        a = *(const float*)(lds_dy + m0 * P + l31 * 4);
         const int xo = xtab[m0] + l31 * 4;
 #pragma unroll
-        for (int tp = 0; tp < NT; ++tp) {
-          const float b = *(const float*)(lds_x + xo + tapoff[tp]);
-          WG<T>::mma(a, b, acc[tp]);
+        for (int tp = 0; tp < NT; ++tp) b[tp] = *(const float*)(lds_x + xo + tapoff[tp]);
+      };
+      float a_c, b_c[NT];
+      load(0, a_c, b_c);
+      for (int kb = 0; kb < ppw; kb += K) {
+        float a_n, b_n[NT];
+        load(kb + K < ppw ? kb + K : kb, a_n, b_n);
+#pragma unroll
+        for (int tp = 0; tp < NT; ++tp) WG<T>::mma(a_c, b_c[tp], acc[tp]);
+        a_c = a_n;
+#pragma unroll
+        for (int tp = 0; tp < NT; ++tp) b_c[tp] = b_n[tp];
+      }
+    }
+    if (it < 4) HRP_STAMP(4 + 2 * it);
+  }
+
+  // ---- combine the 4 waves' partial sums through LDS, half of the accumulator rows at a time: every wave
+  // drops its 16 rows x 32 columns per tap in output order, then the 256 threads add the 4 copies as float4
+  // and write the partial slab (or, without a workspace, fp32 atomics into dW[co][ci][tap]) ------------------
+  __syncthreads();
+  HRP_STAMP(11);
+  float* dump = (float*)smem;
+  // partial slab [g][block][NT*1024], coalesced; a second launch folds the G slabs into dW
+  float* ws = t.use_ws ? (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NT * 1024) : nullptr;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    float* mine = dump + wave * (NT * 512) + 4 * khalf * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)   // MFMA register 8h + j -> row 16h + (j & 3) + 8 (j >> 2) + 4 khalf
+        mine[(tp * 16 + (j & 3) + 8 * (j >> 2)) * 32] = acc[tp][8 * h + j];
+    __syncthreads();
+    for (int f = tid; f < NT * 128; f += 256) {
+      float4 v = ((const float4*)dump)[f];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 u = ((const float4*)(dump + w * (NT * 512)))[f];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      const int tp = f >> 7, rem = f & 127;
+      if (ws) {
+        ((float4*)(ws + tp * 1024 + 512 * h))[rem] = v;
+      } else {
+        const int co = co0 + 16 * h + (rem >> 3), cin = ci0 + 4 * (rem & 7);
+        if (co < d.Cout) {
+          float* o = d.dw + ((size_t)co * d.dw_cin + cin) * d.ntaps + tp;
+          if (cin < d.dw_cin) atomicAdd(o, v.x);
+          if (cin + 1 < d.dw_cin) atomicAdd(o + d.ntaps, v.y);
+          if (cin + 2 < d.dw_cin) atomicAdd(o + 2 * d.ntaps, v.z);
+          if (cin + 3 < d.dw_cin) atomicAdd(o + 3 * d.ntaps, v.w);
         }
       }
     }
-  }
-  // ---- combine the 4 waves' partial sums in LDS, then fp32 atomics to dW -------------------------
-  __syncthreads();
-  for (int i = tid; i < NT * 1024; i += 256) red[i] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int tp = 0; tp < NT; ++tp)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;  // cout within block
-          red[(tp * 32 + row) * 32 + l31] += acc[tp][r];
-        }
-    }
-    __syncthreads();
-  }
-  if (t.use_ws) {
-    // partial slab [g][block][NT*1024], coalesced; a second launch folds the G slabs into dW
-    float* ws = (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NT * 1024);
-    for (int i = tid; i < NT * 1024; i += 256) ws[i] = red[i];
-  } else {
-    for (int i = tid; i < NT * 1024; i += 256) {
-      int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
-      int co = co0 + row, cin = ci0 + ci;
-      if (co < d.Cout && cin < d.dw_cin) atomicAdd(&d.dw[((size_t)co * d.dw_cin + cin) * d.ntaps + tp], red[i]);
-    }
+    HRP_STAMP(12 + h);
   }
 }
 
@@ -259,7 +385,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc 
 template <typename T, int NT>
 static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   constexpr int SZ = Elem<T>::SZ;
-  constexpr int P = 32 * SZ + 16;
+  constexpr int P = 32 * SZ;
   int mindy = 1 << 30, maxdy = -(1 << 30), mindx = 1 << 30, maxdx = -(1 << 30);
   for (int i = 0; i < d.ntaps; ++i) {
     mindy = d.dy_t[i] < mindy ? d.dy_t[i] : mindy; maxdy = d.dy_t[i] > maxdy ? d.dy_t[i] : maxdy;
@@ -277,20 +403,23 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
     t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
     t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
     {
-      int maxti = (budget - BM * P - BM * 4) / (t.IHt * t.IWt * P);
+      int maxti = ((budget - BM * 4) / 2 - BM * P - 2048) / (t.IHt * t.IWt * P);
       if (maxti < 1) maxti = 1;
       if (TI > maxti) TI = maxti;
     }
     t.TI = TI;
     t.in_pix = TI * t.IHt * t.IWt;
-    t.lds_dy_off = round_up(t.in_pix * P, 16);
-    t.lds_tab_off = t.lds_dy_off + BM * P;
+    t.x_pieces = cdiv(t.in_pix * P, 1024);
+    t.dy_pieces = cdiv(BM * P, 1024);
+    t.buf_bytes = (t.x_pieces + t.dy_pieces) * 1024;
+    t.lds_tab_off = 2 * t.buf_bytes;
     int main_bytes = t.lds_tab_off + BM * 4;
-    t.lds_red_off = 0;  // the reduction buffer reuses the tiles
-    int red_bytes = NT * 1024 * 4;
+    if (t.x_pieces > 48 || t.dy_pieces > 32) { lds = 1 << 30; continue; }
+    t.lds_red_off = 0;  // the cross-wave exchange reuses the tiles
+    int red_bytes = NT * 8192;
     lds = main_bytes > red_bytes ? main_bytes : red_bytes;
     long pixels = (long)d.N * d.Ho * d.Wo;
-    if (lds <= budget && (BM == 64 || pixels >= BM)) break;
+    if (lds <= budget + 8192 && (BM == 64 || pixels >= BM)) break;
     if (BM == 64 && lds > 160 * 1024) {
       set_error("wgrad: tile does not fit LDS");
       return HRP_ERR_ARG;
@@ -299,6 +428,16 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   t.lds_bytes = lds;
   t.tiles_x = cdiv(d.Wo, t.TW); t.tiles_y = cdiv(d.Ho, t.TH); t.tiles_n = cdiv(d.N, t.TI);
   t.ntiles = t.tiles_x * t.tiles_y * t.tiles_n;
+  // the DMA plan classifies a lane's validity per tile row / column class: only the first and the last tile
+  // row (column) may reach outside the image
+  if ((t.tiles_y >= 2 && (t.TH * d.in_stride + mindy < 0 ||
+                          (t.tiles_y - 2) * t.TH * d.in_stride + mindy + t.IHt - 1 >= d.H)) ||
+      (t.tiles_x >= 2 && (t.TW * d.in_stride + mindx < 0 ||
+                          (t.tiles_x - 2) * t.TW * d.in_stride + mindx + t.IWt - 1 >= d.W))) {
+    set_error("wgrad: tap offsets reach beyond the border tiles (H=%d W=%d Ho=%d Wo=%d stride=%d)", d.H, d.W, d.Ho, d.Wo,
+              d.in_stride);
+    return HRP_ERR_ARG;
+  }
   t.n_cob = cdiv(d.Cout, 32); t.n_cib = cdiv(d.Cin, 32);
   int pairs = t.n_cob * t.n_cib;
   // workgroups per (cout, cin) block: ~2 per CU over the whole launch; each walks ntiles / G pixel tiles
@@ -329,11 +468,17 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
   t.use_ws = (d.workspace && d.workspace_bytes >= need) ? 1 : 0;
   if (!t.use_ws && !d.accumulate)
     (void)hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
-  auto kern = conv_wgrad_kernel<T, NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  void (*kern)(const hrp_wgrad_desc, const WgradTiling) = nullptr;
+  if constexpr (Elem<T>::SZ == 2) {
+    // bf16: k-steps of 16 pixels per wave and tile = BM / 64, unrolled at compile time
+    kern = t.BM == 256 ? conv_wgrad_kernel<T, NT, 4> : t.BM == 128 ? conv_wgrad_kernel<T, NT, 2> : conv_wgrad_kernel<T, NT, 1>;
+  } else {
+    kern = conv_wgrad_kernel<T, NT, 0>;
+  }
+  static bool attr_set[5] = {};   // per (T, NT) instantiation, indexed by BM / 64
+  if (!attr_set[t.BM / 64]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set[t.BM / 64] = true;
   }
   hipLaunchKernelGGL(kern, dim3(t.G, pairs), dim3(256), t.lds_bytes, s, d, t);
   rc = check_launch("conv_wgrad_kernel");

@@ -18,6 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hrpe_amd  # noqa: E402,F401
 from hrpe_amd import _native as nv  # noqa: E402
 
+TIMELINE = bool(os.environ.get("HRP_TIMELINE"))   # needs `make -C .../csrc timeline`
+if TIMELINE:
+    nv.LIB_PATH = nv.LIB_PATH.replace("libhrp_hip.so", "libhrp_hip_tl.so")
 DEV = torch.device("cuda:0")
 TAPS3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 
@@ -80,19 +83,6 @@ def conv_case(N, H, W, cin, cout, k, stride, dtype, stats):
     if stats:
         d.stats = st.data_ptr()
     us = timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d), None))
-    if os.environ.get("HRP_CYC"):
-        dbg = torch.zeros(4, device=DEV)
-        d.bias, d.relu = dbg.data_ptr(), 4096
-        nv.call("hrp_conv2d_fwd", C.byref(d), None)
-        torch.cuda.synchronize()
-        v = dbg.cpu().tolist()
-        print(f"      cycles/WG: first-stage wait {v[0]/v[3]:.0f}  main loop {v[1]/v[3]:.0f}  epilogue {v[2]/v[3]:.0f}  (WGs {v[3]:.0f})")
-        d.bias, d.relu = None, 0
-    if os.environ.get("HRP_DBG"):
-        for flag, name in ((256, "no-mfma"), (2048, "no-store"), (2048 + 256, "no-mfma-store"), (256 + 512, "dma only"), (1024+256+512, "empty")):
-            d.relu = flag
-            print(f"      {name:12s}: {timeit(lambda: nv.call('hrp_conv2d_fwd', C.byref(d), None)):8.1f} us")
-        d.relu = 0
     fl = 2.0 * N * Ho * Wo * cout * cin * len(taps)
     by = (x.numel() + y.numel()) * esz
     print(f"conv  N={N} {cin:4d}->{cout:4d} k{k} s{stride} @{H:3d}x{W:<3d} stats={int(stats)}: {us:8.1f} us  "
@@ -111,7 +101,19 @@ def conv_case(N, H, W, cin, cout, k, stride, dtype, stats):
     nbytes = int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g)))
     ws = torch.zeros(nbytes // 4 + 4, device=DEV)
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if TIMELINE:
+        ws = torch.zeros(nbytes // 4 + (1 << 18) + 4, device=DEV)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     us = timeit(lambda: nv.call("hrp_conv2d_bwd_weight", C.byref(g), None))
+    if TIMELINE:
+        tl = ws.view(torch.int64)[-(1 << 17):].cpu().view(-1, 16)
+        tl = tl[tl[:, 0] > 0].double()
+        t0 = tl[:, 0].min()
+        names = ["entry", "setup", "issued", "t0 ready", "t0 done", "t1 ready", "t1 done", "t2 ready", "t2 done",
+                 "t3 ready", "t3 done", "loop end", "round1", "stored"]
+        print(f"      timeline over {tl.shape[0]} workgroups (us after the first entry; mean / max):")
+        print("      " + "  ".join(f"{n} {((tl[:, i] - t0).mean() / 100):.2f}/{((tl[:, i] - t0).max() / 100):.2f}"
+                                  for i, n in enumerate(names) if tl[:, i].max() > 0))
     print(f"wgrad N={N} {cin:4d}->{cout:4d} k{k} s{stride} @{H:3d}x{W:<3d}         : {us:8.1f} us  "
           f"{fl / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.1f} GB/s")
 

@@ -286,9 +286,13 @@ def main():
         if os.environ.get("HRP_BENCH_SHAPES"):
             records_shape.append((name, fl, e0, e1, shape_key(name, args)))
 
+    # lanes (concurrent graph branches) are folded onto one stream here: a kernel's duration is its own
+    from hrpe_amd import plan as plan_mod
+    plan_mod.SERIAL_LANES = True
     nv.set_profile_hook(hook)
     fwd_bwd()
     nv.set_profile_hook(None)
+    plan_mod.SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
     torch.cuda.synchronize(dev)
     if os.environ.get("HRP_BENCH_SHAPES"):   # development aid: time per (kernel, shape) class to stderr
         shp = {}

@@ -179,8 +179,8 @@ class HighResolutionModule(PlannedModule):
     def get_num_inchannels(self):
         return self.num_inchannels
 
-    def emit(self, pb, xs):
-        xs = [_emit_seq(pb, self.branches[b], xs[b]) for b in range(self.num_branches)]
+    def emit_fuse(self, pb, xs):
+        """All-to-all cross-resolution fuse of the branch outputs (HRnet.py:243-265)."""
         if self.num_branches == 1:
             return xs
         outs = []
@@ -202,6 +202,15 @@ class HighResolutionModule(PlannedModule):
             outs.append(pb.act(terms, relu=True))
         return outs
 
+    def emit(self, pb, xs):
+        # the branches are independent until the fuse layers: one lane (HIP stream / graph branch) each
+        xs = list(xs)
+        with pb.parallel(self.num_branches) as par:
+            for b in range(self.num_branches):
+                with par.lane(b):
+                    xs[b] = _emit_seq(pb, self.branches[b], xs[b])
+        return self.emit_fuse(pb, xs)
+
     def forward(self, x):
         outs = self._run(*x)
         return list(outs)
@@ -222,6 +231,54 @@ class HighResolutionModule(PlannedModule):
             holder["handle"] = y
             outs.append(("nchw", holder, None))
         return names, outs, imgs
+
+
+def _transition(pb, tr, src):
+    steps = [tr] if isinstance(tr[0], Conv2d) else list(tr)
+    for st in steps:
+        src = pb.act([conv_bn(pb, src, st[0], st[1])], relu=True)
+    return src
+
+
+def emit_trunks(pb, nets, xs):
+    """Trunks (stem .. stage4, reference HRnet.py:500-533) of one or more HRNets with the same stage layout,
+    emitted in lockstep so that every independent chain of every net - stem, each branch of the current
+    module, fuse + transition - gets its own lane inside ONE flat parallel block.  (Blocks are kept flat:
+    forking a lane from a forked lane crashes HIP stream capture on ROCm 7.)  -> per net the list of the
+    stage-4 branch outputs."""
+    n = len(nets)
+    stages = [(net.stage2, net.stage3, net.stage4) for net in nets]
+    assert all(len(st[k]) == len(stages[0][k]) for st in stages for k in range(3)), "nets differ in stage layout"
+    ys = [None] * n
+    with pb.parallel(n) as par:
+        for i, (net, x) in enumerate(zip(nets, xs)):
+            with par.lane(i):
+                h = pb.act([conv_bn(pb, x, net.conv1, net.bn1)], relu=True)
+                h = pb.act([conv_bn(pb, h, net.conv2, net.bn2)], relu=True)
+                h = _emit_seq(pb, net.layer1, h)
+                ys[i] = [h if tr is None else _transition(pb, tr, h) for tr in net.transition1]
+    for k in range(3):
+        for mi in range(len(stages[0][k])):
+            mods = [st[k][mi] for st in stages]
+            with pb.parallel(sum(m.num_branches for m in mods)) as par:
+                lane = 0
+                for i, m in enumerate(mods):
+                    ys[i] = list(ys[i])
+                    for b in range(m.num_branches):
+                        with par.lane(lane):
+                            ys[i][b] = _emit_seq(pb, m.branches[b], ys[i][b])
+                        lane += 1
+            last = mi == len(stages[0][k]) - 1
+            with pb.parallel(n) as par:
+                for i, (net, m) in enumerate(zip(nets, mods)):
+                    with par.lane(i):
+                        ys[i] = m.emit_fuse(pb, ys[i])
+                        trans = (net.transition2, net.transition3, None)[k]
+                        if last and trans is not None:
+                            # a new branch always starts from the LAST (lowest-resolution) output, HRnet.py:516-529
+                            ys[i] = [ys[i][j] if tr is None else _transition(pb, tr, ys[i][-1])
+                                     for j, tr in enumerate(trans)]
+    return ys
 
 
 class PoseHighResolutionNet(PlannedModule):
@@ -299,23 +356,7 @@ class PoseHighResolutionNet(PlannedModule):
 
     # -- plan description ---------------------------------------------------------------------------------
     def emit_trunk(self, pb, x):
-        x = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
-        x = pb.act([conv_bn(pb, x, self.conv2, self.bn2)], relu=True)
-        x = _emit_seq(pb, self.layer1, x)
-        def transition(tr, src):
-            steps = [tr] if isinstance(tr[0], Conv2d) else list(tr)
-            for st in steps:
-                src = pb.act([conv_bn(pb, src, st[0], st[1])], relu=True)
-            return src
-
-        ys = [x if tr is None else transition(tr, x) for tr in self.transition1]
-        for stage, trans in ((self.stage2, self.transition2), (self.stage3, self.transition3), (self.stage4, None)):
-            for m in stage:
-                ys = m.emit(pb, ys)
-            if trans is not None:
-                # a new branch always starts from the LAST (lowest-resolution) output, HRnet.py:516-529
-                ys = [ys[i] if tr is None else transition(tr, ys[-1]) for i, tr in enumerate(trans)]
-        return ys
+        return emit_trunks(pb, [self], [x])[0]
 
     def emit_heads(self, pb, ys, feat_out=None):
         """-> (heat-map tensor or None, fp32 feature tensor or None)."""

@@ -17,7 +17,7 @@ from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
 from hrpe_amd.lib.utils.integral import HeatmapIntegralPose
 from hrpe_amd.lib.utils.urdf_robot import URDFRobot
 from hrpe_amd.runtime import PlannedModule
-from .backbones.HRnet import Conv2d, get_hrnet
+from .backbones.HRnet import Conv2d, emit_trunks, get_hrnet
 
 _RESNETS = ["resnet", "resnet34", "resnet50", "resnet101"]
 _HRNETS = ["hrnet", "hrnet32"]
@@ -141,9 +141,15 @@ class RootNetwithRegInt(PlannedModule):
         xo = pb.image_input("x_root", N, 3, x_root.shape[2], x_root.shape[3])
         kv = pb.vector_input("k_value", N, 1, dense=True)
         Km = pb.vector_input("K", N, 9, dense=True)
-        _, feat_root = self.rootnet_backbone.emit(pb, xo)
-        gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
-        heat, xf = self.reg_backbone.emit(pb, xr)
+        # the two backbones share nothing until pose_geometry: two lanes (concurrent HIP graph branches)
+        # (lockstep emission: see emit_trunks)
+        ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])
+        with pb.parallel(2) as par:
+            with par.lane(0):
+                heat, xf = self.reg_backbone.emit_heads(pb, ys_reg)
+            with par.lane(1):
+                _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
+                gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
         il = self.integral_layer
         uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
         depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,

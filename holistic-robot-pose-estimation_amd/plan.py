@@ -10,8 +10,10 @@ decision of "first writer overwrites / later writers accumulate" for every gradi
 PyTorch is used for device memory (torch.zeros buffers), the stream handle and the public
 ``torch.autograd.Function`` boundary only.
 """
+import contextlib
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -46,6 +48,8 @@ class TensorH:
         self.requires_grad = False
         self.stats = None      # (arena offset) of forward sum/sumsq when produced by a conv in train mode
         self.producer = None
+        self.lane_path = plan.lane_path   # where it is produced; consumers in a concurrent lane are an error
+        self._grad_paths = []
 
     @property
     def esz(self):
@@ -68,7 +72,17 @@ class TensorH:
         """-> accumulate flag for a producer of this tensor's gradient."""
         acc = self.grad_written
         self.grad_written = True
+        root = self.base if self.base is not None else self
+        here = self.plan.lane_path
+        if any(lanes_concurrent(here, q) for q in root._grad_paths):
+            raise RuntimeError("plan: a gradient is accumulated from two concurrent lanes")
+        root._grad_paths.append(here)
         return 1 if acc else 0
+
+    def check_readable(self):
+        """Forward consumers must be ordered after the producer (same lane, or outside its parallel block)."""
+        if lanes_concurrent(self.plan.lane_path, self.lane_path):
+            raise RuntimeError("plan: a tensor is consumed in a lane concurrent with its producer")
 
     def view4(self):
         return self.buf.view(self.N, self.H, self.W, self.pitch)[..., :self.C]
@@ -90,11 +104,61 @@ class ParamW:
         self.grad_written = False
 
 
+# True: every lane runs on the caller's stream (per-kernel timing passes, A/B measurements)
+SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
+
+
+# nesting depth of parallel blocks that really fork; deeper ones stay on their parent lane.  1 = flat: a lane
+# forked from a forked lane crashes hipStreamEndCapture on ROCm 7 (eager multi-stream execution is fine)
+MAX_LANE_DEPTH = int(os.environ.get("HRP_LANE_DEPTH", "1"))
+
+
+class _OpList(list):
+    """Launch list; ``append(op)`` tags the op with the lane (HIP stream) the builder is emitting into."""
+
+    def __init__(self, plan):
+        super().__init__()
+        self.plan = plan
+
+    def append(self, op):
+        list.append(self, (self.plan.cur_lane, op))
+
+
+class _LaneSync:
+    """Fork (children wait for the parent lane) or join (parent waits for the children) between lanes."""
+
+    def __init__(self, kind, parent, children):
+        self.kind, self.parent, self.children = kind, parent, children
+
+    def run(self, streams):
+        for c in self.children:
+            if self.kind == "fork":
+                streams[c].wait_stream(streams[self.parent])
+            else:
+                streams[self.parent].wait_stream(streams[c])
+
+
+def lanes_concurrent(a, b):
+    """Lane paths are tuples of (parallel block id, lane index); two emit positions may run at the same time
+    iff their paths split inside one block."""
+    for (ba, la), (bb, lb) in zip(a, b):
+        if ba != bb:
+            return False
+        if la != lb:
+            return True
+    return False
+
+
 class Plan:
     def __init__(self, device, dtype, training, need_grad):
         self.device, self.dtype, self.training, self.need_grad = device, dtype, training, need_grad
         self.keep = []
-        self.prep, self.fwd, self.post_fwd, self.bwd = [], [], [], []
+        # lanes: independent sub-graphs (the two backbones, the branches of an HRNet module) are emitted into
+        # different lanes = HIP streams, forked from / joined into their parent lane; lane 0 is the caller's
+        # stream.  Captured into a HIP graph the lanes become parallel graph branches.
+        self.cur_lane, self.lane_path, self.n_lanes = 0, (), 1
+        self._lane_ids, self._n_blocks, self._side_streams = {}, 0, []
+        self.fwd, self.bwd = _OpList(self), _OpList(self)
         self.weights = {}          # id(param) -> ParamW
         self.weight_list = []
         self.bn_train = []         # (bn module, stats offset, count)
@@ -111,8 +175,8 @@ class Plan:
         self.out_handles = []      # TensorH whose gradient is seeded from outside
         self.grad_arena = None
         self._grad_views = {}
-        self.wgrad_ws_bytes = 0    # scratch shared by all weight-gradient launches (stream ordered)
-        self.wgrad_ws = None
+        self.wgrad_ws_bytes = {}   # lane -> scratch bytes shared by that lane's weight-gradient launches
+        self.wgrad_ws = {}
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -194,7 +258,9 @@ class Plan:
             tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
             self.keep.append(tdev)
             self._pack_tables.append((tdev, len(ws), _dt(dtype), maxel))
-        self.wgrad_ws = torch.zeros(max(self.wgrad_ws_bytes // 4, 4), dtype=torch.float32, device=dev)
+        self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev)
+                         for lane, nb in self.wgrad_ws_bytes.items()}
+        self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes - 1)]
         # resolve deferred pointers
         for fn in self._late:
             fn()
@@ -259,12 +325,34 @@ class Plan:
         if self._fold_tab:
             nv.call("hrp_bn_fold", self._fold_tab[0].data_ptr(), self._fold_tab[1], s)
 
+    def lane_id(self, parent, index):
+        """Stable lane number of the index-th extra child of a parent lane."""
+        key = (parent, index)
+        if key not in self._lane_ids:
+            self._lane_ids[key] = self.n_lanes
+            self.n_lanes += 1
+        return self._lane_ids[key]
+
+    def _run_list(self, ops):
+        if SERIAL_LANES:
+            h = self._stream()
+            for lane, op in ops:
+                if lane is not None:
+                    op(h)
+            return
+        streams = [torch.cuda.current_stream(self.device)] + self._side_streams
+        handles = [st.cuda_stream for st in streams]
+        for lane, op in ops:
+            if lane is None:
+                op.run(streams)
+            else:
+                op(handles[lane])
+
     def run_forward(self):
         s = self._stream()
         if self.stats_floats:
             self.stats.zero_()
-        for op in self.fwd:
-            op(s)
+        self._run_list(self.fwd)
         if self._run_tab:
             nv.call("hrp_bn_running_update", self._run_tab[0].data_ptr(), self._run_tab[1], s)
 
@@ -274,8 +362,7 @@ class Plan:
             self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
         if self.bsums_floats:
             self.bsums.zero_()
-        for op in self.bwd:
-            op(s)
+        self._run_list(self.bwd)
         if self._pgrad_tab:
             nv.call("hrp_bn_param_grad", self._pgrad_tab[0].data_ptr(), self._pgrad_tab[1], s)
 
@@ -295,10 +382,36 @@ class Plan:
 _TAPS3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 
 
+class _BwdStack(list):
+    """Backward emitters remember the lane they were registered in."""
+
+    def __init__(self, plan):
+        super().__init__()
+        self.plan = plan
+
+    def append(self, fn):
+        list.append(self, (self.plan.cur_lane, self.plan.lane_path, fn))
+
+
+class _Parallel:
+    def __init__(self, pb, block, lanes):
+        self.pb, self.block, self.lanes = pb, block, lanes
+
+    @contextlib.contextmanager
+    def lane(self, i):
+        p = self.pb.plan
+        saved = (p.cur_lane, p.lane_path)
+        p.cur_lane, p.lane_path = self.lanes[i], saved[1] + ((self.block, i),)
+        try:
+            yield
+        finally:
+            p.cur_lane, p.lane_path = saved
+
+
 class PlanBuilder:
     def __init__(self, plan):
         self.plan = plan
-        self.bwd_stack = []   # emitters of backward ops, in forward order (run reversed at the end)
+        self.bwd_stack = _BwdStack(plan)   # emitters of backward ops, in forward order (run reversed at the end)
         self.fuse_inference = (not plan.training) and (not plan.need_grad)
 
     # ---- inputs / outputs ---------------------------------------------------------------------------
@@ -365,6 +478,7 @@ class PlanBuilder:
     def conv(self, x, weight, bias=None, stride=1, want_stats=False, out=None, residual=None, relu=False):
         """y = conv(x) (+bias) (+residual) (ReLU).  weight: torch parameter [Cout, Cin, k, k] or [Cout, Cin]."""
         p = self.plan
+        x.check_readable()
         cout, cin = weight.shape[0], weight.shape[1]
         ksize = weight.shape[2] if weight.dim() == 4 else 1
         ntaps = ksize * ksize
@@ -430,9 +544,10 @@ class PlanBuilder:
             g.dw_cin = w.cin
             g.accumulate = 1 if (w.grad_written or p.grad_arena is not None) else 0
             w.grad_written = True
-            p.wgrad_ws_bytes = max(p.wgrad_ws_bytes, int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
-            p.late(lambda g=g: (setattr(g, "workspace", p.wgrad_ws.data_ptr()),
-                                setattr(g, "workspace_bytes", p.wgrad_ws.numel() * 4)))
+            lane = p.cur_lane
+            p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
+            p.late(lambda g=g, lane=lane: (setattr(g, "workspace", p.wgrad_ws[lane].data_ptr()),
+                                           setattr(g, "workspace_bytes", p.wgrad_ws[lane].numel() * 4)))
             p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
         # data gradient
         if x.requires_grad:
@@ -484,6 +599,8 @@ class PlanBuilder:
         """out = act(sum_j BN_j(t_j) upsampled).  In inference plans a single conv+BN(+identity residual)
         is folded into the producing conv's epilogue instead."""
         p = self.plan
+        for tm in terms:
+            tm.t.check_readable()
         t0 = terms[0]
         ref = max((tm.t for tm in terms), key=lambda t: t.H)  # output geometry = largest input x its up
         H = max(tm.t.H * tm.up for tm in terms)
@@ -595,9 +712,36 @@ class PlanBuilder:
     def finish(self):
         """Emit the backward list (reverse forward order) and resolve pointers."""
         p = self.plan
-        for emit in reversed(self.bwd_stack):
+        assert p.cur_lane == 0 and p.lane_path == ()
+        for lane, path, emit in reversed(self.bwd_stack):
+            if lane is None:
+                list.append(p.bwd, (None, emit))    # lane fork / join marker (already mirrored)
+                continue
+            p.cur_lane, p.lane_path = lane, path
             emit()
+        p.cur_lane, p.lane_path = 0, ()
         p.finalize()
+
+    @contextlib.contextmanager
+    def parallel(self, n):
+        """``with pb.parallel(n) as par: with par.lane(i): ...`` - emit n independent sub-graphs into n lanes
+        (lane 0 stays on the current lane).  Tensors produced before the block may be read by every lane;
+        nothing produced or whose gradient is written inside one lane may be touched by a sibling."""
+        p = self.plan
+        p._n_blocks += 1
+        parent = p.cur_lane
+        if len(p.lane_path) >= MAX_LANE_DEPTH:
+            n = 1   # deeper blocks stay on their parent lane
+        n = min(n, int(os.environ.get("HRP_LANE_MAXN", "64")))
+        children = [p.lane_id(parent, i) for i in range(1, n)]
+        par = _Parallel(self, p._n_blocks, ([parent] + children + [parent] * 64) if children else [parent] * 64)
+        if children:
+            list.append(p.fwd, (None, _LaneSync("fork", parent, children)))
+            list.append(self.bwd_stack, (None, None, _LaneSync("join", parent, children)))
+        yield par
+        if children:
+            list.append(p.fwd, (None, _LaneSync("join", parent, children)))
+            list.append(self.bwd_stack, (None, None, _LaneSync("fork", parent, children)))
 
     # ---- outputs ----------------------------------------------------------------------------------------
     def output(self, t):

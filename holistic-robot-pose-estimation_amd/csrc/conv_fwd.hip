@@ -49,6 +49,15 @@ struct ConvTiling {
 // byte offset of (row r, 16-byte half h) inside a staged region
 __device__ __forceinline__ int row_addr(int r, int h) { return r * ROW + ((h ^ ((r >> 3) & 1)) << 4); }
 
+// -DHRP_TIMELINE (development build only): thread 0 of every workgroup stamps the 100 MHz wall clock at
+// phase boundaries into g_conv_timeline[block][8]; tools/bench_kernels.py reads it with hrp_debug_conv_timeline.
+#ifdef HRP_TIMELINE
+__device__ unsigned long long g_conv_timeline[8192 * 8];
+#define HRP_CSTAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_conv_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HRP_CSTAMP(i) do { } while (0)
+#endif
+
 template <typename T>
 struct Mma;
 template <>
@@ -93,6 +102,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   const int wc = wave % WC, wp = wave / WC;
   const int l31 = lane & 31, khalf = lane >> 5;
 
+  HRP_CSTAMP(0);
   int bid = blockIdx.x;
   if ((t.nblocks & 7) == 0) bid = (bid & 7) * (t.nblocks >> 3) + (bid >> 3);
   int tile = fdiv(bid, t.fd_ncb);
@@ -206,34 +216,55 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     for (int g = 0; g < G; ++g)
       if (st * G + g < nchunks) issue(st * G + g, base + g * t.buf_bytes);
   };
+  HRP_CSTAMP(1);
   issue_stage(0, smem);
+  HRP_CSTAMP(2);
   for (int st = 0; st < nstages; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of stage `st` have landed
     __syncthreads();                                   // everyone's have, and stage st-1 has been consumed
+    if (st == 0) HRP_CSTAMP(3);
     char* sbuf = smem + (st & 1) * stage_bytes;
     if (st + 1 < nstages) issue_stage(st + 1, smem + ((st + 1) & 1) * stage_bytes);
-    for (int g = 0; g < G && st * G + g < nchunks; ++g) {
-      const char* lds_in = sbuf + g * t.buf_bytes;
+    // One step = one (tap, k-step) of a chunk: CT weight fragments, PT pixel fragments, CT x PT MFMAs.  The
+    // fragments of step s+1 (also across the chunk boundary inside the stage) are read while the MFMAs of
+    // step s run: with one or two waves per SIMD nothing else would hide the LDS latency.
+    constexpr int NS = NT * Mma<T>::KSTEPS;
+    const int ng = nchunks - st * G < G ? nchunks - st * G : G;
+    typename Mma<T>::Frag fa[2][CT], fb[2][PT];
+    auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&b)[PT]) {
+      const int tap = step / Mma<T>::KSTEPS, kk = step % Mma<T>::KSTEPS;   // constants after unrolling
       const char* lds_w = lds_in + t.in_pieces * 1024;
+      const int wr = tap * BN + wrow0;
 #pragma unroll
-      for (int tap = 0; tap < NT; ++tap) {
-        const int wr = tap * BN + wrow0;
+      for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
 #pragma unroll
-        for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) {
-          typename Mma<T>::Frag a[CT], b[PT];
+      for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow[tap], kk, khalf);
+    };
+    load(sbuf, 0, fa[0], fb[0]);
+    for (int g = 0; g < ng; ++g) {
+      const char* lds_in = sbuf + g * t.buf_bytes;
 #pragma unroll
-          for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
+      for (int step = 0; step < NS; ++step) {
+        const int cur = step & 1, nxt = cur ^ 1;
+        if (step + 1 < NS) load(lds_in, step + 1, fa[nxt], fb[nxt]);
+        else if (g + 1 < ng) load(lds_in + t.buf_bytes, 0, fa[nxt], fb[nxt]);
 #pragma unroll
-          for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow[tap], kk, khalf);
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-          for (int c = 0; c < CT; ++c)
+          for (int p = 0; p < PT; ++p) Mma<T>::mma(fa[cur][c], fb[cur][p], acc[c][p]);
+        // keep the prefetch where it is: without the fence the scheduler sinks the reads next to their MFMA
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (NS & 1) {   // odd step count: the prefetched fragments of the next chunk sit in slot 1
 #pragma unroll
-            for (int p = 0; p < PT; ++p) Mma<T>::mma(a[c], b[p], acc[c][p]);
-        }
+        for (int c = 0; c < CT; ++c) fa[0][c] = fa[1][c];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) fb[0][p] = fb[1][p];
       }
     }
   }
   __syncthreads();
+  HRP_CSTAMP(4);
 
   // ---- epilogue: accumulators -> LDS tile [pixel][cout] (element type T) ----------------------
   constexpr int OP = BN * SZ + 16;
@@ -272,6 +303,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     }
   }
   __syncthreads();
+  HRP_CSTAMP(5);
 
   // ---- coalesced pass: residual, ReLU, statistics, global store -------------------------------
   constexpr int NV = BN / VEC;
@@ -336,6 +368,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       }
     }
   }
+  HRP_CSTAMP(6);
   if (d.stats) {
     // lanes cv, cv + NV, ... of a wave own the same channels: butterfly over them, then one partial per
     // wave in LDS ([wave][2][BN]), then one global atomic per channel per workgroup
@@ -365,6 +398,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       }
     }
   }
+  HRP_CSTAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -490,3 +524,15 @@ extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   if (d->dtype == HRP_F32) return launch_conv<float>(*d, (hipStream_t)stream);
   return launch_conv<bf16_t>(*d, (hipStream_t)stream);
 }
+
+#ifdef HRP_TIMELINE
+extern "C" int hrp_debug_conv_timeline(void* dst, int nblocks, int clear) {
+  if (dst) (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(hrp::g_conv_timeline), sizeof(unsigned long long) * 8 * nblocks);
+  if (clear) {
+    void* p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(hrp::g_conv_timeline));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 8);
+  }
+  return 0;
+}
+#endif

@@ -83,6 +83,23 @@ def conv_case(N, H, W, cin, cout, k, stride, dtype, stats):
     if stats:
         d.stats = st.data_ptr()
     us = timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d), None))
+    if TIMELINE:
+        L = nv.lib()
+        torch.cuda.synchronize()
+        L.hrp_debug_conv_timeline(None, 0, 1)
+        nv.call("hrp_conv2d_fwd", C.byref(d), None)
+        torch.cuda.synchronize()
+        host = torch.zeros(8192 * 8, dtype=torch.int64)
+        L.hrp_debug_conv_timeline(C.c_void_p(host.data_ptr()), 8192, 0)
+        tl = host.view(-1, 8)
+        tl = tl[tl[:, 0] > 0].double()
+        t0 = tl[:, 0].min()
+        names = ["entry", "setup", "issued", "stage0", "loop end", "in lds", "stored", "end"]
+        print(f"      conv timeline over {tl.shape[0]} workgroups (us after the first entry; mean/max): " +
+              "  ".join(f"{n} {((tl[:, i] - t0).mean() / 100):.2f}/{((tl[:, i] - t0).max() / 100):.2f}"
+                        for i, n in enumerate(names)))
+        print("      per-workgroup phase means (us): " +
+              "  ".join(f"{names[i + 1]} {((tl[:, i + 1] - tl[:, i]).mean() / 100):.2f}" for i in range(7)))
     fl = 2.0 * N * Ho * Wo * cout * cin * len(taps)
     by = (x.numel() + y.numel()) * esz
     print(f"conv  N={N} {cin:4d}->{cout:4d} k{k} s{stride} @{H:3d}x{W:<3d} stats={int(stats)}: {us:8.1f} us  "

@@ -89,7 +89,7 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int CT, int PT, int WC, int WP, int NT>
+template <typename T, int CT, int PT, int WC, int WP, int NT, bool PERSIST>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, const ConvTiling t) {
   static_assert(WC * WP == 4, "4 waves");
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
@@ -101,23 +101,16 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % WC, wp = wave / WC;
   const int l31 = lane & 31, khalf = lane >> 5;
-
-  HRP_CSTAMP(0);
-  int bid = blockIdx.x;
-  if ((t.nblocks & 7) == 0) bid = (bid & 7) * (t.nblocks >> 3) + (bid >> 3);
-  int tile = fdiv(bid, t.fd_ncb);
-  const int cb = bid - tile * t.n_cout_blk;
-  int q = fdiv(tile, t.fd_tx);
-  const int tx_i = tile - q * t.tiles_x;
-  const int tn_i = fdiv(q, t.fd_ty);
-  const int ty_i = q - tn_i * t.tiles_y;
-  const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
   const int IS = d.in_stride;
-  const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
-  const int co0 = cb * BN;
   const int thw = t.TH * t.TW;
   const int ihw = t.IHt * t.IWt;
+  HRP_CSTAMP(0);
 
+  // =====================================================================================================
+  // Tile independent state, computed once.  PERSIST: the workgroup walks tiles b, b + grid, ... (for small
+  // layers the index arithmetic below costs more instructions than the MFMA loop of a tile); otherwise one
+  // tile per workgroup, which keeps the register count - and with it the occupancy of deep-K layers - low.
+  // =====================================================================================================
   int pixrow[PT];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
@@ -129,276 +122,322 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   }
   const int wrow0 = wc * 32 * CT + l31;
 
-  f32x16 acc[CT][PT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int p = 0; p < PT; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[c][p][i] = 0.f;
-
   const int nchunks = (d.Cin + CKE - 1) / CKE;
   const char* xg = (const char*)d.x;
   const char* wg = (const char*)d.w;
   const char* zero = (const char*)g_zero_page;
-  constexpr int w_rows = NT * BN;
-  // tap offsets (in tile rows) live in registers: with NT known the tap loop unrolls completely and the
-  // compiler can run the LDS reads of tap t+1 under the MFMAs of tap t
+  // tap offsets (in tile rows) live in registers: with NT known the tap loop unrolls completely
   int taprow[NT];
 #pragma unroll
   for (int tp = 0; tp < NT; ++tp) taprow[tp] = (d.dy[tp] - t.mindy) * t.IWt + (d.dx[tp] - t.mindx);
 
-  // ---- DMA plan of this wave: per-lane source offsets of its 1 KiB pieces, computed ONCE -----------------
-  // (the per-chunk issue is then one add + one global_load_lds per piece; doing the pixel decode per chunk
-  // made deep-K layers issue-bound: 16 chunks x ~6 pieces x ~40 VALU instructions per wave)
+  // ---- DMA plan of this wave -------------------------------------------------------------------------
+  // Per 1 KiB input piece a lane keeps the byte offset of its 16-byte slot relative to the tile origin
+  // (chunk 0) and a validity code: bit 0/1 = outside the image in the first / last tile row, bit 2/3 = same
+  // for tile columns, bit 4 = beyond the batch in the last image group, bit 5 = never fetched (padding of
+  // the staged region), bit 6 = second half of a chunk (invalid in a half-filled last chunk).  A tile's
+  // class mask selects the bits that apply; the host checks that only border tiles can leave the image.
   constexpr int MAXP_IN = 10;                    // input pieces per wave (tile <= 40 KiB per chunk)
   constexpr int W_PIECES = NT * BN / 32;         // weight pieces per chunk (BN % 32 == 0)
   constexpr int MAXP_W = (W_PIECES + 3) / 4;
-  int in_off[MAXP_IN];                           // byte offset into x for chunk 0, half h; -1 = zero page
-  int in_h[MAXP_IN];
+  int in_rel[MAXP_IN], in_code[MAXP_IN];
+  const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
+  {
+    const int iy_last = y_last * IS + t.mindy, ix_last = x_last * IS + t.mindx;
 #pragma unroll
-  for (int i = 0; i < MAXP_IN; ++i) {
-    in_off[i] = -1; in_h[i] = 0;
-    const int p = wave + 4 * i;
-    if (p < t.in_pieces) {
-      const int s = p * 64 + lane;                 // 16-byte slot of the input region
-      const int r = s >> 1;                        // tile pixel row
-      const int h = (s & 1) ^ ((r >> 3) & 1);      // logical half stored in this slot
-      in_h[i] = h;
-      if (r < t.in_rows) {
-        int ti = fdiv(r, t.fd_ihw), rem = r - ti * ihw;
-        int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
-        int n = n0 + ti, gy = iy0 + iy, gx = ix0 + ix;
-        if (n < d.N && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W)
-          in_off[i] = (int)(((((size_t)n * d.H + gy) * d.W + gx) * (size_t)d.x_pitch + h * VEC) * SZ);
-      }
+    for (int i = 0; i < MAXP_IN; ++i) {
+      in_rel[i] = 0; in_code[i] = 32;
+      if (wave + 4 * i >= t.in_pieces) continue;
+      const int sl = (wave + 4 * i) * 64 + lane;   // 16-byte slot of the input region
+      const int r = sl >> 1;                       // tile pixel row
+      const int h = (sl & 1) ^ ((r >> 3) & 1);     // logical half stored in this slot
+      const int ti = fdiv(r, t.fd_ihw), rem = r - ti * ihw;
+      const int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+      int code = (r >= t.in_rows) ? 32 : 0;
+      code |= (iy + t.mindy < 0) ? 1 : 0;
+      code |= (iy + iy_last >= d.H) ? 2 : 0;
+      code |= (ix + t.mindx < 0) ? 4 : 0;
+      code |= (ix + ix_last >= d.W) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      code |= h ? 64 : 0;
+      in_code[i] = code;
+      in_rel[i] = (((ti * d.H + iy) * d.W + ix) * d.x_pitch + h * VEC) * SZ;
     }
   }
-  int w_off[MAXP_W];                             // byte offset into the packed weights for chunk 0; -1 = zero
+  int w_rel[MAXP_W];                             // byte offset into the packed weights (chunk 0, cout block 0)
 #pragma unroll
   for (int i = 0; i < MAXP_W; ++i) {
-    w_off[i] = -1;
+    w_rel[i] = 0;
     const int p = wave + 4 * i;
     if (p < W_PIECES) {
-      const int s = p * 64 + lane;
-      const int r = s >> 1;                        // tap-major weight row: tl * BN + j
-      const int h = (s & 1) ^ ((r >> 3) & 1);
+      const int sl = p * 64 + lane;
+      const int r = sl >> 1;                       // tap-major weight row: tl * BN + j
+      const int h = (sl & 1) ^ ((r >> 3) & 1);
       const int tl = (p * 32) / BN;                // a piece is 32 rows and BN is a multiple of 32: one tap
       const int j = r - tl * BN;
-      if (co0 + j < d.w_cout_pad) w_off[i] = (int)(((size_t)d.wtap[tl] * d.w_cout_pad + co0 + j) * ROW + h * 16);
+      w_rel[i] = (d.wtap[tl] * d.w_cout_pad + j) * ROW + h * 16;
     }
   }
   const int w_chunk_stride = d.w_ntaps * d.w_cout_pad * ROW;  // bytes between consecutive chunks of the packing
+  const int half_chunk = (d.Cin % CKE) ? nchunks - 1 : -1;    // chunk whose second 16 bytes lie beyond Cin
 
-  auto issue = [&](int chunk, char* buf) {
-    const int c0 = chunk * CKE;
+  // ---- store plan: the rows of the output tile this thread writes in the coalesced pass ----------------
+  constexpr int NV = BN / VEC, KST = BM * NV / 256;
+  const int cv = tid % NV;  // 256 % NV == 0, so a thread keeps its channel group
+  int out_rel[KST], out_code[KST];
 #pragma unroll
-    for (int i = 0; i < MAXP_IN; ++i) {
-      const int p = wave + 4 * i;
-      if (p < t.in_pieces) {
-        const bool ok = in_off[i] >= 0 && (c0 + in_h[i] * VEC < d.Cin);
-        dma16(ok ? xg + (size_t)in_off[i] + (size_t)chunk * ROW : zero, buf + p * 1024);
-      }
-    }
-    char* wbuf = buf + t.in_pieces * 1024;
-#pragma unroll
-    for (int i = 0; i < MAXP_W; ++i) {
-      const int p = wave + 4 * i;
-      if (p < W_PIECES) dma16(w_off[i] >= 0 ? wg + (size_t)w_off[i] + (size_t)chunk * w_chunk_stride : zero, wbuf + p * 1024);
-    }
-  };
+  for (int k = 0; k < KST; ++k) {
+    const int m = tid / NV + k * (256 / NV);
+    const int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
+    const int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+    int code = (ti >= t.TI) ? 32 : 0;
+    code |= (ty + y_last >= d.Ho) ? 2 : 0;
+    code |= (tx + x_last >= d.Wo) ? 8 : 0;
+    code |= (ti + n_last >= d.N) ? 16 : 0;
+    out_code[k] = code;
+    out_rel[k] = (ti * d.y_H + ty * d.out_stride) * d.y_W + tx * d.out_stride;   // in output pixels
+  }
+  HRP_CSTAMP(1);
 
-  // A stage = G consecutive 32-byte chunks (G sub-buffers): the DMA latency of a stage is paid once per G
-  // chunks of MFMA work instead of once per chunk (deep-K layers have 16 chunks of only 9 MFMAs per wave).
   const int G = t.G, stage_bytes = G * t.buf_bytes;
   const int nstages = (nchunks + G - 1) / G;
-  auto issue_stage = [&](int st, char* base) {
-    for (int g = 0; g < G; ++g)
-      if (st * G + g < nchunks) issue(st * G + g, base + g * t.buf_bytes);
-  };
-  HRP_CSTAMP(1);
-  issue_stage(0, smem);
-  HRP_CSTAMP(2);
-  for (int st = 0; st < nstages; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of stage `st` have landed
-    __syncthreads();                                   // everyone's have, and stage st-1 has been consumed
-    if (st == 0) HRP_CSTAMP(3);
-    char* sbuf = smem + (st & 1) * stage_bytes;
-    if (st + 1 < nstages) issue_stage(st + 1, smem + ((st + 1) & 1) * stage_bytes);
-    // One step = one (tap, k-step) of a chunk: CT weight fragments, PT pixel fragments, CT x PT MFMAs.  The
-    // fragments of step s+1 (also across the chunk boundary inside the stage) are read while the MFMAs of
-    // step s run: with one or two waves per SIMD nothing else would hide the LDS latency.
-    constexpr int NS = NT * Mma<T>::KSTEPS;
-    const int ng = nchunks - st * G < G ? nchunks - st * G : G;
-    typename Mma<T>::Frag fa[2][CT], fb[2][PT];
-    auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&b)[PT]) {
-      const int tap = step / Mma<T>::KSTEPS, kk = step % Mma<T>::KSTEPS;   // constants after unrolling
-      const char* lds_w = lds_in + t.in_pieces * 1024;
-      const int wr = tap * BN + wrow0;
-#pragma unroll
-      for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
-#pragma unroll
-      for (int p = 0; p < PT; ++p) b[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow[tap], kk, khalf);
-    };
-    load(sbuf, 0, fa[0], fb[0]);
-    for (int g = 0; g < ng; ++g) {
-      const char* lds_in = sbuf + g * t.buf_bytes;
-#pragma unroll
-      for (int step = 0; step < NS; ++step) {
-        const int cur = step & 1, nxt = cur ^ 1;
-        if (step + 1 < NS) load(lds_in, step + 1, fa[nxt], fb[nxt]);
-        else if (g + 1 < ng) load(lds_in + t.buf_bytes, 0, fa[nxt], fb[nxt]);
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-          for (int p = 0; p < PT; ++p) Mma<T>::mma(fa[cur][c], fb[cur][p], acc[c][p]);
-        // keep the prefetch where it is: without the fence the scheduler sinks the reads next to their MFMA
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (NS & 1) {   // odd step count: the prefetched fragments of the next chunk sit in slot 1
-#pragma unroll
-        for (int c = 0; c < CT; ++c) fa[0][c] = fa[1][c];
-#pragma unroll
-        for (int p = 0; p < PT; ++p) fb[0][p] = fb[1][p];
-      }
-    }
-  }
-  __syncthreads();
-  HRP_CSTAMP(4);
-
-  // ---- epilogue: accumulators -> LDS tile [pixel][cout] (element type T) ----------------------
   constexpr int OP = BN * SZ + 16;
   char* lds_out = smem;
   float* lds_stats = (float*)(smem + t.lds_stats_off);
+
+  for (int b = blockIdx.x; PERSIST ? b < t.nblocks : b == (int)blockIdx.x; b += PERSIST ? gridDim.x : 1) {
+    int bid = b;
+    if ((t.nblocks & 7) == 0) bid = (bid & 7) * (t.nblocks >> 3) + (bid >> 3);
+    const int tile = fdiv(bid, t.fd_ncb);
+    const int cb = bid - tile * t.n_cout_blk;
+    const int q = fdiv(tile, t.fd_tx);
+    const int tx_i = tile - q * t.tiles_x;
+    const int tn_i = fdiv(q, t.fd_ty);
+    const int ty_i = q - tn_i * t.tiles_y;
+    const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
+    const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
+    const int co0 = cb * BN;
+    const int cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
+                    (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
+    // tile origins (the input origin may lie before the tensor: only valid lanes dereference it)
+    const char* xbase = xg + (((long long)n0 * d.H + iy0) * d.W + ix0) * (long long)d.x_pitch * SZ;
+    const char* wbase = wg + (long long)co0 * ROW;
+
+    f32x16 acc[CT][PT];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) {
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int cl = wc * 32 * CT + c * 32 + 8 * q4 + 4 * khalf;  // first of 4 consecutive local couts
-      float bia[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < PT; ++p)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int co = co0 + cl + i;
-        if (co < d.Cout) {
-          if (d.bias) bia[i] = d.bias[co];
-          if (d.scale) { sc[i] = d.scale[co]; sh[i] = d.shift[co]; }
+        for (int i = 0; i < 16; ++i) acc[c][p][i] = 0.f;
+
+    auto issue = [&](int chunk, char* buf) {
+      const int ccls = cls | (chunk == half_chunk ? 64 : 0);
+      const char* xb = xbase + (long long)chunk * ROW;
+#pragma unroll
+      for (int i = 0; i < MAXP_IN; ++i) {
+        const int p = wave + 4 * i;
+        if (p < t.in_pieces) dma16((in_code[i] & ccls) ? zero : xb + (unsigned)in_rel[i], buf + p * 1024);
+      }
+      char* wbuf = buf + t.in_pieces * 1024;
+      const char* wb = wbase + (long long)chunk * w_chunk_stride;
+#pragma unroll
+      for (int i = 0; i < MAXP_W; ++i) {
+        const int p = wave + 4 * i;
+        if (p < W_PIECES) {
+          const bool ok = co0 + (p * 32) % BN < d.w_cout_pad;   // a piece = 32 cout rows of one tap: uniform
+          dma16(ok ? wb + (unsigned)w_rel[i] : zero, wbuf + p * 1024);
         }
       }
+    };
+    // A stage = G consecutive 32-byte chunks (G sub-buffers): the DMA latency of a stage is paid once per G
+    // chunks of MFMA work instead of once per chunk (deep-K layers have 16 chunks of only 9 MFMAs per wave).
+    auto issue_stage = [&](int st, char* base) {
+      for (int g = 0; g < G; ++g)
+        if (st * G + g < nchunks) issue(st * G + g, base + g * t.buf_bytes);
+    };
+    issue_stage(0, smem);
+    HRP_CSTAMP(2);
+    for (int st = 0; st < nstages; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of stage `st` have landed
+      __syncthreads();                                   // everyone's have, and stage st-1 has been consumed
+      if (st == 0) HRP_CSTAMP(3);
+      char* sbuf = smem + (st & 1) * stage_bytes;
+      if (st + 1 < nstages) issue_stage(st + 1, smem + ((st + 1) & 1) * stage_bytes);
+      // One step = one (tap, k-step) of a chunk: CT weight fragments, PT pixel fragments, CT x PT MFMAs.  The
+      // fragments of step s+1 (also across the chunk boundary inside the stage) are read while the MFMAs of
+      // step s run: with one or two waves per SIMD nothing else would hide the LDS latency.
+      constexpr int NS = NT * Mma<T>::KSTEPS;
+      const int ng = nchunks - st * G < G ? nchunks - st * G : G;
+      typename Mma<T>::Frag fa[2][CT], fb[2][PT];
+      auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&bb)[PT]) {
+        const int tap = step / Mma<T>::KSTEPS, kk = step % Mma<T>::KSTEPS;   // constants after unrolling
+        const char* lds_w = lds_in + t.in_pieces * 1024;
+        const int wr = tap * BN + wrow0;
 #pragma unroll
-      for (int p = 0; p < PT; ++p) {
-        const int m = wp * (32 * PT) + p * 32 + l31;
-        float v[4];
+        for (int c = 0; c < CT; ++c) a[c] = Mma<T>::ld(lds_w, wr + c * 32, kk, khalf);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (acc[c][p][4 * q4 + i] + bia[i]) * sc[i] + sh[i];
-        char* dst = lds_out + m * OP + cl * SZ;
-        if constexpr (SZ == 4) {
-          *(uint4*)dst = Elem<float>::pack(v);
-        } else {
-          uint2 r;
-          r.x = pack_bf2(v[0], v[1]);
-          r.y = pack_bf2(v[2], v[3]);
-          *(uint2*)dst = r;
+        for (int p = 0; p < PT; ++p) bb[p] = Mma<T>::ld(lds_in, pixrow[p] + taprow[tap], kk, khalf);
+      };
+      load(sbuf, 0, fa[0], fb[0]);
+      for (int g = 0; g < ng; ++g) {
+        const char* lds_in = sbuf + g * t.buf_bytes;
+#pragma unroll
+        for (int step = 0; step < NS; ++step) {
+          const int cur = step & 1, nxt = cur ^ 1;
+          if (step + 1 < NS) load(lds_in, step + 1, fa[nxt], fb[nxt]);
+          else if (g + 1 < ng) load(lds_in + t.buf_bytes, 0, fa[nxt], fb[nxt]);
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) Mma<T>::mma(fa[cur][c], fb[cur][p], acc[c][p]);
+          // keep the prefetch where it is: without the fence the scheduler sinks the reads next to their MFMA
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NS & 1) {   // odd step count: the prefetched fragments of the next chunk sit in slot 1
+#pragma unroll
+          for (int c = 0; c < CT; ++c) fa[0][c] = fa[1][c];
+#pragma unroll
+          for (int p = 0; p < PT; ++p) fb[0][p] = fb[1][p];
         }
       }
     }
-  }
-  __syncthreads();
-  HRP_CSTAMP(5);
+    __syncthreads();
+    HRP_CSTAMP(4);
 
-  // ---- coalesced pass: residual, ReLU, statistics, global store -------------------------------
-  constexpr int NV = BN / VEC;
-  float s1[VEC], s2[VEC];
+    // ---- epilogue: accumulators -> LDS tile [pixel][cout] (element type T) ----------------------
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
-  const int cv = tid % NV;  // 256 % NV == 0, so a thread keeps its channel group
-  const int co = co0 + cv * VEC;
-  char* yg = (char*)d.y;
-  const char* rg = (const char*)d.res;
-  if (co < d.Cout) {
-    const bool full = t.vec_ok && (co + VEC <= d.Cout);
-    for (int m = tid / NV; m < BM; m += 256 / NV) {
-      int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-      int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
-      int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
-      if (ti >= t.TI || n >= d.N || oy >= d.Ho || ox >= d.Wo) continue;
-      size_t opix = ((size_t)n * d.y_H + (oy * d.out_stride + d.out_off_y)) * d.y_W + (ox * d.out_stride + d.out_off_x);
-      const uint4 raw = *(const uint4*)(lds_out + m * OP + cv * 16);
-      float f[VEC];
-      Elem<T>::unpack(raw, f);
-      if (full && !rg && !d.relu) {
-        // plain conv output (the train-mode case): the LDS image is already the stored value
-        *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = raw;
-        if (d.stats) {
+    for (int c = 0; c < CT; ++c) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int cl = wc * 32 * CT + c * 32 + 8 * q4 + 4 * khalf;  // first of 4 consecutive local couts
+        float bia[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias || d.scale) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int co = co0 + cl + i;
+            if (co < d.Cout) {
+              if (d.bias) bia[i] = d.bias[co];
+              if (d.scale) { sc[i] = d.scale[co]; sh[i] = d.shift[co]; }
+            }
+          }
         }
-      } else if (full) {
-        if (rg) {
-          float r[VEC];
-          Elem<T>::unpack(*(const uint4*)(rg + (opix * d.res_pitch + co) * SZ), r);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) f[i] += r[i];
+        for (int p = 0; p < PT; ++p) {
+          const int m = wp * (32 * PT) + p * 32 + l31;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = (acc[c][p][4 * q4 + i] + bia[i]) * sc[i] + sh[i];
+          char* dst = lds_out + m * OP + cl * SZ;
+          if constexpr (SZ == 4) {
+            *(uint4*)dst = Elem<float>::pack(v);
+          } else {
+            uint2 r;
+            r.x = pack_bf2(v[0], v[1]);
+            r.y = pack_bf2(v[2], v[3]);
+            *(uint2*)dst = r;
+          }
         }
-        if (d.relu) {
+      }
+    }
+    __syncthreads();
+    HRP_CSTAMP(5);
+
+    // ---- coalesced pass: residual, ReLU, statistics, global store -------------------------------
+    float s1[VEC], s2[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
-        }
-        uint4 packed = Elem<T>::pack(f);
-        *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = packed;
-        if (d.stats) {
-          float g[VEC];
-          Elem<T>::unpack(packed, g);  // statistics of the values as stored
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    const int co = co0 + cv * VEC;
+    char* yg = (char*)d.y;
+    const char* rg = (const char*)d.res;
+    const long long ybase = ((long long)n0 * d.y_H + (oy0 * d.out_stride + d.out_off_y)) * d.y_W +
+                            (ox0 * d.out_stride + d.out_off_x);
+    if (co < d.Cout) {
+      const bool full = t.vec_ok && (co + VEC <= d.Cout);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) { s1[i] += g[i]; s2[i] += g[i] * g[i]; }
-        }
-      } else {
+      for (int k = 0; k < KST; ++k) {
+        if (out_code[k] & cls) continue;
+        const int m = tid / NV + k * (256 / NV);
+        const size_t opix = (size_t)(ybase + out_rel[k]);
+        const uint4 raw = *(const uint4*)(lds_out + m * OP + cv * 16);
+        float f[VEC];
+        Elem<T>::unpack(raw, f);
+        if (full && !rg && !d.relu) {
+          // plain conv output (the train-mode case): the LDS image is already the stored value
+          *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = raw;
+          if (d.stats) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          if (co + i < d.Cout) {
-            float val = f[i];
-            if (rg) val += Elem<T>::ld(rg, opix * d.res_pitch + co + i);
-            if (d.relu) val = fmaxf(val, 0.f);
-            Elem<T>::st(yg, opix * d.y_pitch + co + i, val);
-            if (d.stats) {
-              float g = Elem<T>::ld(yg, opix * d.y_pitch + co + i);
-              s1[i] += g; s2[i] += g * g;
+            for (int i = 0; i < VEC; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+          }
+        } else if (full) {
+          if (rg) {
+            float r[VEC];
+            Elem<T>::unpack(*(const uint4*)(rg + (opix * d.res_pitch + co) * SZ), r);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] += r[i];
+          }
+          if (d.relu) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+          }
+          uint4 packed = Elem<T>::pack(f);
+          *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = packed;
+          if (d.stats) {
+            float g[VEC];
+            Elem<T>::unpack(packed, g);  // statistics of the values as stored
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { s1[i] += g[i]; s2[i] += g[i] * g[i]; }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            if (co + i < d.Cout) {
+              float val = f[i];
+              if (rg) val += Elem<T>::ld(rg, opix * d.res_pitch + co + i);
+              if (d.relu) val = fmaxf(val, 0.f);
+              Elem<T>::st(yg, opix * d.y_pitch + co + i, val);
+              if (d.stats) {
+                float g = Elem<T>::ld(yg, opix * d.y_pitch + co + i);
+                s1[i] += g; s2[i] += g * g;
+              }
             }
           }
         }
       }
     }
-  }
-  HRP_CSTAMP(6);
-  if (d.stats) {
-    // lanes cv, cv + NV, ... of a wave own the same channels: butterfly over them, then one partial per
-    // wave in LDS ([wave][2][BN]), then one global atomic per channel per workgroup
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-#pragma unroll
-      for (int o = 32; o >= NV; o >>= 1) {
-        s1[i] += __shfl_xor(s1[i], o, 64);
-        s2[i] += __shfl_xor(s2[i], o, 64);
-      }
-    }
-    if (lane < NV) {
+    HRP_CSTAMP(6);
+    if (d.stats) {
+      // lanes cv, cv + NV, ... of a wave own the same channels: butterfly over them, then one partial per
+      // wave in LDS ([wave][2][BN]), then one global atomic per channel per workgroup
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        lds_stats[(wave * 2 + 0) * BN + lane * VEC + i] = s1[i];
-        lds_stats[(wave * 2 + 1) * BN + lane * VEC + i] = s2[i];
+#pragma unroll
+        for (int o = 32; o >= NV; o >>= 1) {
+          s1[i] += __shfl_xor(s1[i], o, 64);
+          s2[i] += __shfl_xor(s2[i], o, 64);
+        }
+      }
+      if (lane < NV) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          lds_stats[(wave * 2 + 0) * BN + lane * VEC + i] = s1[i];
+          lds_stats[(wave * 2 + 1) * BN + lane * VEC + i] = s2[i];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < 2 * BN; i += 256) {
+        const int which = i / BN, ch = i - which * BN;
+        if (co0 + ch < d.Cout) {
+          float v = lds_stats[(0 * 2 + which) * BN + ch] + lds_stats[(1 * 2 + which) * BN + ch] +
+                    lds_stats[(2 * 2 + which) * BN + ch] + lds_stats[(3 * 2 + which) * BN + ch];
+          float* slot = d.stats + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.Cout;
+          atomicAdd(&slot[which * d.Cout + co0 + ch], v);
+        }
       }
     }
-    __syncthreads();
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int which = i / BN, ch = i - which * BN;
-      if (co0 + ch < d.Cout) {
-        float v = lds_stats[(0 * 2 + which) * BN + ch] + lds_stats[(1 * 2 + which) * BN + ch] +
-                  lds_stats[(2 * 2 + which) * BN + ch] + lds_stats[(3 * 2 + which) * BN + ch];
-        float* slot = d.stats + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.Cout;
-        atomicAdd(&slot[which * d.Cout + co0 + ch], v);
-      }
-    }
+    __syncthreads();   // the next tile's DMA overwrites the output image / statistics partials
+    HRP_CSTAMP(7);
   }
-  HRP_CSTAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -437,6 +476,16 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.n_cout_blk = cdiv(d.Cout, BN);
   t.nblocks = t.tiles_x * t.tiles_y * t.tiles_n * t.n_cout_blk;
+  // the DMA / store plans classify validity per tile row / column class: only the first and the last tile
+  // row (column) may reach outside the image
+  if ((t.tiles_y >= 2 && (TH * d.in_stride + mindy < 0 ||
+                          (t.tiles_y - 2) * TH * d.in_stride + mindy + t.IHt - 1 >= d.H)) ||
+      (t.tiles_x >= 2 && (TW * d.in_stride + mindx < 0 ||
+                          (t.tiles_x - 2) * TW * d.in_stride + mindx + t.IWt - 1 >= d.W))) {
+    set_error("conv: tap offsets reach beyond the border tiles (H=%d W=%d Ho=%d Wo=%d stride=%d)", d.H, d.W, d.Ho, d.Wo,
+              d.in_stride);
+    return HRP_ERR_ARG;
+  }
   const int out_bytes = BM * (BN * SZ + 16);
   {  // chunks per stage: as many as two stages of LDS allow (all of LDS when the launch has at most one
      // workgroup per CU anyway, half of it otherwise), up to 4
@@ -458,13 +507,21 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
   t.fd_thw = make_fastdiv(TH * TW); t.fd_tw = make_fastdiv(TW);
   t.fd_ncb = make_fastdiv(t.n_cout_blk); t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y);
-  auto kern = conv_tile_kernel<T, CT, PT, WC, WP, NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // persistent workgroups (about two per CU, each walking tiles b, b + grid, ...) when a tile is little MFMA
+  // work and there are several tiles per CU; one tile per workgroup otherwise
+  const int mfma_per_tile = cdiv(d.Cin * SZ, ROW) * NT * CT * PT * Mma<T>::KSTEPS;
+  static const int persist_max = getenv("HRP_CONV_PERSIST") ? atoi(getenv("HRP_CONV_PERSIST")) : 48;
+  const bool persist = NT >= 4 && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256;   // 1x1 layers are store bound: many small workgroups
+  auto kern = persist ? conv_tile_kernel<T, CT, PT, WC, WP, NT, true> : conv_tile_kernel<T, CT, PT, WC, WP, NT, false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[persist]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set[persist] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(t.nblocks), dim3(256), lds, s, d, t);
+  int occ = (160 * 1024) / lds;
+  occ = occ < 1 ? 1 : occ > 2 ? 2 : occ;
+  const int grid = persist && t.nblocks > 256 * occ ? 256 * occ : t.nblocks;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d, t);
   return check_launch("conv_tile_kernel");
 }
 

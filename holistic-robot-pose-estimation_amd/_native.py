@@ -66,7 +66,8 @@ class EwBwdDesc(C.Structure):
     _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("dout_pitch", C.c_int32), ("out_pitch", C.c_int32),
                 ("inp", EwInput), ("din", C.c_void_p), ("din_pitch", C.c_int32), ("sums", C.c_void_p),
                 ("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-                ("relu", C.c_int32), ("accumulate", C.c_int32)]
+                ("relu", C.c_int32), ("accumulate", C.c_int32),
+                ("din2", C.c_void_p), ("din2_pitch", C.c_int32), ("accumulate2", C.c_int32)]
 
 
 class BnEntry(C.Structure):

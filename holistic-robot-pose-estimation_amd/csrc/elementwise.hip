@@ -251,6 +251,19 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
     int n = r / Hq;
     float g[V];
     pooled_grad<T, V>(d, n, qy, qx, c, g);
+    if (d.din2) {   // identity sibling of the same activation (up == 1): its gradient is g itself
+      float g2[V];
+      const size_t o2 = (size_t)q * d.din2_pitch + c;
+      if (d.accumulate2) {
+        VecIO<T, V>::ld(d.din2, o2, g2);
+#pragma unroll
+        for (int i = 0; i < V; ++i) g2[i] += g[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) g2[i] = g[i];
+      }
+      VecIO<T, V>::st(d.din2, o2, g2);
+    }
     if (d.in.mode == HRP_EW_BN_TRAIN) {
       float xin[V];
       VecIO<T, V>::ld(d.in.ptr, (size_t)q * d.in.pitch + c, xin);
@@ -314,6 +327,7 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   bool ok = aligned16(d.dout, d.dout_pitch, SZ) && aligned16(d.in.ptr ? d.in.ptr : d.dout, d.in.pitch ? d.in.pitch : d.dout_pitch, SZ);
   if (d.relu) ok = ok && aligned16(d.out, d.out_pitch, SZ);
   if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
+  if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
   const int up = d.in.up;
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : 512);
   dim3 grid(g.gx, g.nslab);
@@ -351,6 +365,7 @@ static int ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
   HRP_REQUIRE(d->in.mode == HRP_EW_IDENTITY || d->in.ptr, "ew_bwd: needs forward input values");
   HRP_REQUIRE(d->in.mode != HRP_EW_BN_TRAIN || (d->sums && d->in.stats && d->in.a), "ew_bwd: bn needs sums/stats");
   HRP_REQUIRE(!apply || d->din, "ew_bwd_apply: din");
+  HRP_REQUIRE(!d->din2 || d->in.up == 1, "ew_bwd: din2 needs up == 1");   /* (the reduce pass ignores din2) */
   HRP_REQUIRE(apply || (d->sums && d->in.ptr), "ew_bwd_reduce: sums / input values");
   return HRP_OK;
 }

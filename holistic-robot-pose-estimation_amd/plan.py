@@ -653,8 +653,13 @@ class PlanBuilder:
         p = self.plan
         if not out.grad_written:
             return
+        # an identity term (residual) at the output resolution rides along with a BN / affine term of the same
+        # activation: one apply launch writes both gradients (hrp_ew_bwd_desc.din2)
+        host = next((j for j, tm in enumerate(terms) if tm.t.requires_grad and tm.bn is not None and tm.up == 1), None)
+        rider = next((j for j, tm in enumerate(terms) if tm.t.requires_grad and tm.bn is None and tm.up == 1
+                      and fd.inp[j].mode == nv.EW_IDENTITY), None) if host is not None else None
         for j, tm in enumerate(terms):
-            if not tm.t.requires_grad:
+            if not tm.t.requires_grad or j == rider:
                 continue
             if tm.bn is not None and not p.training:
                 raise NotImplementedError("gradients through eval-mode BatchNorm are not supported yet")
@@ -669,6 +674,11 @@ class PlanBuilder:
             b.dtype, b.N, b.H, b.W, b.C, b.relu = fd.dtype, fd.N, fd.H, fd.W, fd.C, fd.relu
             b.din, b.din_pitch = tm.t.gptr(), tm.t.pitch
             b.accumulate = tm.t.take_grad_slot()
+            if j == host and rider is not None:
+                rt = terms[rider].t
+                # the check above guarantees the aligned vector path is the same for both outputs
+                b.din2, b.din2_pitch = rt.gptr(), rt.pitch
+                b.accumulate2 = rt.take_grad_slot()
             if tm.bn is not None:
                 off = p.alloc_bsums(fd.C)
                 p.bn_bwd.append((tm.bn, off))

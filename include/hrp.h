@@ -156,6 +156,9 @@ typedef struct hrp_ew_bwd_desc {
   int32_t N, H, W, C;  /* geometry of out */
   int32_t relu;
   int32_t accumulate;  /* apply: din += */
+  void* din2;          /* apply, optional, in.up == 1 only: second output = the masked gradient g itself, i.e. */
+  int32_t din2_pitch;  /* the gradient of an identity (residual) input of the same activation - saves the   */
+  int32_t accumulate2; /* separate identity launch that would re-read dout / out; din2 += when accumulate2  */
 } hrp_ew_bwd_desc;
 
 /* Table entry for the one-launch batch-norm bookkeeping kernels. */

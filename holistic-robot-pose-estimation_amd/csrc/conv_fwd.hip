@@ -90,9 +90,13 @@ __device__ __forceinline__ float dpp_row_ror(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
 }
 
+// 64 lanes x 16 bytes global -> LDS (lane-linear at lds_wave_base).  Inline assembly on purpose: behind the
+// builtin the compiler's wait-count pass may drain the DMA (s_waitcnt vmcnt(0)) before LDS reads it cannot
+// prove disjoint, which would serialise the prefetch with the MFMAs.  The kernel waits explicitly per stage.
 __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(src), "s"(lds) : "memory");   // m0 is scratch for the compiler too: it never keeps a value there
 }
 
 template <typename T, int CT, int PT, int WC, int WP, int NT, bool PERSIST>
@@ -121,10 +125,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     int m = wp * (32 * PT) + pt * 32 + l31;
-    int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-    int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+    int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+    int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
     if (ti >= t.TI) ti = t.TI - 1;  // idle slot of a partially filled tile: read something valid, never stored
-    pixrow[pt] = (ti * t.IHt + ty * IS) * t.IWt + tx * IS;
+    pixrow[pt] = mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS);
   }
   const int wrow0 = wc * 32 * CT + l31;
 
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       const int sl = (wave + 4 * i) * 64 + lane;   // 16-byte slot of the input region
       const int r = sl >> 1;                       // tile pixel row
       const int h = (sl & 1) ^ ((r >> 3) & 1);     // logical half stored in this slot
-      const int ti = fdiv(r, t.fd_ihw), rem = r - ti * ihw;
-      const int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+      const int ti = fdiv16(r, t.fd_ihw), rem = r - mul24(ti, ihw);
+      const int iy = fdiv16(rem, t.fd_iwt), ix = rem - mul24(iy, t.IWt);
       int code = (r >= t.in_rows) ? 32 : 0;
       code |= (iy + t.mindy < 0) ? 1 : 0;
       code |= (iy + iy_last >= d.H) ? 2 : 0;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       code |= (ti + n_last >= d.N) ? 16 : 0;
       code |= h ? 64 : 0;
       in_code[i] = code;
-      in_rel[i] = (((ti * d.H + iy) * d.W + ix) * d.x_pitch + h * VEC) * SZ;
+      in_rel[i] = mul24(mul24(mul24(ti, d.H) + iy, d.W) + ix, d.x_pitch * SZ) + h * (VEC * SZ);
     }
   }
   int w_rel[MAXP_W];                             // byte offset into the packed weights (chunk 0, cout block 0)
@@ -194,14 +198,14 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
   for (int k = 0; k < KST; ++k) {
     const int m = tid / NV + k * (256 / NV);
-    const int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-    const int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+    const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+    const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
     int code = (ti >= t.TI) ? 32 : 0;
     code |= (ty + y_last >= d.Ho) ? 2 : 0;
     code |= (tx + x_last >= d.Wo) ? 8 : 0;
     code |= (ti + n_last >= d.N) ? 16 : 0;
     out_code[k] = code;
-    out_rel[k] = (ti * d.y_H + ty * d.out_stride) * d.y_W + tx * d.out_stride;   // in output pixels
+    out_rel[k] = mul24(mul24(ti, d.y_H) + mul24(ty, d.out_stride), d.y_W) + mul24(tx, d.out_stride);   // in output pixels
   }
   HRP_CSTAMP(1);
 
@@ -237,22 +241,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][p][i] = 0.f;
 
-    auto issue = [&](int chunk, char* buf) {
-      const int ccls = cls | (chunk == half_chunk ? 64 : 0);
-      const char* xb = xbase + (long long)chunk * ROW;
-#pragma unroll
-      for (int i = 0; i < MAXP_IN; ++i) {
-        const int p = wave + 4 * i;
-        if (p < t.in_pieces) dma16((in_code[i] & ccls) ? zero : xb + (unsigned)in_rel[i], buf + p * 1024);
-      }
-      char* wbuf = buf + t.in_pieces * 1024;
-      const char* wb = wbase + (long long)chunk * w_chunk_stride;
-#pragma unroll
-      for (int i = 0; i < MAXP_W; ++i) {
-        const int p = wave + 4 * i;
+    // DMA slot = one 1 KiB piece of this wave: slots 0 .. MAXP_IN-1 belong to the input tile of the chunk,
+    // the rest to its weight slab (slot is a constant after unrolling)
+    auto issue_slot = [&](int chunk, char* buf, int slot) {
+      if (slot < MAXP_IN) {
+        const int p = wave + 4 * slot;
+        if (p < t.in_pieces) {
+          const int ccls = cls | (chunk == half_chunk ? 64 : 0);
+          dma16((in_code[slot] & ccls) ? zero : xbase + (long long)chunk * ROW + (unsigned)in_rel[slot], buf + p * 1024);
+        }
+      } else if (slot < MAXP_IN + MAXP_W) {
+        const int i = slot - MAXP_IN, p = wave + 4 * i;
         if (p < W_PIECES) {
           const bool ok = co0 + (p * 32) % BN < d.w_cout_pad;   // a piece = 32 cout rows of one tap: uniform
-          dma16(ok ? wb + (unsigned)w_rel[i] : zero, wbuf + p * 1024);
+          dma16(ok ? wbase + (long long)chunk * w_chunk_stride + (unsigned)w_rel[i] : zero,
+                buf + (t.in_pieces + p) * 1024);
         }
       }
     };
@@ -260,7 +263,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     // chunks of MFMA work instead of once per chunk (deep-K layers have 16 chunks of only 9 MFMAs per wave).
     auto issue_stage = [&](int st, char* base) {
       for (int g = 0; g < G; ++g)
-        if (st * G + g < nchunks) issue(st * G + g, base + g * t.buf_bytes);
+        if (st * G + g < nchunks) {
+#pragma unroll
+          for (int slot = 0; slot < MAXP_IN + MAXP_W; ++slot) issue_slot(st * G + g, base + g * t.buf_bytes, slot);
+        }
     };
     issue_stage(0, smem);
     HRP_CSTAMP(2);
@@ -269,11 +275,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       __syncthreads();                                   // everyone's have, and stage st-1 has been consumed
       if (st == 0) HRP_CSTAMP(3);
       char* sbuf = smem + (st & 1) * stage_bytes;
-      if (st + 1 < nstages) issue_stage(st + 1, smem + ((st + 1) & 1) * stage_bytes);
+      char* nbuf = smem + ((st + 1) & 1) * stage_bytes;
+      const bool more = st + 1 < nstages;
       // One step = one (tap, k-step) of a chunk: CT weight fragments, PT pixel fragments, CT x PT MFMAs.  The
       // fragments of step s+1 (also across the chunk boundary inside the stage) are read while the MFMAs of
       // step s run: with one or two waves per SIMD nothing else would hide the LDS latency.
+      // The pieces of stage st+1 are issued between the MFMA steps (chunk g of the next stage during chunk g of
+      // this one, SPP slots per step): issued in one burst a full memory queue stalls the wave for ~2 us.
       constexpr int NS = NT * Mma<T>::KSTEPS;
+      constexpr int SPP = (MAXP_IN + MAXP_W + NS - 1) / NS;
       const int ng = nchunks - st * G < G ? nchunks - st * G : G;
       typename Mma<T>::Frag fa[2][CT], fb[2][PT];
       auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&bb)[PT]) {
@@ -297,6 +307,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
           for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int p = 0; p < PT; ++p) Mma<T>::mma(fa[cur][c], fb[cur][p], acc[c][p]);
+          if (more && (st + 1) * G + g < nchunks) {
+#pragma unroll
+            for (int u = 0; u < SPP; ++u) issue_slot((st + 1) * G + g, nbuf + g * t.buf_bytes, step * SPP + u);
+          }
           // keep the prefetch where it is: without the fence the scheduler sinks the reads next to their MFMA
           __builtin_amdgcn_sched_barrier(0);
         }

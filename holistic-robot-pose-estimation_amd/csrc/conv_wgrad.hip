@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
       xcode[i] = 32; xrel[i] = 0;
       if (wave + 4 * i >= x_pieces) continue;
       const int sl = (wave + 4 * i) * 64 + lane, pix = sl / NVEC, vec = sl - pix * NVEC;
-      const int ti = fdiv(pix, t.fd_ihw), rem = pix - ti * ihw;
-      const int iy = fdiv(rem, t.fd_iwt), ix = rem - iy * t.IWt;
+      const int ti = fdiv16(pix, t.fd_ihw), rem = pix - mul24(ti, ihw);
+      const int iy = fdiv16(rem, t.fd_iwt), ix = rem - mul24(iy, t.IWt);
       const int c = ci0 + vec * VEC;
       int code = (pix >= t.in_pix || c >= d.Cin) ? 32 : 0;
       code |= (iy + t.mindy < 0) ? 1 : 0;
@@ -155,22 +155,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
       code |= (ix + ix_last >= d.W) ? 8 : 0;
       code |= (ti + n_last >= d.N) ? 16 : 0;
       xcode[i] = code;
-      xrel[i] = (((ti * d.H + iy) * d.W + ix) * d.x_pitch + c) * SZ;
+      xrel[i] = mul24(mul24(mul24(ti, d.H) + iy, d.W) + ix, d.x_pitch * SZ) + c * SZ;
     }
 #pragma unroll
     for (int i = 0; i < MAXP_DY; ++i) {
       dycode[i] = 32; dyrel[i] = 0;
       if (wave + 4 * i >= dy_pieces) continue;
       const int sl = (wave + 4 * i) * 64 + lane, m = sl / NVEC, vec = sl - m * NVEC;
-      const int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-      const int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+      const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
       const int c = co0 + vec * VEC;
       int code = (m >= t.BM || ti >= t.TI || c >= d.Cout) ? 32 : 0;
       code |= (ty + y_last >= d.Ho) ? 2 : 0;
       code |= (tx + x_last >= d.Wo) ? 8 : 0;
       code |= (ti + n_last >= d.N) ? 16 : 0;
       dycode[i] = code;
-      dyrel[i] = (((ti * d.Ho + ty) * d.Wo + tx) * d.dy_pitch + c) * SZ;
+      dyrel[i] = mul24(mul24(mul24(ti, d.Ho) + ty, d.Wo) + tx, d.dy_pitch * SZ) + c * SZ;
     }
   }
 
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
   int xo0[NKS_], xo1[NKS_], ao[NKS_];
   if constexpr (SZ == 2) {
     auto xoff = [&](int m) {
-      int ti = fdiv(m, t.fd_thw), rem = m - ti * thw;
-      int ty = fdiv(rem, t.fd_tw), tx = rem - ty * t.TW;
+      int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
       if (ti >= t.TI) ti = t.TI - 1;
-      return ((ti * t.IHt + ty * IS) * t.IWt + tx * IS) * P + tr_coff;
+      return mul24(mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS), P) + tr_coff;
     };
 #pragma unroll
     for (int ks = 0; ks < NKS_; ++ks) {

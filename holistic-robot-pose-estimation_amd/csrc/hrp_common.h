@@ -97,14 +97,22 @@ __device__ __forceinline__ float wave_max(float v) {
 // division by a launch-invariant divisor: q = umulhi(v, m) is exact while v * d < 2^32 (m = 2^32/d + 1)
 struct FastDiv {
   uint32_t m, d;
+  float inv;
 };
 static inline FastDiv make_fastdiv(int d) {
   FastDiv f;
   f.d = (uint32_t)d;
   f.m = d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull);
+  f.inv = 1.0f / (float)(d < 1 ? 1 : d);
   return f;
 }
 __device__ __forceinline__ int fdiv(int v, const FastDiv& f) { return f.m ? (int)__umulhi((uint32_t)v, f.m) : v; }
+// v / d for 0 <= v < 65536 with three full-rate instructions (cvt, mul, cvt) instead of a quarter-rate
+// 32-bit multiply: (v + 0.5) / d is at least 0.5 / d away from an integer and the fp32 error is below
+// 2^-7 / d, so the truncation is exact (tests/test_host_cpu.py checks the same arithmetic in numpy).
+__device__ __forceinline__ int fdiv16(int v, const FastDiv& f) { return (int)(((float)v + 0.5f) * f.inv); }
+// a * b for 0 <= a, b < 2^24 (full-rate v_mul_u32_u24; v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

@@ -177,3 +177,14 @@ def test_data_parallel_reducer_gloo_world2():
     mean = np.arange(5, dtype=np.float32) * 1.5                    # (1x + 2x) / 2
     assert np.allclose(res[0][2], mean) and np.allclose(res[1][2], mean)
     assert abs(res[0][3] - 9999 * 1.5) < 1e-3
+
+
+def test_fdiv16_arithmetic_is_exact():
+    """csrc/hrp_common.h fdiv16: (int)((float(v) + 0.5f) * (1.0f / d)) == v // d for 0 <= v < 65536 - the
+    plan arithmetic of the conv kernels relies on it (same fp32 operations restated in numpy)."""
+    v = np.arange(65536, dtype=np.float32)
+    ds = list(range(1, 700)) + [1023, 1024, 1025, 1296, 2047, 4095, 4096, 10000, 40000, 65535]
+    for d in ds:
+        inv = np.float32(1.0) / np.float32(d)
+        q = ((v + np.float32(0.5)) * inv).astype(np.int32)
+        assert np.array_equal(q, (np.arange(65536) // d).astype(np.int32)), d

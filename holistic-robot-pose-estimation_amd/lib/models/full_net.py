@@ -154,8 +154,18 @@ class RootNetwithRegInt(PlannedModule):
         uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
         depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,
                                                           il.depth_factor)
-        pose = self._iter_head(pb, xf, self.init_pose, self.init_pose.shape[1], self.fc_pose_1, self.fc_pose_2, self.decpose)
-        rot = self._iter_head(pb, xf, self.init_rot, self.rotation_dim, self.fc_rot_1, self.fc_rot_2, self.decrot)
+        # the pose and the rotation regressor are independent chains of 12 small GEMMs each: two lanes.  Each
+        # gets a private copy of the feature so that its gradient accumulates lane-locally.
+        xf_pose, xf_rot = pb.new_like(xf), pb.new_like(xf)
+        pb.copy_cols(xf, xf_pose)
+        pb.copy_cols(xf, xf_rot)
+        with pb.parallel(2) as par:
+            with par.lane(0):
+                pose = self._iter_head(pb, xf_pose, self.init_pose, self.init_pose.shape[1], self.fc_pose_1,
+                                       self.fc_pose_2, self.decpose)
+            with par.lane(1):
+                rot = self._iter_head(pb, xf_rot, self.init_rot, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
+                                      self.decrot)
         pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
         outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, 6)), ("dense", trans, (N, 3)),

@@ -704,6 +704,9 @@ class PlanBuilder:
             self.bwd_stack.append(bw)
         return y
 
+    def new_like(self, t):
+        return self.plan.new(t.N, t.H, t.W, t.C, t.dtype, pitch=t.pitch)
+
     def copy_cols(self, src, dst):
         """dst[:, :src.C] = src (fp32), gradient flows back additively."""
         p = self.plan

@@ -175,6 +175,7 @@ class Plan:
         self.out_handles = []      # TensorH whose gradient is seeded from outside
         self.grad_arena = None
         self._grad_views = {}
+        self.counters = {}         # build statistics (HRP_PLAN_STATS=1 prints them at finalize)
         self.wgrad_ws_bytes = {}   # lane -> scratch bytes shared by that lane's weight-gradient launches
         self.wgrad_ws = {}
 
@@ -267,6 +268,10 @@ class Plan:
         self._late = []
         self._bn_tables()
         self.built = True
+        if os.environ.get("HRP_PLAN_STATS"):
+            import sys
+            print(f"plan: {len(self.fwd)} forward / {len(self.bwd)} backward ops, {self.n_lanes} lanes, {self.counters}",
+                  file=sys.stderr)
 
     def late(self, fn):
         """Defer pointer patching until the arenas exist (finalize)."""

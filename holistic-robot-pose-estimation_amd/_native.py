@@ -59,7 +59,8 @@ class EwInput(C.Structure):
 class EwDesc(C.Structure):
     _fields_ = [("inp", EwInput * EW_MAX_IN), ("nin", C.c_int32), ("out", C.c_void_p),
                 ("out_pitch", C.c_int32), ("dtype", C.c_int32),
-                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("relu", C.c_int32)]
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("relu", C.c_int32),
+                ("mask", C.c_void_p), ("mask_pitch", C.c_int32)]
 
 
 class EwBwdDesc(C.Structure):
@@ -67,6 +68,7 @@ class EwBwdDesc(C.Structure):
                 ("inp", EwInput), ("din", C.c_void_p), ("din_pitch", C.c_int32), ("sums", C.c_void_p),
                 ("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("relu", C.c_int32), ("accumulate", C.c_int32),
+                ("mask", C.c_void_p), ("mask_pitch", C.c_int32),
                 ("din2", C.c_void_p), ("din2_pitch", C.c_int32), ("accumulate2", C.c_int32)]
 
 
@@ -163,7 +165,13 @@ def set_profile_hook(fn):
     _profile_hook = fn
 
 
+# development aid (timing ablations only - results are wrong): HRP_SKIP=name1,name2 turns those launches into no-ops
+_skip = frozenset(filter(None, os.environ.get("HRP_SKIP", "").split(",")))
+
+
 def call(name, *args):
+    if _skip and name in _skip:
+        return
     if _profile_hook is not None:
         _profile_hook(name, args, lambda: check(getattr(lib(), name)(*args), name))
         return

@@ -8,6 +8,7 @@
 // Train-mode BN needs no separate finalize kernel: each workgroup derives scale/shift of its channel slab
 // once (into LDS) from the (sum, sumsq) statistic slots the producing conv accumulated in its epilogue.
 #include "hrp_common.h"
+#include <stdlib.h>
 
 namespace hrp {
 
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
       for (int i = 0; i < V; ++i) acc[i] += f[i] * sc[j][i] + sh[j][i];
     }
     if (d.relu) {
+      if (V > 1 && d.mask) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) bits |= (acc[i] > 0.f ? 1u : 0u) << i;
+        d.mask[(size_t)p * d.mask_pitch + cv] = (uint8_t)bits;
+      }
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
     }
@@ -126,10 +133,16 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, int n, int
       float go[V];
       VecIO<T, V>::ld(d.dout, p * d.dout_pitch + c, go);
       if (d.relu) {
-        float o[V];
-        VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
+        if (V > 1 && d.mask) {
+          const unsigned bits = d.mask[p * d.mask_pitch + c / V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : 0.f;
+          for (int i = 0; i < V; ++i) go[i] = (bits >> i) & 1u ? go[i] : 0.f;
+        } else {
+          float o[V];
+          VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
+#pragma unroll
+          for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : 0.f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < V; ++i) g[i] += go[i];
@@ -302,7 +315,8 @@ static EwGeom geom(int C, int vec, bool vec_ok, long npix, int maxblocks) {
   g.nslab = cdiv(nv, tpr);
   int ppb = 256 / tpr;
   long blocks = (npix + ppb - 1) / ppb;
-  long cap = maxblocks / g.nslab;
+  static const int mult = getenv("HRP_EW_BLOCKS") ? atoi(getenv("HRP_EW_BLOCKS")) : 1;   // tuning knob
+  long cap = (long)maxblocks * mult / g.nslab;
   if (cap < 1) cap = 1;
   g.gx = (int)(blocks < cap ? blocks : cap);
   if (g.gx < 1) g.gx = 1;
@@ -315,6 +329,7 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   bool ok = aligned16(d.out, d.out_pitch, SZ);
   for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, 1024);
+  HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_fwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
   else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
@@ -330,6 +345,7 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
   const int up = d.in.up;
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : 512);
+  HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   if (APPLY) {
     if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr);

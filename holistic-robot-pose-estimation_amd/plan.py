@@ -104,6 +104,9 @@ class ParamW:
         self.grad_written = False
 
 
+# ReLU sign bits written by the forward element-wise pass, read by its backward instead of the activation
+RELU_BITMASK = not os.environ.get("HRP_NO_RELU_BITMASK")
+
 # True: every lane runs on the caller's stream (per-kernel timing passes, A/B measurements)
 SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
 
@@ -649,6 +652,12 @@ class PlanBuilder:
                 e.mode = nv.EW_AFFINE
                 e.a, e.b = sc.data_ptr(), sh.data_ptr()
             ins.append(e)
+        vec = 16 // out.esz
+        if relu and out.requires_grad and RELU_BITMASK and Cc % vec == 0 and all(tm.t.pitch % vec == 0 for tm in terms):
+            # the backward needs only the sign of the output: one byte per 16-byte vector instead of the tensor
+            mask = torch.zeros(N * H * W * (Cc // vec), dtype=torch.uint8, device=p.device)
+            p.keep.append(mask)
+            d.mask, d.mask_pitch = mask.data_ptr(), Cc // vec
         p.fwd.append(lambda s, d=d: nv.call("hrp_ew_fwd", C.byref(d), s))
         if p.need_grad:
             self.bwd_stack.append(lambda: self._act_bwd(terms, out, relu, d))
@@ -677,6 +686,7 @@ class PlanBuilder:
             # the statistics pointer of the forward descriptor is patched at finalize: copy it then
             p.late(lambda b=b, src=src: setattr(b.inp, "stats", src.stats))
             b.dtype, b.N, b.H, b.W, b.C, b.relu = fd.dtype, fd.N, fd.H, fd.W, fd.C, fd.relu
+            b.mask, b.mask_pitch = fd.mask, fd.mask_pitch
             b.din, b.din_pitch = tm.t.gptr(), tm.t.pitch
             b.accumulate = tm.t.take_grad_slot()
             if j == host and rider is not None:

@@ -139,6 +139,10 @@ typedef struct hrp_ew_desc {
   int32_t dtype;
   int32_t N, H, W, C;
   int32_t relu;
+  uint8_t* mask;       /* optional with relu: one byte per 16-byte output vector (8 bf16 / 4 fp32 channels),   */
+  int32_t mask_pitch;  /* bit i = (channel i of the vector > 0); [N*H*W][mask_pitch] bytes.  The backward then  */
+                       /* reads 1/16 of the bytes of `out` for the ReLU mask.  Vector path only (C, pitches and */
+                       /* pointers 16-byte aligned), an error otherwise.                                        */
 } hrp_ew_desc;
 
 /* Backward of one input j of an ew op.  g = dOut * (out > 0 if relu), pooled (summed) over the
@@ -156,6 +160,8 @@ typedef struct hrp_ew_bwd_desc {
   int32_t N, H, W, C;  /* geometry of out */
   int32_t relu;
   int32_t accumulate;  /* apply: din += */
+  const uint8_t* mask; /* optional ReLU bit mask written by hrp_ew_fwd (see hrp_ew_desc.mask); replaces `out` */
+  int32_t mask_pitch;
   void* din2;          /* apply, optional, in.up == 1 only: second output = the masked gradient g itself, i.e. */
   int32_t din2_pitch;  /* the gradient of an identity (residual) input of the same activation - saves the   */
   int32_t accumulate2; /* separate identity launch that would re-read dout / out; din2 += when accumulate2  */

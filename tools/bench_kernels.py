@@ -47,7 +47,7 @@ def pack(w, dtype):
     return dst, dst_t
 
 
-def timeit(fn, reps=50):
+def timeit(fn, reps=int(os.environ.get("HRP_REPS", "50"))):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

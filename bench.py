@@ -30,6 +30,7 @@ from hrpe_amd import _native as nv  # noqa: E402
 from hrpe_amd.lib.core.function import compute_k_values, full_loss  # noqa: E402
 from hrpe_amd.lib.dataset.const import INITIAL_JOINT_ANGLE, JOINT_BOUNDS  # noqa: E402
 from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d  # noqa: E402
+from hrpe_amd.optim import FusedClipAdam  # noqa: E402
 from hrpe_amd.parallel import GradAllReducer, broadcast_module, init_distributed  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
@@ -141,6 +142,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-optim", action="store_true", help="clip_grad_norm_ + torch.optim.Adam(fused) instead of FusedClipAdam")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--p-dropout", type=float, default=0.5, help="lib/core/config.py:70 default")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -171,7 +173,10 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     # Adam(lr 1e-4) as scripts/train_full.py:42; fused multi-tensor kernels (the default foreach path spends
     # ~3 500 tiny launches per step on the per-parameter step counters)
-    opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=not a.no_graph)
+    if a.torch_optim:
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=not a.no_graph)
+    else:   # clip_grad_norm_(5) + Adam as two table-driven launches (hrpe_amd/optim.py)
+        opt = FusedClipAdam(params, lr=1e-4, max_norm=5.0)
     reducer = GradAllReducer(bucket_mb=64)
 
     d = {k: torch.tensor(v).to(dev) for k, v in synthetic_batch(B, 808 + rank).items()}
@@ -192,7 +197,8 @@ def main():
         loss_holder["loss"] = loss.detach()
 
     def update():
-        torch.nn.utils.clip_grad_norm_(params, 5.0)   # configs/panda/full.yaml:39
+        if a.torch_optim:
+            torch.nn.utils.clip_grad_norm_(params, 5.0)   # configs/panda/full.yaml:39
         opt.step()
 
     def step_eager():
@@ -328,7 +334,9 @@ def main():
                                "fwd+loss+bwd+clip+Adam, BASELINE.json configs[2]",
                    "global_batch": B * world, "per_gpu_batch": B, "image": "3x256x256",
                    "hrnet_w32_passes_per_image": 2, "parallelism": f"dp{world}", "hip_graph": use_graph,
-                   "p_dropout": a.p_dropout},
+                   "p_dropout": a.p_dropout,
+                   "optimizer": "clip_grad_norm_(5)+torch.optim.Adam(fused)" if a.torch_optim else
+                                "hrpe_amd.optim.FusedClipAdam (clip 5 + Adam, lr 1e-4)"},
         "hrnet_w32_passes_per_sec": round(2 * value, 2),
         "step_model_tflops": round(step_tflops, 2),
         "step_frac_of_mfma_peak": round(step_tflops / peak, 4),

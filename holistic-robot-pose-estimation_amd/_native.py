@@ -79,6 +79,18 @@ class BnEntry(C.Structure):
                 ("accumulate", C.c_int32)]
 
 
+OPT_CHUNK = 4096
+
+
+class OptTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64)]
+
+
+class OptChunk(C.Structure):
+    _fields_ = [("tensor", C.c_int32), ("offset", C.c_int32)]
+
+
 class FkChain(C.Structure):
     _fields_ = [("njoints", C.c_int32), ("parent", C.c_int32 * FK_MAX_JOINTS), ("type", C.c_int32 * FK_MAX_JOINTS),
                 ("cfg", C.c_int32 * FK_MAX_JOINTS), ("mimic_mul", C.c_float * FK_MAX_JOINTS),
@@ -113,6 +125,8 @@ PROTOTYPES = {
     "hrp_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_scale_rows": [_P, _I, _I, _I, _P, _F, _P],
     "hrp_mul_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hrp_opt_grad_sumsq": [_P, _P, _I, _P, _P],
+    "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
     "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],
     "hrp_project_bwd": [_P, _P, _P, _I, _I, _P, _P],
 }

@@ -271,6 +271,89 @@ extern "C" int hrp_bn_param_grad(const hrp_bn_entry* table_dev, int count, void*
   return check_launch("bn_param_grad");
 }
 
+// ---- clip_grad_norm_ + Adam over all parameters, table driven -----------------------------------------
+__global__ __launch_bounds__(256) void opt_grad_sumsq_kernel(const hrp_opt_tensor* __restrict__ tensors,
+                                                             const hrp_opt_chunk* __restrict__ chunks,
+                                                             float* __restrict__ slots) {
+  const hrp_opt_chunk ck = chunks[blockIdx.x];
+  const hrp_opt_tensor t = tensors[ck.tensor];
+  const int64_t base = (int64_t)ck.offset * HRP_OPT_CHUNK;
+  const int64_t left = t.numel - base;
+  const int n = left < HRP_OPT_CHUNK ? (int)left : HRP_OPT_CHUNK;
+  const float* g = t.grad + base;
+  float s = 0.f;
+  if ((n & 3) == 0 && ((uintptr_t)g & 15) == 0) {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      const float4 v = *(const float4*)(g + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  }
+  s = wave_sum(s);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&slots[blockIdx.x & (HRP_STAT_SLOTS - 1)], part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void opt_adam_kernel(const hrp_opt_tensor* __restrict__ tensors,
+                                                       const hrp_opt_chunk* __restrict__ chunks,
+                                                       const float* __restrict__ slots, float max_norm,
+                                                       const float* __restrict__ step_dev, float lr, float b1, float b2,
+                                                       float eps) {
+  const hrp_opt_chunk ck = chunks[blockIdx.x];
+  const hrp_opt_tensor t = tensors[ck.tensor];
+  const int64_t base = (int64_t)ck.offset * HRP_OPT_CHUNK;
+  const int64_t left = t.numel - base;
+  const int n = left < HRP_OPT_CHUNK ? (int)left : HRP_OPT_CHUNK;
+  float clip = 1.f;
+  if (max_norm > 0.f) {
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < HRP_STAT_SLOTS; ++k) ss += slots[k];
+    clip = fminf(1.f, max_norm / (sqrtf(ss) + 1e-6f));
+  }
+  const float step = *step_dev;
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  float* p = t.param + base;
+  float* g = t.grad + base;
+  float* m = t.exp_avg + base;
+  float* v = t.exp_avg_sq + base;
+  auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
+    gg *= clip;
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    pp -= step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+  };
+  if ((n & 3) == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      float4 pp = *(float4*)(p + i), gg = *(float4*)(g + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
+      upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+      *(float4*)(p + i) = pp; *(float4*)(g + i) = gg; *(float4*)(m + i) = mm; *(float4*)(v + i) = vv;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
+  }
+}
+
+extern "C" int hrp_opt_grad_sumsq(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,
+                                  float* sumsq_slots, void* stream) {
+  HRP_REQUIRE(tensors_dev && chunks_dev && sumsq_slots && nchunks > 0, "opt_grad_sumsq: bad args");
+  hipLaunchKernelGGL(opt_grad_sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors_dev, chunks_dev, sumsq_slots);
+  return check_launch("opt_grad_sumsq");
+}
+extern "C" int hrp_opt_adam_step(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,
+                                 const float* sumsq_slots, float max_norm, const float* step_dev,
+                                 float lr, float beta1, float beta2, float eps, void* stream) {
+  HRP_REQUIRE(tensors_dev && chunks_dev && step_dev && nchunks > 0, "opt_adam_step: bad args");
+  HRP_REQUIRE(max_norm <= 0.f || sumsq_slots, "opt_adam_step: clipping needs the sum-of-squares slots");
+  hipLaunchKernelGGL(opt_adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors_dev, chunks_dev, sumsq_slots,
+                     max_norm, step_dev, lr, beta1, beta2, eps);
+  return check_launch("opt_adam_step");
+}
+
 extern "C" int hrp_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, int pitch, float* out, int out_pitch, void* stream) {
   HRP_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, "avgpool_fwd: bad args");
   dim3 grid(cdiv(C, 256), N);

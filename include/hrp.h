@@ -215,6 +215,32 @@ int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d);
 /* out[c] (+)= sum over rows of x[rows, pitch] (bias gradients) */
 int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream);
 
+/* ---- optimizer step of the training loop (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step, the pair
+ * scripts/train_full.py:42 / lib/core/function.py use), table driven: one launch per pass for all parameters.
+ * A chunk is up to HRP_OPT_CHUNK consecutive elements of one tensor. */
+#define HRP_OPT_CHUNK 4096
+typedef struct hrp_opt_tensor {
+  float* param;        /* fp32 master parameter                    */
+  float* grad;         /* fp32 gradient (scaled in place by the clip coefficient, as clip_grad_norm_ does) */
+  float* exp_avg;      /* Adam first moment                         */
+  float* exp_avg_sq;   /* Adam second moment                        */
+  int64_t numel;
+} hrp_opt_tensor;
+typedef struct hrp_opt_chunk {
+  int32_t tensor;      /* index into the tensor table               */
+  int32_t offset;      /* first element, in units of HRP_OPT_CHUNK  */
+} hrp_opt_chunk;
+/* sumsq_slots[HRP_STAT_SLOTS] += sum of grad^2 (the caller zeroes the slots) */
+int hrp_opt_grad_sumsq(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,
+                       float* sumsq_slots, void* stream);
+/* total_norm = sqrt(sum of the slots); clip = min(1, max_norm / (total_norm + 1e-6)) (max_norm <= 0: no clipping);
+ * g = grad * clip (written back); *step_dev is the number of the step being taken (the caller increments it
+ * before the launch); Adam without weight decay / amsgrad:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps) */
+int hrp_opt_adam_step(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,
+                      const float* sumsq_slots, float max_norm, const float* step_dev,
+                      float lr, float beta1, float beta2, float eps, void* stream);
+
 int hrp_ew_fwd(const hrp_ew_desc* d, void* stream);
 int hrp_ew_bwd_reduce(const hrp_ew_bwd_desc* d, void* stream);
 int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream);

@@ -295,3 +295,27 @@ def test_c_abi_rejects_bad_descriptors():
     d.ntaps = 99
     assert nv.lib().hrp_conv2d_fwd(C.byref(d), None) == -1
     assert nv.lib().hrp_device_ok() == 1
+
+
+@pytest.mark.gpu
+def test_fused_clip_adam_matches_torch():
+    """hrpe_amd.optim.FusedClipAdam == clip_grad_norm_ + torch.optim.Adam (scripts/train_full.py:42, full.yaml:39)."""
+    from hrpe_amd.optim import FusedClipAdam
+    torch.manual_seed(3)
+    shapes = [(64, 32, 3, 3), (64,), (1000, 7), (5000,), (3,), (128, 128, 3, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    opt_ref = torch.optim.Adam(ref, lr=1e-2)
+    opt = FusedClipAdam(mine, lr=1e-2, max_norm=5.0)
+    for it in range(4):
+        gs = [torch.randn(s, device=DEV) * (3.0 if it % 2 == 0 else 0.01) for s in shapes]
+        for p, q, g in zip(ref, mine, gs):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt_ref.step()
+        opt.step()
+        assert abs(opt.total_norm().item() - tn.item()) <= 1e-4 * tn.item()
+        for p, q in zip(ref, mine):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)   # clipped in place like torch
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (it, (p - q).abs().max().item())

@@ -35,6 +35,7 @@ from hrpe_amd.parallel import GradAllReducer, broadcast_module, init_distributed
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # HBM3E peak (MI355X_MICROARCH.md; ~6300 achievable)
 PEAK_HBM_GBS = 8000.0
 # algorithmic forward FLOP per image (2*MAC over conv/linear), SURVEY.md 6: HRNet-W32 hm+feat 23.416 G,
 # DepthNet trunk 23.299 G, heads 0.05 G; fwd+bwd = 3x
@@ -131,6 +132,20 @@ def conv_flops(name, args):
         d = args[0]._obj
         return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps
     return 0.0
+
+
+def conv_bytes(name, args):
+    """Algorithmic HBM bytes of one launch: every operand read once, the result written once."""
+    if name not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
+        return 0.0
+    d = args[0]._obj
+    esz = 2 if d.dtype == nv.HRP_BF16 else 4
+    if name == "hrp_conv2d_fwd":
+        b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
+        if d.res:
+            b += d.N * d.Ho * d.Wo * d.Cout * esz
+        return float(b)
+    return float((d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout) * esz + d.Cout * d.dw_cin * d.ntaps * 4)
 
 
 def main():
@@ -288,7 +303,7 @@ def main():
         launch()
         e1.record()
         fl = conv_flops(name, args)
-        records.append((name, fl, e0, e1))
+        records.append((name, fl, e0, e1, conv_bytes(name, args)))
         if os.environ.get("HRP_BENCH_SHAPES"):
             records_shape.append((name, fl, e0, e1, shape_key(name, args)))
 
@@ -296,6 +311,9 @@ def main():
     from hrpe_amd import plan as plan_mod
     plan_mod.SERIAL_LANES = True
     nv.set_profile_hook(hook)
+    # park the stream behind a spin kernel while the host enqueues the step: the event intervals then are the
+    # device-side durations (the Python launch loop alone would pace small kernels at ~10 us each)
+    torch.cuda._sleep(int(os.environ.get("HRP_BENCH_SLEEP_CYCLES", "400000000")))
     fwd_bwd()
     nv.set_profile_hook(None)
     plan_mod.SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
@@ -311,19 +329,35 @@ def main():
             tf = f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s" if v[2] else ""
             print(f"{name:24s} {key:44s} n={v[0]:4d} {v[1]:8.3f} ms  avg {v[1] / v[0] * 1e3:7.1f} us {tf}", file=sys.stderr)
     fam = {}
-    for name, fl, e0, e1 in records:
-        f = fam.setdefault(name, [0, 0.0, 0.0])
+    for name, fl, e0, e1, by in records:
+        f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
         f[0] += 1
         f[1] += e0.elapsed_time(e1)
         f[2] += fl
+        f[3] += by
     kernels = {n: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
                for n, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}
     dom = max(fam.items(), key=lambda kv: kv[1][1])
     peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-    ach = dom[1][2] / (dom[1][1] * 1e-3) / 1e12 if dom[1][2] else 0.0
-    roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches": dom[1][0],
-                "avg_launch_us": round(dom[1][1] / dom[1][0] * 1e3, 2)}
+    ach_tf = dom[1][2] / (dom[1][1] * 1e-3) / 1e12 if dom[1][2] else 0.0
+    ach_gb = dom[1][3] / (dom[1][1] * 1e-3) / 1e9 if dom[1][3] else 0.0
+    # which roof binds the family: its arithmetic intensity against the ridge point peak_flops / peak_bytes
+    intensity = dom[1][2] / dom[1][3] if dom[1][3] else float("inf")
+    hbm_bound = intensity < peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    fam_kernel = {"hrp_conv2d_fwd": "conv_tile_kernel", "hrp_conv2d_bwd_weight": "conv_wgrad_kernel", "hrp_ew_fwd": "ew_fwd_kernel",
+                  "hrp_ew_bwd_reduce": "ew_bwd_reduce_kernel", "hrp_ew_bwd_apply": "ew_bwd_apply_kernel"}.get(dom[0])
+    if os.path.exists(tpath) and fam_kernel and B == 64 and a.dtype == "bf16":
+        with open(tpath) as fh:   # PMC passes (FETCH_SIZE x2, WRITE_SIZE) of the same workload, see the file's header
+            traffic = json.load(fh)["families"].get(fam_kernel, {}).get("hbm_bytes_per_launch")
+    roofline = {"kernel": dom[0], "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(ach_gb if hbm_bound else ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((ach_gb / PEAK_HBM_GBS) if hbm_bound else (ach_tf / peak), 4),
+                "traffic": traffic, "launches": dom[1][0], "avg_launch_us": round(dom[1][1] / dom[1][0] * 1e3, 2),
+                "algorithmic_bytes_per_launch": round(dom[1][3] / dom[1][0]), "flop_per_byte": round(intensity, 1),
+                "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4)}
     step_tflops = 3 * FWD_GFLOP_PER_IMAGE["full"] * 1e9 * B / (ms_per_step * 1e-3) / 1e12
     out = {
         "metric": "images/sec/GPU fwd+bwd HRNet-W32 256x256 bs=64; 1/2/4/8-GPU scaling",

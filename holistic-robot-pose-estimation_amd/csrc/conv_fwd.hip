@@ -43,6 +43,7 @@ struct ConvTiling {
   int lds_stats_off;
   int nblocks;
   int vec_ok;
+  int ksplit, cps;           // split-K (fp32 skinny layers): K slices per output tile, chunks per slice
   FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_ncb, fd_tx, fd_ty;
 };
 
@@ -210,7 +211,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   HRP_CSTAMP(1);
 
   const int G = t.G, stage_bytes = G * t.buf_bytes;
-  const int nstages = (nchunks + G - 1) / G;
   constexpr int OP = BN * SZ + 16;
   char* lds_out = smem;
   float* lds_stats = (float*)(smem + t.lds_stats_off);
@@ -218,6 +218,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   for (int b = blockIdx.x; PERSIST ? b < t.nblocks : b == (int)blockIdx.x; b += PERSIST ? gridDim.x : 1) {
     int bid = b;
     if ((t.nblocks & 7) == 0) bid = (bid & 7) * (t.nblocks >> 3) + (bid >> 3);
+    int kz = 0;
+    if (t.ksplit > 1) { kz = bid % t.ksplit; bid /= t.ksplit; }
+    const int cbeg = kz * t.cps;                                     // first chunk of this K slice
+    const int nloc = t.ksplit > 1 ? min(t.cps, nchunks - cbeg) : nchunks;
+    const int nstages = (nloc + G - 1) / G;
     const int tile = fdiv(bid, t.fd_ncb);
     const int cb = bid - tile * t.n_cout_blk;
     const int q = fdiv(tile, t.fd_tx);
@@ -263,9 +268,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
     // chunks of MFMA work instead of once per chunk (deep-K layers have 16 chunks of only 9 MFMAs per wave).
     auto issue_stage = [&](int st, char* base) {
       for (int g = 0; g < G; ++g)
-        if (st * G + g < nchunks) {
+        if (st * G + g < nloc) {
 #pragma unroll
-          for (int slot = 0; slot < MAXP_IN + MAXP_W; ++slot) issue_slot(st * G + g, base + g * t.buf_bytes, slot);
+          for (int slot = 0; slot < MAXP_IN + MAXP_W; ++slot) issue_slot(cbeg + st * G + g, base + g * t.buf_bytes, slot);
         }
     };
     issue_stage(0, smem);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       // this one, SPP slots per step): issued in one burst a full memory queue stalls the wave for ~2 us.
       constexpr int NS = NT * Mma<T>::KSTEPS;
       constexpr int SPP = (MAXP_IN + MAXP_W + NS - 1) / NS;
-      const int ng = nchunks - st * G < G ? nchunks - st * G : G;
+      const int ng = nloc - st * G < G ? nloc - st * G : G;
       typename Mma<T>::Frag fa[2][CT], fb[2][PT];
       auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&bb)[PT]) {
         const int tap = step / Mma<T>::KSTEPS, kk = step % Mma<T>::KSTEPS;   // constants after unrolling
@@ -307,9 +312,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
           for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int p = 0; p < PT; ++p) Mma<T>::mma(fa[cur][c], fb[cur][p], acc[c][p]);
-          if (more && (st + 1) * G + g < nchunks) {
+          if (more && (st + 1) * G + g < nloc) {
 #pragma unroll
-            for (int u = 0; u < SPP; ++u) issue_slot((st + 1) * G + g, nbuf + g * t.buf_bytes, step * SPP + u);
+            for (int u = 0; u < SPP; ++u) issue_slot(cbeg + (st + 1) * G + g, nbuf + g * t.buf_bytes, step * SPP + u);
           }
           // keep the prefetch where it is: without the fence the scheduler sinks the reads next to their MFMA
           __builtin_amdgcn_sched_barrier(0);
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
           for (int i = 0; i < 4; ++i) {
             int co = co0 + cl + i;
             if (co < d.Cout) {
-              if (d.bias) bia[i] = d.bias[co];
+              if (d.bias && kz == 0) bia[i] = d.bias[co];
               if (d.scale) { sc[i] = d.scale[co]; sh[i] = d.shift[co]; }
             }
           }
@@ -382,6 +387,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
         const uint4 raw = *(const uint4*)(lds_out + m * OP + cv * 16);
         float f[VEC];
         Elem<T>::unpack(raw, f);
+        if constexpr (SZ == 4) {
+          if (t.ksplit > 1) {
+            // split-K partial: fp32 atomics into y (zeroed by the launcher, or holding the value to accumulate
+            // onto when res == y); slice 0 also adds a separate residual
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              if (co + i < d.Cout) {
+                float val = f[i];
+                if (rg && rg != (const char*)yg && kz == 0) val += Elem<T>::ld(rg, opix * d.res_pitch + co + i);
+                atomicAdd((float*)yg + opix * d.y_pitch + co + i, val);
+              }
+            }
+            continue;
+          }
+        }
         if (full && !rg && !d.relu) {
           // plain conv output (the train-mode case): the LDS image is already the stored value
           *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = raw;
@@ -500,6 +520,19 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.n_cout_blk = cdiv(d.Cout, BN);
   t.nblocks = t.tiles_x * t.tiles_y * t.tiles_n * t.n_cout_blk;
+  // split-K for skinny fp32 layers (the fully connected heads: 64 rows x 1024..2056 inputs give 16 workgroups
+  // otherwise): K slices in separate workgroups, partial sums leave as fp32 atomics
+  t.ksplit = 1;
+  {
+    const int nch = cdiv(d.Cin * SZ, ROW);
+    t.cps = nch;
+    // (out_stride == 1: the launch covers all of y, which it zeroes first)
+    if (SZ == 4 && !d.relu && !d.scale && !d.stats && d.out_stride == 1 && d.y_H == d.Ho && d.y_W == d.Wo && t.nblocks <= 64) {
+      int ks = 1;
+      while (ks < 16 && t.nblocks * ks * 2 <= 256 && nch / (ks * 2) >= 8) ks *= 2;
+      if (ks > 1) { t.ksplit = ks; t.cps = cdiv(nch, ks); t.nblocks *= ks; }
+    }
+  }
   // the DMA / store plans classify validity per tile row / column class: only the first and the last tile
   // row (column) may reach outside the image
   if ((t.tiles_y >= 2 && (TH * d.in_stride + mindy < 0 ||
@@ -513,7 +546,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   const int out_bytes = BM * (BN * SZ + 16);
   {  // chunks per stage: as many as two stages of LDS allow (all of LDS when the launch has at most one
      // workgroup per CU anyway, half of it otherwise), up to 4
-    const int nsub = cdiv(d.Cin * SZ, ROW);
+    const int nsub = t.cps;
     int G = (t.nblocks <= 256 ? 144 * 1024 : budget) / (2 * t.buf_bytes);
     if (G < 1) G = 1;
     if (G > 16) G = 16;
@@ -545,6 +578,8 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   int occ = (160 * 1024) / lds;
   occ = occ < 1 ? 1 : occ > 2 ? 2 : occ;
   const int grid = persist && t.nblocks > 256 * occ ? 256 * occ : t.nblocks;
+  if (t.ksplit > 1 && d.res != d.y)
+    (void)hipMemsetAsync(d.y, 0, (size_t)d.N * d.y_H * d.y_W * d.y_pitch * SZ, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d, t);
   return check_launch("conv_tile_kernel");
 }

@@ -233,7 +233,7 @@ def main():
             step_eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        if world == 1:
+        if world == 1 and not os.environ.get("HRP_BENCH_TWO_GRAPHS"):   # (the flag exercises the N > 1 structure on one GPU)
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 fwd_bwd()

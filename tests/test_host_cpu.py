@@ -190,3 +190,48 @@ def test_fdiv16_arithmetic_is_exact():
         inv = np.float32(1.0) / np.float32(d)
         q = ((v + np.float32(0.5)) * inv).astype(np.int32)
         assert np.array_equal(q, (np.arange(65536) // d).astype(np.int32)), d
+
+
+def test_plan_lanes_bookkeeping():
+    """plan.py lanes: flat parallel blocks fork / join around their ops, the backward mirrors them, and the
+    concurrency predicate only fires for different lanes of ONE block (host logic, no GPU needed)."""
+    import torch
+    from hrpe_amd import plan as P
+    assert P.lanes_concurrent(((1, 0),), ((1, 1),))
+    assert not P.lanes_concurrent(((1, 0),), ((1, 0),))
+    assert not P.lanes_concurrent(((1, 0),), ((2, 1),))          # different (sequential) blocks
+    assert not P.lanes_concurrent((), ((1, 1),))                   # outside any block
+    assert P.lanes_concurrent(((1, 0), (3, 0)), ((1, 1), (4, 2)))  # split in the outer block
+
+    pl = P.Plan(torch.device("cpu"), torch.float32, True, True)
+    pb = P.PlanBuilder(pl)
+    ran = []
+    pl.fwd.append(lambda s: ran.append("pre"))
+    with pb.parallel(3) as par:
+        for i in range(3):
+            with par.lane(i):
+                pl.fwd.append(lambda s, i=i: ran.append(f"lane{i}"))
+                pb.bwd_stack.append(lambda i=i: pl.bwd.append(lambda s, i=i: ran.append(f"b{i}")))
+                assert pl.lane_path == ((1, i),)
+    pl.fwd.append(lambda s: ran.append("post"))
+    kinds = [(lane, getattr(op, "kind", None)) for lane, op in pl.fwd]
+    assert kinds[0] == (0, None) and kinds[1] == (None, "fork") and kinds[-2] == (None, "join") and kinds[-1] == (0, None)
+    assert [lane for lane, _ in pl.fwd[2:5]] == [0, 1, 2] and pl.n_lanes == 3
+    # a tensor whose gradient is written from two concurrent lanes is rejected at build time
+    t = P.TensorH(pl, 1, 1, 1, 8, torch.float32, buf=torch.zeros(8))
+    with pb.parallel(2) as par:
+        with par.lane(0):
+            t.take_grad_slot()
+        with par.lane(1):
+            with pytest.raises(RuntimeError):
+                t.take_grad_slot()
+    # backward: reverse order, the forward join becomes a fork and vice versa
+    for lane, path, emit in reversed(pb.bwd_stack):
+        if lane is None:
+            list.append(pl.bwd, (None, emit))
+        else:
+            pl.cur_lane, pl.lane_path = lane, path
+            emit()
+    bk = [(lane, getattr(op, "kind", None)) for lane, op in pl.bwd]
+    first = next(i for i, (l, k) in enumerate(bk) if k == "fork" and bk[i + 1][0] == 2)
+    assert [l for l, _ in bk[first + 1:first + 4]] == [2, 1, 0] and bk[first + 4] == (None, "join")

@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-optim", action="store_true", help="clip_grad_norm_ + torch.optim.Adam(fused) instead of FusedClipAdam")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="BASELINE.json configs[1]: eval-mode forward of the full network (folded BN), images/s to stderr-free JSON")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--p-dropout", type=float, default=0.5, help="lib/core/config.py:70 default")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -183,6 +185,38 @@ def main():
     B = a.batch
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
+    if a.forward_only:
+        # informational: inference path (BASELINE.json configs[1]); BatchNorm folded into the conv epilogues
+        model = build_model(0.0).to(dev).set_compute_dtype(dtype).eval()
+        d = {k: torch.tensor(v).to(dev) for k, v in synthetic_batch(B, 808 + rank).items()}
+        kv = compute_k_values(d["K"][:, 0, 0], d["K"][:, 1, 1], d["bbox"])
+        with torch.no_grad():
+            model(d["x_reg"], d["x_root"], kv, d["K"])
+            torch.cuda.synchronize(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                model(d["x_reg"], d["x_root"], kv, d["K"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                model(d["x_reg"], d["x_root"], kv, d["K"])
+            for _ in range(a.warmup):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "images/sec forward-only full network (eval, folded BN), informational",
+                              "value": round(B * a.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "dtype": a.dtype,
+                              "data": "synthetic", "config": {"workload": "BASELINE.json configs[1]: two HRNet-W32 + heads + FK, "
+                                                                          "forward only", "per_gpu_batch": B}}))
+        return
     model = build_model(a.p_dropout).to(dev).set_compute_dtype(dtype).train()
     broadcast_module(model)
     params = [p for p in model.parameters() if p.requires_grad]

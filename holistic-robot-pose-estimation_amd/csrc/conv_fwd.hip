@@ -544,10 +544,11 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
     return HRP_ERR_ARG;
   }
   const int out_bytes = BM * (BN * SZ + 16);
-  {  // chunks per stage: as many as two stages of LDS allow (all of LDS when the launch has at most one
-     // workgroup per CU anyway, half of it otherwise), up to 4
+  {  // chunks per stage: as many as two stages fit in half of LDS
     const int nsub = t.cps;
-    int G = (t.nblocks <= 256 ? 144 * 1024 : budget) / (2 * t.buf_bytes);
+    // (always half of LDS: a launch with one workgroup per CU shares the CU with kernels of other lanes -
+    // taking all of LDS for deeper stages cost 2 ms per step)
+    int G = budget / (2 * t.buf_bytes);
     if (G < 1) G = 1;
     if (G > 16) G = 16;
     if (G > nsub) G = nsub;

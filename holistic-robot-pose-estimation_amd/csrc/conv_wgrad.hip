@@ -26,6 +26,10 @@
 #define HRP_STAMP(i) do { } while (0)
 #endif
 
+#ifndef WGRAD_OCC
+#define WGRAD_OCC
+#endif
+
 namespace hrp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -81,12 +85,12 @@ __device__ __forceinline__ void wg_dma16(const char* src, char* lds_wave_base) {
 }
 
 template <typename T, int NT, int NKS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d, const WgradTiling t) {
+__global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgrad_desc d, const WgradTiling t) {
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
   constexpr int P = 32 * SZ;        // LDS pixel row: 32 channels, unpadded (DMA writes lane-linear)
   constexpr int NVEC = P / 16;      // 16-byte slots per pixel row
   constexpr int K = WG<T>::K;
-  constexpr int MAXP_X = 12, MAXP_DY = 8;   // 1 KiB DMA pieces per wave (host keeps tiles below 48 / 32 KiB)
+  constexpr int MAXP_X = 8, MAXP_DY = 6;    // 1 KiB DMA pieces per wave (host keeps tiles below 32 / 24 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* xtab = (int*)(smem + t.lds_tab_off);
 
@@ -252,32 +256,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const hrp_wgrad_desc d,
       constexpr int SPP = (MAXP_X + MAXP_DY + NKS_ * NT - 1) / (NKS_ * NT);
       TileCtx nx{};
       if (more) nx = tile_ctx(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
-      bf16x8 a[2], b[2][NT];
+      // Flattened MFMA sequence q = ks * NT + tp of the tile.  The X fragment of MFMA q + D is read while MFMA q
+      // runs (ring of D + 1 fragments: a full next-k-step prefetch would cost 36 more registers and with them
+      // the second wave per SIMD that lets this kernel share a CU with the kernels of other lanes); the dY
+      // fragment of k-step ks + 1 is read at the start of k-step ks.
+      constexpr int D = NT >= 4 ? 4 : NT, TOT = NKS_ * NT;
+      bf16x8 a[2], b[D + 1];
       auto load_a = [&](int ks, bf16x8& f) {
         bf16x4 lo = WG<T>::tr(lds_dy + ao[ks]), hi = WG<T>::tr(lds_dy + ao[ks] + 4 * P);
         f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       };
-      auto load_b = [&](int ks, int tp, bf16x8& f) {
+      auto load_b = [&](int q, bf16x8& f) {
+        const int ks = q / NT, tp = q % NT;   // constants after unrolling
         bf16x4 lo = WG<T>::tr(lds_x + xo0[ks] + tapoff[tp]), hi = WG<T>::tr(lds_x + xo1[ks] + tapoff[tp]);
         f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       };
       load_a(0, a[0]);
 #pragma unroll
-      for (int tp = 0; tp < NT; ++tp) load_b(0, tp, b[0][tp]);
+      for (int q = 0; q < D && q < TOT; ++q) load_b(q, b[q % (D + 1)]);
 #pragma unroll
-      for (int ks = 0; ks < NKS_; ++ks) {
-        const int c = ks & 1, n = c ^ 1;
-        if (ks + 1 < NKS_) load_a(ks + 1, a[n]);
+      for (int q = 0; q < TOT; ++q) {
+        const int ks = q / NT, tp = q % NT;
+        if (tp == 0 && ks + 1 < NKS_) load_a(ks + 1, a[(ks + 1) & 1]);
+        if (q + D < TOT) load_b(q + D, b[(q + D) % (D + 1)]);
+        WG<T>::mma(a[ks & 1], b[q % (D + 1)], acc[tp]);
+        if (more) {
 #pragma unroll
-        for (int tp = 0; tp < NT; ++tp) {
-          if (ks + 1 < NKS_) load_b(ks + 1, tp, b[n][tp]);
-          WG<T>::mma(a[c], b[c][tp], acc[tp]);
-          if (more) {
-#pragma unroll
-            for (int u = 0; u < SPP; ++u) issue_slot(nx, (ks * NT + tp) * SPP + u);
-          }
+          for (int u = 0; u < SPP; ++u) issue_slot(nx, q * SPP + u);
         }
-        // keep the prefetch in this k-step: without the fence the scheduler sinks the reads next to their MFMA
+        // keep the prefetch distance: without the fence the scheduler sinks the reads next to their MFMA
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -394,7 +401,8 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   t.mindy = mindy; t.mindx = mindx;
   const int budget = 72 * 1024;
   int lds = 0;
-  for (int BM = 256; BM >= 64; BM >>= 1) {
+  constexpr int BM_MIN = SZ == 4 ? 16 : 64;   // bf16 needs 16 pixels per wave and k-step; fp32 tiles are twice the bytes
+  for (int BM = 256; BM >= BM_MIN; BM >>= 1) {
     int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
     int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
     int TI = BM / (TW * TH);
@@ -414,16 +422,16 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
     t.buf_bytes = (t.x_pieces + t.dy_pieces) * 1024;
     t.lds_tab_off = 2 * t.buf_bytes;
     int main_bytes = t.lds_tab_off + BM * 4;
-    if (t.x_pieces > 48 || t.dy_pieces > 32) { lds = 1 << 30; continue; }
+    if (t.x_pieces > 32 || t.dy_pieces > 24) { lds = 1 << 30; continue; }
     t.lds_red_off = 0;  // the cross-wave exchange reuses the tiles
     int red_bytes = NT * 8192;
     lds = main_bytes > red_bytes ? main_bytes : red_bytes;
     long pixels = (long)d.N * d.Ho * d.Wo;
-    if (lds <= budget + 8192 && (BM == 64 || pixels >= BM)) break;
-    if (BM == 64 && lds > 160 * 1024) {
-      set_error("wgrad: tile does not fit LDS");
-      return HRP_ERR_ARG;
-    }
+    if (lds <= budget + 8192 && (BM == BM_MIN || pixels >= BM)) break;
+  }
+  if (lds > 160 * 1024) {
+    set_error("wgrad: tile does not fit LDS / the DMA plan (H=%d W=%d stride=%d taps=%d)", d.H, d.W, d.in_stride, d.ntaps);
+    return HRP_ERR_ARG;
   }
   t.lds_bytes = lds;
   t.tiles_x = cdiv(d.Wo, t.TW); t.tiles_y = cdiv(d.Ho, t.TH); t.tiles_n = cdiv(d.N, t.TI);

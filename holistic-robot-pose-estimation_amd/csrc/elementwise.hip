@@ -46,17 +46,19 @@ __device__ __forceinline__ void channel_consts(const hrp_ew_input& in, int c, in
 // Fill tab[f][e] (f = 0 scale, 1 shift, 2 mean, 3 invstd) for the block's channels cbase .. cbase+nch-1.
 // nch <= TAB_CH: computed once per block; otherwise every thread computes its own V channels.
 template <int V>
-__device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int cbase, int nch, int c, float (*tab)[TAB_CH],
+__device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int cbase, int nch, int c, float* tab,
                                             float* sc, float* sh, float* mean, float* inv) {
+  // tab = 4 rows of nch floats in dynamic LDS (sized by the launcher: a static worst-case table kept 12-28 KiB
+  // of LDS per block away from the conv / wgrad workgroups of other lanes sharing the CU)
   if (nch <= TAB_CH) {
     for (int e = threadIdx.x; e < nch; e += 256)
-      channel_consts(in, cbase + e, C, tab[0][e], tab[1][e], tab[2][e], tab[3][e]);
+      channel_consts(in, cbase + e, C, tab[e], tab[nch + e], tab[2 * nch + e], tab[3 * nch + e]);
     __syncthreads();
     const int e0 = c - cbase;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int e = min(e0 + i, TAB_CH - 1);
-      sc[i] = tab[0][e]; sh[i] = tab[1][e]; mean[i] = tab[2][e]; inv[i] = tab[3][e];
+      const int e = min(e0 + i, nch - 1);
+      sc[i] = tab[e]; sh[i] = tab[nch + e]; mean[i] = tab[2 * nch + e]; inv[i] = tab[3 * nch + e];
     }
     __syncthreads();  // the table may be reused for the next input
   } else {
@@ -67,7 +69,8 @@ __device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int c
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
-  __shared__ float tab[4][TAB_CH];
+  extern __shared__ float ew_lds[];
+  float* tab = ew_lds;
   const int cv = (blockIdx.y * tpr + threadIdx.x % tpr);
   const int c = cv * V;
   const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
@@ -151,8 +154,12 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, int n, int
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_desc d, int tpr) {
-  __shared__ float red[2][256 * (V > 1 ? V : 1)];
-  __shared__ float tab[4][TAB_CH];
+  extern __shared__ float ew_lds[];
+  const int tabn = min(tpr * V, TAB_CH);
+  float* tab = ew_lds;
+  const int nred = (tpr < 64 ? 4 : 256 / tpr) * tpr * V;
+  float* red0 = ew_lds + 4 * tabn;
+  float* red1 = red0 + nred;
   const int lane_c = threadIdx.x % tpr;
   const int cv = blockIdx.y * tpr + lane_c;
   const int c = cv * V;
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   if (writer) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      red[0][(part * tpr + lane_c) * V + i] = s0[i];
-      red[1][(part * tpr + lane_c) * V + i] = s1[i];
+      red0[(part * tpr + lane_c) * V + i] = s0[i];
+      red1[(part * tpr + lane_c) * V + i] = s1[i];
     }
   }
   __syncthreads();
@@ -211,8 +218,8 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
     if (ch >= d.C) continue;
     float a0 = 0.f, a1 = 0.f;
     for (int k = 0; k < nparts; ++k) {
-      a0 += red[0][(k * tpr + lc) * V + i];
-      a1 += red[1][(k * tpr + lc) * V + i];
+      a0 += red0[(k * tpr + lc) * V + i];
+      a1 += red1[(k * tpr + lc) * V + i];
     }
     float* slot = d.sums + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.C;
     atomicAdd(&slot[ch], a0);
@@ -222,8 +229,11 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
-  __shared__ float tab[4][TAB_CH];
-  __shared__ float ktab[2][TAB_CH];
+  extern __shared__ float ew_lds[];
+  const int tabn = min(tpr * V, TAB_CH);
+  float* tab = ew_lds;
+  float* ktab0 = ew_lds + 4 * tabn;
+  float* ktab1 = ktab0 + tabn;
   const int cv = blockIdx.y * tpr + threadIdx.x % tpr;
   const int c = cv * V;
   const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
@@ -237,14 +247,14 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
     if (nch <= TAB_CH) {
       for (int e = threadIdx.x; e < nch; e += 256) {
         const int ch = cbase + e;
-        ktab[0][e] = ch < d.C ? slot_sum(d.sums, ch, 2 * d.C) / d.in.count : 0.f;
-        ktab[1][e] = ch < d.C ? slot_sum(d.sums, d.C + ch, 2 * d.C) / d.in.count : 0.f;
+        ktab0[e] = ch < d.C ? slot_sum(d.sums, ch, 2 * d.C) / d.in.count : 0.f;
+        ktab1[e] = ch < d.C ? slot_sum(d.sums, d.C + ch, 2 * d.C) / d.in.count : 0.f;
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        const int e = min(c - cbase + i, TAB_CH - 1);
-        k0[i] = ktab[0][e]; k1[i] = ktab[1][e];
+        const int e = min(c - cbase + i, tabn - 1);
+        k0[i] = ktab0[e]; k1[i] = ktab1[e];
       }
     } else {
 #pragma unroll
@@ -331,8 +341,10 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, 1024);
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_fwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
-  if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
-  else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr, g.nslab);
+  const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
+  const int lds = 4 * tabn * 4;
+  if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
+  else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
   return check_launch("ew_fwd");
 }
 
@@ -347,12 +359,16 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : 512);
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
+  const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
   if (APPLY) {
-    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr);
-    else hipLaunchKernelGGL((ew_bwd_apply_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr);
+    const int lds = 6 * tabn * 4;
+    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), lds, s, d, g.tpr);
+    else hipLaunchKernelGGL((ew_bwd_apply_kernel<T, VEC>), grid, dim3(256), lds, s, d, g.tpr);
   } else {
-    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, d, g.tpr);
-    else hipLaunchKernelGGL((ew_bwd_reduce_kernel<T, VEC>), grid, dim3(256), 0, s, d, g.tpr);
+    const int nred = (g.tpr < 64 ? 4 : 256 / g.tpr) * g.tpr * g.V;
+    const int lds = (4 * tabn + 2 * nred) * 4;
+    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_reduce_kernel<T, 1>), grid, dim3(256), lds, s, d, g.tpr);
+    else hipLaunchKernelGGL((ew_bwd_reduce_kernel<T, VEC>), grid, dim3(256), lds, s, d, g.tpr);
   }
   return check_launch(APPLY ? "ew_bwd_apply" : "ew_bwd_reduce");
 }

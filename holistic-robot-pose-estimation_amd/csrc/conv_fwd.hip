@@ -504,7 +504,8 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.mindy = mindy; t.mindx = mindx;
   t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
   t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
-  const int budget = 76 * 1024;  // two workgroups per CU
+  static const int budget_kb = getenv("HRP_CONV_LDS_KB") ? atoi(getenv("HRP_CONV_LDS_KB")) : 76;
+  const int budget = budget_kb * 1024;  // two workgroups per CU
   t.w_pieces = NT * BN / 32;
   {  // shrink the number of images per tile until two stage buffers fit
     int per_img = t.IHt * t.IWt * ROW;

@@ -17,6 +17,7 @@
 // build one 8-deep MFMA operand; every source lane carries its own pixel address, so tap shifts and
 // stride-2 sampling cost nothing extra.  fp32 needs one 32-bit read per operand.
 #include "hrp_common.h"
+#include <stdlib.h>
 
 // -DHRP_TIMELINE (tools/bench_kernels.py timeline, never in the shipped library): wave 0 of every workgroup
 // stamps the 100 MHz wall clock at phase boundaries into the last MiB of the workspace.
@@ -399,7 +400,8 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
     mindx = d.dx_t[i] < mindx ? d.dx_t[i] : mindx; maxdx = d.dx_t[i] > maxdx ? d.dx_t[i] : maxdx;
   }
   t.mindy = mindy; t.mindx = mindx;
-  const int budget = 72 * 1024;
+  static const int budget_kb = getenv("HRP_WGRAD_LDS_KB") ? atoi(getenv("HRP_WGRAD_LDS_KB")) : 72;
+  const int budget = budget_kb * 1024;
   int lds = 0;
   constexpr int BM_MIN = SZ == 4 ? 16 : 64;   // bf16 needs 16 pixels per wave and k-step; fp32 tiles are twice the bytes
   for (int BM = 256; BM >= BM_MIN; BM >>= 1) {

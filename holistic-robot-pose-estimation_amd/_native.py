@@ -41,7 +41,7 @@ class WgradDesc(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("dy_pitch", C.c_int32),
                 ("in_stride", C.c_int32), ("ntaps", C.c_int32),
                 ("dy_t", C.c_int32 * MAX_TAPS), ("dx_t", C.c_int32 * MAX_TAPS),
-                ("dw_cin", C.c_int32), ("accumulate", C.c_int32),
+                ("dw_cin", C.c_int32), ("dw_tap_stride", C.c_int32), ("dw_tap_off", C.c_int32), ("accumulate", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
@@ -107,6 +107,11 @@ PROTOTYPES = {
     "hrp_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_nchw_grad_from_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_pack_weights": [_P, _I, _I, _I, _P],
+    "hrp_nchw_to_nhwc_s2d": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hrp_gather_f32": [_P, _P, _P, _I, _I, _P],
+    "hrp_fill_zero": [_P, _L, _P],
+    "hrp_maxpool3x3s2_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
+    "hrp_maxpool3x3s2_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hrp_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "hrp_conv2d_bwd_weight": [C.POINTER(WgradDesc), _P],
     "hrp_colsum": [_P, _I, _L, _I, _I, _P, _I, _P],

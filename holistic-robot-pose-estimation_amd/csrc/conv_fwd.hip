@@ -603,6 +603,7 @@ static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
     if (rc == -100 && pixels / 128 * nb >= want) rc = launch_cfg<T, 2, 1, 1, 4, NT>(d, s);
     if (rc == -100) rc = launch_cfg<T, 1, 1, 2, 2, NT>(d, s);
     if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4, NT>(d, s);
+    if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4, NT>(d, s);   // 32 couts per workgroup: halves the weight slab (16-tap kernels)
   }
   if (rc == -100) {
     set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
@@ -618,8 +619,9 @@ static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
     case 2: return launch_conv_nt<T, 2>(d, s);
     case 4: return launch_conv_nt<T, 4>(d, s);
     case 9: return launch_conv_nt<T, 9>(d, s);
+    case 16: return launch_conv_nt<T, 16>(d, s);   // 4x4 kernels: ResNet stem after space-to-depth, ConvTranspose2d backward
     default:
-      set_error("conv: ntaps=%d is not one of the built tap counts (1, 2, 4, 9)", d.ntaps);
+      set_error("conv: ntaps=%d is not one of the built tap counts (1, 2, 4, 9, 16)", d.ntaps);
       return HRP_ERR_ARG;
   }
 }

@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   __syncthreads();
   HRP_STAMP(11);
   float* dump = (float*)smem;
+  const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
   // partial slab [g][block][NT*1024], coalesced; a second launch folds the G slabs into dW
   float* ws = t.use_ws ? (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NT * 1024) : nullptr;
 #pragma unroll
@@ -343,11 +344,11 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
       } else {
         const int co = co0 + 16 * h + (rem >> 3), cin = ci0 + 4 * (rem & 7);
         if (co < d.Cout) {
-          float* o = d.dw + ((size_t)co * d.dw_cin + cin) * d.ntaps + tp;
+          float* o = d.dw + ((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tp;
           if (cin < d.dw_cin) atomicAdd(o, v.x);
-          if (cin + 1 < d.dw_cin) atomicAdd(o + d.ntaps, v.y);
-          if (cin + 2 < d.dw_cin) atomicAdd(o + 2 * d.ntaps, v.z);
-          if (cin + 3 < d.dw_cin) atomicAdd(o + 3 * d.ntaps, v.w);
+          if (cin + 1 < d.dw_cin) atomicAdd(o + tstride, v.y);
+          if (cin + 2 < d.dw_cin) atomicAdd(o + 2 * tstride, v.z);
+          if (cin + 3 < d.dw_cin) atomicAdd(o + 3 * tstride, v.w);
         }
       }
     }
@@ -360,6 +361,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc d, int G, int pairs, int n_cib) {
   const int blk = blockIdx.y;
   const int cob = blk / n_cib, cib = blk - cob * n_cib;
+  const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
   // block = 64 consecutive elements x 4 slab phases; lanes read 256 contiguous bytes of a slab, 8 loads
   // in flight per thread
   __shared__ float part[4][64];
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc 
     int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
     int co = cob * 32 + row, cin = cib * 32 + ci;
     if (co < d.Cout && cin < d.dw_cin) {
-      float* o = &d.dw[((size_t)co * d.dw_cin + cin) * d.ntaps + tp];
+      float* o = &d.dw[((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tp];
       *o = d.accumulate ? *o + s : s;
     }
   }
@@ -476,8 +478,13 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
   const int pairs = t.n_cob * t.n_cib;
   const int64_t need = (int64_t)t.G * pairs * NT * 1024 * 4;
   t.use_ws = (d.workspace && d.workspace_bytes >= need) ? 1 : 0;
-  if (!t.use_ws && !d.accumulate)
+  if (!t.use_ws && !d.accumulate) {
+    if (d.dw_tap_stride > 0 && d.dw_tap_stride != d.ntaps) {
+      set_error("wgrad: a tap group without a workspace must accumulate (the caller zeroes dw)");
+      return HRP_ERR_ARG;
+    }
     (void)hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
+  }
   void (*kern)(const hrp_wgrad_desc, const WgradTiling) = nullptr;
   if constexpr (Elem<T>::SZ == 2) {
     // bf16: k-steps of 16 pixels per wave and tile = BM / 64, unrolled at compile time
@@ -510,6 +517,7 @@ extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
               "wgrad: dy pitch must be a multiple of %d and cover Cout rounded up (Cout=%d pitch=%d)", vec, d->Cout, d->dy_pitch);
   HRP_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "wgrad: ntaps=%d unsupported", d->ntaps);
   HRP_REQUIRE(d->dw_cin <= d->Cin, "wgrad: dw_cin > Cin");
+  HRP_REQUIRE(d->dw_tap_stride == 0 || (d->dw_tap_off >= 0 && d->dw_tap_off + d->ntaps <= d->dw_tap_stride), "wgrad: tap group");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == HRP_F32) {
     if (d->ntaps == 1) return launch_wgrad<float, 1>(*d, s);

@@ -37,6 +37,124 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   for (int c = 0; c < pitch; ++c) Elem<T>::st(dst, o + c, c < C ? s[(size_t)c * HW] : 0.f);
 }
 
+// NCHW fp32 [N,C,H,W] -> NHWC [N,H/2,W/2,pitch] with 2x2 space-to-depth: channel (dy*2+dx)*C + c of output pixel
+// (y,x) = src[n, c, 2y+dy, 2x+dx] (odd H / W: the missing row / column reads as zero).  Turns the 7x7 stride-2 stem
+// of ResNet into a 4x4 stride-1 convolution over 12 channels (one 16-channel chunk of the MFMA conv kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_s2d_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                               int C, int H, int W, int pitch) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= (size_t)Ho * Wo) return;
+  const int y = p / Wo, x = p - (size_t)y * Wo;
+  const float* sn = src + (size_t)n * C * H * W;
+  size_t o = ((size_t)n * Ho * Wo + p) * pitch;
+  for (int k = 0; k < pitch; ++k) {
+    float v = 0.f;
+    if (k < 4 * C) {
+      const int q = k / C, c = k - q * C, iy = 2 * y + (q >> 1), ix = 2 * x + (q & 1);
+      if (iy < H && ix < W) v = sn[((size_t)c * H + iy) * W + ix];
+    }
+    Elem<T>::st(dst, o + k, v);
+  }
+}
+
+// dst[i] (+)= idx[i] >= 0 ? src[idx[i]] : 0  (weight re-layouts whose source is a PyTorch-shaped parameter)
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                         float* __restrict__ dst, int n, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = idx[i];
+  const float v = j >= 0 ? src[j] : 0.f;
+  dst[i] = accumulate ? dst[i] + v : v;
+}
+
+// ---- max pool 3x3, stride 2, padding 1 (ResNet stem, Resnet.py:25) ----------------------------------------
+// forward: thread = (output pixel, 16-byte channel vector); `arg` (optional) keeps the window position 0..8 of the
+// first maximum in scan order, which is the element PyTorch routes the gradient to.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* __restrict__ x, int H, int W, int C, int pitch,
+                                                          void* __restrict__ y, int Ho, int Wo, int y_pitch,
+                                                          uint8_t* __restrict__ arg, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int nv = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = i % nv;
+    long r = i / nv;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho;
+    const long n = r / Ho;
+    float best[V];
+    int bi[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float f[V];
+        Elem<T>::unpack(*(const uint4*)((const char*)x + ((((size_t)n * H + iy) * W + ix) * pitch + cv * V) * Elem<T>::SZ), f);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if (f[k] > best[k]) { best[k] = f[k]; bi[k] = ky * 3 + kx; }
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox);
+    *(uint4*)((char*)y + (o * y_pitch + cv * V) * Elem<T>::SZ) = Elem<T>::pack(best);
+    if (arg) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) arg[o * C + cv * V + k] = (uint8_t)bi[k];
+    }
+  }
+}
+
+// backward (gather form, no atomics): input pixel (iy,ix) collects dy of the <= 4 windows that selected it
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* __restrict__ dy, int Ho, int Wo, int dy_pitch,
+                                                          const uint8_t* __restrict__ arg, void* __restrict__ dx, int H, int W,
+                                                          int C, int pitch, int accumulate, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int nv = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = i % nv;
+    long r = i / nv;
+    const int ix = r % W; r /= W;
+    const int iy = r % H;
+    const long n = r / H;
+    float g[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = 0.f;
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {   // windows [2 oy - 1, 2 oy + 1] that contain iy
+      if (oy < 0 || oy >= Ho) continue;
+      const int ky = iy - (2 * oy - 1);
+      if (ky < 0 || ky > 2) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        const int kx = ix - (2 * ox - 1);
+        if (kx < 0 || kx > 2) continue;
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox);
+        float f[V];
+        Elem<T>::unpack(*(const uint4*)((const char*)dy + (o * dy_pitch + cv * V) * Elem<T>::SZ), f);
+        const uint8_t* a = arg + o * C + cv * V;
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if (a[k] == ky * 3 + kx) g[k] += f[k];
+      }
+    }
+    char* dst = (char*)dx + ((((size_t)n * H + iy) * W + ix) * pitch + cv * V) * Elem<T>::SZ;
+    if (accumulate) {
+      float old[V];
+      Elem<T>::unpack(*(const uint4*)dst, old);
+#pragma unroll
+      for (int k = 0; k < V; ++k) g[k] += old[k];
+    }
+    *(uint4*)dst = Elem<T>::pack(g);
+  }
+}
+
 template <typename T, bool GRAD>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst,
                                                            int C, int HW, int pitch) {
@@ -218,6 +336,60 @@ extern "C" int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, i
   if (dtype == HRP_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch);
   return check_launch("nchw_to_nhwc");
+}
+
+extern "C" int hrp_nchw_to_nhwc_s2d(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream) {
+  HRP_REQUIRE(src && dst && N > 0 && C > 0 && dst_pitch >= 4 * C, "nchw_to_nhwc_s2d: bad args");
+  dim3 grid(cdiv(((H + 1) / 2) * ((W + 1) / 2), 256), N);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(nchw_to_nhwc_s2d_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, dst_pitch);
+  else hipLaunchKernelGGL(nchw_to_nhwc_s2d_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, dst_pitch);
+  return check_launch("nchw_to_nhwc_s2d");
+}
+
+extern "C" int hrp_fill_zero(void* p, int64_t bytes, void* stream) {
+  HRP_REQUIRE(p && bytes >= 0, "fill_zero: bad args");
+  if (hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+    set_error("fill_zero: hipMemsetAsync failed");
+    return HRP_ERR_LAUNCH;
+  }
+  return HRP_OK;
+}
+
+extern "C" int hrp_gather_f32(const float* src, const int32_t* idx, float* dst, int n, int accumulate, void* stream) {
+  HRP_REQUIRE(src && idx && dst && n > 0, "gather_f32: bad args");
+  hipLaunchKernelGGL(gather_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, accumulate);
+  return check_launch("gather_f32");
+}
+
+extern "C" int hrp_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, int pitch, void* y, int y_pitch,
+                                    uint8_t* argmax, void* stream) {
+  const int vec = dtype == HRP_F32 ? 4 : 8, sz = dtype == HRP_F32 ? 4 : 2;
+  HRP_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool_fwd: bad args");
+  HRP_REQUIRE(C % vec == 0 && pitch % vec == 0 && y_pitch % vec == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
+              "maxpool_fwd: channels / pitches must be multiples of %d and the tensors 16-byte aligned", vec);
+  (void)sz;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * (C / vec);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == HRP_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, H, W, C, pitch, y, Ho, Wo, y_pitch, argmax, total);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, H, W, C, pitch, y, Ho, Wo, y_pitch, argmax, total);
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int hrp_maxpool3x3s2_bwd(const void* dy, int dy_pitch, const uint8_t* argmax, void* dx, int dtype, int N, int H, int W,
+                                    int C, int pitch, int accumulate, void* stream) {
+  const int vec = dtype == HRP_F32 ? 4 : 8;
+  HRP_REQUIRE(dy && argmax && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd: bad args");
+  HRP_REQUIRE(C % vec == 0 && pitch % vec == 0 && dy_pitch % vec == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dy % 16 == 0,
+              "maxpool_bwd: channels / pitches must be multiples of %d and the tensors 16-byte aligned", vec);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * H * W * (C / vec);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == HRP_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, Ho, Wo, dy_pitch, argmax, dx, H, W, C, pitch, accumulate, total);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, Ho, Wo, dy_pitch, argmax, dx, H, W, C, pitch, accumulate, total);
+  return check_launch("maxpool_bwd");
 }
 
 extern "C" int hrp_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream) {

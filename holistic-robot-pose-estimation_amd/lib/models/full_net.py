@@ -17,7 +17,9 @@ from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
 from hrpe_amd.lib.utils.integral import HeatmapIntegralPose
 from hrpe_amd.lib.utils.urdf_robot import URDFRobot
 from hrpe_amd.runtime import PlannedModule
-from .backbones.HRnet import Conv2d, emit_trunks, get_hrnet
+from hrpe_amd.plan import Term
+from .backbones.HRnet import BatchNorm2d, Conv2d, emit_trunks, get_hrnet
+from .backbones.Resnet import _StemConv, get_resnet
 
 _RESNETS = ["resnet", "resnet34", "resnet50", "resnet101"]
 _HRNETS = ["hrnet", "hrnet32"]
@@ -37,6 +39,17 @@ class Linear(PlannedModule):
 
     def emit(self, pb, x, residual=None):
         return pb.conv(x, self.weight, self.bias, residual=residual)
+
+
+class ConvTranspose2d(PlannedModule):
+    """Parameter holder of nn.ConvTranspose2d(cin, cout, 4, stride 2, padding 1, bias=False) (full_net.py:196-203):
+    weight [cin, cout, 4, 4]; executed by PlanBuilder.deconv4x4s2."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, 4, 4))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
 
 class RootNetwithRegInt(PlannedModule):
@@ -64,8 +77,12 @@ class RootNetwithRegInt(PlannedModule):
         self.rotation_dim = args.rotation_dim
         self.p_dropout = args.p_dropout
         if self.backbone_name in _RESNETS:
-            raise NotImplementedError("ResNet regression backbone + deconv head (full_net.py:74-79, 194-216) is not "
-                                      "built yet; use backbone_name='hrnet32'")
+            # the shipped full.yaml: ResNet trunk -> (global pool -> FC heads) and (3 x ConvTranspose2d+BN+ReLU -> 1x1)
+            self.reg_backbone = get_resnet(self.backbone_name)
+            self.feature_channel = self.reg_backbone.block.expansion * 512
+            self.deconv_dim = [256, 256, 256]
+            self.deconv_layers = self._make_deconv_layer()
+            self.final_layer = Conv2d(self.deconv_dim[2], self.num_joints * self.depth_dim, 1, bias=True)
         elif self.backbone_name in _HRNETS:
             self.reg_backbone = get_hrnet(type_name=32, num_joints=self.num_joints, depth_dim=self.depth_dim,
                                           pretrain=True, generate_feat=True, generate_hm=True)
@@ -113,6 +130,8 @@ class RootNetwithRegInt(PlannedModule):
             if isinstance(m, Conv2d):
                 n = m.kernel_size * m.kernel_size * m.out_channels
                 m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, _StemConv):
+                m.weight.data.normal_(0, math.sqrt(2.0 / (7 * 7 * 64)))
         nn.init.normal_(self.depth_layer.weight, std=0.001)
         nn.init.constant_(self.depth_layer.bias, 0)
         pose_params = init_param_dict["pose_params"]
@@ -122,6 +141,24 @@ class RootNetwithRegInt(PlannedModule):
         init_rot = rotmat_to_rot6d(torch.from_numpy(cam[:3, :3]).unsqueeze(0)).float()
         self.register_buffer("init_pose", init_pose)
         self.register_buffer("init_rot", init_rot)
+
+    def _make_deconv_layer(self):
+        """full_net.py:194-216: keys deconv_layers.{0,3,6}.weight ([Cin, Cout, 4, 4]) and .{1,4,7}.* (BatchNorm)."""
+        mods, cin = [], self.feature_channel
+        for cout in self.deconv_dim:
+            mods += [ConvTranspose2d(cin, cout), BatchNorm2d(cout), nn.Identity()]
+            cin = cout
+        return nn.Sequential(*mods)
+
+    def _emit_resnet_reg(self, pb, xs):
+        """full_net.py:293-298: x_out = trunk(x); xf = avgpool(x_out); heat-map = final_layer(deconv_layers(x_out))."""
+        x_out = self.reg_backbone.emit(pb, xs)
+        xf = pb.avgpool(x_out)
+        h = x_out
+        for i in range(0, len(self.deconv_layers), 3):
+            y = pb.deconv4x4s2(h, self.deconv_layers[i].weight, want_stats=pb.plan.training)
+            h = pb.act([Term(y, self.deconv_layers[i + 1])], relu=True)
+        return self.final_layer.emit(pb, h), xf
 
     def _iter_head(self, pb, xf, init_buf, np_, fc1, fc2, dec):
         """full_net.py:318-331: p <- p + dec(drop(fc2(drop(fc1([xf; p])))))  x n_iter."""
@@ -137,19 +174,30 @@ class RootNetwithRegInt(PlannedModule):
     def _build(self, pb, x_reg, x_root, k_value, K):
         N = x_reg.shape[0]
         J, root = self.num_joints, self.reference_keypoint_id
-        xr = pb.image_input("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3])
+        resnet_reg = self.backbone_name in _RESNETS
+        xr = (pb.image_input_s2d if resnet_reg else pb.image_input)("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3])
         xo = pb.image_input("x_root", N, 3, x_root.shape[2], x_root.shape[3])
         kv = pb.vector_input("k_value", N, 1, dense=True)
         Km = pb.vector_input("K", N, 9, dense=True)
         # the two backbones share nothing until pose_geometry: two lanes (concurrent HIP graph branches)
         # (lockstep emission: see emit_trunks)
-        ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])
-        with pb.parallel(2) as par:
-            with par.lane(0):
-                heat, xf = self.reg_backbone.emit_heads(pb, ys_reg)
-            with par.lane(1):
-                _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
-                gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+        if resnet_reg:
+            # ResNet regression trunk + deconv head in lane 0, the HRNet root trunk (branches serial: nested
+            # parallel blocks stay on their lane) in lane 1
+            with pb.parallel(2) as par:
+                with par.lane(0):
+                    heat, xf = self._emit_resnet_reg(pb, xr)
+                with par.lane(1):
+                    _, feat_root = self.rootnet_backbone.emit(pb, xo)
+                    gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+        else:
+            ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])
+            with pb.parallel(2) as par:
+                with par.lane(0):
+                    heat, xf = self.reg_backbone.emit_heads(pb, ys_reg)
+                with par.lane(1):
+                    _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
+                    gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
         il = self.integral_layer
         uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
         depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,

@@ -26,8 +26,10 @@ class HeatmapIntegralPose(PlannedModule):
         self.bbox_3d_shape = torch.tensor(bbox).float()
         self.depth_factor = float(self.bbox_3d_shape[2]) * 1e-3
         self.image_size = kwargs["image_size"]
-        if backbone not in ("hrnet", "hrnet32", "hrnet48"):
-            raise NotImplementedError("only the HRNet soft-argmax variant is built (integral.py:147-186)")
+        # integral.py:105-145 (ResNet) and :147-186 (HRNet) compute the same soft-argmax - the ResNet branch divides
+        # the softmax by its own sum (= 1) once more; one kernel serves both (checked against the reference for both)
+        if backbone not in ("hrnet", "hrnet32", "hrnet48", "resnet", "resnet34", "resnet50"):
+            raise NotImplementedError(f"soft-argmax head for backbone {backbone!r}")
 
     def emit(self, pb, heat, z_root_dense, Kmat):
         """heat NHWC logits; z_root [N,1] dense metres; K [N,9] -> (uvd, xyz) dense fp32."""

@@ -102,6 +102,7 @@ class ParamW:
         self.param, self.cout, self.cin, self.ntaps = param, cout, cin, ntaps
         self.fwd_off = self.bwd_off = None
         self.grad_written = False
+        self.src = None          # fp32 tensor packed instead of `param` (derived layouts, e.g. the 4x4 form of the stem)
 
 
 # ReLU sign bits written by the forward element-wise pass, read by its backward instead of the activation
@@ -178,6 +179,7 @@ class Plan:
         self.out_handles = []      # TensorH whose gradient is seeded from outside
         self.grad_arena = None
         self._grad_views = {}
+        self.pre_pack = []         # ops run before the weight packing of every step (derived weight layouts)
         self.counters = {}         # build statistics (HRP_PLAN_STATS=1 prints them at finalize)
         self.wgrad_ws_bytes = {}   # lane -> scratch bytes shared by that lane's weight-gradient launches
         self.wgrad_ws = {}
@@ -255,7 +257,7 @@ class Plan:
             tab = (nv.PackEntry * len(ws))()
             for i, w in enumerate(ws):
                 w.arena = arena
-                tab[i].src = w.param.data_ptr()
+                tab[i].src = (w.src if w.src is not None else w.param).data_ptr()
                 tab[i].dst = arena.data_ptr() + w.fwd_off * esz
                 tab[i].dst_t = (arena.data_ptr() + w.bwd_off * esz) if w.need_t else None
                 tab[i].Cout, tab[i].Cin, tab[i].ntaps = w.cout, w.cin, w.ntaps
@@ -328,6 +330,8 @@ class Plan:
         if not (force or self.params_dirty()):
             return
         s = self._stream()
+        for op in self.pre_pack:
+            op(s)
         for tdev, n, dt, maxel in self._pack_tables:
             nv.call("hrp_pack_weights", tdev.data_ptr(), n, dt, maxel, s)
         if self._fold_tab:
@@ -435,6 +439,213 @@ class PlanBuilder:
         p.fwd.append(op)
         t.external = name
         return t
+
+    def image_input_s2d(self, name, N, Cc, H, W):
+        """NCHW fp32 external image -> NHWC 2x2 space-to-depth tensor [N, H/2, W/2, 4*Cc] (ResNet stem input)."""
+        p = self.plan
+        t = p.new(N, (H + 1) // 2, (W + 1) // 2, 4 * Cc, pitch=_rup(4 * Cc, 16))
+        dt = _dt(t.dtype)
+
+        def op(s):
+            x = p.dyn[name]
+            nv.call("hrp_nchw_to_nhwc_s2d", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
+        p.fwd.append(op)
+        t.external = name
+        return t
+
+    def stem7x7_s2d(self, xs, weight, want_stats=False):
+        """Conv2d(3, Cout, 7, stride 2, padding 3, bias=False) (Resnet.py:21) on the space-to-depth image `xs`:
+        out[oy] = sum_ky w[ky] x[2 oy + ky - 3]; with ky + 1 = 2 ty + dy this is a 4x4 stride-1 convolution over the
+        12 channels (dy, dx, c) with tap offsets ty - 2, tx - 2 and w'[co][(dy,dx,c)][ty,tx] = w[co][c][2ty+dy-1][2tx+dx-1]
+        (zero where the 8x8 embedding has no 7x7 entry).  The weight gradient comes back through the same index map."""
+        p = self.plan
+        cout, cin = weight.shape[0], weight.shape[1]
+        assert tuple(weight.shape[2:]) == (7, 7) and xs.C == 4 * cin
+        dev, dtype = p.device, xs.dtype
+        # index maps (host, once): w' element -> flat index into w (or -1), w element -> flat index into dW'
+        idx_w = torch.full((cout, 4 * cin, 16), -1, dtype=torch.int32)
+        idx_g = torch.zeros((cout, cin, 49), dtype=torch.int32)
+        for dy in range(2):
+            for dx in range(2):
+                for ty in range(4):
+                    for tx in range(4):
+                        ky, kx = 2 * ty + dy - 1, 2 * tx + dx - 1
+                        if ky < 0 or kx < 0:
+                            continue
+                        for c in range(cin):
+                            q = (dy * 2 + dx) * cin + c
+                            for co in range(cout):
+                                idx_w[co, q, ty * 4 + tx] = (co * cin + c) * 49 + ky * 7 + kx
+                                idx_g[co, c, ky * 7 + kx] = (co * 4 * cin + q) * 16 + ty * 4 + tx
+        idx_w, idx_g = idx_w.to(dev), idx_g.to(dev)
+        w12 = torch.zeros(cout, 4 * cin, 4, 4, dtype=torch.float32, device=dev)
+        gw12 = torch.zeros(cout, 4 * cin, 16, dtype=torch.float32, device=dev)
+        p.keep += [idx_w, idx_g, w12, gw12]
+        p.pre_pack.append(lambda s: nv.call("hrp_gather_f32", weight.data_ptr(), idx_w.data_ptr(), w12.data_ptr(),
+                                            w12.numel(), 0, s))
+        w = ParamW(weight, cout, 4 * cin, 16)
+        w.src, w.dtype, w.cin_used, w.need_t = w12, dtype, 4 * cin, False
+        p.weights[("s2d", id(weight))] = w
+        p.weight_list.append(w)
+        y = p.new(xs.N, xs.H, xs.W, cout, dtype)
+        y.requires_grad = p.need_grad
+        taps = [(ty - 2, tx - 2) for ty in range(4) for tx in range(4)]
+        vec = 8 if dtype == torch.bfloat16 else 4
+        d = nv.ConvDesc()
+        d.x, d.y, d.dtype = xs.ptr(), y.ptr(), _dt(dtype)
+        d.N, d.H, d.W, d.Cin, d.x_pitch = xs.N, xs.H, xs.W, _rup(xs.C, vec), xs.pitch
+        d.Ho, d.Wo, d.Cout = y.H, y.W, cout
+        d.y_H, d.y_W, d.y_pitch, d.res_pitch = y.H, y.W, y.pitch, y.pitch
+        d.out_stride, d.in_stride, d.ntaps, d.w_ntaps, d.w_cout_pad = 1, 1, 16, 16, _rup(cout, 32)
+        for i, (a, b) in enumerate(taps):
+            d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+        if want_stats:
+            y.stats = p.alloc_stats(cout)
+        esz = 4 if dtype == torch.float32 else 2
+
+        def late():
+            d.w = w.arena.data_ptr() + w.fwd_off * esz
+            if y.stats is not None:
+                d.stats = p.stats.data_ptr() + 4 * y.stats
+        p.late(late)
+        p.fwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+        y.producer = ("conv", d)
+        if p.need_grad and weight.requires_grad:
+            def bw():
+                if not y.grad_written:
+                    return
+                lane = p.cur_lane
+                for grp in range(4):   # weight gradient of the 16 taps in 4 groups of 4 (one kernel row each)
+                    g = nv.WgradDesc()
+                    g.x, g.dy, g.dw, g.dtype = xs.ptr(), y.gptr(), gw12.data_ptr(), _dt(dtype)
+                    g.N, g.H, g.W, g.Cin, g.x_pitch = xs.N, xs.H, xs.W, _rup(xs.C, vec), xs.pitch
+                    g.Ho, g.Wo, g.Cout, g.dy_pitch = y.H, y.W, cout, y.pitch
+                    g.in_stride, g.ntaps = 1, 4
+                    for i in range(4):
+                        g.dy_t[i], g.dx_t[i] = taps[4 * grp + i]
+                    g.dw_cin, g.dw_tap_stride, g.dw_tap_off, g.accumulate = xs.C, 16, 4 * grp, 0
+                    p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
+                    p.late(lambda g=g, lane=lane: (setattr(g, "workspace", p.wgrad_ws[lane].data_ptr()),
+                                                   setattr(g, "workspace_bytes", p.wgrad_ws[lane].numel() * 4)))
+                    p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
+                gp = p.grad_of_param(weight)
+                acc = 1 if p.grad_arena is not None else 0
+                p.bwd.append(lambda s: nv.call("hrp_gather_f32", gw12.data_ptr(), idx_g.data_ptr(), gp.data_ptr(),
+                                               gp.numel(), acc, s))
+            self.bwd_stack.append(bw)
+        return y
+
+    def maxpool3x3s2(self, x):
+        """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (Resnet.py:25)."""
+        p = self.plan
+        x.check_readable()
+        Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        y = p.new(x.N, Ho, Wo, x.C, x.dtype)
+        y.requires_grad = p.need_grad and x.requires_grad
+        arg = None
+        if y.requires_grad:
+            arg = torch.zeros(x.N * Ho * Wo * x.C, dtype=torch.uint8, device=p.device)
+            p.keep.append(arg)
+        p.fwd.append(lambda s: nv.call("hrp_maxpool3x3s2_fwd", x.ptr(), _dt(x.dtype), x.N, x.H, x.W, x.C, x.pitch, y.ptr(),
+                                       y.pitch, arg.data_ptr() if arg is not None else None, s))
+        if y.requires_grad:
+            def bw():
+                if not y.grad_written:
+                    return
+                acc = x.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_maxpool3x3s2_bwd", y.gptr(), y.pitch, arg.data_ptr(), x.gptr(), _dt(x.dtype),
+                                               x.N, x.H, x.W, x.C, x.pitch, acc, s))
+            self.bwd_stack.append(bw)
+        return y
+
+    @staticmethod
+    def _class_taps(k, pad, py, px):
+        """Taps of output-parity class (py, px) of a stride-2 transposed convolution / data gradient: the forward conv
+        reads iy = 2 oy + ky - pad, so pixel iy = 2 a + py receives from (ky, oy = a + (py + pad - ky) / 2)."""
+        ys = [(ky, (py + pad - ky) // 2) for ky in range(k) if (py + pad - ky) % 2 == 0]
+        xs = [(kx, (px + pad - kx) // 2) for kx in range(k) if (px + pad - kx) % 2 == 0]
+        return [(oy, ox, ky * k + kx) for (ky, oy) in ys for (kx, ox) in xs]
+
+    def deconv4x4s2(self, x, weight, want_stats=False):
+        """nn.ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1, bias=False) (full_net.py:194-216).  With V = the
+        Conv2d(Cout -> Cin, 4, stride 2, padding 1) whose weight tensor is `weight` itself ([Cin, Cout, 4, 4] = V's
+        [out, in, 4, 4]): forward = V's data gradient (four output-parity launches of 2x2 taps, no zero insertion),
+        gradient wrt the input = V's forward (16 taps), weight gradient = V's weight gradient (4 groups of 4 taps)."""
+        p = self.plan
+        x.check_readable()
+        cin_t, cout_t = weight.shape[0], weight.shape[1]
+        assert tuple(weight.shape[2:]) == (4, 4) and x.C == cin_t
+        dtype = x.dtype
+        vec = 8 if dtype == torch.bfloat16 else 4
+        esz = 4 if dtype == torch.float32 else 2
+        w = p.weight(weight, cin_t, cout_t, 16)      # as V's weight: cout_V = Cin_T, cin_V = Cout_T
+        w.dtype, w.cin_used, w.need_t = dtype, cout_t, True
+        y = p.new(x.N, 2 * x.H, 2 * x.W, cout_t, dtype)
+        y.requires_grad = p.need_grad
+        if want_stats:
+            y.stats = p.alloc_stats(cout_t)
+        for (py, px) in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+            d = nv.ConvDesc()
+            d.x, d.y, d.dtype = x.ptr(), y.ptr(), _dt(dtype)
+            d.N, d.H, d.W, d.Cin, d.x_pitch = x.N, x.H, x.W, _rup(x.C, vec), x.pitch
+            d.Cout = cout_t
+            d.y_H, d.y_W, d.y_pitch, d.res_pitch = y.H, y.W, y.pitch, y.pitch
+            d.in_stride, d.out_stride, d.out_off_y, d.out_off_x = 1, 2, py, px
+            d.Ho, d.Wo = (y.H - py + 1) // 2, (y.W - px + 1) // 2
+            tl = self._class_taps(4, 1, py, px)
+            d.ntaps = len(tl)
+            for i, (a, b, t) in enumerate(tl):
+                d.dy[i], d.dx[i], d.wtap[i] = a, b, t
+            d.w_ntaps, d.w_cout_pad = 16, _rup(cout_t, 32)
+
+            def late(d=d):
+                d.w = w.arena.data_ptr() + w.bwd_off * esz
+                if y.stats is not None:
+                    d.stats = p.stats.data_ptr() + 4 * y.stats
+            p.late(late)
+            p.fwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+        if p.need_grad:
+            self.bwd_stack.append(lambda: self._deconv_bwd(x, w, y, dtype))
+        return y
+
+    def _deconv_bwd(self, x, w, y, dtype):
+        p = self.plan
+        if not y.grad_written:
+            return
+        vec = 8 if dtype == torch.bfloat16 else 4
+        esz = 4 if dtype == torch.float32 else 2
+        taps = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]
+        if w.param.requires_grad:
+            lane = p.cur_lane
+            for grp in range(4):
+                g = nv.WgradDesc()
+                g.x, g.dy, g.dw, g.dtype = y.gptr(), x.ptr(), p.grad_of_param(w.param).data_ptr(), _dt(dtype)
+                g.N, g.H, g.W, g.Cin, g.x_pitch = y.N, y.H, y.W, _rup(y.C, vec), y.pitch
+                g.Ho, g.Wo, g.Cout, g.dy_pitch = x.H, x.W, x.C, x.pitch
+                g.in_stride, g.ntaps = 2, 4
+                for i in range(4):
+                    g.dy_t[i], g.dx_t[i] = taps[4 * grp + i]
+                g.dw_cin, g.dw_tap_stride, g.dw_tap_off = y.C, 16, 4 * grp
+                g.accumulate = 1 if (w.grad_written or p.grad_arena is not None) else 0
+                p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
+                p.late(lambda g=g, lane=lane: (setattr(g, "workspace", p.wgrad_ws[lane].data_ptr()),
+                                               setattr(g, "workspace_bytes", p.wgrad_ws[lane].numel() * 4)))
+                p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
+            w.grad_written = True
+        if x.requires_grad:
+            acc = x.take_grad_slot()
+            d = nv.ConvDesc()
+            d.x, d.y, d.dtype = y.gptr(), x.gptr(), _dt(dtype)
+            d.N, d.H, d.W, d.Cin, d.x_pitch = y.N, y.H, y.W, _rup(y.C, vec), y.pitch
+            d.Ho, d.Wo, d.Cout = x.H, x.W, x.C
+            d.y_H, d.y_W, d.y_pitch, d.res_pitch = x.H, x.W, x.pitch, x.pitch
+            d.out_stride, d.in_stride, d.ntaps, d.w_ntaps, d.w_cout_pad = 1, 2, 16, 16, _rup(x.C, 32)
+            for i, (a, b) in enumerate(taps):
+                d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+            if acc:
+                d.res = x.gptr()
+            p.late(lambda d=d: setattr(d, "w", w.arena.data_ptr() + w.fwd_off * esz))
+            p.bwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
 
     def constant(self, N, Cc, value):
         t = self.plan.new(N, 1, 1, Cc, torch.float32, pitch=Cc)
@@ -561,6 +772,11 @@ class PlanBuilder:
         if x.requires_grad:
             acc = x.take_grad_slot()
             classes = [(0, 0)] if stride == 1 else [(0, 0), (0, 1), (1, 0), (1, 1)]
+            if stride == 2 and ksize == 1 and not acc:
+                # only the even pixels are written below: clear the buffer, then accumulate into it
+                gb_bytes = x.N * x.H * x.W * x.pitch * esz
+                p.bwd.append(lambda s: nv.call("hrp_fill_zero", x.gptr(), gb_bytes, s))
+                acc = 1
             for (py, px) in classes:
                 d = nv.ConvDesc()
                 d.x, d.y = y.gptr(), x.gptr()
@@ -574,13 +790,13 @@ class PlanBuilder:
                     d.out_stride, d.out_off_y, d.out_off_x = 1, 0, 0
                     tl = [(-a, -b, i) for i, (a, b) in enumerate(taps)]
                 else:
-                    assert ksize == 3 and stride == 2
+                    assert ksize in (1, 3) and stride == 2
                     d.Ho, d.Wo = (x.H - py + 1) // 2, (x.W - px + 1) // 2
                     d.out_stride, d.out_off_y, d.out_off_x = 2, py, px
-                    # forward: iy = 2*oy + ky - 1  ->  iy = 2a+py: py=0: ky=1, oy=a ; py=1: (ky=0, oy=a+1), (ky=2, oy=a)
-                    ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]
-                    xs = [(1, 0)] if px == 0 else [(0, 1), (2, 0)]
-                    tl = [(oy, ox, ky * 3 + kx) for (ky, oy) in ys for (kx, ox) in xs]
+                    # forward: iy = 2*oy + ky - pad  ->  pixel 2a+py receives from (ky, oy = a + (py + pad - ky) / 2)
+                    tl = self._class_taps(ksize, ksize // 2, py, px)
+                    if not tl:       # 1x1 stride 2: the odd pixels get no gradient from this conv
+                        continue
                 d.ntaps = len(tl)
                 for i, (a, b, t) in enumerate(tl):
                     d.dy[i], d.dx[i], d.wtap[i] = a, b, t

@@ -96,6 +96,9 @@ typedef struct hrp_wgrad_desc {
   int32_t in_stride, ntaps;
   int32_t dy_t[HRP_MAX_TAPS], dx_t[HRP_MAX_TAPS];
   int32_t dw_cin;      /* row length (in taps groups) of dw: element (co,ci,t) at (co*dw_cin+ci)*ntaps+t */
+  int32_t dw_tap_stride; /* 0: ntaps.  > 0: taps per (co,ci) in dw when this launch computes only the tap group  */
+  int32_t dw_tap_off;    /* [dw_tap_off, dw_tap_off + ntaps) of a larger kernel (4x4 / 7x7 kernels run as groups  */
+                         /* of 4 / 9 taps): element (co,ci,t) at (co*dw_cin+ci)*dw_tap_stride + dw_tap_off + t     */
   int32_t accumulate;  /* 0: dw is overwritten, 1: add to existing */
   void* workspace;     /* optional scratch of hrp_wgrad_workspace_bytes(): partial sums are written there
                           and reduced by a second launch instead of fp32 atomics into dw */
@@ -207,6 +210,20 @@ int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H
 int hrp_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream);
 int hrp_nchw_grad_from_nhwc(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream);
 int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int max_elems, void* stream);
+/* ResNet stem (lib/models/backbones/Resnet.py:21-25): the 7x7 stride-2 convolution runs as a 4x4 stride-1
+ * convolution over the 2x2 space-to-depth image.  dst[n, y, x, (dy*2+dx)*C + c] = src[n, c, 2y+dy, 2x+dx]. */
+int hrp_nchw_to_nhwc_s2d(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream);
+/* dst[i] (+)= idx[i] >= 0 ? src[idx[i]] : 0 - the re-layout of the stem weight into its 4x4 / 12-channel form and
+ * of the weight gradient back into the [64, 3, 7, 7] parameter. */
+int hrp_gather_f32(const float* src, const int32_t* idx, float* dst, int n, int accumulate, void* stream);
+/* stream-ordered memset(p, 0, bytes) (gradient buffers only partly written by a strided data gradient) */
+int hrp_fill_zero(void* p, int64_t bytes, void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) (Resnet.py:25) on NHWC; argmax (optional, [N,Ho,Wo,C] bytes) keeps the window
+ * slot 0..8 of the first maximum for the backward, which is a gather over the <= 4 windows of an input pixel. */
+int hrp_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, int pitch, void* y, int y_pitch,
+                         uint8_t* argmax, void* stream);
+int hrp_maxpool3x3s2_bwd(const void* dy, int dy_pitch, const uint8_t* argmax, void* dx, int dtype, int N, int H, int W,
+                         int C, int pitch, int accumulate, void* stream);
 
 int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream);
 int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream);

@@ -77,16 +77,22 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
-                 fix_root=True, image_size=256.0, depth_factor=1.3):
-    """RootNetwithRegInt.forward with backbone_name = rootnet_backbone_name = 'hrnet32'
-    (full_net.py:239-397).  Returns the reference's 8-tuple."""
+                 fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32"):
+    """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
+    with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
     feat_root = hrnet_w32_forward(sd, x_root, prefix="rootnet_backbone.", generate_hm=False,
                                   generate_feat=True, training=training)
     gamma = F.conv2d(feat_root[:, :, None, None], sd["depth_layer.weight"], sd["depth_layer.bias"])
     pred_depth = (gamma.view(-1, 1) * k_value.view(-1, 1)).reshape(B, 1) / 1000.0   # :281-282
-    heat, xf = hrnet_w32_forward(sd, x_reg, prefix="reg_backbone.", generate_hm=True,
-                                 generate_feat=True, training=training)
+    if reg_backbone.startswith("resnet"):                                             # :293-296
+        from .resnet import deconv_head_forward, resnet_forward
+        x_out = resnet_forward(sd, x_reg, prefix="reg_backbone.", name="resnet50" if reg_backbone == "resnet" else reg_backbone,
+                               training=training)
+        heat, xf = deconv_head_forward(sd, x_out, training=training)
+    else:
+        heat, xf = hrnet_w32_forward(sd, x_reg, prefix="reg_backbone.", generate_hm=True,
+                                     generate_feat=True, training=training)
     uvd = soft_argmax_uvd(heat, root=root, fix_root=fix_root)
     xyz_int = uvd_to_xyz(uvd, K, pred_depth, image_size, depth_factor)
     root_uv = (uvd[:, root, :2] + 0.5) * image_size                                  # :302

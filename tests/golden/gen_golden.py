@@ -13,6 +13,8 @@ Fixtures (reference call site that produced each):
   golden_depthnet.npz    RootNet('hrnet32') eval forward, and train-mode L1 loss + grads
                          (lib/models/depth_net.py:92-137, scripts/train_depthnet.py:231-250).
   golden_full_eval.npz   RootNetwithRegInt.forward eval 8-tuple (lib/models/full_net.py:239-397).
+  golden_full_eval_resnet.npz / golden_full_train_resnet.npz   the same with backbone_name = "resnet50" (ResNet-50
+                         trunk + deconv head of the shipped full.yaml), generated with `full_eval_resnet full_train_resnet`.
   golden_full_train.npz  lib/core/function.py farward_loss(train=True): loss terms + grads + BN
                          running stats after one step.
 """
@@ -207,8 +209,14 @@ def gen_depthnet():
     print("depthnet ok", out["depth_eval"].ravel(), out["loss"])
 
 
-def build_full():
+def build_full(backbone_name=None):
     args = rh.default_args()
+    if backbone_name is not None:
+        # the shipped full.yaml pairs a ResNet regression trunk (+ deconv head) with the HRNet root trunk;
+        # get_resnet() copies torchvision's ImageNet weights, which do not exist here and are overwritten anyway
+        from lib.models.backbones import Resnet as ref_resnet
+        ref_resnet.ResNet.init_weights = lambda self, name: None
+        args.backbone_name = backbone_name
     init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE,
             "cam_params": np.eye(4, dtype=float), "init_pose_from_mean": True}
     full = RootNetwithRegInt(init, args)
@@ -228,6 +236,21 @@ def gen_full_eval():
     np.savez_compressed(os.path.join(HERE, "golden_full_eval.npz"),
                         **{n: t.numpy() for n, t in zip(NAMES8, o)})
     print("full eval ok", o[0][0, :3])
+
+
+def gen_full_eval_resnet():
+    full, _ = build_full("resnet50")
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+        x_out = full.reg_backbone(x_reg)
+        heat = full.final_layer(full.deconv_layers(x_out))
+    out = {n: t.numpy() for n, t in zip(NAMES8, o)}
+    out["tap:x_out"] = x_out[:, ::64].numpy()         # every 64th channel of the trunk output
+    out["tap:heat"] = heat[:, ::56, ::4, ::4].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_resnet.npz"), **out)
+    print("full eval (resnet50 reg backbone) ok", o[0][0, :3])
 
 
 def make_batch(B, robot, seed=2024):
@@ -299,9 +322,18 @@ def import_reference_step_function():
     return function
 
 
-def gen_full_train():
+PICK_GRADS_RESNET = [
+    "reg_backbone.conv1.weight", "reg_backbone.bn1.weight", "reg_backbone.layer1.0.conv1.weight",
+    "reg_backbone.layer1.0.downsample.0.weight", "reg_backbone.layer2.0.conv2.weight",
+    "reg_backbone.layer2.0.downsample.0.weight", "reg_backbone.layer3.5.conv3.weight", "reg_backbone.layer4.2.bn3.bias",
+    "deconv_layers.0.weight", "deconv_layers.4.weight", "deconv_layers.6.weight", "final_layer.weight", "final_layer.bias",
+    "rootnet_backbone.conv1.weight", "fc_pose_1.weight", "decrot.bias", "depth_layer.weight",
+]
+
+
+def gen_full_train(backbone_name=None):
     function = import_reference_step_function()
-    full, margs = build_full()
+    full, margs = build_full(backbone_name)
     B = 2
     batch, small = make_batch(B, full.robot)
     args = rh._AttrDict(dict(margs))
@@ -321,9 +353,10 @@ def gen_full_train():
     for k, v in terms.items():
         out["term:" + k] = np.array(v.item())
     out.update({"in:" + k: v for k, v in small.items()})
-    grad_fixture(full, PICK_GRADS_FULL, out, "")
+    grad_fixture(full, PICK_GRADS_RESNET if backbone_name else PICK_GRADS_FULL, out, "")
     sd = full.state_dict()
-    for n in ["reg_backbone.bn1.running_mean", "rootnet_backbone.stage4.2.branches.3.3.bn2.running_var"]:
+    for n in (["reg_backbone.bn1.running_mean", "deconv_layers.7.running_var"] if backbone_name else
+              ["reg_backbone.bn1.running_mean", "rootnet_backbone.stage4.2.branches.3.3.bn2.running_var"]):
         out["buf:" + n] = sd[n][:64].numpy()
     # the forward outputs of the same train-mode call, for localisation of a mismatch
     full.zero_grad()
@@ -341,11 +374,14 @@ def gen_full_train():
     for n, t in zip(NAMES8, o):
         out["fwd:" + n] = t.numpy()
     out["k_values"] = kv.numpy()
-    np.savez_compressed(os.path.join(HERE, "golden_full_train.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "golden_full_train_resnet.npz" if backbone_name else "golden_full_train.npz"), **out)
     print("full train ok", out["loss"], {k: float(v) for k, v in terms.items()})
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fk", "integral", "hrnet_eval", "depthnet", "full_eval", "full_train"]
     for w in which:
-        globals()["gen_" + w]()
+        if w == "full_train_resnet":
+            gen_full_train("resnet50")
+        else:
+            globals()["gen_" + w]()

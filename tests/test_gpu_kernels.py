@@ -319,3 +319,67 @@ def test_fused_clip_adam_matches_torch():
         for p, q in zip(ref, mine):
             assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)   # clipped in place like torch
             assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (it, (p - q).abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resnet_stem_maxpool_deconv_kernels(dtype):
+    """Plan pieces of the ResNet path against plain torch: the 7x7 stride-2 stem run as a 4x4 convolution over the
+    space-to-depth image (+ train-mode BN + ReLU + max-pool 3x3 s2) and ConvTranspose2d(4, s2, p1) + BN + ReLU,
+    forward and backward (Resnet.py:21-25, full_net.py:194-216)."""
+    import torch.nn as nn
+    from hrpe_amd.lib.models.backbones.HRnet import BatchNorm2d
+    from hrpe_amd.lib.models.backbones.Resnet import _StemConv
+    from hrpe_amd.lib.models.full_net import ConvTranspose2d
+    from hrpe_amd.plan import Term
+    from hrpe_amd.runtime import PlannedModule
+
+    class Stem(PlannedModule):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = _StemConv(), BatchNorm2d(64)
+            self.up, self.bn2 = ConvTranspose2d(64, 24), BatchNorm2d(24)
+
+        def _build(self, pb, x):
+            N, Cc, H, W = x.shape
+            t = pb.image_input_s2d("x", N, Cc, H, W)
+            h = pb.act([Term(pb.stem7x7_s2d(t, self.conv1.weight, want_stats=True), self.bn1)], relu=True)
+            h = pb.maxpool3x3s2(h)
+            h = pb.act([Term(pb.deconv4x4s2(h, self.up.weight, want_stats=True), self.bn2)], relu=True)
+            holder = pb.nchw_output(h)
+            holder["handle"] = h
+            return ["x"], [("nchw", holder, None)], {"x": t}
+
+        def forward(self, x):
+            return self._run(x)[0]
+
+    torch.manual_seed(5)
+    m = Stem()
+    with torch.no_grad():
+        m.conv1.weight.normal_(0, 0.08)
+        m.up.weight.normal_(0, 0.06)
+        for bn in (m.bn1, m.bn2):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    x = torch.rand(2, 3, 44, 36)
+    gy = torch.randn(2, 24, 22, 18)
+    # torch reference (fp32, CPU)
+    w1 = m.conv1.weight.detach().clone().requires_grad_(True)
+    w2 = m.up.weight.detach().clone().requires_grad_(True)
+    g1, b1 = m.bn1.weight.detach().clone().requires_grad_(True), m.bn1.bias.detach().clone().requires_grad_(True)
+    h = F.conv2d(x, w1, None, stride=2, padding=3)
+    h = F.relu(F.batch_norm(h, None, None, g1, b1, True, 0.1, 1e-5))
+    h = F.max_pool2d(h, 3, 2, 1)
+    h = F.conv_transpose2d(h, w2, None, stride=2, padding=1)
+    yr = F.relu(F.batch_norm(h, None, None, m.bn2.weight.detach(), m.bn2.bias.detach(), True, 0.1, 1e-5))
+    (yr * gy).sum().backward()
+    m = m.to(DEV).set_compute_dtype(dtype).train()
+    y = m(x.to(DEV))
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < tol(dtype), f"fwd {rel_err(y, yr)}"
+    (y * gy.to(DEV)).sum().backward()
+    l2 = lambda a, b: ((a.detach().cpu().float() - b).norm() / (b.norm() + 1e-30)).item()
+    lim = 2e-3 if dtype == torch.float32 else 1.5e-1   # bf16: ReLU-mask and max-pool argmax flips next to ties (fp32 pins the arithmetic)
+    assert l2(m.up.weight.grad, w2.grad) < lim, f"deconv wgrad {l2(m.up.weight.grad, w2.grad)}"
+    assert l2(m.conv1.weight.grad, w1.grad) < lim, f"stem wgrad {l2(m.conv1.weight.grad, w1.grad)}"
+    assert l2(m.bn1.weight.grad, g1.grad) < lim and l2(m.bn1.bias.grad, b1.grad) < lim

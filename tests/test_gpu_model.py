@@ -59,12 +59,12 @@ def model_args(**over):
     return a
 
 
-def build_full():
+def build_full(**over):
     from hrpe_amd.lib.dataset.const import INITIAL_JOINT_ANGLE
     from hrpe_amd.lib.models.full_net import RootNetwithRegInt
     init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE, "cam_params": np.eye(4),
             "init_pose_from_mean": True}
-    m = RootNetwithRegInt(init, model_args())
+    m = RootNetwithRegInt(init, model_args(**over))
     m.load_state_dict(synth_state_dict(m.state_dict()))
     return m.to(DEV)
 
@@ -175,6 +175,65 @@ def test_full_train_step_golden():
     for key in g.files:
         if key.startswith("buf:"):
             np.testing.assert_allclose(sd[key[4:]][:64].cpu().numpy(), g[key], rtol=1e-3, atol=1e-6)
+
+
+def test_full_eval_resnet_golden():
+    """Shipped full.yaml: ResNet-50 regression trunk + deconv head (Resnet.py:56-67, full_net.py:194-216, 293-298)."""
+    g = load("golden_full_eval_resnet.npz")
+    m = build_full(backbone_name="resnet50").eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+        x_out = m.reg_backbone(x_reg.to(DEV))
+    ref = g["tap:x_out"]
+    err = np.abs(x_out[:, ::64].cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 3e-4, f"resnet trunk: rel err {err}"
+    for n, t in zip(NAMES8, out):
+        ref = g[n]
+        assert tuple(t.shape) == ref.shape, n
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    assert np.abs(out[3].cpu().numpy() - g["root_uv"]).max() < 1e-2
+
+
+def test_full_train_step_resnet_golden():
+    """Reference training step with the ResNet-50 regression trunk vs model + harness here (fp32)."""
+    from hrpe_amd.lib.core.function import compute_k_values, full_loss
+    from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+    g = load("golden_full_train_resnet.npz")
+    m = build_full(backbone_name="resnet50").train()
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    x_root = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    K = torch.tensor(g["in:K"]).to(DEV)
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], torch.tensor(g["in:bbox"]).to(DEV))
+    q, R, t = [torch.tensor(g[k]).to(DEV) for k in ("in:q", "in:R", "in:t")]
+    kp3d, kp2d, mask = [torch.tensor(g[k]).to(DEV) for k in ("in:kp3d", "in:kp2d", "in:mask")]
+    gt = dict(pose=q, root_rot=m.robot.get_rotation_at_specific_root(q, rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    pred = m(x_reg, x_root, kv, K)
+    for n, p in zip(NAMES8, pred):
+        ref = g["fwd:" + n]
+        err = np.abs(p.detach().cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 1e-3, f"train fwd {n}: rel err {err}"
+    loss, terms = full_loss(pred, gt, K)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-3)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            summary_check(params[name].grad, g, f"grad:{name}:", GRAD_TOL, what="full/resnet ")
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("buf:"):
+            np.testing.assert_allclose(sd[key[4:]][:64].cpu().numpy(), g[key], rtol=1e-3, atol=1e-6)
+    # bf16 trunk: one training step runs and stays finite
+    m.set_compute_dtype(torch.bfloat16)
+    m.zero_grad()
+    loss, _ = full_loss(m(x_reg, x_root, kv, K), gt, K)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(params["reg_backbone.conv1.weight"].grad).all()
 
 
 def test_state_dict_roundtrip_and_rootnet_transfer(tmp_path):

@@ -235,3 +235,27 @@ def test_plan_lanes_bookkeeping():
     bk = [(lane, getattr(op, "kind", None)) for lane, op in pl.bwd]
     first = next(i for i, (l, k) in enumerate(bk) if k == "fork" and bk[i + 1][0] == 2)
     assert [l for l, _ in bk[first + 1:first + 4]] == [2, 1, 0] and bk[first + 4] == (None, "join")
+
+
+def test_resnet_full_net_state_dict_keys():
+    """backbone_name='resnet50' (the shipped full.yaml): key names / shapes of the reference's RootNetwithRegInt
+    (reg_backbone.* 318 entries, deconv_layers.* 18, final_layer.*)."""
+    from hrpe_amd.lib.dataset.const import INITIAL_JOINT_ANGLE
+    from hrpe_amd.lib.models.full_net import RootNetwithRegInt
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    args = A(backbone_name="resnet50", rootnet_backbone_name="hrnet32", other_image_size=256.0, use_rpmg=False,
+             n_iter=4, p_dropout=0.0, reg_joint_map=False, joint_conv_dim=[], rotation_dim=6, direct_reg_rot=False,
+             rot_iterative_matmul=False, fix_root=True, bbox_3d_shape=[1300, 1300, 1300], reference_keypoint_id=3,
+             add_fc=False, multi_kp=False, kps_need_depth=None, pretrained_rootnet=None)
+    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE, "cam_params": np.eye(4), "init_pose_from_mean": True}
+    sd = RootNetwithRegInt(init, args).state_dict()
+    assert sum(k.startswith("reg_backbone.") for k in sd) == 318
+    assert sum(k.startswith("deconv_layers.") for k in sd) == 18
+    assert len(sd) == 2308
+    assert tuple(sd["reg_backbone.conv1.weight"].shape) == (64, 3, 7, 7)
+    assert tuple(sd["reg_backbone.layer2.0.downsample.0.weight"].shape) == (512, 256, 1, 1)
+    assert tuple(sd["deconv_layers.0.weight"].shape) == (2048, 256, 4, 4)
+    assert tuple(sd["deconv_layers.7.running_var"].shape) == (256,)
+    assert tuple(sd["final_layer.weight"].shape) == (448, 256, 1, 1)

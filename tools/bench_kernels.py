@@ -167,6 +167,53 @@ def ew_case(N, H, W, Cc, dtype):
     print(f"ew_bwd_apply         N={N} C={Cc:4d} @{H:3d}x{W:<3d}: {us:8.1f} us  {4 * a.numel() * esz / us / 1e3:7.1f} GB/s")
 
 
+def interleave_case(N, hw, c, dtype):
+    """Cold-start effects: the same conv launched back to back vs alternating with an element-wise kernel and
+    with a second conv of another template instance (different code, different weights)."""
+    esz = 2
+    x = torch.randn(N * hw * hw * c, device=DEV).to(dtype)
+    y = torch.zeros_like(x)
+
+    def mk(cin, cout, k):
+        w = torch.randn(cout, cin, k, k, device=DEV) / (cin * k * k) ** 0.5
+        wp, _ = pack(w, dtype)
+        d = nv.ConvDesc()
+        d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+        d.dtype = nv.HRP_BF16
+        d.N, d.H, d.W, d.Cin, d.x_pitch = N, hw, hw, cin, c
+        d.Ho, d.Wo, d.Cout = hw, hw, cout
+        d.y_H, d.y_W, d.y_pitch, d.res_pitch = hw, hw, c, c
+        d.out_stride, d.in_stride = 1, 1
+        taps = TAPS3 if k == 3 else [(0, 0)]
+        d.ntaps = d.w_ntaps = len(taps)
+        for i, (a, b) in enumerate(taps):
+            d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+        d.w_cout_pad = rup(cout, 32)
+        return d, wp
+
+    d1, k1 = mk(c, c, 3)
+    ds = [mk(c, c, 3) for _ in range(8)]          # same kernel, 8 different weight sets
+    d2, k2 = mk(c, c, 1)                          # another template instance
+    e = nv.EwDesc()
+    out = torch.zeros_like(x)
+    e.nin, e.out, e.out_pitch, e.dtype = 1, out.data_ptr(), c, nv.HRP_BF16
+    e.N, e.H, e.W, e.C, e.relu = N, hw, hw, c, 1
+    e.inp[0].ptr, e.inp[0].pitch, e.inp[0].up, e.inp[0].mode = y.data_ptr(), c, 1, nv.EW_IDENTITY
+    t_conv = timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d1), None))
+    t_ew = timeit(lambda: nv.call("hrp_ew_fwd", C.byref(e), None))
+    t_c1 = timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d2), None))
+    it = [0]
+
+    def rot():
+        nv.call("hrp_conv2d_fwd", C.byref(ds[it[0] % 8][0]), None)
+        it[0] += 1
+    t_rot = timeit(rot)
+    t_alt = timeit(lambda: (nv.call("hrp_conv2d_fwd", C.byref(d1), None), nv.call("hrp_ew_fwd", C.byref(e), None)))
+    t_alt2 = timeit(lambda: (nv.call("hrp_conv2d_fwd", C.byref(d1), None), nv.call("hrp_conv2d_fwd", C.byref(d2), None)))
+    print(f"interleave C={c} @{hw}: conv3x3 {t_conv:.1f}  ew {t_ew:.1f}  conv1x1 {t_c1:.1f} | 8 weight sets {t_rot:.1f} | "
+          f"conv3x3+ew {t_alt:.1f} (sum {t_conv + t_ew:.1f}) | conv3x3+conv1x1 {t_alt2:.1f} (sum {t_conv + t_c1:.1f})")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -181,6 +228,9 @@ if __name__ == "__main__":
                                       (32, 448, 1, 1, 64), (1024, 2048, 1, 1, 8)]:
             for stats in ((False, True) if cin == 32 and cout == 32 else (True,)):
                 conv_case(B, hw, hw, cin, cout, k, s, dt, stats)
+    if a.what == "interleave":
+        for (c, hw) in [(32, 64), (64, 32), (128, 16), (256, 8)]:
+            interleave_case(B, hw, c, dt)
     if a.what in ("ew", "all"):
         for (c, hw) in [(32, 64), (64, 32), (128, 16), (256, 8), (256, 64)]:
             ew_case(B, hw, hw, c, dt)

@@ -46,8 +46,11 @@ class Args(dict):
     __getattr__ = dict.__getitem__
 
 
+REG_BACKBONE = os.environ.get("HRP_BENCH_REG_BACKBONE", "hrnet32")   # "resnet50" = the shipped full.yaml pairing
+
+
 def model_args(p_dropout):
-    return Args(backbone_name="hrnet32", rootnet_backbone_name="hrnet32", other_image_size=256.0, use_rpmg=False,
+    return Args(backbone_name=REG_BACKBONE, rootnet_backbone_name="hrnet32", other_image_size=256.0, use_rpmg=False,
                 n_iter=4, p_dropout=p_dropout, reg_joint_map=False, joint_conv_dim=[], rotation_dim=6,
                 direct_reg_rot=False, rot_iterative_matmul=False, fix_root=True, bbox_3d_shape=[1300, 1300, 1300],
                 reference_keypoint_id=3, add_fc=False, multi_kp=False, kps_need_depth=None, pretrained_rootnet=None)
@@ -398,7 +401,8 @@ def main():
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "full network (HRNet-W32 reg backbone + HRNet-W32 DepthNet + heads + FK loss) "
+        "config": {"workload": f"full network ({'HRNet-W32' if REG_BACKBONE.startswith('hrnet') else REG_BACKBONE + ' + deconv head'} "
+                               "reg backbone + HRNet-W32 DepthNet + heads + FK loss) "
                                "fwd+loss+bwd+clip+Adam, BASELINE.json configs[2]",
                    "global_batch": B * world, "per_gpu_batch": B, "image": "3x256x256",
                    "hrnet_w32_passes_per_image": 2, "parallelism": f"dp{world}", "hip_graph": use_graph,

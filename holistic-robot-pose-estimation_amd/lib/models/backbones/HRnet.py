@@ -240,17 +240,33 @@ def _transition(pb, tr, src):
     return src
 
 
-def emit_trunks(pb, nets, xs):
+def emit_trunks(pb, nets, xs, rider=None):
     """Trunks (stem .. stage4, reference HRnet.py:500-533) of one or more HRNets with the same stage layout,
     emitted in lockstep so that every independent chain of every net - stem, each branch of the current
     module, fuse + transition - gets its own lane inside ONE flat parallel block.  (Blocks are kept flat:
     forking a lane from a forked lane crashes HIP stream capture on ROCm 7.)  -> per net the list of the
-    stage-4 branch outputs."""
+    stage-4 branch outputs.
+
+    `rider`: optional generator that emits an independent chain unit by unit (the ResNet regression trunk of the
+    shipped full.yaml next to the HRNet root trunk); every parallel block gets one more lane that advances it by
+    one unit, so the chain overlaps the HRNet branches without nesting blocks."""
     n = len(nets)
+    alive = [rider is not None]
+
+    def ride(par, lane):
+        if alive[0]:
+            with par.lane(lane):
+                try:
+                    next(rider)
+                except StopIteration:
+                    alive[0] = False
+
+    extra = lambda: 1 if alive[0] else 0
     stages = [(net.stage2, net.stage3, net.stage4) for net in nets]
     assert all(len(st[k]) == len(stages[0][k]) for st in stages for k in range(3)), "nets differ in stage layout"
     ys = [None] * n
-    with pb.parallel(n) as par:
+    with pb.parallel(n + extra()) as par:
+        ride(par, n)
         for i, (net, x) in enumerate(zip(nets, xs)):
             with par.lane(i):
                 h = pb.act([conv_bn(pb, x, net.conv1, net.bn1)], relu=True)
@@ -260,7 +276,9 @@ def emit_trunks(pb, nets, xs):
     for k in range(3):
         for mi in range(len(stages[0][k])):
             mods = [st[k][mi] for st in stages]
-            with pb.parallel(sum(m.num_branches for m in mods)) as par:
+            nl = sum(m.num_branches for m in mods)
+            with pb.parallel(nl + extra()) as par:
+                ride(par, nl)
                 lane = 0
                 for i, m in enumerate(mods):
                     ys[i] = list(ys[i])
@@ -269,7 +287,8 @@ def emit_trunks(pb, nets, xs):
                             ys[i][b] = _emit_seq(pb, m.branches[b], ys[i][b])
                         lane += 1
             last = mi == len(stages[0][k]) - 1
-            with pb.parallel(n) as par:
+            with pb.parallel(n + extra()) as par:
+                ride(par, n)
                 for i, (net, m) in enumerate(zip(nets, mods)):
                     with par.lane(i):
                         ys[i] = m.emit_fuse(pb, ys[i])

@@ -150,15 +150,24 @@ class RootNetwithRegInt(PlannedModule):
             cin = cout
         return nn.Sequential(*mods)
 
-    def _emit_resnet_reg(self, pb, xs):
-        """full_net.py:293-298: x_out = trunk(x); xf = avgpool(x_out); heat-map = final_layer(deconv_layers(x_out))."""
-        x_out = self.reg_backbone.emit(pb, xs)
-        xf = pb.avgpool(x_out)
-        h = x_out
+    def _resnet_reg_units(self, pb, xs, out):
+        """Generator over the regression path of the shipped full.yaml (full_net.py:293-298: x_out = trunk(x);
+        xf = avgpool(x_out); heat-map = final_layer(deconv_layers(x_out))), one unit (stem, a residual block, a deconv
+        layer) per step; emit_trunks advances it in a lane of its own next to the HRNet root trunk."""
+        rb = self.reg_backbone
+        y = pb.stem7x7_s2d(xs, rb.conv1.weight, want_stats=pb.plan.training)
+        h = pb.maxpool3x3s2(pb.act([Term(y, rb.bn1)], relu=True))
+        yield
+        for layer in (rb.layer1, rb.layer2, rb.layer3, rb.layer4):
+            for blk in layer:
+                h = blk.emit(pb, h)
+                yield
+        out["xf"] = pb.avgpool(h)
         for i in range(0, len(self.deconv_layers), 3):
             y = pb.deconv4x4s2(h, self.deconv_layers[i].weight, want_stats=pb.plan.training)
             h = pb.act([Term(y, self.deconv_layers[i + 1])], relu=True)
-        return self.final_layer.emit(pb, h), xf
+            yield
+        out["heat"] = self.final_layer.emit(pb, h)
 
     def _iter_head(self, pb, xf, init_buf, np_, fc1, fc2, dec):
         """full_net.py:318-331: p <- p + dec(drop(fc2(drop(fc1([xf; p])))))  x n_iter."""
@@ -182,13 +191,17 @@ class RootNetwithRegInt(PlannedModule):
         # the two backbones share nothing until pose_geometry: two lanes (concurrent HIP graph branches)
         # (lockstep emission: see emit_trunks)
         if resnet_reg:
-            # ResNet regression trunk + deconv head in lane 0, the HRNet root trunk (branches serial: nested
-            # parallel blocks stay on their lane) in lane 1
+            # the ResNet regression chain rides along the flat blocks of the HRNet root trunk (one unit per block)
+            res = {}
+            rider = self._resnet_reg_units(pb, xr, res)
+            (ys_root,) = emit_trunks(pb, [self.rootnet_backbone], [xo], rider=rider)
             with pb.parallel(2) as par:
                 with par.lane(0):
-                    heat, xf = self._emit_resnet_reg(pb, xr)
+                    for _ in rider:      # whatever the trunk blocks did not reach
+                        pass
+                    heat, xf = res["heat"], res["xf"]
                 with par.lane(1):
-                    _, feat_root = self.rootnet_backbone.emit(pb, xo)
+                    _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
                     gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
         else:
             ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])

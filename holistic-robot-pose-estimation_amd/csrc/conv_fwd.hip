@@ -485,6 +485,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 }
 
 // ---------------------------------------------------------------------------------------------
+static thread_local int g_conv_lds_budget_kb = 76;
+
 template <typename T, int CT, int PT, int WC, int WP, int NT>
 static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
@@ -504,8 +506,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   t.mindy = mindy; t.mindx = mindx;
   t.IHt = (TH - 1) * d.in_stride + (maxdy - mindy) + 1;
   t.IWt = (TW - 1) * d.in_stride + (maxdx - mindx) + 1;
-  static const int budget_kb = getenv("HRP_CONV_LDS_KB") ? atoi(getenv("HRP_CONV_LDS_KB")) : 76;
-  const int budget = budget_kb * 1024;  // two workgroups per CU
+  const int budget = g_conv_lds_budget_kb * 1024;  // 76: two workgroups per CU; a lower first try leaves room for a third
   t.w_pieces = NT * BN / 32;
   {  // shrink the number of images per tile until two stage buffers fit
     int per_img = t.IHt * t.IWt * ROW;
@@ -593,7 +594,11 @@ template <typename T, int NT>
 static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
   const long pixels = (long)d.N * d.Ho * d.Wo;
   static const long want = getenv("HRP_CONV_WANT") ? atol(getenv("HRP_CONV_WANT")) : 256;
+  static const int low_kb = getenv("HRP_CONV_LDS_KB") ? atoi(getenv("HRP_CONV_LDS_KB")) : 76;
   int rc = -100;
+  for (int pass = 0; pass < 2 && rc == -100; ++pass) {
+  g_conv_lds_budget_kb = pass == 0 ? low_kb : 76;
+  if (pass == 1 && low_kb >= 76) break;
   if (d.Cout <= 32) {
     if (pixels / 256 >= want) rc = launch_cfg<T, 1, 2, 1, 4, NT>(d, s);
     if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4, NT>(d, s);
@@ -605,6 +610,8 @@ static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
     if (rc == -100) rc = launch_cfg<T, 2, 1, 1, 4, NT>(d, s);
     if (rc == -100) rc = launch_cfg<T, 1, 1, 1, 4, NT>(d, s);   // 32 couts per workgroup: halves the weight slab (16-tap kernels)
   }
+  }
+  g_conv_lds_budget_kb = 76;
   if (rc == -100) {
     set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
     return HRP_ERR_ARG;

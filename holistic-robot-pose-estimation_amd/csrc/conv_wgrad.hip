@@ -453,7 +453,8 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   t.n_cob = cdiv(d.Cout, 32); t.n_cib = cdiv(d.Cin, 32);
   int pairs = t.n_cob * t.n_cib;
   // workgroups per (cout, cin) block: ~2 per CU over the whole launch; each walks ntiles / G pixel tiles
-  int G = 256 / pairs;
+  static const int wg_total = getenv("HRP_WGRAD_WGS") ? atoi(getenv("HRP_WGRAD_WGS")) : 256;   // tuning knob
+  int G = wg_total / pairs;
   if (G < 1) G = 1;
   if (G > t.ntiles) G = t.ntiles;
   t.G = G;

@@ -356,7 +356,8 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
   if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
   const int up = d.in.up;
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : 512);
+  static const int red_blocks = getenv("HRP_EW_RED_BLOCKS") ? atoi(getenv("HRP_EW_RED_BLOCKS")) : 512;   // tuning knob
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : red_blocks);
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;

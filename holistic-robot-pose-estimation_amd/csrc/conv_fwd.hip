@@ -352,7 +352,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
           const int m = wp * (32 * PT) + p * 32 + l31;
           float v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = (acc[c][p][4 * q4 + i] + bia[i]) * sc[i] + sh[i];
+          for (int i = 0; i < 4; ++i) v[i] = acc[c][p][4 * q4 + i];
+          if (d.bias || d.scale) {   // uniform: the plain (train-mode) conv skips 2 VALU per value
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (v[i] + bia[i]) * sc[i] + sh[i];
+          }
           char* dst = lds_out + m * OP + cl * SZ;
           if constexpr (SZ == 4) {
             *(uint4*)dst = Elem<float>::pack(v);

@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhrp_hip.so")
+LIB_PATH = os.environ.get("HRP_LIB") or os.path.join(_HERE, "libhrp_hip.so")   # HRP_LIB: development builds (A/B variants)
 CSRC = os.path.join(_HERE, "csrc")
 
 HRP_F32, HRP_BF16 = 0, 1

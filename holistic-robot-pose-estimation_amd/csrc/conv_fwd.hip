@@ -21,6 +21,10 @@
 #include "hrp_common.h"
 #include <stdlib.h>
 
+#ifndef HRP_CONV_ISSUE_STEPS
+#define HRP_CONV_ISSUE_STEPS 64
+#endif
+
 namespace hrp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -288,7 +292,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
       // The pieces of stage st+1 are issued between the MFMA steps (chunk g of the next stage during chunk g of
       // this one, SPP slots per step): issued in one burst a full memory queue stalls the wave for ~2 us.
       constexpr int NS = NT * Mma<T>::KSTEPS;
-      constexpr int SPP = (MAXP_IN + MAXP_W + NS - 1) / NS;
+      constexpr int ISSUE_STEPS = NS < HRP_CONV_ISSUE_STEPS ? NS : HRP_CONV_ISSUE_STEPS;   // front-load the next stage's DMA
+      constexpr int SPP = (MAXP_IN + MAXP_W + ISSUE_STEPS - 1) / ISSUE_STEPS;
       const int ng = nloc - st * G < G ? nloc - st * G : G;
       typename Mma<T>::Frag fa[2][CT], fb[2][PT];
       auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&bb)[PT]) {

@@ -55,6 +55,10 @@ CONV_CASES = [
     (32, 32, 3, 1, 13, 9, 3, False),       # ragged everything
     (64, 64, 3, 2, 13, 9, 3, False),       # ragged stride 2 (odd sizes)
     (32, 32, 3, 1, 1, 1, 5, False),        # degenerate 1x1 image
+    (32, 32, 3, 1, 64, 64, 48, False),     # 768 tiles: persistent conv workgroups, 3 tiles per wgrad workgroup (as at B = 64)
+    (64, 64, 3, 1, 32, 32, 40, False),     # multi-tile weight gradient with 4 (cout, cin) block pairs
+    (256, 128, 1, 2, 16, 16, 2, False),    # ResNet projection: 1x1 stride 2 (data gradient only on even pixels)
+    (2056, 1024, 1, 1, 1, 1, 64, True),    # fc_pose_1 as a 1x1 conv on 64 rows (fp32: split-K with atomics)
 ]
 
 

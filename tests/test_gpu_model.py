@@ -236,6 +236,32 @@ def test_full_train_step_resnet_golden():
     assert torch.isfinite(loss) and torch.isfinite(params["reg_backbone.conv1.weight"].grad).all()
 
 
+def test_lanes_match_serial_execution():
+    """The lane (multi-stream) schedule of a plan computes what the same launch list computes on one stream.  Two
+    runs of one schedule already differ (fp32 atomics in the BN statistics, amplified by the B = 2 train-mode net),
+    so the lanes are held to a small multiple of that run-to-run noise."""
+    from hrpe_amd import plan as plan_mod
+    m = build_full().train()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+
+    def run(serial):
+        plan_mod.SERIAL_LANES = serial
+        try:
+            m.zero_grad()
+            out = m(x_reg, x_root, kv, K)
+            sum(o.float().square().mean() for o in out).backward()
+            torch.cuda.synchronize()
+            return torch.cat([o.detach().reshape(-1) for o in out]), m.flat_grads()[0].clone()
+        finally:
+            plan_mod.SERIAL_LANES = False
+
+    rel = lambda a, b: ((a - b).norm() / (a.norm() + 1e-30)).item()
+    s1, s2, l1 = run(True), run(True), run(False)
+    noise_o, noise_g = rel(s1[0], s2[0]), rel(s1[1], s2[1])
+    assert rel(s1[0], l1[0]) <= max(10 * noise_o, 1e-4), (rel(s1[0], l1[0]), noise_o)
+    assert rel(s1[1], l1[1]) <= max(10 * noise_g, 1e-3), (rel(s1[1], l1[1]), noise_g)
+
+
 def test_state_dict_roundtrip_and_rootnet_transfer(tmp_path):
     """Checkpoint contract: DepthNet state dict -> full net via the backbone. -> rootnet_backbone.
     rename of the reference factory (full_net.py:417-430)."""

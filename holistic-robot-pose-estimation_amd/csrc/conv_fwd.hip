@@ -32,7 +32,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int ROW = 32;  // bytes of input channels per pixel / weight row staged per K chunk
 
-__device__ uint4 g_zero_page[4];  // 64 zero bytes: DMA source of padding pixels / rows beyond the tensor
+static __device__ uint4 g_zero_page[1024];  // 16 KiB of zeros: DMA source of padding pixels / rows beyond the tensor (a lane parked
+                                     // here still advances 32 bytes per K chunk, <= 8.3 KiB for the widest layer)
 
 struct ConvTiling {
   int TH, TW, TI;   // TI = images per tile actually staged (TI*TH*TW <= BM; the rest of the tile is idle)
@@ -57,7 +58,7 @@ __device__ __forceinline__ int row_addr(int r, int h) { return r * ROW + ((h ^ (
 // -DHRP_TIMELINE (development build only): thread 0 of every workgroup stamps the 100 MHz wall clock at
 // phase boundaries into g_conv_timeline[block][8]; tools/bench_kernels.py reads it with hrp_debug_conv_timeline.
 #ifdef HRP_TIMELINE
-__device__ unsigned long long g_conv_timeline[8192 * 8];
+static __device__ unsigned long long g_conv_timeline[8192 * 8];
 #define HRP_CSTAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_conv_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define HRP_CSTAMP(i) do { } while (0)
@@ -104,7 +105,7 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
                :: "v"(src), "s"(lds) : "memory");   // m0 is scratch for the compiler too: it never keeps a value there
 }
 
-template <typename T, int CT, int PT, int WC, int WP, int NT, bool PERSIST>
+template <typename T, int CT, int PT, int WC, int WP, int NT, bool PERSIST, bool FAST>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, const ConvTiling t) {
   static_assert(WC * WP == 4, "4 waves");
   constexpr int BN = 32 * CT * WC, BM = 32 * PT * WP;
@@ -140,7 +141,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   const int nchunks = (d.Cin + CKE - 1) / CKE;
   const char* xg = (const char*)d.x;
   const char* wg = (const char*)d.w;
-  const char* zero = (const char*)g_zero_page;
+  const char* zero_sym = (const char*)g_zero_page;
+  const char* zero = zero_sym;
+  // keep the zero-page pointer in a VGPR pair: left to itself the compiler rematerialises it (s_getpc, 2 s_add,
+  // 2 v_mov) in front of every DMA piece, a third of the instructions of the K loop
+  asm volatile("" : "+v"(zero));
   // tap offsets (in tile rows) live in registers: with NT known the tap loop unrolls completely
   int taprow[NT];
 #pragma unroll
@@ -250,9 +255,45 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][p][i] = 0.f;
 
+    // Per-piece source pointers of this tile, advanced by one chunk after every issue (chunks are issued in
+    // order, exactly once): the K loop then pays one 64-bit add per piece instead of mask / compare / select.
+    // Not with a half-filled last chunk (Cin % 16 != 0: its upper 16 bytes must read zeros) - that keeps the
+    // select path.
+    constexpr bool fast = FAST;    // host: Cin * sizeof(T) is a multiple of 32
+    const char* pin[MAXP_IN];
+    const char* pw[MAXP_W];
+    int wstep[MAXP_W];
+    if constexpr (fast) {
+      const char* xb0 = xbase + (long long)cbeg * ROW;
+#pragma unroll
+      for (int i = 0; i < MAXP_IN; ++i) pin[i] = (in_code[i] & cls) ? zero : xb0 + (unsigned)in_rel[i];
+      const char* wb0 = wbase + (long long)cbeg * w_chunk_stride;
+#pragma unroll
+      for (int i = 0; i < MAXP_W; ++i) {
+        const bool ok = co0 + ((wave + 4 * i) * 32) % BN < d.w_cout_pad;
+        pw[i] = ok ? wb0 + (unsigned)w_rel[i] : zero;
+        wstep[i] = ok ? w_chunk_stride : 0;
+      }
+    }
     // DMA slot = one 1 KiB piece of this wave: slots 0 .. MAXP_IN-1 belong to the input tile of the chunk,
     // the rest to its weight slab (slot is a constant after unrolling)
     auto issue_slot = [&](int chunk, char* buf, int slot) {
+      if constexpr (fast) {
+        if (slot < MAXP_IN) {
+          const int p = wave + 4 * slot;
+          if (p < t.in_pieces) {
+            dma16(pin[slot], buf + p * 1024);
+            pin[slot] += ROW;
+          }
+        } else if (slot < MAXP_IN + MAXP_W) {
+          const int i = slot - MAXP_IN, p = wave + 4 * i;
+          if (p < W_PIECES) {
+            dma16(pw[i], buf + (t.in_pieces + p) * 1024);
+            pw[i] += wstep[i];
+          }
+        }
+        return;
+      }
       if (slot < MAXP_IN) {
         const int p = wave + 4 * slot;
         if (p < t.in_pieces) {
@@ -580,12 +621,18 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   // work and there are several tiles per CU; one tile per workgroup otherwise
   const int mfma_per_tile = cdiv(d.Cin * SZ, ROW) * NT * CT * PT * Mma<T>::KSTEPS;
   static const int persist_max = getenv("HRP_CONV_PERSIST") ? atoi(getenv("HRP_CONV_PERSIST")) : 48;
-  const bool persist = NT >= 4 && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256;   // 1x1 layers are store bound: many small workgroups
-  auto kern = persist ? conv_tile_kernel<T, CT, PT, WC, WP, NT, true> : conv_tile_kernel<T, CT, PT, WC, WP, NT, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[persist]) {
+  constexpr bool CAN_PERSIST = NT == 9;   // (only 3x3 layers have tiles small enough to profit; keeps the instantiation count down)
+  const bool persist = CAN_PERSIST && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256;   // 1x1 layers are store bound: many small workgroups
+  const bool fastp = (d.Cin * SZ) % ROW == 0;   // no half-filled last chunk: per-piece advancing pointers
+  void (*kern)(const hrp_conv_desc, const ConvTiling) =
+      fastp ? conv_tile_kernel<T, CT, PT, WC, WP, NT, false, true> : conv_tile_kernel<T, CT, PT, WC, WP, NT, false, false>;
+  if constexpr (CAN_PERSIST) {
+    if (persist) kern = fastp ? conv_tile_kernel<T, CT, PT, WC, WP, NT, true, true> : conv_tile_kernel<T, CT, PT, WC, WP, NT, true, false>;
+  }
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[persist * 2 + fastp]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[persist] = true;
+    attr_set[persist * 2 + fastp] = true;
   }
   int occ = (160 * 1024) / lds;
   occ = occ < 1 ? 1 : occ > 2 ? 2 : occ;
@@ -644,6 +691,13 @@ static int launch_conv(const hrp_conv_desc& d, hipStream_t s) {
 
 }  // namespace hrp
 
+// Two translation units (compile time): this file instantiates the bf16 kernels and the C entry point,
+// conv_fwd_f32.hip (#define HRP_CONV_TU_F32 + #include of this file) the fp32 ones.
+#ifdef HRP_CONV_TU_F32
+namespace hrp { int launch_conv_f32(const hrp_conv_desc& d, hipStream_t s) { return launch_conv<float>(d, s); } }
+#else
+namespace hrp { int launch_conv_f32(const hrp_conv_desc& d, hipStream_t s); }
+
 extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   using namespace hrp;
   HRP_REQUIRE(d && d->x && d->w && d->y, "conv: null pointer");
@@ -657,7 +711,7 @@ extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
   HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
   HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
-  if (d->dtype == HRP_F32) return launch_conv<float>(*d, (hipStream_t)stream);
+  if (d->dtype == HRP_F32) return launch_conv_f32(*d, (hipStream_t)stream);
   return launch_conv<bf16_t>(*d, (hipStream_t)stream);
 }
 
@@ -672,3 +726,4 @@ extern "C" int hrp_debug_conv_timeline(void* dst, int nblocks, int clear) {
   return 0;
 }
 #endif
+#endif  // HRP_CONV_TU_F32

@@ -127,7 +127,11 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
 
   const char* xg = (const char*)d.x;
   const char* dyg = (const char*)d.dy;
-  const char* zero = (const char*)g_wg_zero_page;
+  const char* zero_sym = (const char*)g_wg_zero_page;
+  const char* zero = zero_sym;
+  // keep the zero-page pointer in a VGPR pair: left to itself the compiler rematerialises it (s_getpc, 2 s_add,
+  // 2 v_mov) in front of every DMA piece, a third of the instructions of the K loop
+  asm volatile("" : "+v"(zero));
   const int ppw = t.BM / 4;  // pixels per wave
 
   int tapoff[NT];

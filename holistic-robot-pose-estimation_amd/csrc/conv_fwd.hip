@@ -127,15 +127,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   // layers the index arithmetic below costs more instructions than the MFMA loop of a tile); otherwise one
   // tile per workgroup, which keeps the register count - and with it the occupancy of deep-K layers - low.
   // =====================================================================================================
-  int pixrow[PT];
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    int m = wp * (32 * PT) + pt * 32 + l31;
-    int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
-    int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
-    if (ti >= t.TI) ti = t.TI - 1;  // idle slot of a partially filled tile: read something valid, never stored
-    pixrow[pt] = mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS);
-  }
+  int pixrow[PT];   // filled by late_setup()
   const int wrow0 = wc * 32 * CT + l31;
 
   const int nchunks = (d.Cin + CKE - 1) / CKE;
@@ -205,18 +197,31 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
   constexpr int NV = BN / VEC, KST = BM * NV / 256;
   const int cv = tid % NV;  // 256 % NV == 0, so a thread keeps its channel group
   int out_rel[KST], out_code[KST];
+  // The part of the setup that the first DMA stage does not need (fragment rows, store plan) runs after that stage
+  // has been issued, under its latency.
+  auto late_setup = [&]() {
 #pragma unroll
-  for (int k = 0; k < KST; ++k) {
-    const int m = tid / NV + k * (256 / NV);
-    const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
-    const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
-    int code = (ti >= t.TI) ? 32 : 0;
-    code |= (ty + y_last >= d.Ho) ? 2 : 0;
-    code |= (tx + x_last >= d.Wo) ? 8 : 0;
-    code |= (ti + n_last >= d.N) ? 16 : 0;
-    out_code[k] = code;
-    out_rel[k] = mul24(mul24(ti, d.y_H) + mul24(ty, d.out_stride), d.y_W) + mul24(tx, d.out_stride);   // in output pixels
-  }
+    for (int pt = 0; pt < PT; ++pt) {
+      int m = wp * (32 * PT) + pt * 32 + l31;
+      int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      if (ti >= t.TI) ti = t.TI - 1;  // idle slot of a partially filled tile: read something valid, never stored
+      pixrow[pt] = mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS);
+    }
+#pragma unroll
+    for (int k = 0; k < KST; ++k) {
+      const int m = tid / NV + k * (256 / NV);
+      const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      int code = (ti >= t.TI) ? 32 : 0;
+      code |= (ty + y_last >= d.Ho) ? 2 : 0;
+      code |= (tx + x_last >= d.Wo) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      out_code[k] = code;
+      out_rel[k] = mul24(mul24(ti, d.y_H) + mul24(ty, d.out_stride), d.y_W) + mul24(tx, d.out_stride);   // in output pixels
+    }
+  };
+  bool first_tile = true;
   HRP_CSTAMP(1);
 
   const int G = t.G, stage_bytes = G * t.buf_bytes;
@@ -319,6 +324,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
         }
     };
     issue_stage(0, smem);
+    if (first_tile) { late_setup(); first_tile = false; }
     HRP_CSTAMP(2);
     for (int st = 0; st < nstages; ++st) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of stage `st` have landed

@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   const int tr_pix = (lane & 15) >> 2;
   const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * SZ;
 
+  // tile loop, double buffered: the DMA of tile i+1 runs under the MFMAs of tile i.  Inside a tile the
+  // operand reads of k-step s+1 are issued between the MFMAs of k-step s (one wave per SIMD: nobody else
+  // hides the LDS latency).
+  int it = 0;
+  HRP_STAMP(1);
+  if ((int)blockIdx.x < t.ntiles) issue(blockIdx.x, smem);
+  // (computed here, under the latency of the first tile's DMA)
   // bf16: the LDS offsets of a lane's operands do not depend on the tile -> registers, NKS k-steps of 16 pixels
   constexpr int NKS_ = NKS > 0 ? NKS : 1;
   int xo0[NKS_], xo1[NKS_], ao[NKS_];
@@ -241,12 +248,6 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
     }
   }
 
-  // tile loop, double buffered: the DMA of tile i+1 runs under the MFMAs of tile i.  Inside a tile the
-  // operand reads of k-step s+1 are issued between the MFMAs of k-step s (one wave per SIMD: nobody else
-  // hides the LDS latency).
-  int it = 0;
-  HRP_STAMP(1);
-  if ((int)blockIdx.x < t.ntiles) issue(blockIdx.x, smem);
   HRP_STAMP(2);
   for (int tile = blockIdx.x; tile < t.ntiles; tile += t.G, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

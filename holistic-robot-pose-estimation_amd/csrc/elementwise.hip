@@ -90,12 +90,21 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
       }
   }
   if (c >= d.C) return;
-  const long npix = (long)d.N * d.H * d.W;
-  for (long p = (long)blockIdx.x * ppb + threadIdx.x / tpr; p < npix; p += (long)gridDim.x * ppb) {
-    int x = p % d.W;
-    long r = p / d.W;
-    int y = r % d.H;
-    int n = r / d.H;
+  // index arithmetic in 32 bits (the launcher checks N*H*W < 2^31); the pixel decomposition - two integer
+  // divisions - only when some input is upsampled (64-bit divisions per vector made this kernel VALU bound)
+  const unsigned npix = (unsigned)d.N * d.H * d.W;
+  bool any_up = false;
+#pragma unroll
+  for (int j = 0; j < HRP_EW_MAX_IN; ++j) any_up = any_up || (j < d.nin && d.in[j].up != 1);
+  const unsigned uW = d.W, uH = d.H;
+  for (unsigned p = blockIdx.x * ppb + threadIdx.x / tpr; p < npix; p += gridDim.x * ppb) {
+    unsigned x = 0, y = 0, n = 0;
+    if (any_up) {
+      const unsigned r = p / uW;
+      x = p - r * uW;
+      n = r / uH;
+      y = r - n * uH;
+    }
     float acc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
@@ -103,8 +112,13 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
     for (int j = 0; j < HRP_EW_MAX_IN; ++j) {
       if (j >= d.nin) break;
       const hrp_ew_input& in = d.in[j];
-      const int up = in.up;
-      size_t q = (((size_t)n * (d.H / up) + y / up) * (d.W / up) + x / up) * in.pitch + c;
+      size_t q;
+      if (in.up == 1) {
+        q = (size_t)p * in.pitch + c;
+      } else {
+        const int lg = __ffs(in.up) - 1;   // up is 2, 4 or 8
+        q = (((size_t)n * (uH >> lg) + (y >> lg)) * (uW >> lg) + (x >> lg)) * in.pitch + c;
+      }
       float f[V];
       VecIO<T, V>::ld(in.ptr, q, f);
 #pragma unroll
@@ -126,13 +140,21 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
 
 // pooled, masked output gradient at input pixel q = (n, qy, qx)
 template <typename T, int V>
-__device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, int n, int qy, int qx, int c, float* g) {
+__device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q, int c, float* g) {
 #pragma unroll
   for (int i = 0; i < V; ++i) g[i] = 0.f;
   const int up = d.in.up;
+  unsigned n = 0, qy = 0, qx = 0;
+  if (up != 1) {   // (32-bit divisions, only for the upsampled inputs of the fuse layers)
+    const unsigned Wq = d.W / up, Hq = d.H / up;
+    const unsigned r = q / Wq;
+    qx = q - r * Wq;
+    n = r / Hq;
+    qy = r - n * Hq;
+  }
   for (int dy = 0; dy < up; ++dy)
     for (int dx = 0; dx < up; ++dx) {
-      size_t p = ((size_t)n * d.H + qy * up + dy) * d.W + qx * up + dx;
+      const size_t p = up == 1 ? (size_t)q : ((size_t)n * d.H + qy * up + dy) * d.W + qx * up + dx;
       float go[V];
       VecIO<T, V>::ld(d.dout, p * d.dout_pitch + c, go);
       if (d.relu) {
@@ -172,14 +194,10 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   float sc[V], sh[V], mean[V], inv[V];
   load_consts<V>(d.in, d.C, cbase, nch, c, tab, sc, sh, mean, inv);
   if (c < d.C) {
-    const long nq = (long)d.N * Hq * Wq;
-    for (long q = (long)blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += (long)gridDim.x * ppb) {
-      int qx = q % Wq;
-      long r = q / Wq;
-      int qy = r % Hq;
-      int n = r / Hq;
+    const unsigned nq = (unsigned)d.N * Hq * Wq;
+    for (unsigned q = blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += gridDim.x * ppb) {
       float g[V], xin[V];
-      pooled_grad<T, V>(d, n, qy, qx, c, g);
+      pooled_grad<T, V>(d, q, c, g);
       VecIO<T, V>::ld(d.in.ptr, (size_t)q * d.in.pitch + c, xin);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
@@ -266,14 +284,10 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
     }
   }
   if (c >= d.C) return;
-  const long nq = (long)d.N * Hq * Wq;
-  for (long q = (long)blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += (long)gridDim.x * ppb) {
-    int qx = q % Wq;
-    long r = q / Wq;
-    int qy = r % Hq;
-    int n = r / Hq;
+  const unsigned nq = (unsigned)d.N * Hq * Wq;
+  for (unsigned q = blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += gridDim.x * ppb) {
     float g[V];
-    pooled_grad<T, V>(d, n, qy, qx, c, g);
+    pooled_grad<T, V>(d, q, c, g);
     if (d.din2) {   // identity sibling of the same activation (up == 1): its gradient is g itself
       float g2[V];
       const size_t o2 = (size_t)q * d.din2_pitch + c;
@@ -381,6 +395,7 @@ using namespace hrp;
 extern "C" int hrp_ew_fwd(const hrp_ew_desc* d, void* stream) {
   HRP_REQUIRE(d && d->out && d->nin >= 1 && d->nin <= HRP_EW_MAX_IN, "ew_fwd: bad descriptor");
   HRP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0, "ew_fwd: empty");
+  HRP_REQUIRE((int64_t)d->N * d->H * d->W < (1ll << 31), "ew_fwd: more than 2^31 pixels");
   for (int j = 0; j < d->nin; ++j) {
     const hrp_ew_input& in = d->in[j];
     HRP_REQUIRE(in.ptr && in.up >= 1 && d->H % in.up == 0 && d->W % in.up == 0, "ew_fwd: input %d geometry", j);
@@ -395,6 +410,7 @@ static int ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
   HRP_REQUIRE(d && d->dout, "ew_bwd: bad descriptor");
   HRP_REQUIRE(!d->relu || d->out, "ew_bwd: relu needs the forward output");
   HRP_REQUIRE(d->in.up >= 1 && d->H % d->in.up == 0 && d->W % d->in.up == 0, "ew_bwd: geometry");
+  HRP_REQUIRE((int64_t)d->N * d->H * d->W < (1ll << 31), "ew_bwd: more than 2^31 pixels");
   HRP_REQUIRE(d->in.mode == HRP_EW_IDENTITY || d->in.ptr, "ew_bwd: needs forward input values");
   HRP_REQUIRE(d->in.mode != HRP_EW_BN_TRAIN || (d->sums && d->in.stats && d->in.a), "ew_bwd: bn needs sums/stats");
   HRP_REQUIRE(!apply || d->din, "ew_bwd_apply: din");

@@ -85,10 +85,16 @@ __device__ __forceinline__ void wg_dma16(const char* src, char* lds_wave_base) {
                :: "v"(src), "s"(lds) : "memory");   // m0 is scratch for the compiler too: it never keeps a value there
 }
 
-template <typename T, int NT, int NKS>
+// NB = 32-channel blocks per workgroup in each of the cout / cin dimensions.  NB = 2 (1x1 layers, bf16): a
+// 64 x 64 block of dW per workgroup = 4 MFMAs per 4 fragment reads instead of 1 per 2, and half the re-reads of
+// X and dY across workgroups (the 32 x 32 version of the 1x1 layers ran at 80 TFLOP/s, LDS-read bound).
+template <typename T, int NT, int NKS, int NB>
 __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgrad_desc d, const WgradTiling t) {
+  static_assert(NB == 1 || (NT == 1 && Elem<T>::SZ == 2), "NB = 2 is built for 1x1 bf16 only");
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
-  constexpr int P = 32 * SZ;        // LDS pixel row: 32 channels, unpadded (DMA writes lane-linear)
+  constexpr int CB = 32 * NB;       // channels per workgroup block (cout and cin)
+  constexpr int NTE = NT * NB * NB; // accumulator tiles: [tap][cout block][cin block]
+  constexpr int P = CB * SZ;        // LDS pixel row: CB channels, unpadded (DMA writes lane-linear)
   constexpr int NVEC = P / 16;      // 16-byte slots per pixel row
   constexpr int K = WG<T>::K;
   constexpr int MAXP_X = 8, MAXP_DY = 6;    // 1 KiB DMA pieces per wave (host keeps tiles below 32 / 24 KiB)
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   const int l31 = lane & 31, khalf = lane >> 5;
   const int blk = blockIdx.y;
   const int cob = fdiv(blk, t.fd_cib), cib = blk - cob * t.n_cib;
-  const int co0 = cob * 32, ci0 = cib * 32;
+  const int co0 = cob * CB, ci0 = cib * CB;
   const int IS = d.in_stride;
   const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
 #ifdef HRP_TIMELINE
@@ -119,9 +125,9 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
     }
   }
 
-  f32x16 acc[NT];
+  f32x16 acc[NTE];
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NTE; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
@@ -259,9 +265,38 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
     if constexpr (SZ == 2) {
       // the next tile's DMA pieces are issued between the MFMAs (SPP slots per MFMA) so that a full memory
       // queue stalls the wave while the matrix pipe still has work
-      constexpr int SPP = (MAXP_X + MAXP_DY + NKS_ * NT - 1) / (NKS_ * NT);
+      constexpr int SPP = (MAXP_X + MAXP_DY + NKS_ * NTE - 1) / (NKS_ * NTE);
       TileCtx nx{};
       if (more) nx = tile_ctx(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
+      if constexpr (NB == 2) {
+        // 1x1 layer, 64 x 64 block: per k-step 2 dY fragments x 2 X fragments -> 4 MFMAs; the fragments of
+        // k-step ks + 1 are read under the MFMAs of k-step ks
+        bf16x8 fa[2][2], fb[2][2];
+        auto ld2 = [&](int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            bf16x4 lo = WG<T>::tr(lds_dy + ao[ks] + k * 32 * SZ), hi = WG<T>::tr(lds_dy + ao[ks] + k * 32 * SZ + 4 * P);
+            a[k] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            bf16x4 l2 = WG<T>::tr(lds_x + xo0[ks] + tapoff[0] + k * 32 * SZ), h2 = WG<T>::tr(lds_x + xo1[ks] + tapoff[0] + k * 32 * SZ);
+            b[k] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        };
+        ld2(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < NKS_; ++ks) {
+          const int c = ks & 1, n = c ^ 1;
+          if (ks + 1 < NKS_) ld2(ks + 1, fa[n], fb[n]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            WG<T>::mma(fa[c][e >> 1], fb[c][e & 1], acc[e]);
+            if (more) {
+#pragma unroll
+              for (int u = 0; u < SPP; ++u) issue_slot(nx, (ks * 4 + e) * SPP + u);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       // Flattened MFMA sequence q = ks * NT + tp of the tile.  The X fragment of MFMA q + D is read while MFMA q
       // runs (ring of D + 1 fragments: a full next-k-step prefetch would cost 36 more registers and with them
       // the second wave per SIMD that lets this kernel share a CU with the kernels of other lanes); the dY
@@ -293,6 +328,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
         // keep the prefetch distance: without the fence the scheduler sinks the reads next to their MFMA
         __builtin_amdgcn_sched_barrier(0);
       }
+      }   // NB == 1
     } else {
       if (more) issue(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
       auto load = [&](int kb, float& a, float (&b)[NT]) {
@@ -325,31 +361,32 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   float* dump = (float*)smem;
   const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
   // partial slab [g][block][NT*1024], coalesced; a second launch folds the G slabs into dW
-  float* ws = t.use_ws ? (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NT * 1024) : nullptr;
+  float* ws = t.use_ws ? (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NTE * 1024) : nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();
-    float* mine = dump + wave * (NT * 512) + 4 * khalf * 32 + l31;
+    float* mine = dump + wave * (NTE * 512) + 4 * khalf * 32 + l31;
 #pragma unroll
-    for (int tp = 0; tp < NT; ++tp)
+    for (int tp = 0; tp < NTE; ++tp)
 #pragma unroll
       for (int j = 0; j < 8; ++j)   // MFMA register 8h + j -> row 16h + (j & 3) + 8 (j >> 2) + 4 khalf
         mine[(tp * 16 + (j & 3) + 8 * (j >> 2)) * 32] = acc[tp][8 * h + j];
     __syncthreads();
-    for (int f = tid; f < NT * 128; f += 256) {
+    for (int f = tid; f < NTE * 128; f += 256) {
       float4 v = ((const float4*)dump)[f];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
-        const float4 u = ((const float4*)(dump + w * (NT * 512)))[f];
+        const float4 u = ((const float4*)(dump + w * (NTE * 512)))[f];
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
       const int tp = f >> 7, rem = f & 127;
       if (ws) {
         ((float4*)(ws + tp * 1024 + 512 * h))[rem] = v;
       } else {
-        const int co = co0 + 16 * h + (rem >> 3), cin = ci0 + 4 * (rem & 7);
+        const int tap = tp / (NB * NB), cbk = (tp % (NB * NB)) / NB, ibk = tp % NB;
+        const int co = co0 + 32 * cbk + 16 * h + (rem >> 3), cin = ci0 + 32 * ibk + 4 * (rem & 7);
         if (co < d.Cout) {
-          float* o = d.dw + ((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tp;
+          float* o = d.dw + ((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tap;
           if (cin < d.dw_cin) atomicAdd(o, v.x);
           if (cin + 1 < d.dw_cin) atomicAdd(o + tstride, v.y);
           if (cin + 2 < d.dw_cin) atomicAdd(o + 2 * tstride, v.z);
@@ -362,7 +399,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
 }
 
 // dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci]
-template <int NT>
+template <int NTE, int NB>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc d, int G, int pairs, int n_cib) {
   const int blk = blockIdx.y;
   const int cob = blk / n_cib, cib = blk - cob * n_cib;
@@ -370,8 +407,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc 
   // block = 64 consecutive elements x 4 slab phases; lanes read 256 contiguous bytes of a slab, 8 loads
   // in flight per thread
   __shared__ float part[4][64];
-  const float* ws = (const float*)d.workspace + (size_t)blk * (NT * 1024);
-  const size_t gstride = (size_t)pairs * (NT * 1024);
+  const float* ws = (const float*)d.workspace + (size_t)blk * (NTE * 1024);
+  const size_t gstride = (size_t)pairs * (NTE * 1024);
   const int e = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + e;
   float s = 0.f;
@@ -388,19 +425,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc 
   __syncthreads();
   if (ph == 0) {
     s = part[0][e] + part[1][e] + part[2][e] + part[3][e];
-    int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
-    int co = cob * 32 + row, cin = cib * 32 + ci;
+    const int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
+    const int tap = tp / (NB * NB), cbk = (tp % (NB * NB)) / NB, ibk = tp % NB;
+    const int co = (cob * NB + cbk) * 32 + row, cin = (cib * NB + ibk) * 32 + ci;
     if (co < d.Cout && cin < d.dw_cin) {
-      float* o = &d.dw[((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tp];
+      float* o = &d.dw[((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tap];
       *o = d.accumulate ? *o + s : s;
     }
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int NB>
 static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   constexpr int SZ = Elem<T>::SZ;
-  constexpr int P = 32 * SZ;
+  constexpr int P = 32 * NB * SZ;
+  constexpr int NTE = NT * NB * NB;
   int mindy = 1 << 30, maxdy = -(1 << 30), mindx = 1 << 30, maxdx = -(1 << 30);
   for (int i = 0; i < d.ntaps; ++i) {
     mindy = d.dy_t[i] < mindy ? d.dy_t[i] : mindy; maxdy = d.dy_t[i] > maxdy ? d.dy_t[i] : maxdy;
@@ -433,7 +472,7 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
     int main_bytes = t.lds_tab_off + BM * 4;
     if (t.x_pieces > 32 || t.dy_pieces > 24) { lds = 1 << 30; continue; }
     t.lds_red_off = 0;  // the cross-wave exchange reuses the tiles
-    int red_bytes = NT * 8192;
+    int red_bytes = NTE * 8192;
     lds = main_bytes > red_bytes ? main_bytes : red_bytes;
     long pixels = (long)d.N * d.Ho * d.Wo;
     if (lds <= budget + 8192 && (BM == BM_MIN || pixels >= BM)) break;
@@ -455,7 +494,7 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
               d.in_stride);
     return HRP_ERR_ARG;
   }
-  t.n_cob = cdiv(d.Cout, 32); t.n_cib = cdiv(d.Cin, 32);
+  t.n_cob = cdiv(d.Cout, 32 * NB); t.n_cib = cdiv(d.Cin, 32 * NB);
   int pairs = t.n_cob * t.n_cib;
   // workgroups per (cout, cin) block: ~2 per CU over the whole launch; each walks ntiles / G pixel tiles
   static const int wg_total = getenv("HRP_WGRAD_WGS") ? atoi(getenv("HRP_WGRAD_WGS")) : 256;   // tuning knob
@@ -469,20 +508,33 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   return HRP_OK;
 }
 
+// 64 x 64 blocks for the 1x1 bf16 layers with at least 64 channels on both sides
+template <typename T, int NT>
+static constexpr bool can_nb2() { return NT == 1 && Elem<T>::SZ == 2; }
+static inline bool want_nb2(const hrp_wgrad_desc& d) { return d.Cout >= 64 && d.Cin >= 64 && d.dw_cin >= 64; }
+
+template <typename T, int NT, int NB>
+static int64_t wgrad_ws_bytes_nb(const hrp_wgrad_desc& d) {
+  WgradTiling t{};
+  if (wgrad_tiling<T, NT, NB>(d, t) != HRP_OK) return 0;
+  return (int64_t)t.G * t.n_cob * t.n_cib * (NT * NB * NB) * 1024 * 4;
+}
 template <typename T, int NT>
 static int64_t wgrad_ws_bytes(const hrp_wgrad_desc& d) {
-  WgradTiling t{};
-  if (wgrad_tiling<T, NT>(d, t) != HRP_OK) return 0;
-  return (int64_t)t.G * t.n_cob * t.n_cib * NT * 1024 * 4;
+  if constexpr (can_nb2<T, NT>()) {
+    if (want_nb2(d)) return wgrad_ws_bytes_nb<T, NT, 2>(d);
+  }
+  return wgrad_ws_bytes_nb<T, NT, 1>(d);
 }
 
-template <typename T, int NT>
-static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
+template <typename T, int NT, int NB>
+static int launch_wgrad_nb(const hrp_wgrad_desc& d, hipStream_t s) {
+  constexpr int NTE = NT * NB * NB;
   WgradTiling t{};
-  int rc = wgrad_tiling<T, NT>(d, t);
+  int rc = wgrad_tiling<T, NT, NB>(d, t);
   if (rc != HRP_OK) return rc;
   const int pairs = t.n_cob * t.n_cib;
-  const int64_t need = (int64_t)t.G * pairs * NT * 1024 * 4;
+  const int64_t need = (int64_t)t.G * pairs * NTE * 1024 * 4;
   t.use_ws = (d.workspace && d.workspace_bytes >= need) ? 1 : 0;
   if (!t.use_ws && !d.accumulate) {
     if (d.dw_tap_stride > 0 && d.dw_tap_stride != d.ntaps) {
@@ -494,11 +546,11 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
   void (*kern)(const hrp_wgrad_desc, const WgradTiling) = nullptr;
   if constexpr (Elem<T>::SZ == 2) {
     // bf16: k-steps of 16 pixels per wave and tile = BM / 64, unrolled at compile time
-    kern = t.BM == 256 ? conv_wgrad_kernel<T, NT, 4> : t.BM == 128 ? conv_wgrad_kernel<T, NT, 2> : conv_wgrad_kernel<T, NT, 1>;
+    kern = t.BM == 256 ? conv_wgrad_kernel<T, NT, 4, NB> : t.BM == 128 ? conv_wgrad_kernel<T, NT, 2, NB> : conv_wgrad_kernel<T, NT, 1, NB>;
   } else {
-    kern = conv_wgrad_kernel<T, NT, 0>;
+    kern = conv_wgrad_kernel<T, NT, 0, NB>;
   }
-  static bool attr_set[5] = {};   // per (T, NT) instantiation, indexed by BM / 64
+  static bool attr_set[5] = {};   // per (T, NT, NB) instantiation, indexed by BM / 64
   if (!attr_set[t.BM / 64]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[t.BM / 64] = true;
@@ -506,8 +558,15 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(t.G, pairs), dim3(256), t.lds_bytes, s, d, t);
   rc = check_launch("conv_wgrad_kernel");
   if (rc != HRP_OK || !t.use_ws) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel<NT>, dim3(NT * 1024 / 64, pairs), dim3(256), 0, s, d, t.G, pairs, t.n_cib);
+  hipLaunchKernelGGL((wgrad_reduce_kernel<NTE, NB>), dim3(NTE * 1024 / 64, pairs), dim3(256), 0, s, d, t.G, pairs, t.n_cib);
   return check_launch("wgrad_reduce_kernel");
+}
+template <typename T, int NT>
+static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
+  if constexpr (can_nb2<T, NT>()) {
+    if (want_nb2(d)) return launch_wgrad_nb<T, NT, 2>(d, s);
+  }
+  return launch_wgrad_nb<T, NT, 1>(d, s);
 }
 
 }  // namespace hrp

@@ -334,7 +334,11 @@ static EwGeom geom(int C, int vec, bool vec_ok, long npix, int maxblocks) {
   g.V = (vec_ok && C % vec == 0) ? vec : 1;
   int nv = C / g.V;
   int tpr = 1;
-  while (tpr < nv && tpr < 256) tpr <<= 1;
+  // at most 64 vector columns (512 channels) per block: the block's channel constants then always go through the
+  // LDS table (per-thread derivation = 16 dependent-latency loads per channel, 10x slower on the 1024 / 2048-channel
+  // ResNet layers); wider tensors are split into channel slabs (grid.y)
+  const int tpr_max = vec_ok && C % vec == 0 ? TAB_CH / vec : 256;
+  while (tpr < nv && tpr < tpr_max && tpr < 256) tpr <<= 1;
   g.tpr = tpr;
   g.nslab = cdiv(nv, tpr);
   int ppb = 256 / tpr;

@@ -362,7 +362,7 @@ def main():
             v[0] += 1
             v[1] += e0.elapsed_time(e1)
             v[2] += fl
-        for (name, key), v in sorted(shp.items(), key=lambda kv: -kv[1][1])[:40]:
+        for (name, key), v in sorted(shp.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("HRP_BENCH_SHAPES", "40")) if os.environ.get("HRP_BENCH_SHAPES", "1") != "1" else 40]:
             tf = f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s" if v[2] else ""
             print(f"{name:24s} {key:44s} n={v[0]:4d} {v[1]:8.3f} ms  avg {v[1] / v[0] * 1e3:7.1f} us {tf}", file=sys.stderr)
     fam = {}

@@ -25,6 +25,12 @@ struct VecIO {
   }
 };
 
+// x rotated right by N lanes inside each row of 16 lanes (DPP row_ror)
+template <int N>
+__device__ __forceinline__ float ew_row_ror(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+
 constexpr int TAB_CH = 512;  // channels per block whose constants are shared through LDS
 
 // scale / shift / mean / invstd of ONE channel of an input
@@ -210,7 +216,12 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   if (tpr < 64) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      for (int o = 32; o >= tpr; o >>= 1) {
+      // inside a row of 16 lanes: DPP rotations (VALU speed); across rows: shuffles
+      if (tpr <= 8) { s0[i] += ew_row_ror<8>(s0[i]); s1[i] += ew_row_ror<8>(s1[i]); }
+      if (tpr <= 4) { s0[i] += ew_row_ror<4>(s0[i]); s1[i] += ew_row_ror<4>(s1[i]); }
+      if (tpr <= 2) { s0[i] += ew_row_ror<2>(s0[i]); s1[i] += ew_row_ror<2>(s1[i]); }
+      if (tpr <= 1) { s0[i] += ew_row_ror<1>(s0[i]); s1[i] += ew_row_ror<1>(s1[i]); }
+      for (int o = 32; o >= (tpr > 16 ? tpr : 16); o >>= 1) {
         s0[i] += __shfl_xor(s0[i], o, 64);
         s1[i] += __shfl_xor(s1[i], o, 64);
       }
@@ -375,7 +386,10 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
   const int up = d.in.up;
   static const int red_blocks = getenv("HRP_EW_RED_BLOCKS") ? atoi(getenv("HRP_EW_RED_BLOCKS")) : 512;   // tuning knob
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : red_blocks);
+  // (the reduce ends with 2 C atomics per block: 512 blocks, except on the >= 64 MiB tensors where the streaming
+  // part dominates - 126 -> 85 us on 256 channels @64x64)
+  const bool big = (int64_t)d.N * d.H * d.W * d.C * SZ >= (64ll << 20);
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : (big ? 2 * red_blocks : red_blocks));
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;

@@ -181,6 +181,8 @@ def main():
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    if os.environ.get("HRP_BENCH_DEVICE"):   # functional test of the N > 1 structure with all ranks on one GPU (gloo)
+        local = int(os.environ["HRP_BENCH_DEVICE"])
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if not nv.lib().hrp_device_ok():

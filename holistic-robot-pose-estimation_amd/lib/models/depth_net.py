@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from hrpe_amd.runtime import PlannedModule
 from .backbones.HRnet import Conv2d, get_hrnet
+from .backbones.Resnet import get_resnet
 
 
 class RootNet(PlannedModule):
@@ -17,8 +18,8 @@ class RootNet(PlannedModule):
                                       generate_feat=True, generate_hm=False)
             self.inplanes = 2048
         elif backbone in ["resnet34", "resnet50", "resnet"]:
-            raise NotImplementedError("ResNet root backbones are not built yet (HRNet-W32 is the shipped DepthNet, "
-                                      "configs/panda/depthnet.yaml:17)")
+            self.backbone = get_resnet(backbone)                       # depth_net.py:16-18
+            self.inplanes = self.backbone.block.expansion * 512
         else:
             raise NotImplementedError
         if pred_xy or use_offset or add_fc:
@@ -31,9 +32,13 @@ class RootNet(PlannedModule):
 
     def _build(self, pb, x, k_value):
         N, Cc, H, W = x.shape
-        t = pb.image_input("x", N, Cc, H, W)
         kv = pb.vector_input("k_value", N, 1, dense=True)
-        _, feat = self.backbone.emit(pb, t)
+        if self.backbone_name in ["hrnet", "hrnet32"]:
+            t = pb.image_input("x", N, Cc, H, W)
+            _, feat = self.backbone.emit(pb, t)
+        else:   # depth_net.py:93-95: global average pooling of the ResNet feature map
+            t = pb.image_input_s2d("x", N, Cc, H, W)
+            feat = pb.avgpool(self.backbone.emit(pb, t))
         gamma = self.depth_layer.emit(pb, feat)          # 1x1 conv on [N,2048,1,1] == linear (depth_net.py:121-123)
         depth = pb.row_scale(gamma, kv)                  # depth = gamma * k_value (depth_net.py:125)
         return ["x", "k_value"], [("dense", depth, (N, 1))], {"x": t}

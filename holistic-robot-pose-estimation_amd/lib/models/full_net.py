@@ -115,7 +115,8 @@ class RootNetwithRegInt(PlannedModule):
                                               pretrain=True, generate_feat=True, generate_hm=False)
             self.inplanes = 2048
         elif self.rootnet_backbone_name in ["resnet", "resnet50", "resnet34"]:
-            raise NotImplementedError("ResNet root backbone is not built yet; use rootnet_backbone_name='hrnet32'")
+            self.rootnet_backbone = get_resnet(self.rootnet_backbone_name)       # full_net.py:136-138
+            self.inplanes = self.rootnet_backbone.block.expansion * 512
         else:
             raise NotImplementedError
         self.multi_kp = args.multi_kp
@@ -169,6 +170,19 @@ class RootNetwithRegInt(PlannedModule):
             yield
         out["heat"] = self.final_layer.emit(pb, h)
 
+    def _resnet_root_units(self, pb, xs, out):
+        """Generator over a ResNet root trunk (full_net.py:262-266: global average pool of the feature map), one unit
+        per step, for emit_trunks' rider lane."""
+        rb = self.rootnet_backbone
+        y = pb.stem7x7_s2d(xs, rb.conv1.weight, want_stats=pb.plan.training)
+        h = pb.maxpool3x3s2(pb.act([Term(y, rb.bn1)], relu=True))
+        yield
+        for layer in (rb.layer1, rb.layer2, rb.layer3, rb.layer4):
+            for blk in layer:
+                h = blk.emit(pb, h)
+                yield
+        out["feat"] = pb.avgpool(h)
+
     def _iter_head(self, pb, xf, init_buf, np_, fc1, fc2, dec):
         """full_net.py:318-331: p <- p + dec(drop(fc2(drop(fc1([xf; p])))))  x n_iter."""
         N = xf.N
@@ -184,25 +198,45 @@ class RootNetwithRegInt(PlannedModule):
         N = x_reg.shape[0]
         J, root = self.num_joints, self.reference_keypoint_id
         resnet_reg = self.backbone_name in _RESNETS
+        resnet_root = self.rootnet_backbone_name not in _HRNETS
         xr = (pb.image_input_s2d if resnet_reg else pb.image_input)("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3])
-        xo = pb.image_input("x_root", N, 3, x_root.shape[2], x_root.shape[3])
+        xo = (pb.image_input_s2d if resnet_root else pb.image_input)("x_root", N, 3, x_root.shape[2], x_root.shape[3])
         kv = pb.vector_input("k_value", N, 1, dense=True)
         Km = pb.vector_input("K", N, 9, dense=True)
-        # the two backbones share nothing until pose_geometry: two lanes (concurrent HIP graph branches)
-        # (lockstep emission: see emit_trunks)
-        if resnet_reg:
-            # the ResNet regression chain rides along the flat blocks of the HRNet root trunk (one unit per block)
-            res = {}
-            rider = self._resnet_reg_units(pb, xr, res)
-            (ys_root,) = emit_trunks(pb, [self.rootnet_backbone], [xo], rider=rider)
+        # The trunks share nothing until pose_geometry.  HRNet trunks are emitted in lockstep (emit_trunks: one flat
+        # parallel block per step, a lane per branch); a ResNet chain rides along those blocks as one more lane.
+        res, rootd = {}, {}
+        reg_units = self._resnet_reg_units(pb, xr, res) if resnet_reg else None
+        root_units = self._resnet_root_units(pb, xo, rootd) if resnet_root else None
+        if resnet_reg and resnet_root:
             with pb.parallel(2) as par:
                 with par.lane(0):
-                    for _ in rider:      # whatever the trunk blocks did not reach
+                    for _ in reg_units:
+                        pass
+                with par.lane(1):
+                    for _ in root_units:
+                        pass
+            heat, xf, feat_root = res["heat"], res["xf"], rootd["feat"]
+            gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+        elif resnet_reg:
+            (ys_root,) = emit_trunks(pb, [self.rootnet_backbone], [xo], rider=reg_units)
+            with pb.parallel(2) as par:
+                with par.lane(0):
+                    for _ in reg_units:      # whatever the trunk blocks did not reach
                         pass
                     heat, xf = res["heat"], res["xf"]
                 with par.lane(1):
                     _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
                     gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+        elif resnet_root:
+            (ys_reg,) = emit_trunks(pb, [self.reg_backbone], [xr], rider=root_units)
+            with pb.parallel(2) as par:
+                with par.lane(0):
+                    heat, xf = self.reg_backbone.emit_heads(pb, ys_reg)
+                with par.lane(1):
+                    for _ in root_units:
+                        pass
+                    gamma = pb.dense(self.depth_layer.emit(pb, rootd["feat"]))
         else:
             ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])
             with pb.parallel(2) as par:

@@ -58,10 +58,16 @@ def uvz2xyz_singlepoint(uv, z, K):
     return torch.matmul(inv_intrinsics(K), v.unsqueeze(-1)).squeeze(-1)
 
 
-def rootnet_forward(sd, x, k_value, training=False):
-    """RootNet('hrnet32').forward, depth_net.py:92-137 (pred_xy/use_offset/add_fc off)."""
-    feat = hrnet_w32_forward(sd, x, prefix="backbone.", generate_hm=False, generate_feat=True,
-                             training=training)
+def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32"):
+    """RootNet(backbone).forward, depth_net.py:92-137 (pred_xy/use_offset/add_fc off); a ResNet trunk is followed by
+    global average pooling (:93-95)."""
+    if backbone.startswith("resnet"):
+        from .resnet import resnet_forward
+        fm = resnet_forward(sd, x, prefix="backbone.", name="resnet50" if backbone == "resnet" else backbone, training=training)
+        feat = fm.flatten(2).mean(2)
+    else:
+        feat = hrnet_w32_forward(sd, x, prefix="backbone.", generate_hm=False, generate_feat=True,
+                                 training=training)
     gamma = F.conv2d(feat[:, :, None, None], sd["depth_layer.weight"], sd["depth_layer.bias"])
     return gamma.view(-1, 1) * k_value.view(-1, 1)
 
@@ -77,12 +83,17 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
-                 fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32"):
+                 fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32"):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
-    feat_root = hrnet_w32_forward(sd, x_root, prefix="rootnet_backbone.", generate_hm=False,
-                                  generate_feat=True, training=training)
+    if root_backbone.startswith("resnet"):                                            # :262-266
+        from .resnet import resnet_forward
+        feat_root = resnet_forward(sd, x_root, prefix="rootnet_backbone.",
+                                   name="resnet50" if root_backbone == "resnet" else root_backbone, training=training).flatten(2).mean(2)
+    else:
+        feat_root = hrnet_w32_forward(sd, x_root, prefix="rootnet_backbone.", generate_hm=False,
+                                      generate_feat=True, training=training)
     gamma = F.conv2d(feat_root[:, :, None, None], sd["depth_layer.weight"], sd["depth_layer.bias"])
     pred_depth = (gamma.view(-1, 1) * k_value.view(-1, 1)).reshape(B, 1) / 1000.0   # :281-282
     if reg_backbone.startswith("resnet"):                                             # :293-296

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from .hrnet import _Ctx, _bn, _conv
 
-LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}
+LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}   # Bottleneck variants (Resnet.py:9-13)
 
 
 def _bottleneck(c, key, x, stride):

@@ -209,6 +209,42 @@ def gen_depthnet():
     print("depthnet ok", out["depth_eval"].ravel(), out["loss"])
 
 
+def gen_depthnet_resnet():
+    """DepthNet with a ResNet-50 trunk (depth_net.py:16-18, 93-95) and the full network with ResNet-50 for BOTH
+    trunks, eval; one DepthNet training step (train_depthnet.py:231-250)."""
+    from lib.models.backbones import Resnet as ref_resnet
+    ref_resnet.ResNet.init_weights = lambda self, name: None
+    m = get_rootnet("resnet50")
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    x, _, kv, _ = synth_inputs(2)
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        out["depth_eval"] = m(x, kv).numpy()
+    m.train()
+    gt = torch.tensor([[1.1], [0.7]])
+    pred = m(x, kv) / 1000.0
+    loss = torch.nn.L1Loss()(pred, gt)
+    loss.backward()
+    out["depth_train"], out["loss"], out["gt_depth"] = pred.detach().numpy(), np.array(loss.item()), gt.numpy()
+    grad_fixture(m, ["backbone.conv1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer3.2.conv2.weight",
+                     "backbone.layer4.0.downsample.0.weight", "backbone.layer4.2.bn3.weight", "depth_layer.weight"], out, "")
+    args = rh.default_args()
+    args.backbone_name = args.rootnet_backbone_name = "resnet50"
+    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE,
+            "cam_params": np.eye(4, dtype=float), "init_pose_from_mean": True}
+    full = RootNetwithRegInt(init, args)
+    full.load_state_dict(synth_state_dict(full.state_dict()))
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    for n, t in zip(NAMES8, o):
+        out["full:" + n] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_depthnet_resnet.npz"), **out)
+    print("depthnet resnet ok", out["depth_eval"].ravel(), out["loss"])
+
+
 def build_full(backbone_name=None):
     args = rh.default_args()
     if backbone_name is not None:

@@ -236,6 +236,37 @@ def test_full_train_step_resnet_golden():
     assert torch.isfinite(loss) and torch.isfinite(params["reg_backbone.conv1.weight"].grad).all()
 
 
+def test_depthnet_and_full_resnet_root_golden():
+    """ResNet-50 as the DepthNet trunk (eval + one training step) and as both trunks of the full network (eval)."""
+    from hrpe_amd.lib.models.depth_net import get_rootnet
+    g = load("golden_depthnet_resnet.npz")
+    m = get_rootnet("resnet50")
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m = m.to(DEV).eval()
+    x, _, kv, _ = synth_inputs(2)
+    with torch.no_grad():
+        d = m(x.to(DEV), kv.to(DEV))
+    np.testing.assert_allclose(d.cpu().numpy(), g["depth_eval"], rtol=3e-4)
+    m.train()
+    pred = m(x.to(DEV), kv.to(DEV)) / 1000.0
+    loss = torch.nn.functional.l1_loss(pred, torch.tensor(g["gt_depth"]).to(DEV))
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["depth_train"], rtol=1e-3)
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            summary_check(params[name].grad, g, f"grad:{name}:", GRAD_TOL, what="depthnet/resnet ")
+    full = build_full(backbone_name="resnet50", rootnet_backbone_name="resnet50").eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = full(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    for n, t in zip(NAMES8, out):
+        ref = g["full:" + n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+
+
 def test_lanes_match_serial_execution():
     """The lane (multi-stream) schedule of a plan computes what the same launch list computes on one stream.  Two
     runs of one schedule already differ (fp32 atomics in the BN statistics, amplified by the B = 2 train-mode net),

@@ -250,3 +250,37 @@ def test_full_train_golden(robot):
             check_summary(sd[name].grad, g, f"grad:{name}:", rtol=5e-3, atol=1e-8)
         if key.startswith("buf:"):
             np.testing.assert_allclose(sd[key[4:]][:64].detach().numpy(), g[key], rtol=1e-5, atol=1e-7)
+
+
+def test_depthnet_resnet_golden(robot):
+    """ResNet-50 as the DepthNet trunk and as both trunks of the full network (depth_net.py:16-18, 93-95;
+    full_net.py:136-138, 262-266)."""
+    from hrpe_amd.lib.models.backbones.Resnet import get_resnet
+    g = load("golden_depthnet_resnet.npz")
+    shapes = {"backbone." + k: v for k, v in get_resnet("resnet50", pretrain=False).state_dict().items()}
+    shapes["depth_layer.weight"], shapes["depth_layer.bias"] = torch.empty(1, 2048, 1, 1), torch.empty(1)
+    sd = synth_state_dict(shapes)
+    x, _, kv, _ = synth_inputs(2)
+    with torch.no_grad():
+        d = heads.rootnet_forward(sd, x, kv, backbone="resnet50")
+    np.testing.assert_allclose(d.numpy(), g["depth_eval"], rtol=1e-5)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    pred = heads.rootnet_forward(sd, x, kv, training=True, backbone="resnet50") / 1000.0
+    loss = torch.nn.functional.l1_loss(pred, torch.tensor(g["gt_depth"]))
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().numpy(), g["depth_train"], rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            check_summary(sd[name].grad, g, f"grad:{name}:", rtol=5e-3, atol=1e-8)
+    fsd = full_sd_resnet()
+    fsd = {k: v for k, v in fsd.items() if not k.startswith("rootnet_backbone.")}
+    fsd.update(synth_state_dict({"rootnet_backbone." + k: v for k, v in get_resnet("resnet50", pretrain=False).state_dict().items()}))
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(fsd, robot, x_reg, x_root, kv, K, reg_backbone="resnet50", root_backbone="resnet50")
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g["full:" + n], atol=1e-5, rtol=1e-5, err_msg=n)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from hrpe_amd import _native as nv
-from hrpe_amd.lib.dataset.const import JOINT_NAMES, LINK_NAMES
+from hrpe_amd.lib.dataset.const import BAXTER_KEYPOINT_JOINTS, JOINT_NAMES, LINK_NAMES
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "assets")
 
@@ -22,7 +22,10 @@ _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 def _default_urdf(robot_type):
     # reference location first (lib/config.py:33), then the kinematics-only file shipped with this package
     cands = {"panda": ["data/deps/panda-description/panda.urdf", os.path.join(_ASSETS, "panda_kinematics.urdf")],
-             "kuka": ["data/deps/kuka-description/iiwa_description/urdf/iiwa7.urdf"]}
+             "kuka": ["data/deps/kuka-description/iiwa_description/urdf/iiwa7.urdf",
+                      os.path.join(_ASSETS, "kuka_kinematics.urdf")],
+             "baxter": ["data/deps/baxter-description/baxter_description/urdf/baxter.urdf",
+                        os.path.join(_ASSETS, "baxter_kinematics.urdf")]}
     for c in cands.get(robot_type, []):
         if os.path.isfile(c):
             return c
@@ -149,17 +152,31 @@ class URDFRobot:
             raise NotImplementedError(f"robot '{robot_type}' has no keypoint table in this build")
         self.robot_type = robot_type
         self.urdf_path = urdf_path or _default_urdf(robot_type)
-        self.link_names = LINK_NAMES[robot_type]
         self.actuated_joint_names = JOINT_NAMES[robot_type]
         self.global_scale = 1.0
-        # panda / kuka keypoints sit at the link origins (reference urdf_robot.py:53-56)
-        self.offsets = torch.zeros(1, len(self.link_names), 3, 1)
-        self.chain, names = parse_chain(self.urdf_path, self.link_names)
+        self.link_names, offsets = self.get_link_names_and_offsets()
+        self.offsets = torch.as_tensor(offsets, dtype=torch.float32).reshape(1, len(self.link_names), 3, 1)
+        self.chain, names = parse_chain(self.urdf_path, self.link_names, offsets)
         if names != list(self.actuated_joint_names):
             raise ValueError(f"URDF actuated joints {names} differ from JOINT_NAMES {self.actuated_joint_names}")
         self.dof = self.chain.dof
         self.nkp = len(self.link_names)
         self._dev = {}
+
+    def get_link_names_and_offsets(self):
+        """(keypoint link names, [nkp,3] offsets in those links' frames), reference urdf_robot.py:52-74."""
+        if self.robot_type in ("panda", "kuka"):  # keypoints at the link origins
+            names = LINK_NAMES[self.robot_type]
+            return names, np.zeros((len(names), 3))
+        if self.robot_type == "baxter":  # keypoints at joint origins, carried by the joints' parent links
+            joints = {n.attrib["name"]: n for n in ET.parse(self.urdf_path).getroot().findall("joint")}
+            names, offsets = [], []
+            for jn in BAXTER_KEYPOINT_JOINTS:
+                o = joints[jn].find("origin")
+                offsets.append([float(v) for v in o.attrib.get("xyz", "0 0 0").split()] if o is not None else [0.0, 0.0, 0.0])
+                names.append(joints[jn].find("parent").attrib["link"])
+            return names, np.array(offsets)
+        raise NotImplementedError(self.robot_type)
 
     def chain_on(self, device):
         key = str(device)

@@ -19,11 +19,19 @@ import torch
 LINK_NAMES = {
     "panda": ["panda_link0", "panda_link2", "panda_link3", "panda_link4",
               "panda_link6", "panda_link7", "panda_hand"],
+    "kuka": ["iiwa_link_0", "iiwa_link_1", "iiwa_link_2", "iiwa_link_3",
+             "iiwa_link_4", "iiwa_link_5", "iiwa_link_6", "iiwa_link_7"],
 }
+_ARM = ["s0", "s1", "e0", "e1", "w0", "w1", "w2"]
 JOINT_NAMES = {
     "panda": ["panda_joint1", "panda_joint2", "panda_joint3", "panda_joint4",
               "panda_joint5", "panda_joint6", "panda_joint7", "panda_finger_joint1"],
+    "kuka": ["iiwa_joint_1", "iiwa_joint_2", "iiwa_joint_3", "iiwa_joint_4",
+             "iiwa_joint_5", "iiwa_joint_6", "iiwa_joint_7"],
+    "baxter": ["head_pan"] + [side + "_" + j for j in _ARM for side in ("right", "left")],
 }
+# urdf_robot.py:61-65: baxter keypoints are the origins of these joints in their parent links
+BAXTER_KEYPOINT_JOINTS = ["torso_t0"] + [side + "_" + j for j in _ARM + ["hand"] for side in ("right", "left")]
 
 
 def _rpy_matrix(rpy):
@@ -153,10 +161,15 @@ class Robot:
 
     def __init__(self, urdf_path, robot_type="panda"):
         self.tree = Tree(urdf_path)
-        self.link_names = LINK_NAMES[robot_type]
         self.dof = len(JOINT_NAMES[robot_type])
         assert [j["name"] for j in self.tree.actuated] == JOINT_NAMES[robot_type]
-        self.offsets = torch.zeros(len(self.link_names), 3)  # panda / kuka: urdf_robot.py:53-56
+        if robot_type == "baxter":  # urdf_robot.py:57-74
+            by_name = {j["name"]: j for j in self.tree.joints}
+            self.link_names = [by_name[n]["parent"] for n in BAXTER_KEYPOINT_JOINTS]
+            self.offsets = torch.as_tensor(np.stack([by_name[n]["origin"][:3, 3] for n in BAXTER_KEYPOINT_JOINTS])).float()
+        else:  # panda / kuka: urdf_robot.py:53-56
+            self.link_names = LINK_NAMES[robot_type]
+            self.offsets = torch.zeros(len(self.link_names), 3)
 
     def get_TWL(self, q):
         return link_poses(self.tree, q, self.link_names)

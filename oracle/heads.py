@@ -104,7 +104,7 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
     else:
         heat, xf = hrnet_w32_forward(sd, x_reg, prefix="reg_backbone.", generate_hm=True,
                                      generate_feat=True, training=training)
-    uvd = soft_argmax_uvd(heat, root=root, fix_root=fix_root)
+    uvd = soft_argmax_uvd(heat, num_joints=len(robot.link_names), root=root, fix_root=fix_root)
     xyz_int = uvd_to_xyz(uvd, K, pred_depth, image_size, depth_factor)
     root_uv = (uvd[:, root, :2] + 0.5) * image_size                                  # :302
     trans = uvz2xyz_singlepoint(root_uv, pred_depth, K)                               # :305

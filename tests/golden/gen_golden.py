@@ -8,11 +8,14 @@ Fixtures (reference call site that produced each):
   golden_fk.npz          URDFRobot.get_keypoints / get_keypoints_root / get_rotation_at_specific_root
                          (lib/utils/urdf_robot.py:82-199), point_projection_from_3d_tensor
                          (lib/utils/transforms.py:17-21), autograd grads; q=0 limb lengths.
+  golden_fk_kuka.npz / golden_fk_baxter.npz   the same for the 7-DoF iiwa7 chain and the 15-DoF Baxter tree
+                         (keypoint offsets of urdf_robot.py:57-74), generated with `fk_kuka fk_baxter`.
   golden_integral.npz    HeatmapIntegralPose.forward, hrnet branch (lib/utils/integral.py:97-186).
   golden_hrnet_eval.npz  PoseHighResolutionNet.forward eval, hm+feat (HRnet.py:499-570) + stage taps.
   golden_depthnet.npz    RootNet('hrnet32') eval forward, and train-mode L1 loss + grads
                          (lib/models/depth_net.py:92-137, scripts/train_depthnet.py:231-250).
   golden_full_eval.npz   RootNetwithRegInt.forward eval 8-tuple (lib/models/full_net.py:239-397).
+  golden_full_eval_baxter.npz   the same for robot_type = "baxter" (15 DoF, 17 key-points), `full_eval_baxter`.
   golden_full_eval_resnet.npz / golden_full_train_resnet.npz   the same with backbone_name = "resnet50" (ResNet-50
                          trunk + deconv head of the shipped full.yaml), generated with `full_eval_resnet full_train_resnet`.
   golden_full_train.npz  lib/core/function.py farward_loss(train=True): loss terms + grads + BN
@@ -67,12 +70,13 @@ def random_rotations(g, n):
     return R.reshape(n, 3, 3).astype(np.float32)
 
 
-def gen_fk():
-    robot = URDFRobot("panda")
+def gen_fk(robot_type="panda", other_root=3):
+    robot = URDFRobot(robot_type)
     g = np.random.Generator(np.random.PCG64(1234))
     n = 256
-    b = np.array(JOINT_BOUNDS["panda"], dtype=np.float64)
-    q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((n, 8))).astype(np.float32)
+    b = np.array(JOINT_BOUNDS[robot_type], dtype=np.float64)
+    dof, nkp = len(b), len(robot.link_names)
+    q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((n, dof))).astype(np.float32)
     rot6d = (random_rotations(g, n)[:, :2, :].reshape(n, 6)
              * g.uniform(0.5, 2.0, (n, 1)) + g.normal(0, 0.05, (n, 6))).astype(np.float32)
     t = np.stack([g.uniform(-.3, .3, n), g.uniform(-.3, .3, n), g.uniform(.6, 2.0, n)], 1).astype(np.float32)
@@ -84,10 +88,11 @@ def gen_fk():
     K[:, 1, 2] = 128 + g.uniform(-20, 20, n)
     K[:, 2, 2] = 1
     out = dict(q=q, rot6d=rot6d, t=t, K=K)
-    wx = g.normal(size=(n, 7, 3)).astype(np.float32)
-    wu = g.normal(size=(n, 7, 2)).astype(np.float32) * 1e-2
+    wx = g.normal(size=(n, nkp, 3)).astype(np.float32)
+    wu = g.normal(size=(n, nkp, 2)).astype(np.float32) * 1e-2
     out["w_xyz"], out["w_uv"] = wx, wu
-    for root in (0, 3):
+    out["roots"] = np.array([0, other_root])
+    for root in (0, other_root):
         tq, tr, tt = [torch.tensor(a, requires_grad=True) for a in (q, rot6d, t)]
         xyz = robot.get_keypoints_root(tq, tr, tt, root=root)
         uv = point_projection_from_3d_tensor(torch.tensor(K), xyz)
@@ -103,9 +108,18 @@ def gen_fk():
                 torch.tensor(q), torch.tensor(rot6d), torch.tensor(t), root=root).numpy()
     with torch.no_grad():
         out["fk_only"] = robot.get_keypoints_only_fk(torch.tensor(q)).numpy()
-        out["fk_q0"] = robot.get_keypoints_only_fk(torch.zeros(1, 8)).numpy()
-    np.savez_compressed(os.path.join(HERE, "golden_fk.npz"), **out)
-    print("fk ok", out["xyz_root3"][0, :2])
+        out["fk_q0"] = robot.get_keypoints_only_fk(torch.zeros(1, dof)).numpy()
+    name = "golden_fk.npz" if robot_type == "panda" else f"golden_fk_{robot_type}.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("fk ok", robot_type, out[f"xyz_root{other_root}"][0, :2])
+
+
+def gen_fk_kuka():
+    gen_fk("kuka", 3)
+
+
+def gen_fk_baxter():
+    gen_fk("baxter", 5)
 
 
 def gen_integral():
@@ -231,7 +245,7 @@ def gen_depthnet_resnet():
                      "backbone.layer4.0.downsample.0.weight", "backbone.layer4.2.bn3.weight", "depth_layer.weight"], out, "")
     args = rh.default_args()
     args.backbone_name = args.rootnet_backbone_name = "resnet50"
-    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE,
+    init = {"robot_type": robot_type, "pose_params": INITIAL_JOINT_ANGLE,
             "cam_params": np.eye(4, dtype=float), "init_pose_from_mean": True}
     full = RootNetwithRegInt(init, args)
     full.load_state_dict(synth_state_dict(full.state_dict()))
@@ -245,7 +259,7 @@ def gen_depthnet_resnet():
     print("depthnet resnet ok", out["depth_eval"].ravel(), out["loss"])
 
 
-def build_full(backbone_name=None):
+def build_full(backbone_name=None, robot_type="panda"):
     args = rh.default_args()
     if backbone_name is not None:
         # the shipped full.yaml pairs a ResNet regression trunk (+ deconv head) with the HRNet root trunk;
@@ -253,7 +267,7 @@ def build_full(backbone_name=None):
         from lib.models.backbones import Resnet as ref_resnet
         ref_resnet.ResNet.init_weights = lambda self, name: None
         args.backbone_name = backbone_name
-    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE,
+    init = {"robot_type": robot_type, "pose_params": INITIAL_JOINT_ANGLE,
             "cam_params": np.eye(4, dtype=float), "init_pose_from_mean": True}
     full = RootNetwithRegInt(init, args)
     full.load_state_dict(synth_state_dict(full.state_dict()))
@@ -272,6 +286,18 @@ def gen_full_eval():
     np.savez_compressed(os.path.join(HERE, "golden_full_eval.npz"),
                         **{n: t.numpy() for n, t in zip(NAMES8, o)})
     print("full eval ok", o[0][0, :3])
+
+
+def gen_full_eval_baxter():
+    """15 DoF / 17 key-points: 1088 heat-map channels, 2063-wide pose regressor, tree FK with key-point offsets."""
+    full, _ = build_full(robot_type="baxter")
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_baxter.npz"),
+                        **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval (baxter) ok", o[0][0, :3], o[7][0, :2])
 
 
 def gen_full_eval_resnet():

@@ -59,10 +59,10 @@ def model_args(**over):
     return a
 
 
-def build_full(**over):
+def build_full(robot_type="panda", **over):
     from hrpe_amd.lib.dataset.const import INITIAL_JOINT_ANGLE
     from hrpe_amd.lib.models.full_net import RootNetwithRegInt
-    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE, "cam_params": np.eye(4),
+    init = {"robot_type": robot_type, "pose_params": INITIAL_JOINT_ANGLE, "cam_params": np.eye(4),
             "init_pose_from_mean": True}
     m = RootNetwithRegInt(init, model_args(**over))
     m.load_state_dict(synth_state_dict(m.state_dict()))
@@ -136,6 +136,22 @@ def test_full_eval_golden():
         err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
         assert err < 3e-4, f"{n}: rel err {err}"
     # key-points in pixels: soft-argmax root uv within 1e-2 px of the reference after ~330 fp32 convs
+    assert np.abs(out[3].cpu().numpy() - g["root_uv"]).max() < 1e-2
+
+
+def test_full_eval_baxter_golden():
+    """robot_type = 'baxter' (reference full_net.py:48-50): 15 DoF / 17 key-points -> 1088-channel heat-map head,
+    17-joint soft-argmax, 2063-wide pose regressor and the tree FK with key-point offsets."""
+    g = load("golden_full_eval_baxter.npz")
+    m = build_full("baxter").eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    for n, t in zip(NAMES8, out):
+        ref = g[n]
+        assert tuple(t.shape) == ref.shape, n
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
     assert np.abs(out[3].cpu().numpy() - g["root_uv"]).max() < 1e-2
 
 

@@ -99,6 +99,33 @@ def test_urdf_chain_descriptor_matches_oracle_tree():
         robot.get_keypoints_only_fk(torch.zeros(1, 8))      # CPU tensor: no fallback
 
 
+def test_urdf_chain_descriptors_kuka_baxter():
+    """Serial 7-DoF chain and the Baxter tree: actuated-joint column order (reference urdf.py:3795-3813), key-point
+    frames and offsets (urdf_robot.py:52-74) as the FK kernel will see them."""
+    import os
+    from hrpe_amd.lib.dataset.const import JOINT_NAMES, LINK_NAMES
+    from hrpe_amd.lib.utils.urdf_robot import URDFRobot
+    from oracle import fk
+    assets = os.path.dirname(PANDA_URDF)
+    kuka = URDFRobot("kuka", urdf_path=os.path.join(assets, "kuka_kinematics.urdf"))
+    assert kuka.dof == 7 and kuka.nkp == 8 and kuka.link_names == LINK_NAMES["kuka"]
+    assert float(kuka.offsets.abs().max()) == 0.0 and kuka.chain.kp_frame[0] == -1
+    bax = URDFRobot("baxter", urdf_path=os.path.join(assets, "baxter_kinematics.urdf"))
+    orb = fk.Robot(os.path.join(assets, "baxter_kinematics.urdf"), "baxter")
+    assert bax.dof == 15 and bax.nkp == 17 and list(bax.actuated_joint_names) == JOINT_NAMES["baxter"]
+    assert bax.link_names == orb.link_names and bax.link_names[:3] == ["base", "right_arm_mount", "left_arm_mount"]
+    np.testing.assert_allclose(bax.offsets.reshape(17, 3).numpy(), orb.offsets.numpy(), atol=1e-7)
+    ch = bax.chain
+    assert ch.kp_frame[0] == -1 and all(ch.kp_frame[k] >= 0 for k in range(1, 17))
+    for j in range(ch.njoints):
+        assert ch.parent[j] < j
+    # two arms hang off the torso: the tree has joints whose parent is not the previous joint
+    assert sum(1 for j in range(1, ch.njoints) if ch.parent[j] != j - 1) > 2
+    assert sorted(ch.cfg[j] for j in range(ch.njoints) if ch.cfg[j] >= 0) == list(range(15))
+    with pytest.raises(NotImplementedError):
+        URDFRobot("owi535")
+
+
 def test_module_surface_and_state_dict_contract():
     """Names / kwargs of the reference's lib.models surface and the state-dict sizes it documents
     (RootNet 1956 entries; full net = 2 HRNets + heads + 2 buffers)."""

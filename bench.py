@@ -243,6 +243,10 @@ def main():
                   root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d,
                   mask=torch.ones(B, 7, device=dev))
     loss_holder = {}
+    h2d = os.environ.get("HRP_BENCH_H2D")
+    if h2d in ("u8", "u8res"):     # the dataset's bytes: the model's input kernel divides by 255
+        for k in ("x_reg", "x_root"):
+            d[k] = (d[k] * 255).to(torch.uint8)
 
     def fwd_bwd():
         pred = model(d["x_reg"], d["x_root"], kv, K)
@@ -293,6 +297,38 @@ def main():
                 g2.replay()
     else:
         step = step_eager
+
+    # Opt-in (never the headline `value`): HRP_BENCH_H2D=u8|f32 feeds every step's two image batches from pinned host
+    # memory - the dataset's bytes (the model's input kernel divides by 255) or the reference's fp32
+    # images - through a staging buffer filled on a copy stream while the previous step computes.
+    if h2d:
+        assert h2d in ("u8", "f32", "u8res") and use_graph
+        inner = step
+        host = {k: d[k].cpu().pin_memory() for k in ("x_reg", "x_root")}
+        staging = {k: torch.empty_like(d[k]) for k in host}
+        copy_stream = torch.cuda.Stream(dev)
+        ready, consumed = torch.cuda.Event(), torch.cuda.Event()
+        consumed.record()
+
+        def fill():
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed)
+                for k in host:
+                    staging[k].copy_(host[k], non_blocking=True)
+                ready.record()
+
+        fill()
+
+        def step():
+            if h2d == "u8res":      # development aid: uint8 images resident in HBM
+                return inner()
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ready)
+            for k in host:
+                d[k].copy_(staging[k])
+            consumed.record(cur)
+            fill()
+            inner()
 
     def barrier():
         if world > 1:
@@ -409,6 +445,9 @@ def main():
                    "global_batch": B * world, "per_gpu_batch": B, "image": "3x256x256",
                    "hrnet_w32_passes_per_image": 2, "parallelism": f"dp{world}", "hip_graph": use_graph,
                    "p_dropout": a.p_dropout,
+                   "inputs": {None: "resident in HBM", "u8": "uint8 images from pinned host memory every step (PCIe-inclusive)",
+                              "f32": "fp32 images from pinned host memory every step (PCIe-inclusive)",
+                              "u8res": "uint8 images resident in HBM"}[h2d],
                    "optimizer": "clip_grad_norm_(5)+torch.optim.Adam(fused)" if a.torch_optim else
                                 "hrpe_amd.optim.FusedClipAdam (clip 5 + Adam, lr 1e-4)"},
         "hrnet_w32_passes_per_sec": round(2 * value, 2),

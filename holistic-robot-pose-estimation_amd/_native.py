@@ -108,6 +108,7 @@ PROTOTYPES = {
     "hrp_nchw_grad_from_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_pack_weights": [_P, _I, _I, _I, _P],
     "hrp_nchw_to_nhwc_s2d": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hrp_u8_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "hrp_gather_f32": [_P, _P, _P, _I, _I, _P],
     "hrp_fill_zero": [_P, _L, _P],
     "hrp_maxpool3x3s2_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],

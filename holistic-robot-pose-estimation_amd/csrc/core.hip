@@ -25,36 +25,44 @@ int check_launch(const char* what) {
 
 // ---- NCHW fp32 <-> NHWC T ----------------------------------------------------------------------
 // One workgroup handles 64 pixels x all channels through an LDS transpose so both sides are coalesced.
-template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst,
-                                                           int C, int HW, int pitch) {
+// S = float: the reference's fp32 image in [0,1]; S = uint8_t: the dataset's bytes, divided by `div` on the way
+// (lib/core/function.py:26,29 `.float() / 255.` on the device: ATen's GPU division by a host scalar multiplies by
+// the fp32 reciprocal, and so does this kernel, so the values are bit-identical to the reference's GPU path).
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const S* __restrict__ src, void* __restrict__ dst,
+                                                           int C, int HW, int pitch, float div) {
   // small-C path (stem: C = 3): thread per pixel, writes `pitch` channels (zero padded)
   size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
   int n = blockIdx.y;
   if (p >= (size_t)HW) return;
-  const float* s = src + (size_t)n * C * HW + p;
+  const S* s = src + (size_t)n * C * HW + p;
   size_t o = ((size_t)n * HW + p) * pitch;
-  for (int c = 0; c < pitch; ++c) Elem<T>::st(dst, o + c, c < C ? s[(size_t)c * HW] : 0.f);
+  for (int c = 0; c < pitch; ++c) {
+    float v = c < C ? (float)s[(size_t)c * HW] : 0.f;
+    if (sizeof(S) == 1) v = v * (1.0f / div);
+    Elem<T>::st(dst, o + c, v);
+  }
 }
 
 // NCHW fp32 [N,C,H,W] -> NHWC [N,H/2,W/2,pitch] with 2x2 space-to-depth: channel (dy*2+dx)*C + c of output pixel
 // (y,x) = src[n, c, 2y+dy, 2x+dx] (odd H / W: the missing row / column reads as zero).  Turns the 7x7 stride-2 stem
 // of ResNet into a 4x4 stride-1 convolution over 12 channels (one 16-channel chunk of the MFMA conv kernel).
-template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_s2d_kernel(const float* __restrict__ src, void* __restrict__ dst,
-                                                               int C, int H, int W, int pitch) {
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_s2d_kernel(const S* __restrict__ src, void* __restrict__ dst,
+                                                               int C, int H, int W, int pitch, float div) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (p >= (size_t)Ho * Wo) return;
   const int y = p / Wo, x = p - (size_t)y * Wo;
-  const float* sn = src + (size_t)n * C * H * W;
+  const S* sn = src + (size_t)n * C * H * W;
   size_t o = ((size_t)n * Ho * Wo + p) * pitch;
   for (int k = 0; k < pitch; ++k) {
     float v = 0.f;
     if (k < 4 * C) {
       const int q = k / C, c = k - q * C, iy = 2 * y + (q >> 1), ix = 2 * x + (q & 1);
-      if (iy < H && ix < W) v = sn[((size_t)c * H + iy) * W + ix];
+      if (iy < H && ix < W) v = (float)sn[((size_t)c * H + iy) * W + ix];
+      if (sizeof(S) == 1) v = v * (1.0f / div);
     }
     Elem<T>::st(dst, o + k, v);
   }
@@ -333,16 +341,33 @@ extern "C" int hrp_device_ok(void) {
 extern "C" int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream) {
   HRP_REQUIRE(src && dst && N > 0 && C > 0 && dst_pitch >= C, "nchw_to_nhwc: bad args");
   dim3 grid(cdiv(H * W, 256), N);
-  if (dtype == HRP_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch);
-  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch);
+  if (dtype == HRP_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch, 1.f);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_pitch, 1.f);
   return check_launch("nchw_to_nhwc");
+}
+
+extern "C" int hrp_u8_nchw_to_nhwc(const uint8_t* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch,
+                                   float divisor, int s2d, void* stream) {
+  HRP_REQUIRE(src && dst && N > 0 && C > 0 && divisor > 0.f, "u8_nchw_to_nhwc: bad args");
+  HRP_REQUIRE(dst_pitch >= (s2d ? 4 * C : C), "u8_nchw_to_nhwc: dst_pitch too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (s2d) {
+    dim3 grid(cdiv(((H + 1) / 2) * ((W + 1) / 2), 256), N);
+    if (dtype == HRP_F32) hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, uint8_t>), grid, dim3(256), 0, st, src, dst, C, H, W, dst_pitch, divisor);
+    else hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<bf16_t, uint8_t>), grid, dim3(256), 0, st, src, dst, C, H, W, dst_pitch, divisor);
+  } else {
+    dim3 grid(cdiv(H * W, 256), N);
+    if (dtype == HRP_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, uint8_t>), grid, dim3(256), 0, st, src, dst, C, H * W, dst_pitch, divisor);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, uint8_t>), grid, dim3(256), 0, st, src, dst, C, H * W, dst_pitch, divisor);
+  }
+  return check_launch("u8_nchw_to_nhwc");
 }
 
 extern "C" int hrp_nchw_to_nhwc_s2d(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream) {
   HRP_REQUIRE(src && dst && N > 0 && C > 0 && dst_pitch >= 4 * C, "nchw_to_nhwc_s2d: bad args");
   dim3 grid(cdiv(((H + 1) / 2) * ((W + 1) / 2), 256), N);
-  if (dtype == HRP_F32) hipLaunchKernelGGL(nchw_to_nhwc_s2d_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, dst_pitch);
-  else hipLaunchKernelGGL(nchw_to_nhwc_s2d_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, dst_pitch);
+  if (dtype == HRP_F32) hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, dst_pitch, 1.f);
+  else hipLaunchKernelGGL((nchw_to_nhwc_s2d_kernel<bf16_t, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, dst_pitch, 1.f);
   return check_launch("nchw_to_nhwc_s2d");
 }
 

@@ -8,6 +8,8 @@ element tensor expressions (torch ops, not part of the accelerated path); the tw
 projections go through the projection kernel."""
 import torch
 
+from hrpe_amd.lib.dataset.const import JOINT_NAMES
+from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
 from hrpe_amd.lib.utils.transforms import point_projection_from_3d_tensor
 
 FULL_YAML_WEIGHTS = dict(pose=1.0, rot=1.0, trans=1.0, depth=10.0, uv=1.0, kp2d=10.0, kp3d=10.0,
@@ -18,6 +20,56 @@ def compute_k_values(fx, fy, bboxes, real_bbox=(1000.0, 1000.0)):
     """k = sqrt(fx*fy*1000*1000 / max(|x2-x1|, |y2-y1|)^2)   (function.py:88-98)."""
     area = torch.max(torch.abs(bboxes[:, 2] - bboxes[:, 0]), torch.abs(bboxes[:, 3] - bboxes[:, 1])) ** 2
     return torch.sqrt(fx * fy * real_bbox[0] * real_bbox[1] / area).to(torch.float32)
+
+
+def prepare_batch(input_batch, robot, device, reference_keypoint_id=3, use_origin_bbox=False, use_extended_bbox=True,
+                  synthetic=True):
+    """The batch unpacking of function.py:25-98 for a DreamDataset batch (lib/dataset/dream.py:393-413), without the
+    per-sample Python loops (gt pose/rot/trans at :50-64, k_values at :98) and without the fp32 image round trip:
+    uint8 images stay uint8 on the way to the device (4x less PCIe traffic) and the model's input kernel does the
+    ``.float() / 255.`` of :26,29 while it writes the trunk's NHWC layout (hrp_u8_nchw_to_nhwc); float images (the
+    reference's loaders hand over float tensors holding 0..255) are scaled here as the reference does.
+
+    Returns dict(reg_images, root_images, root_K, other_K, k_values, gt = dict(pose, rot, trans, root_rot,
+    root_trans, root_depth, root_uv, kp3d, kp2d, mask)); ``gt`` feeds ``full_loss``.  `synthetic=False` (real
+    datasets) needs the reference's BPnP solve on the CPU (function.py:66-74), which is outside this build."""
+    if not synthetic:
+        raise NotImplementedError("BPnP ground-truth rotation for real datasets (function.py:66-74) is not part of this build")
+
+    def dev(t, dtype=torch.float32):
+        return torch.as_tensor(t).to(device=device, dtype=dtype, non_blocking=True)
+
+    def images(t):
+        t = torch.as_tensor(t)
+        if t.dtype == torch.uint8:
+            return t.to(device, non_blocking=True)
+        return dev(t) / 255.
+
+    root, other = input_batch["root"], input_batch["other"]
+    out = dict(root_images=images(root["images"]), reg_images=images(other["images"]),
+               root_K=dev(root["K"]), other_K=dev(other["K"]))
+    TCO = dev(input_batch["TCO"])
+    jp = input_batch["jointpose"]
+    pose = torch.stack([dev(jp[k]) for k in JOINT_NAMES[robot.robot_type]], dim=1)        # :51
+    rot, trans = rotmat_to_rot6d(TCO[:, :3, :3]), TCO[:, :3, 3].contiguous()                # :53-54
+    kp3d, kp2d = dev(other["keypoints_3d"]), dev(other["keypoints_2d"])
+    if reference_keypoint_id == 0:                                                         # :76-78
+        root_trans, root_rot = trans, rot
+    else:                                                                                  # :80-82
+        assert reference_keypoint_id < len(robot.link_names), reference_keypoint_id
+        root_trans = kp3d[:, reference_keypoint_id, :]
+        root_rot = robot.get_rotation_at_specific_root(pose, rot, trans, root=reference_keypoint_id)
+    if use_extended_bbox:                                                                  # :43-48, 89-94
+        bboxes, Kk = dev(root["bbox_gt2d_extended"]), out["root_K"]
+    elif use_origin_bbox:
+        bboxes, Kk = dev(input_batch["bbox_strict_bounded_original"]), dev(input_batch["K_original"])
+    else:
+        bboxes, Kk = dev(root["bbox_strict_bounded"]), out["root_K"]
+    out["k_values"] = compute_k_values(Kk[:, 0, 0], Kk[:, 1, 1], bboxes)
+    out["gt"] = dict(pose=pose, rot=rot, trans=trans, root_rot=root_rot, root_trans=root_trans,
+                     root_depth=root_trans[:, 2:3], root_uv=kp2d[:, reference_keypoint_id, 0:2],
+                     kp3d=kp3d, kp2d=kp2d, mask=dev(other["valid_mask_crop"]))
+    return out
 
 
 def full_loss(pred, gt, K, root=3, image_size=256.0, weights=FULL_YAML_WEIGHTS):

@@ -219,7 +219,7 @@ class HighResolutionModule(PlannedModule):
         names, hs, imgs = [], [], {}
         for i, x in enumerate(xs):
             N, Cc, H, W = x.shape
-            t = pb.image_input(f"x{i}", N, Cc, H, W)
+            t = pb.image_input(f"x{i}", N, Cc, H, W, u8=x.dtype == torch.uint8)
             t.requires_grad = pb.plan.need_grad and x.requires_grad
             names.append(f"x{i}")
             hs.append(t)
@@ -397,7 +397,7 @@ class PoseHighResolutionNet(PlannedModule):
 
     def _build(self, pb, x):
         N, Cc, H, W = x.shape
-        t = pb.image_input("x", N, Cc, H, W)
+        t = pb.image_input("x", N, Cc, H, W, u8=x.dtype == torch.uint8)
         t.requires_grad = pb.plan.need_grad and x.requires_grad
         heat, feat = self.emit(pb, t)
         outs = []

@@ -62,7 +62,7 @@ class ResNet(PlannedModule):
 
     def _build(self, pb, x):
         N, Cc, H, W = x.shape
-        t = pb.image_input_s2d("x", N, Cc, H, W)
+        t = pb.image_input_s2d("x", N, Cc, H, W, u8=x.dtype == torch.uint8)
         y = self.emit(pb, t)
         holder = pb.nchw_output(y)
         holder["handle"] = y

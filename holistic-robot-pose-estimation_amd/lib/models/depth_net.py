@@ -2,6 +2,7 @@
 
 ``RootNet('hrnet32').forward(x, k_value)`` -> depth [B, 1] in the reference's unit (gamma * k_value, mm).
 State-dict keys: ``backbone.*`` + ``depth_layer.{weight,bias}`` as in the reference."""
+import torch
 import torch.nn as nn
 
 from hrpe_amd.runtime import PlannedModule
@@ -34,10 +35,10 @@ class RootNet(PlannedModule):
         N, Cc, H, W = x.shape
         kv = pb.vector_input("k_value", N, 1, dense=True)
         if self.backbone_name in ["hrnet", "hrnet32"]:
-            t = pb.image_input("x", N, Cc, H, W)
+            t = pb.image_input("x", N, Cc, H, W, u8=x.dtype == torch.uint8)
             _, feat = self.backbone.emit(pb, t)
         else:   # depth_net.py:93-95: global average pooling of the ResNet feature map
-            t = pb.image_input_s2d("x", N, Cc, H, W)
+            t = pb.image_input_s2d("x", N, Cc, H, W, u8=x.dtype == torch.uint8)
             feat = pb.avgpool(self.backbone.emit(pb, t))
         gamma = self.depth_layer.emit(pb, feat)          # 1x1 conv on [N,2048,1,1] == linear (depth_net.py:121-123)
         depth = pb.row_scale(gamma, kv)                  # depth = gamma * k_value (depth_net.py:125)

@@ -199,8 +199,8 @@ class RootNetwithRegInt(PlannedModule):
         J, root = self.num_joints, self.reference_keypoint_id
         resnet_reg = self.backbone_name in _RESNETS
         resnet_root = self.rootnet_backbone_name not in _HRNETS
-        xr = (pb.image_input_s2d if resnet_reg else pb.image_input)("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3])
-        xo = (pb.image_input_s2d if resnet_root else pb.image_input)("x_root", N, 3, x_root.shape[2], x_root.shape[3])
+        xr = (pb.image_input_s2d if resnet_reg else pb.image_input)("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3], u8=x_reg.dtype == torch.uint8)
+        xo = (pb.image_input_s2d if resnet_root else pb.image_input)("x_root", N, 3, x_root.shape[2], x_root.shape[3], u8=x_root.dtype == torch.uint8)
         kv = pb.vector_input("k_value", N, 1, dense=True)
         Km = pb.vector_input("K", N, 9, dense=True)
         # The trunks share nothing until pose_geometry.  HRNet trunks are emitted in lockstep (emit_trunks: one flat

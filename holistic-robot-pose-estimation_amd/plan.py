@@ -427,28 +427,38 @@ class PlanBuilder:
         self.fuse_inference = (not plan.training) and (not plan.need_grad)
 
     # ---- inputs / outputs ---------------------------------------------------------------------------
-    def image_input(self, name, N, Cc, H, W):
-        """NCHW fp32 external tensor -> NHWC plan tensor (channel-padded to 8)."""
+    def image_input(self, name, N, Cc, H, W, u8=False):
+        """NCHW fp32 external tensor -> NHWC plan tensor (channel-padded to 8).  u8: the external tensor holds the
+        dataset's bytes and is divided by 255 on the way in (reference lib/core/function.py:26,29)."""
         p = self.plan
         t = p.new(N, H, W, Cc)
         dt = _dt(t.dtype)
 
         def op(s):
             x = p.dyn[name]
-            nv.call("hrp_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
+            if u8:
+                assert x.dtype == torch.uint8
+                nv.call("hrp_u8_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, 255.0, 0, s)
+            else:
+                nv.call("hrp_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
         p.fwd.append(op)
         t.external = name
         return t
 
-    def image_input_s2d(self, name, N, Cc, H, W):
-        """NCHW fp32 external image -> NHWC 2x2 space-to-depth tensor [N, H/2, W/2, 4*Cc] (ResNet stem input)."""
+    def image_input_s2d(self, name, N, Cc, H, W, u8=False):
+        """NCHW fp32 (or, u8, byte / 255) external image -> NHWC 2x2 space-to-depth tensor [N, H/2, W/2, 4*Cc]
+        (ResNet stem input)."""
         p = self.plan
         t = p.new(N, (H + 1) // 2, (W + 1) // 2, 4 * Cc, pitch=_rup(4 * Cc, 16))
         dt = _dt(t.dtype)
 
         def op(s):
             x = p.dyn[name]
-            nv.call("hrp_nchw_to_nhwc_s2d", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
+            if u8:
+                assert x.dtype == torch.uint8
+                nv.call("hrp_u8_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, 255.0, 1, s)
+            else:
+                nv.call("hrp_nchw_to_nhwc_s2d", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
         p.fwd.append(op)
         t.external = name
         return t

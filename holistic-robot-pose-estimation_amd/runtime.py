@@ -134,8 +134,10 @@ class PlannedModule(nn.Module):
         require_gpu(dev)
         need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                                  or any(t.requires_grad for t in tensors))
+        # uint8 inputs are raw images (dataset bytes): the plan's input kernel divides them by 255 on the way in
         key = (tuple(tuple(t.shape) for t in tensors), self._compute_dtype, self.training, need_grad,
-               tuple(bool(t.requires_grad) for t in tensors) if need_grad else ())
+               tuple(bool(t.requires_grad) for t in tensors) if need_grad else (),
+               tuple(t.dtype == torch.uint8 for t in tensors))
         runner = self._plans.get(key)
         if runner is None:
             plan = Plan(dev, self._compute_dtype, self.training, need_grad)
@@ -149,7 +151,8 @@ class PlannedModule(nn.Module):
             pb.finish()
             runner = Runner(plan, in_names, outs, img_inputs)
             self._plans[key] = runner
-        tensors = tuple(t.contiguous().float() if t.dtype != torch.float32 or not t.is_contiguous() else t
+        tensors = tuple(t.contiguous() if t.dtype == torch.uint8 else
+                        (t.contiguous().float() if t.dtype != torch.float32 or not t.is_contiguous() else t)
                         for t in tensors)
         if need_grad:
             anchor = next((p for p in self.parameters() if p.requires_grad), None)
@@ -167,7 +170,7 @@ class SingleTensorModule(PlannedModule):
 
     def _build(self, pb, x):
         N, Cc, H, W = x.shape
-        t = pb.image_input("x", N, Cc, H, W)
+        t = pb.image_input("x", N, Cc, H, W, u8=x.dtype == torch.uint8)
         t.requires_grad = pb.plan.need_grad and x.requires_grad
         y = self.emit(pb, t)
         holder = pb.nchw_output(y)

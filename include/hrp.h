@@ -209,6 +209,11 @@ int hrp_device_ok(void);  /* 1 when the current HIP device is gfx950 */
 int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream);
 int hrp_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream);
 int hrp_nchw_grad_from_nhwc(const void* src, float* dst, int dtype, int N, int C, int H, int W, int src_pitch, void* stream);
+/* Dataset bytes straight into the trunk's input layout: dst = float(src) * (1.0f / divisor) - what
+ * `.float() / 255.` (lib/core/function.py:26,29) evaluates to on the device, where ATen multiplies by the fp32
+ * reciprocal of a host scalar - as NHWC or (s2d != 0) the 2x2 space-to-depth form of the ResNet stem. */
+int hrp_u8_nchw_to_nhwc(const uint8_t* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch,
+                        float divisor, int s2d, void* stream);
 int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int max_elems, void* stream);
 /* ResNet stem (lib/models/backbones/Resnet.py:21-25): the 7x7 stride-2 convolution runs as a 4x4 stride-1
  * convolution over the 2x2 space-to-depth image.  dst[n, y, x, (dy*2+dx)*C + c] = src[n, c, 2y+dy, 2x+dx]. */

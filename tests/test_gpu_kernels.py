@@ -317,6 +317,32 @@ def test_fk_golden_other_robots(robot_type):
         _check_uv(uv2.cpu().numpy(), g[f"uv_root{root}"], g[f"xyz_root{root}"])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("s2d", [0, 1])
+def test_u8_image_input_kernel(dtype, s2d):
+    """hrp_u8_nchw_to_nhwc == (bytes.float() / 255.) laid out NHWC (or 2x2 space-to-depth), bit for bit."""
+    from hrpe_amd import _native as nv
+    torch.manual_seed(5)
+    N, C, H, W = 3, 3, 37, 50
+    x = torch.randint(0, 256, (N, C, H, W), dtype=torch.uint8, device=DEV)
+    ref = (x.float() / 255.)
+    if s2d:
+        Ho, Wo, pitch = (H + 1) // 2, (W + 1) // 2, 16
+        pad = torch.zeros(N, C, 2 * Ho, 2 * Wo, device=DEV)
+        pad[:, :, :H, :W] = ref
+        # channel (dy*2+dx)*C + c
+        r = pad.reshape(N, C, Ho, 2, Wo, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, Ho, Wo, 4 * C)
+    else:
+        Ho, Wo, pitch = H, W, 8
+        r = ref.permute(0, 2, 3, 1)
+    out = torch.full((N, Ho, Wo, pitch), 7.0, device=DEV, dtype=dtype)
+    nv.call("hrp_u8_nchw_to_nhwc", x.data_ptr(), out.data_ptr(), nv.HRP_F32 if dtype == torch.float32 else nv.HRP_BF16,
+            N, C, H, W, pitch, 255.0, s2d, None)
+    torch.cuda.synchronize()
+    nc = r.shape[-1]
+    assert torch.equal(out[..., :nc], r.to(dtype)) and float(out[..., nc:].abs().max()) == 0.0
+
+
 def test_c_abi_rejects_bad_descriptors():
     """Error behaviour of the C ABI: bad arguments return HRP_ERR_ARG with a message, nothing launches."""
     import ctypes as C

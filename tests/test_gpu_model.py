@@ -193,6 +193,55 @@ def test_full_train_step_golden():
             np.testing.assert_allclose(sd[key[4:]][:64].cpu().numpy(), g[key], rtol=1e-3, atol=1e-6)
 
 
+def _dream_batch(g, seed=2024):
+    """The DreamDataset-shaped batch tests/golden/gen_golden.py::make_batch fed to the reference, rebuilt from the
+    fixture's inputs: uint8 images, dict-of-lists joint pose (lib/dataset/dream.py:393-413)."""
+    from hrpe_amd.lib.dataset.const import JOINT_NAMES
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img_reg = torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.uint8))
+    img_root = torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.uint8))
+    TCO = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+    TCO[:, :3, :3], TCO[:, :3, 3] = g["in:R"], g["in:t"]
+    K, bbox = torch.tensor(g["in:K"]), torch.tensor(g["in:bbox"])
+    return {"root": {"images": img_root, "K": K, "bbox_strict_bounded": bbox, "bbox_gt2d_extended": bbox},
+            "other": {"images": img_reg, "K": K, "keypoints_2d": torch.tensor(g["in:kp2d"]),
+                      "valid_mask_crop": torch.tensor(g["in:mask"]), "keypoints_3d": torch.tensor(g["in:kp3d"])},
+            "TCO": torch.tensor(TCO), "K_original": K,
+            "jointpose": {n: [float(g["in:q"][i, j]) for i in range(2)] for j, n in enumerate(JOINT_NAMES["panda"])}}
+
+
+def test_prepare_batch_and_uint8_images_match_reference_step():
+    """the batch unpacking of lib/core/function.py:25-98 on the device with the dataset's bytes going
+    straight into the trunks (hrp_u8_nchw_to_nhwc does the `.float() / 255.`).  Same fixture as the float path: the
+    reference's k_values, forward 8-tuple and loss terms; and bit-identical outputs to feeding float images."""
+    from hrpe_amd.lib.core.function import full_loss, prepare_batch
+    g = load("golden_full_train.npz")
+    m = build_full().train()
+    b = prepare_batch(_dream_batch(g), m.robot, DEV, reference_keypoint_id=3)
+    assert b["reg_images"].dtype == torch.uint8 and b["reg_images"].device.type == "cuda"
+    np.testing.assert_allclose(b["k_values"].cpu().numpy(), g["k_values"], rtol=1e-6)
+    np.testing.assert_array_equal(b["gt"]["pose"].cpu().numpy(), g["in:q"])
+    np.testing.assert_array_equal(b["gt"]["trans"].cpu().numpy(), g["in:t"])
+    torch.manual_seed(0)
+    pred = m(b["reg_images"], b["root_images"], b["k_values"], b["other_K"])
+    for n, p in zip(NAMES8, pred):
+        ref = g["fwd:" + n]
+        err = np.abs(p.detach().cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 1e-3, f"train fwd {n}: rel err {err}"
+    loss, terms = full_loss(pred, b["gt"], b["other_K"])
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g["term:" + k], rtol=2e-3, err_msg=k)
+    # float images through the reference's own scaling: the trunks see identical inputs (the kernel test pins that
+    # bit for bit); the outputs agree to the run-to-run noise of the fp32-atomic reductions (split-K, statistics).
+    # eval mode so that BN uses the running statistics in both calls
+    m.eval()
+    with torch.no_grad():
+        o_u8 = m(b["reg_images"], b["root_images"], b["k_values"], b["other_K"])
+        o_f = m(b["reg_images"].float() / 255., b["root_images"].float() / 255., b["k_values"], b["other_K"])
+    for n, a, c in zip(NAMES8, o_u8, o_f):
+        assert float((a - c).abs().max()) <= 2e-6 * max(1.0, float(c.abs().max())), n
+
+
 def test_full_eval_resnet_golden():
     """Shipped full.yaml: ResNet-50 regression trunk + deconv head (Resnet.py:56-67, full_net.py:194-216, 293-298)."""
     g = load("golden_full_eval_resnet.npz")

@@ -18,6 +18,7 @@ Fixtures (reference call site that produced each):
   golden_full_eval_baxter.npz   the same for robot_type = "baxter" (15 DoF, 17 key-points), `full_eval_baxter`.
   golden_full_eval_resnet.npz / golden_full_train_resnet.npz   the same with backbone_name = "resnet50" (ResNet-50
                          trunk + deconv head of the shipped full.yaml), generated with `full_eval_resnet full_train_resnet`.
+  golden_metrics.npz     lib/utils/metrics.py compute_metrics_batch (:8-113) and summary_add_pck (:116-162), `metrics`.
   golden_full_train.npz  lib/core/function.py farward_loss(train=True): loss terms + grads + BN
                          running stats after one step.
 """
@@ -120,6 +121,64 @@ def gen_fk_kuka():
 
 def gen_fk_baxter():
     gen_fk("baxter", 5)
+
+
+def gen_metrics():
+    """compute_metrics_batch (both call forms of function.py:139-168) and summary_add_pck (function.py:378) of the
+    reference's lib/utils/metrics.py on seeded predictions; seaborn / matplotlib only draw curves there."""
+    for name in ("seaborn", "matplotlib", "matplotlib.pyplot"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                sys.modules[name] = types.ModuleType(name)
+    from lib.utils.metrics import compute_metrics_batch, summary_add_pck
+    robot = URDFRobot("panda")
+    g = np.random.Generator(np.random.PCG64(77))
+    B, nb = 16, 3
+    b = np.array(JOINT_BOUNDS["panda"], dtype=np.float64)
+    out, alldis, alldis_int = {}, {"dis3d": [], "dis2d": []}, {"dis3d": [], "dis2d": []}
+    names = ["error3d", "error2d", "dis3d", "dis2d", "l1_jointerror", "mean_jointerror", "error_depth",
+             "batch_error_relative", "error3d_relative"]
+    for i in range(nb):
+        q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((B, 8))).astype(np.float32)
+        R = random_rotations(g, B)
+        t = np.stack([g.uniform(-.4, .4, B), g.uniform(-.3, .3, B), g.uniform(.7, 2.0, B)], 1).astype(np.float32)
+        K = np.tile(np.array([[615.0, 0, 320], [0, 615.0, 240], [0, 0, 1]], np.float32), (B, 1, 1))
+        K[:, 0, 0] *= g.uniform(0.9, 1.1, B).astype(np.float32)
+        rot6d = rotmat_to_rot6d(torch.tensor(R))
+        with torch.no_grad():
+            gt3d = robot.get_keypoints(torch.tensor(q), rot6d, torch.tensor(t))
+            gt2d = point_projection_from_3d_tensor(torch.tensor(K), gt3d)
+        scale = [0.002, 0.02, 0.2][i]                       # three error regimes so the AUC curves are not flat
+        pq = q + g.normal(0, scale, q.shape).astype(np.float32)
+        prot = rot6d.numpy() + g.normal(0, scale, (B, 6)).astype(np.float32)
+        pt = t + g.normal(0, scale * 0.5, t.shape).astype(np.float32)
+        pint = gt3d.numpy() + g.normal(0, scale * 0.3, gt3d.shape).astype(np.float32)
+        with torch.no_grad():
+            root_rot = robot.get_rotation_at_specific_root(torch.tensor(pq), torch.tensor(prot), torch.tensor(pt), root=3)
+            root_t = robot.get_keypoints(torch.tensor(pq), torch.tensor(prot), torch.tensor(pt))[:, 3]
+        ins = dict(gt3d=gt3d.numpy(), gt2d=gt2d.numpy(), K=K, q=q, pq=pq, prot=root_rot.numpy(), pt=root_t.numpy(), pint=pint)
+        for k, v in ins.items():
+            out[f"in{i}:{k}"] = v
+        common = dict(robot=robot, gt_keypoints3d=gt3d, gt_keypoints2d=gt2d, K_original=torch.tensor(K),
+                      gt_joint=torch.tensor(q), pred_depth=None, pred_xy=None, reference_keypoint_id=3)
+        r = compute_metrics_batch(pred_joint=torch.tensor(pq), pred_rot=root_rot, pred_trans=root_t,
+                                  pred_xyz_integral=None, **common)
+        ri = compute_metrics_batch(pred_joint=None, pred_rot=None, pred_trans=None,
+                                   pred_xyz_integral=torch.tensor(pint), **common)
+        for n, a, c in zip(names, r, ri):
+            out[f"fk{i}:{n}"] = np.asarray(a, dtype=np.float64)
+            out[f"int{i}:{n}"] = np.asarray(c, dtype=np.float64)
+        alldis["dis3d"].extend(list(r[0]))          # function.py:355-360: per-image means accumulate over the epoch
+        alldis["dis2d"].extend(list(r[1]))
+        alldis_int["dis3d"].extend(list(ri[0]))
+        alldis_int["dis2d"].extend(list(ri[1]))
+    for tag, ad in (("fk", alldis), ("int", alldis_int)):
+        for k, v in summary_add_pck(ad).items():
+            out[f"summary_{tag}:{k}"] = np.float64(v)
+    np.savez_compressed(os.path.join(HERE, "golden_metrics.npz"), **out)
+    print("metrics ok", {k: float(v) for k, v in out.items() if k.startswith("summary_fk:")})
 
 
 def gen_integral():

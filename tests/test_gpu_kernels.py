@@ -343,6 +343,35 @@ def test_u8_image_input_kernel(dtype, s2d):
     assert torch.equal(out[..., :nc], r.to(dtype)) and float(out[..., nc:].abs().max()) == 0.0
 
 
+def test_metrics_on_device_match_reference():
+    """hrpe_amd.lib.utils.metrics.compute_metrics_batch (device tensors, FK + projection kernels) against the
+    reference's numpy implementation (lib/utils/metrics.py:8-113) in both call forms of function.py:139-168."""
+    from hrpe_amd.lib.utils.metrics import compute_metrics_batch, summary_add_pck
+    from hrpe_amd.lib.utils.urdf_robot import URDFRobot
+    g = np.load(os.path.join(GOLDEN, "golden_metrics.npz"))
+    robot = URDFRobot("panda", urdf_path=PANDA_URDF)
+    names = ["error3d", "error2d", "dis3d", "dis2d", "l1_jointerror", "mean_jointerror", "error_depth",
+             "batch_error_relative", "error3d_relative"]
+    alldis = {"dis3d": [], "dis2d": []}
+    for i in range(3):
+        t = {k: torch.tensor(g[f"in{i}:{k}"]).to(DEV) for k in ("gt3d", "gt2d", "K", "q", "pq", "prot", "pt", "pint")}
+        common = dict(robot=robot, gt_keypoints3d=t["gt3d"], gt_keypoints2d=t["gt2d"], K_original=t["K"],
+                      gt_joint=t["q"], pred_depth=None, pred_xy=None, reference_keypoint_id=3)
+        r = compute_metrics_batch(pred_joint=t["pq"], pred_rot=t["prot"], pred_trans=t["pt"], pred_xyz_integral=None, **common)
+        ri = compute_metrics_batch(pred_joint=None, pred_rot=None, pred_trans=None, pred_xyz_integral=t["pint"], **common)
+        for tag, res in (("fk", r), ("int", ri)):
+            assert len(res) == 9
+            for n, v in zip(names, res):
+                ref = g[f"{tag}{i}:{n}"]
+                assert v.is_cuda and tuple(v.shape) == ref.shape, n
+                np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=2e-4, atol=2e-5, err_msg=f"{tag}{i}:{n}")
+        alldis["dis3d"].append(r[0])
+        alldis["dis2d"].append(r[1])
+    s = summary_add_pck(alldis)       # lists of device tensors, one sync per summary value
+    for k in ("ADD/mean", "ADD/AUC", "ADD_2D/mean", "PCK/AUC"):
+        np.testing.assert_allclose(s[k], float(g["summary_fk:" + k]), rtol=2e-3, err_msg=k)
+
+
 def test_c_abi_rejects_bad_descriptors():
     """Error behaviour of the C ABI: bad arguments return HRP_ERR_ARG with a message, nothing launches."""
     import ctypes as C

@@ -126,6 +126,27 @@ def test_urdf_chain_descriptors_kuka_baxter():
         URDFRobot("owi535")
 
 
+def test_summary_add_pck_matches_reference():
+    """lib/utils/metrics.py:116-162 (AUC by a 10 000-step Python loop) against the sort + searchsorted form, on the
+    per-image errors the reference itself produced (tests/golden/golden_metrics.npz)."""
+    import os
+    from hrpe_amd.lib.utils.metrics import summary_add_pck
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_metrics.npz"))
+    for tag in ("fk", "int"):
+        alldis = {"dis3d": [], "dis2d": []}
+        for i in range(3):
+            alldis["dis3d"].extend(list(g[f"{tag}{i}:error3d"].astype(np.float32)))
+            alldis["dis2d"].extend(list(g[f"{tag}{i}:error2d"].astype(np.float32)))
+        s = summary_add_pck(alldis)
+        keys = [k for k in g.files if k.startswith(f"summary_{tag}:")]
+        assert len(keys) == len(s) == 22
+        for k in keys:
+            np.testing.assert_allclose(s[k.split(":", 1)[1]], float(g[k]), rtol=1e-6, atol=1e-9, err_msg=k)
+        # tensors in, same numbers
+        s2 = summary_add_pck({k: torch.tensor(np.array(v)) for k, v in alldis.items()})
+        assert s2 == s
+
+
 def test_module_surface_and_state_dict_contract():
     """Names / kwargs of the reference's lib.models surface and the state-dict sizes it documents
     (RootNet 1956 entries; full net = 2 HRNets + heads + 2 buffers)."""

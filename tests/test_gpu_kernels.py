@@ -411,6 +411,66 @@ def test_fused_clip_adam_matches_torch():
 
 
 @pytest.mark.gpu
+def test_fused_clip_adam_checkpoint_interchange_with_torch_adam():
+    """The reference's checkpoints carry torch.optim.Adam's optimizer_state_dict (lib/utils/utils.py:204-208, 246-252):
+    it must load into FusedClipAdam, and what FusedClipAdam saves must load into torch.optim.Adam, through
+    torch.save / torch.load, with training continuing identically on both sides."""
+    import io
+    from hrpe_amd.optim import FusedClipAdam
+    torch.manual_seed(11)
+    shapes = [(32, 16, 3, 3), (32,), (77, 5), (4097,)]
+
+    def grads(it):
+        g = torch.Generator(device="cpu").manual_seed(100 + it)
+        return [torch.randn(s, generator=g).to(DEV) * 0.1 for s in shapes]
+
+    def run(opt, params, its):
+        for it in its:
+            for p, g in zip(params, grads(it)):
+                p.grad = g.clone()
+            opt.step()
+
+    def through_file(obj):
+        buf = io.BytesIO()
+        torch.save(obj, buf)
+        buf.seek(0)
+        return torch.load(buf, map_location=DEV, weights_only=False)
+
+    init = [torch.randn(s, device=DEV) for s in shapes]
+    # torch Adam for 3 steps -> checkpoint -> FusedClipAdam continues for 2; reference: torch Adam for all 5
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    opt_ref = torch.optim.Adam(ref, lr=3e-3)
+    run(opt_ref, ref, range(3))
+    ckpt = through_file({"model": [p.detach().clone() for p in ref], "optimizer_state_dict": opt_ref.state_dict()})
+    mine = [torch.nn.Parameter(t.clone()) for t in ckpt["model"]]
+    opt = FusedClipAdam(mine, lr=1.0)                       # lr comes from the checkpoint
+    opt.load_state_dict(ckpt["optimizer_state_dict"])
+    assert opt.param_groups[0]["lr"] == 3e-3 and float(opt.step_count) == 3.0
+    run(opt_ref, ref, range(3, 5))
+    run(opt, mine, range(3, 5))
+    for p, q in zip(ref, mine):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (p - q).abs().max().item()
+    # FusedClipAdam's checkpoint -> torch Adam continues for 2 more; reference: FusedClipAdam itself
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["state"]) == len(shapes)
+    ckpt = through_file({"model": [p.detach().clone() for p in mine], "optimizer_state_dict": sd})
+    back = [torch.nn.Parameter(t.clone()) for t in ckpt["model"]]
+    opt_back = torch.optim.Adam(back, lr=1.0)
+    opt_back.load_state_dict(ckpt["optimizer_state_dict"])
+    run(opt, mine, range(5, 7))
+    run(opt_back, back, range(5, 7))
+    for p, q in zip(back, mine):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (p - q).abs().max().item()
+    # a learning-rate scheduler drives param_groups like it does for torch.optim.Adam (utils.py:160-189)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: 0.5 ** e)
+    before = [p.detach().clone() for p in mine]
+    run(opt, mine, [7])
+    sched.step()
+    assert abs(opt.param_groups[0]["lr"] - 1.5e-3) < 1e-12
+    assert any((p.detach() - b).abs().max() > 0 for p, b in zip(mine, before))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_resnet_stem_maxpool_deconv_kernels(dtype):
     """Plan pieces of the ResNet path against plain torch: the 7x7 stride-2 stem run as a 4x4 convolution over the

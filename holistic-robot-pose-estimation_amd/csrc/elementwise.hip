@@ -180,6 +180,38 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q
     }
 }
 
+// Pixel loop of the reduce kernel for up == 1 (every activation except the upsampled fuse-layer inputs): U pixels per
+// thread and trip, all loads issued before the first use.  One pixel per trip kept a single round of loads in flight
+// per thread - 8 dependent HBM latencies on a [64,64,64,32] tensor, 1.6 TB/s.
+// RM: 0 = no ReLU, 1 = ReLU through the bit mask, 2 = ReLU by comparing the saved output.
+template <typename T, int V, int RM, int U>
+__device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int c, unsigned q, unsigned stride, unsigned nq,
+                                                  const float (&mean)[V], const float (&inv)[V], float (&s0)[V], float (&s1)[V]) {
+  for (; q + (U - 1) * stride < nq; q += U * stride) {
+    float go[U][V], xin[U][V], o[RM == 2 ? U : 1][V];
+    unsigned bits[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t p = (size_t)q + (size_t)u * stride;
+      VecIO<T, V>::ld(d.dout, p * d.dout_pitch + c, go[u]);
+      VecIO<T, V>::ld(d.in.ptr, p * d.in.pitch + c, xin[u]);
+      if constexpr (RM == 1) bits[u] = d.mask[p * d.mask_pitch + c / V];
+      if constexpr (RM == 2) VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float g = go[u][i];
+        if constexpr (RM == 1) g = (bits[u] >> i) & 1u ? g : 0.f;
+        if constexpr (RM == 2) g = o[u][i] > 0.f ? g : 0.f;
+        s0[i] += g;
+        s1[i] += g * (xin[u][i] - mean[i]) * inv[i];
+      }
+  }
+  return q;
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_desc d, int tpr) {
   extern __shared__ float ew_lds[];
@@ -201,7 +233,14 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   load_consts<V>(d.in, d.C, cbase, nch, c, tab, sc, sh, mean, inv);
   if (c < d.C) {
     const unsigned nq = (unsigned)d.N * Hq * Wq;
-    for (unsigned q = blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += gridDim.x * ppb) {
+    const unsigned stride = gridDim.x * ppb;
+    unsigned q = blockIdx.x * ppb + threadIdx.x / tpr;
+    if (up == 1) {   // (uniform) batched pixel loop, then its single-pixel tail
+      if (!d.relu) { q = reduce_pixels<T, V, 0, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 0, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
+      else if (V > 1 && d.mask) { q = reduce_pixels<T, V, 1, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 1, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
+      else { q = reduce_pixels<T, V, 2, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 2, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
+    }
+    for (; q < nq; q += stride) {
       float g[V], xin[V];
       pooled_grad<T, V>(d, q, c, g);
       VecIO<T, V>::ld(d.in.ptr, (size_t)q * d.in.pitch + c, xin);
@@ -385,9 +424,10 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
   if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
   const int up = d.in.up;
-  static const int red_blocks = getenv("HRP_EW_RED_BLOCKS") ? atoi(getenv("HRP_EW_RED_BLOCKS")) : 512;   // tuning knob
-  // (the reduce ends with 2 C atomics per block: 512 blocks, except on the >= 64 MiB tensors where the streaming
-  // part dominates - 126 -> 85 us on 256 channels @64x64)
+  static const int red_blocks = getenv("HRP_EW_RED_BLOCKS") ? atoi(getenv("HRP_EW_RED_BLOCKS")) : 256;   // tuning knob
+  // (the reduce ends with 2 C atomics per block and keeps 4 pixels of loads in flight per thread: one block per CU
+  // streams as fast alone as 512 and leaves the CUs to the kernels of the other lanes - 48.3 -> 47.6 ms per step;
+  // twice as many on the >= 64 MiB tensors, where the streaming part dominates)
   const bool big = (int64_t)d.N * d.H * d.W * d.C * SZ >= (64ll << 20);
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : (big ? 2 * red_blocks : red_blocks));
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");

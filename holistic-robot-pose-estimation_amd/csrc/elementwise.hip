@@ -103,7 +103,46 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
 #pragma unroll
   for (int j = 0; j < HRP_EW_MAX_IN; ++j) any_up = any_up || (j < d.nin && d.in[j].up != 1);
   const unsigned uW = d.W, uH = d.H;
-  for (unsigned p = blockIdx.x * ppb + threadIdx.x / tpr; p < npix; p += gridDim.x * ppb) {
+  const unsigned stride = gridDim.x * ppb;
+  unsigned p = blockIdx.x * ppb + threadIdx.x / tpr;
+  if (!any_up && d.nin <= 2) {
+    // one or two same-resolution inputs (every activation of the blocks): U pixels per thread and trip, all loads
+    // issued before the first use; one block per CU then streams as fast as four with one-pixel trips
+    constexpr int U = 4;
+    const bool two = d.nin == 2;
+    for (; p + (U - 1) * stride < npix; p += U * stride) {
+      float f0[U][V], f1[U][V];
+#pragma unroll
+      for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.in[0].ptr, ((size_t)p + (size_t)u * stride) * d.in[0].pitch + c, f0[u]);
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.in[1].ptr, ((size_t)p + (size_t)u * stride) * d.in[1].pitch + c, f1[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t pu = (size_t)p + (size_t)u * stride;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = f0[u][i] * sc[0][i] + sh[0][i];
+        if (two) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[i] += f1[u][i] * sc[1][i] + sh[1][i];
+        }
+        if (d.relu) {
+          if (V > 1 && d.mask) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) bits |= (acc[i] > 0.f ? 1u : 0u) << i;
+            d.mask[pu * d.mask_pitch + cv] = (uint8_t)bits;
+          }
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        }
+        VecIO<T, V>::st(d.out, pu * d.out_pitch + c, acc);
+      }
+    }
+  }
+  for (; p < npix; p += stride) {
     unsigned x = 0, y = 0, n = 0;
     if (any_up) {
       const unsigned r = p / uW;
@@ -295,6 +334,9 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   }
 }
 
+#ifndef HRP_EW_APPLY_U
+#define HRP_EW_APPLY_U 4
+#endif
 template <typename T, int V>
 __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
   extern __shared__ float ew_lds[];
@@ -335,7 +377,72 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
   }
   if (c >= d.C) return;
   const unsigned nq = (unsigned)d.N * Hq * Wq;
-  for (unsigned q = blockIdx.x * ppb + threadIdx.x / tpr; q < nq; q += gridDim.x * ppb) {
+  const unsigned stride = gridDim.x * ppb;
+  unsigned q = blockIdx.x * ppb + threadIdx.x / tpr;
+  if (up == 1) {
+    // U pixels per thread and trip, every load of the trip issued before the first use (the branches are uniform)
+    constexpr int U = HRP_EW_APPLY_U;
+    const bool bn = d.in.mode == HRP_EW_BN_TRAIN, use_bits = d.relu && V > 1 && d.mask, use_out = d.relu && !use_bits;
+    for (; q + (U - 1) * stride < nq; q += U * stride) {
+      float g[U][V], xin[U][V], o[U][V], old[U][V], g2[U][V];
+      unsigned bits[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.dout, ((size_t)q + (size_t)u * stride) * d.dout_pitch + c, g[u]);
+      if (bn) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.in.ptr, ((size_t)q + (size_t)u * stride) * d.in.pitch + c, xin[u]);
+      }
+      if (use_bits) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) bits[u] = d.mask[((size_t)q + (size_t)u * stride) * d.mask_pitch + c / V];
+      }
+      if (use_out) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.out, ((size_t)q + (size_t)u * stride) * d.out_pitch + c, o[u]);
+      }
+      if (d.accumulate) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.din, ((size_t)q + (size_t)u * stride) * d.din_pitch + c, old[u]);
+      }
+      if (d.din2 && d.accumulate2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.din2, ((size_t)q + (size_t)u * stride) * d.din2_pitch + c, g2[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t p = (size_t)q + (size_t)u * stride;
+        if (use_bits) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[u][i] = (bits[u] >> i) & 1u ? g[u][i] : 0.f;
+        } else if (use_out) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[u][i] = o[u][i] > 0.f ? g[u][i] : 0.f;
+        }
+        if (d.din2) {
+          if (d.accumulate2) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) g2[u][i] += g[u][i];
+            VecIO<T, V>::st(d.din2, p * d.din2_pitch + c, g2[u]);
+          } else {
+            VecIO<T, V>::st(d.din2, p * d.din2_pitch + c, g[u]);
+          }
+        }
+        if (bn) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[u][i] = sc[i] * (g[u][i] - k0[i] - (xin[u][i] - mean[i]) * inv[i] * k1[i]);
+        } else if (d.in.mode == HRP_EW_AFFINE) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[u][i] *= sc[i];
+        }
+        if (d.accumulate) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[u][i] += old[u][i];
+        }
+        VecIO<T, V>::st(d.din, p * d.din_pitch + c, g[u]);
+      }
+    }
+  }
+  for (; q < nq; q += stride) {
     float g[V];
     pooled_grad<T, V>(d, q, c, g);
     if (d.din2) {   // identity sibling of the same activation (up == 1): its gradient is g itself
@@ -406,7 +513,9 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
   bool ok = aligned16(d.out, d.out_pitch, SZ);
   for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, 1024);
+  // (one block per CU with 4 pixels in flight per thread: 47.1 ms per step at 1 024 blocks, 46.8 at 512, 46.4 at 256)
+  static const int fwd_blocks = getenv("HRP_EW_FWD_BLOCKS") ? atoi(getenv("HRP_EW_FWD_BLOCKS")) : 256;   // tuning knob
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, fwd_blocks);
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_fwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
@@ -429,7 +538,11 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   // streams as fast alone as 512 and leaves the CUs to the kernels of the other lanes - 48.3 -> 47.6 ms per step;
   // twice as many on the >= 64 MiB tensors, where the streaming part dominates)
   const bool big = (int64_t)d.N * d.H * d.W * d.C * SZ >= (64ll << 20);
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? 1024 : (big ? 2 * red_blocks : red_blocks));
+  // (apply: 4 pixels of loads in flight per thread and ONE block per CU - 1 024 blocks of one-pixel trips took 9.2 ms
+  // of kernel time per step and a 47.6 ms step, this 9.8 ms and 46.8 ms: the CUs stay free for the other lanes;
+  // block counts that are not a multiple of the 256 CUs (192, 320, 384) lose 0.5-1 ms to the uneven tail)
+  static const int apply_blocks = getenv("HRP_EW_APPLY_BLOCKS") ? atoi(getenv("HRP_EW_APPLY_BLOCKS")) : 256;   // tuning knob
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? apply_blocks : (big ? 2 * red_blocks : red_blocks));
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;

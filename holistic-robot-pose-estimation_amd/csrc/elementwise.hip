@@ -515,7 +515,9 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
   // (one block per CU with 4 pixels in flight per thread: 47.1 ms per step at 1 024 blocks, 46.8 at 512, 46.4 at 256)
   static const int fwd_blocks = getenv("HRP_EW_FWD_BLOCKS") ? atoi(getenv("HRP_EW_FWD_BLOCKS")) : 256;   // tuning knob
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, fwd_blocks);
+  bool batched = d.nin <= 2;   // the kernel's four-pixel path; fuse sums (3-4 inputs, upsampled ones) keep 4 blocks per CU
+  for (int j = 0; j < d.nin; ++j) batched = batched && d.in[j].up == 1;
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, batched ? fwd_blocks : 1024);
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_fwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
@@ -542,7 +544,9 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   // of kernel time per step and a 47.6 ms step, this 9.8 ms and 46.8 ms: the CUs stay free for the other lanes;
   // block counts that are not a multiple of the 256 CUs (192, 320, 384) lose 0.5-1 ms to the uneven tail)
   static const int apply_blocks = getenv("HRP_EW_APPLY_BLOCKS") ? atoi(getenv("HRP_EW_APPLY_BLOCKS")) : 256;   // tuning knob
-  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), APPLY ? apply_blocks : (big ? 2 * red_blocks : red_blocks));
+  // (the upsampled fuse-layer inputs keep the one-pixel loop: they get the block counts that suited it)
+  const int nblk = up != 1 ? (APPLY ? 1024 : 512) : APPLY ? apply_blocks : (big ? 2 * red_blocks : red_blocks);
+  EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), nblk);
   HRP_REQUIRE(!d.mask || (d.relu && g.V == VEC && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;

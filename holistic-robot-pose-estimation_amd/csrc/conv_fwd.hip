@@ -642,7 +642,9 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   }
   int occ = (160 * 1024) / lds;
   occ = occ < 1 ? 1 : occ > 2 ? 2 : occ;
-  const int grid = persist && t.nblocks > 256 * occ ? 256 * occ : t.nblocks;
+  static const int pgrid = getenv("HRP_CONV_PGRID") ? atoi(getenv("HRP_CONV_PGRID")) : 0;   // tuning knob: persistent workgroups per CU
+  const int pocc = pgrid > 0 ? pgrid : occ;
+  const int grid = persist && t.nblocks > 256 * pocc ? 256 * pocc : t.nblocks;
   if (t.ksplit > 1 && d.res != d.y)
     (void)hipMemsetAsync(d.y, 0, (size_t)d.N * d.y_H * d.y_W * d.y_pitch * SZ, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d, t);

@@ -143,7 +143,7 @@ def cpu_baseline(B, threads):
     def step():
         for v in sd.values():
             v.grad = None
-        pred = oheads.full_forward(sd, robot, d["x_reg"], d["x_root"], kv, K, training=True)
+        pred = oheads.full_forward(sd, robot, d["x_reg"], d["x_root"], kv, K, training=True, reg_backbone=REG_BACKBONE)
         loss, _ = oheads.full_loss(pred, gt, K)
         loss.backward()
 

@@ -111,6 +111,18 @@ def _rand_sd(module, seed):
 def test_residual_blocks(kind, training, dtype):
     """BasicBlock / Bottleneck (reference HRnet.py:28-98) forward + backward, eval (folded BN, fused
     epilogue) and train (batch statistics, running-stat update)."""
+    _run_block(kind, training, dtype, (3, 20, 12))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["basic", "bottleneck_ds"])
+def test_residual_blocks_large_tensor(kind, dtype):
+    """The same blocks on [16, C, 64, 64]: enough pixels per workgroup for the element-wise kernels' batched loops
+    (four pixels per thread and trip) and the persistent conv workgroups, which the small case never enters."""
+    _run_block(kind, True, dtype, (16, 64, 64))
+
+
+def _run_block(kind, training, dtype, shape):
     from hrpe_amd.lib.models.backbones import HRnet as H
     from oracle import hrnet as O
     if kind == "basic":
@@ -124,7 +136,7 @@ def test_residual_blocks(kind, training, dtype):
         ofn = O._bottleneck
     sd = _rand_sd(m, 3)
     _load_into(m, sd)
-    x = torch.randn(3, cin, 20, 12, generator=torch.Generator().manual_seed(5))
+    x = torch.randn(shape[0], cin, shape[1], shape[2], generator=torch.Generator().manual_seed(5))
     # oracle
     osd = {"b." + k: v.clone() for k, v in sd.items()}
     for k, v in osd.items():

@@ -228,6 +228,9 @@ if __name__ == "__main__":
                                       (32, 448, 1, 1, 64), (1024, 2048, 1, 1, 8)]:
             for stats in ((False, True) if cin == 32 and cout == 32 else (True,)):
                 conv_case(B, hw, hw, cin, cout, k, s, dt, stats)
+    if a.what == "fc":     # the regression heads' fully connected layers on the conv path (fp32, 64 rows)
+        for (cin, cout) in [(1024, 1024), (2056, 1024), (1024, 8)]:
+            conv_case(B, 1, 1, cin, cout, 1, 1, torch.float32, False)
     if a.what == "interleave":
         for (c, hw) in [(32, 64), (64, 32), (128, 16), (256, 8)]:
             interleave_case(B, hw, c, dt)

@@ -102,6 +102,7 @@ class ParamW:
         self.param, self.cout, self.cin, self.ntaps = param, cout, cin, ntaps
         self.fwd_off = self.bwd_off = None
         self.grad_written = False
+        self.first_use = None    # index into Plan.fwd at (or before) the first launch that reads the packed copy
         self.src = None          # fp32 tensor packed instead of `param` (derived layouts, e.g. the 4x4 form of the stem)
 
 
@@ -140,6 +141,17 @@ class _LaneSync:
                 streams[c].wait_stream(streams[self.parent])
             else:
                 streams[self.parent].wait_stream(streams[c])
+
+
+class _PackJoin:
+    """Forward-list entry: the main lane waits for the side stream that packs the late weights (Plan.run_prep)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def run(self, streams):
+        if self.plan._pack_stream is not None:
+            streams[0].wait_stream(self.plan._pack_stream)
 
 
 def lanes_concurrent(a, b):
@@ -194,6 +206,8 @@ class Plan:
             w = ParamW(param, cout, cin, ntaps)
             self.weights[id(param)] = w
             self.weight_list.append(w)
+        if w.first_use is None:
+            w.first_use = len(self.fwd)   # every forward consumer looks the weight up right before it emits
         return w
 
     def preallocate_param_grads(self, params):
@@ -233,37 +247,51 @@ class Plan:
         dev = self.device
         self.stats = torch.zeros(max(self.stats_floats, 2), dtype=torch.float32, device=dev)
         self.bsums = torch.zeros(max(self.bsums_floats, 2), dtype=torch.float32, device=dev)
-        # packed weights: separate arenas per element type
-        self._pack_tables = []
+        # packed weights: separate arenas per element type.  Training plans with parallel blocks pack in two parts:
+        # the weights of the first block (stem, layer1) on the main stream, the rest (99 % of the bytes) on a side
+        # stream that the forward list joins right after that block - the 0.7 ms gather runs under the stem instead of
+        # in front of it.  `cut` = index in fwd of the join.
+        self._pack_tables, self._pack_tables_late = [], []
+        cut = self._late_pack_cut()
         for dtype in (torch.float32, torch.bfloat16):
             ws = [w for w in self.weight_list if w.dtype == dtype]
             if not ws:
                 continue
             esz = 4 if dtype == torch.float32 else 2
             ck = 32 // esz   # channels per 32-byte K chunk (csrc/conv_fwd.hip ROW, core.hip pack kernel)
-            total, maxel = 0, 0
+            total = 0
             for w in ws:
                 nf = math.ceil(w.cin_used / ck) * w.ntaps * _rup(w.cout, 32) * ck
                 w.fwd_off = total
                 total += _rup(nf, 64)
-                maxel = max(maxel, nf)
+                w.max_elems = nf
                 if w.need_t:
                     nb = math.ceil(w.cout / ck) * w.ntaps * _rup(w.cin_used, 32) * ck
                     w.bwd_off = total
                     total += _rup(nb, 64)
-                    maxel = max(maxel, nb)
+                    w.max_elems = max(nf, nb)
             arena = torch.zeros(total, dtype=dtype, device=dev)
             self.keep.append(arena)
-            tab = (nv.PackEntry * len(ws))()
-            for i, w in enumerate(ws):
+            for w in ws:
                 w.arena = arena
-                tab[i].src = (w.src if w.src is not None else w.param).data_ptr()
-                tab[i].dst = arena.data_ptr() + w.fwd_off * esz
-                tab[i].dst_t = (arena.data_ptr() + w.bwd_off * esz) if w.need_t else None
-                tab[i].Cout, tab[i].Cin, tab[i].ntaps = w.cout, w.cin, w.ntaps
-            tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
-            self.keep.append(tdev)
-            self._pack_tables.append((tdev, len(ws), _dt(dtype), maxel))
+            early = [w for w in ws if cut is None or w.first_use is None or w.first_use < cut]
+            late = [w for w in ws if not (cut is None or w.first_use is None or w.first_use < cut)]
+            for group, dest in ((early, self._pack_tables), (late, self._pack_tables_late)):
+                if not group:
+                    continue
+                tab = (nv.PackEntry * len(group))()
+                for i, w in enumerate(group):
+                    tab[i].src = (w.src if w.src is not None else w.param).data_ptr()
+                    tab[i].dst = arena.data_ptr() + w.fwd_off * esz
+                    tab[i].dst_t = (arena.data_ptr() + w.bwd_off * esz) if w.need_t else None
+                    tab[i].Cout, tab[i].Cin, tab[i].ntaps = w.cout, w.cin, w.ntaps
+                tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+                self.keep.append(tdev)
+                dest.append((tdev, len(group), _dt(dtype), max(w.max_elems for w in group)))
+        self._pack_stream = None
+        if self._pack_tables_late:
+            self._pack_stream = torch.cuda.Stream(device=dev)
+            list.insert(self.fwd, cut, (None, _PackJoin(self)))
         self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev)
                          for lane, nb in self.wgrad_ws_bytes.items()}
         self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes - 1)]
@@ -277,6 +305,17 @@ class Plan:
             import sys
             print(f"plan: {len(self.fwd)} forward / {len(self.bwd)} backward ops, {self.n_lanes} lanes, {self.counters}",
                   file=sys.stderr)
+
+    def _late_pack_cut(self):
+        """Index in self.fwd right after the first parallel block (the join back into the main lane), or None when the
+        plan is not a training plan with at least two parallel blocks and a network's worth of weights."""
+        if not self.need_grad or os.environ.get("HRP_NO_LATE_PACK") or len(self.weight_list) < 64:
+            return None
+        joins = [i for i, (lane, op) in enumerate(self.fwd) if lane is None and getattr(op, "kind", None) == "join"]
+        forks = [i for i, (lane, op) in enumerate(self.fwd) if lane is None and getattr(op, "kind", None) == "fork"]
+        if len(forks) < 2 or not joins or forks[1] < joins[0]:
+            return None           # (nested or single blocks: keep the simple order)
+        return joins[0] + 1
 
     def late(self, fn):
         """Defer pointer patching until the arenas exist (finalize)."""
@@ -332,6 +371,12 @@ class Plan:
         s = self._stream()
         for op in self.pre_pack:
             op(s)
+        late_s = s
+        if self._pack_stream is not None and not SERIAL_LANES:   # (serial runs skip the join entry of the forward list)
+            self._pack_stream.wait_stream(torch.cuda.current_stream(self.device))
+            late_s = self._pack_stream.cuda_stream
+        for tdev, n, dt, maxel in self._pack_tables_late:
+            nv.call("hrp_pack_weights", tdev.data_ptr(), n, dt, maxel, late_s)
         for tdev, n, dt, maxel in self._pack_tables:
             nv.call("hrp_pack_weights", tdev.data_ptr(), n, dt, maxel, s)
         if self._fold_tab:
@@ -494,6 +539,7 @@ class PlanBuilder:
         p.pre_pack.append(lambda s: nv.call("hrp_gather_f32", weight.data_ptr(), idx_w.data_ptr(), w12.data_ptr(),
                                             w12.numel(), 0, s))
         w = ParamW(weight, cout, 4 * cin, 16)
+        w.first_use = len(p.fwd)
         w.src, w.dtype, w.cin_used, w.need_t = w12, dtype, 4 * cin, False
         p.weights[("s2d", id(weight))] = w
         p.weight_list.append(w)

@@ -262,6 +262,7 @@ def main():
     else:   # clip_grad_norm_(5) + Adam as two table-driven launches (hrpe_amd/optim.py)
         opt = FusedClipAdam(params, lr=1e-4, max_norm=5.0)
     reducer = GradAllReducer(bucket_mb=64)
+    info = {}
 
     d = {k: torch.tensor(v).to(dev) for k, v in synthetic_batch(B, 808 + rank).items()}
     K = d["K"]
@@ -315,16 +316,69 @@ def main():
             def step():
                 g1.replay()
         else:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-            with torch.cuda.graph(g2):
-                update()
+            def capture_plain():
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    fwd_bwd()
+                with torch.cuda.graph(g2):
+                    update()
 
-            def step():
-                g1.replay()
-                reducer(model.flat_grads())
-                g2.replay()
+                def step():
+                    g1.replay()
+                    reducer(model.flat_grads())
+                    g2.replay()
+                return step
+
+            def capture_overlapped():
+                """Backward in two graphs around the plan's split: the gradients that are final after the first (the
+                late stages and the heads, most of the bytes) are all-reduced while the second runs."""
+                sp = None if os.environ.get("HRP_NO_AR_OVERLAP") else model.enable_split_backward()
+                if sp is None:
+                    return None
+                plan, final = sp
+                arena = plan.grad_arena
+                # small final ranges are not worth a collective of their own: they travel with the rest
+                final = [(o, n) for o, n in final if n >= (1 << 18)]
+                rest = GradAllReducer.complement(final, arena.numel())
+                g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1a):
+                    fwd_bwd()                       # (split active: the backward stops at the split)
+                with torch.cuda.graph(g1b):
+                    plan.run_backward("rest")
+                with torch.cuda.graph(g2):
+                    update()
+                # self-check on this machine: the second graph must not touch the ranges already handed to RCCL
+                g1a.replay()
+                torch.cuda.synchronize(dev)
+                before = torch.cat([arena[o:o + n] for o, n in final]).clone()
+                g1b.replay()
+                torch.cuda.synchronize(dev)
+                same = torch.equal(before, torch.cat([arena[o:o + n] for o, n in final]))
+                covered = sum(n for _, n in final) + sum(n for _, n in rest) == arena.numel()
+                if not (same and covered and bool(torch.isfinite(arena).all())):
+                    raise RuntimeError("split backward self-check failed")
+                info["ar_overlap"] = {"final_fraction": round(sum(n for _, n in final) / arena.numel(), 3),
+                                      "ranges_mb": [round(n * 4 / 2 ** 20, 1) for _, n in final],
+                                      "rest_ranges": len(rest), "split_at": plan.bwd_split, "bwd_ops": len(plan.bwd)}
+
+                def step():
+                    g1a.replay()
+                    w = reducer.start(arena, final)
+                    g1b.replay()
+                    w += reducer.start(arena, rest)
+                    reducer.finish(w, [arena])
+                    g2.replay()
+                return step
+
+            step = None
+            try:
+                step = capture_overlapped()
+            except Exception as e:   # anything unexpected: the plain two-graph step
+                print(f"warning: overlapped all-reduce disabled ({e!r})", file=sys.stderr)
+                step = None
+            if step is None:
+                model.disable_split_backward()
+                step = capture_plain()
     else:
         step = step_eager
 
@@ -414,6 +468,7 @@ def main():
 
     # lanes (concurrent graph branches) are folded onto one stream here: a kernel's duration is its own
     from hrpe_amd import plan as plan_mod
+    model.disable_split_backward()      # (N > 1: the timed step ran the backward in two graphs)
     plan_mod.SERIAL_LANES = True
     nv.set_profile_hook(hook)
     # park the stream behind a spin kernel while the host enqueues the step: the event intervals then are the
@@ -486,6 +541,7 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "loss": final_loss,
+        **info,
     }
     if not a.no_cpu_baseline:
         # separate process (own thread pool, hard time limit): the baseline must never take the GPU number

@@ -48,6 +48,37 @@ class GradAllReducer:
         n = flat.numel()
         return [flat[i:min(i + self.bucket_elems, n)] for i in range(0, n, self.bucket_elems)]
 
+    def start(self, flat, ranges):
+        """Asynchronous all-reduce (sum) of the (offset, numel) ranges of one flat buffer, in buckets; -> work handles.
+        The collective is ordered after the work already enqueued on the current stream."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return []
+        works = []
+        for off, n in ranges:
+            for b in self.buckets(flat[off:off + n]):
+                works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True))
+        return works
+
+    def finish(self, works, flats):
+        """Wait for `works` (the current stream waits) and turn the sums into means."""
+        for w in works:
+            w.wait()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for flat in flats:
+                flat.div_(dist.get_world_size())
+
+    @staticmethod
+    def complement(ranges, total):
+        """Ranges of [0, total) not covered by the sorted, disjoint `ranges`."""
+        out, pos = [], 0
+        for off, n in sorted(ranges):
+            if off > pos:
+                out.append((pos, off - pos))
+            pos = max(pos, off + n)
+        if pos < total:
+            out.append((pos, total - pos))
+        return out
+
     def __call__(self, flats):
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return

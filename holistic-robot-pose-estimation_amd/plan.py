@@ -191,6 +191,8 @@ class Plan:
         self.out_handles = []      # TensorH whose gradient is seeded from outside
         self.grad_arena = None
         self._grad_views = {}
+        self._grad_layout = []
+        self.bwd_split, self.split_active = None, False
         self.pre_pack = []         # ops run before the weight packing of every step (derived weight layouts)
         self.counters = {}         # build statistics (HRP_PLAN_STATS=1 prints them at finalize)
         self.wgrad_ws_bytes = {}   # lane -> scratch bytes shared by that lane's weight-gradient launches
@@ -214,11 +216,17 @@ class Plan:
         """One flat fp32 arena for every parameter gradient (what the data-parallel all-reduce walks in
         large buckets); .grad tensors are views into it."""
         params = [p for p in params if p.requires_grad]
+        # conv / linear weights first, in registration (= forward) order, then the vectors (BN affine parameters, biases):
+        # the weight gradients of a trunk's late stages - final early in the backward - are then one contiguous range
+        # (analyze_backward_split), not interleaved with BatchNorm gradients that one launch writes at the very end
+        params = [p for p in params if p.dim() > 1] + [p for p in params if p.dim() <= 1]
         total = sum(_rup(p.numel(), 4) for p in params)
         self.grad_arena = torch.zeros(max(total, 4), dtype=torch.float32, device=self.device)
         off = 0
+        self._grad_layout = []     # (offset, numel) in arena order
         for p in params:
             self._grad_views[id(p)] = self.grad_arena[off:off + p.numel()].view(p.shape)
+            self._grad_layout.append((off, p.numel()))
             off += _rup(p.numel(), 4)
 
     def grad_of_param(self, p):
@@ -413,15 +421,106 @@ class Plan:
         if self._run_tab:
             nv.call("hrp_bn_running_update", self._run_tab[0].data_ptr(), self._run_tab[1], s)
 
-    def run_backward(self):
+    def run_backward(self, part=None):
+        """part None: the whole backward.  "first" / "rest": the two halves around self.bwd_split (a top-level position
+        of the launch list chosen by analyze_backward_split) - the data-parallel step all-reduces the gradients that
+        are final after the first half while the second half runs."""
         s = self._stream()
-        if self.grad_arena is not None:
-            self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
-        if self.bsums_floats:
-            self.bsums.zero_()
-        self._run_list(self.bwd)
-        if self._pgrad_tab:
+        if part in (None, "first"):
+            if self.grad_arena is not None:
+                self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
+            if self.bsums_floats:
+                self.bsums.zero_()
+        if part is None:
+            self._run_list(self.bwd)
+        elif part == "first":
+            self._run_list(list.__getitem__(self.bwd, slice(0, self.bwd_split)))
+        else:
+            self._run_list(list.__getitem__(self.bwd, slice(self.bwd_split, None)))
+        if part in (None, "rest") and self._pgrad_tab:
             nv.call("hrp_bn_param_grad", self._pgrad_tab[0].data_ptr(), self._pgrad_tab[1], s)
+
+    def analyze_backward_split(self, min_frac=0.55):
+        """-> (split index, [(offset, numel)] arena ranges that no launch at or after the split touches) or None.
+
+        Every backward launch is replayed against a recording stand-in for the C ABI (nothing runs); any pointer
+        argument or descriptor field that points into the gradient arena marks that parameter as touched by that
+        launch.  The split is the first top-level position (outside every parallel block) after which at least
+        `min_frac` of the gradient bytes are final."""
+        import bisect
+        if self.grad_arena is None or not self._grad_layout:
+            return None
+        base, nbytes = self.grad_arena.data_ptr(), self.grad_arena.numel() * 4
+        starts = [o * 4 for o, _ in self._grad_layout]
+        last = [-1] * len(starts)
+        hits = []
+
+        def walk(v):
+            if isinstance(v, bool) or v is None:
+                return
+            if isinstance(v, int):
+                if base <= v < base + nbytes:
+                    hits.append(v - base)
+            elif isinstance(v, C.Structure):
+                for name, _t in v._fields_:
+                    walk(getattr(v, name))
+            elif isinstance(v, C.Array):
+                if issubclass(v._type_, (C.Structure, C.Array, C.c_void_p)):
+                    for e in v:
+                        walk(e)
+            elif hasattr(v, "_obj"):          # ctypes.byref(struct)
+                walk(v._obj)
+            elif isinstance(v, C.c_void_p):
+                walk(v.value)
+
+        real = nv.call
+        try:
+            nv.call = lambda name, *args: [walk(a) for a in args] and 0
+            depth, tops = 0, []
+            for i, (lane, op) in enumerate(self.bwd):
+                if lane is None:
+                    if getattr(op, "kind", None) == "fork":
+                        if depth == 0:
+                            tops.append(i)
+                        depth += 1
+                    elif getattr(op, "kind", None) == "join":
+                        depth -= 1
+                    continue
+                if depth == 0:
+                    tops.append(i)
+                del hits[:]
+                op(0)
+                for h in hits:
+                    last[bisect.bisect_right(starts, h) - 1] = i
+        finally:
+            nv.call = real
+        if self._pgrad_tab:   # hrp_bn_param_grad after the list writes the BatchNorm weight / bias gradients
+            bn_ptrs = set()
+            for bn, _off in self.bn_bwd:
+                for t in (bn.weight, bn.bias):
+                    g = self._grad_views.get(id(t))
+                    if g is not None:
+                        bn_ptrs.add(g.data_ptr() - base)
+            for k, st in enumerate(starts):
+                if st in bn_ptrs:
+                    last[k] = len(self.bwd)
+        total = sum(n for _, n in self._grad_layout)
+        for c in tops:
+            if c == 0:
+                continue
+            final = sum(n for (_, n), l in zip(self._grad_layout, last) if l < c)
+            if final >= min_frac * total:
+                ranges = []
+                for (off, n), l in zip(self._grad_layout, last):
+                    if l >= c:
+                        continue
+                    n4 = _rup(n, 4)
+                    if ranges and ranges[-1][0] + ranges[-1][1] == off:
+                        ranges[-1][1] += n4
+                    else:
+                        ranges.append([off, n4])
+                return c, [tuple(r) for r in ranges]
+        return None
 
     def publish_param_grads(self):
         """Hand the plan-owned gradient buffers to the parameters (torch semantics: .grad holds this

@@ -56,7 +56,7 @@ class Runner:
                 nv.call("hrp_nchw_to_nhwc", g.data_ptr(), t.gptr(), _dt(t.dtype), t.N, t.C, t.H, t.W, t.pitch, s)
             else:
                 gb.view(t.N, t.pitch)[:, : t.C].copy_(g.reshape(t.N, t.C))
-        p.run_backward()
+        p.run_backward("first" if p.split_active else None)   # (split: the caller runs plan.run_backward("rest"))
         p.publish_param_grads()
         gin = []
         for n in self.in_names:
@@ -108,6 +108,26 @@ class PlannedModule(nn.Module):
     def flat_grads(self):
         """Flat fp32 gradient arena of the training plan(s) (views of it are the parameters' .grad)."""
         return [r.plan.grad_arena for r in self._plans.values() if r.plan.grad_arena is not None]
+
+    def enable_split_backward(self, min_frac=0.55):
+        """Data-parallel overlap: from now on a backward through this module runs only the first part of the training
+        plan's backward list; the caller runs ``plan.run_backward("rest")`` itself (e.g. in a second HIP graph) and may
+        all-reduce the returned arena ranges in between - no launch of the second part touches them.
+        -> (plan, [(offset, numel), ...]) or None when the plan has no suitable split."""
+        runners = [r for r in self._plans.values() if r.plan.grad_arena is not None]
+        if len(runners) != 1:
+            return None
+        plan = runners[0].plan
+        info = plan.analyze_backward_split(min_frac)
+        if info is None:
+            return None
+        plan.bwd_split, ranges = info
+        plan.split_active = True
+        return plan, ranges
+
+    def disable_split_backward(self):
+        for r in self._plans.values():
+            r.plan.split_active = False
 
     def invalidate_plans(self):
         for m in self.modules():

@@ -242,6 +242,59 @@ def test_prepare_batch_and_uint8_images_match_reference_step():
         assert float((a - c).abs().max()) <= 2e-6 * max(1.0, float(c.abs().max())), n
 
 
+def test_split_backward_for_allreduce_overlap():
+    """The data-parallel step runs the backward as two launch lists and all-reduces the gradients that are final after
+    the first while the second runs (bench.py at N > 1).  Here: the split is found, most of the gradient bytes are
+    final at the split, the second part leaves those ranges untouched (bit for bit), and the two parts together give
+    the gradients of the unsplit backward."""
+    from hrpe_amd.lib.core.function import compute_k_values, full_loss
+    from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+    from hrpe_amd.parallel import GradAllReducer
+    g = load("golden_full_train.npz")
+    m = build_full().train()
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    x_root = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    K = torch.tensor(g["in:K"]).to(DEV)
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], torch.tensor(g["in:bbox"]).to(DEV))
+    q, R, t = [torch.tensor(g[k]).to(DEV) for k in ("in:q", "in:R", "in:t")]
+    kp3d, kp2d, mask = [torch.tensor(g[k]).to(DEV) for k in ("in:kp3d", "in:kp2d", "in:mask")]
+    gt = dict(pose=q, root_rot=m.robot.get_rotation_at_specific_root(q, rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+
+    def fwd_bwd():
+        loss, _ = full_loss(m(x_reg, x_root, kv, K), gt, K)
+        loss.backward()
+
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()
+    fwd_bwd()
+    arena = m.flat_grads()[0]
+    whole = arena.clone()
+    fwd_bwd()
+    noise = rel(arena, whole)                         # run-to-run noise of the unsplit backward (fp32 atomics, B = 2)
+    sp = m.enable_split_backward()
+    assert sp is not None
+    plan, final = sp
+    nfinal = sum(n for _, n in final)
+    assert nfinal >= 0.55 * arena.numel() and len(final) <= 16, (nfinal / arena.numel(), len(final))
+    assert 0 < plan.bwd_split < len(plan.bwd)
+    fwd_bwd()                                         # first part only
+    torch.cuda.synchronize()
+    first = torch.cat([arena[o:o + n] for o, n in final]).clone()
+    rest = GradAllReducer.complement(final, arena.numel())
+    assert sum(n for _, n in rest) + nfinal == arena.numel()
+    # the gradients handed to the all-reduce are already those of the whole backward ...
+    assert rel(first, torch.cat([whole[o:o + n] for o, n in final])) <= max(10 * noise, 1e-3)
+    plan.run_backward("rest")
+    torch.cuda.synchronize()
+    # ... the second part does not touch them (bit for bit) and completes the others
+    assert torch.equal(first, torch.cat([arena[o:o + n] for o, n in final]))
+    assert rel(arena, whole) <= max(10 * noise, 1e-3), (rel(arena, whole), noise)
+    m.disable_split_backward()
+    fwd_bwd()
+    assert rel(arena, whole) <= max(10 * noise, 1e-3), (rel(arena, whole), noise)
+
+
 def test_full_eval_resnet_golden():
     """Shipped full.yaml: ResNet-50 regression trunk + deconv head (Resnet.py:56-67, full_net.py:194-216, 293-298)."""
     g = load("golden_full_eval_resnet.npz")

@@ -207,6 +207,16 @@ def _ddp_worker(rank, world, port, q):
     broadcast_module(lin)                     # everyone takes rank 0's parameters
     flat = torch.arange(10_000, dtype=torch.float32) * (rank + 1)
     GradAllReducer(bucket_mb=0.01)([flat])    # several buckets
+    # the overlapped form: some ranges first, their complement later, one finish (bench.py at N > 1)
+    red = GradAllReducer(bucket_mb=0.01)
+    flat2 = torch.arange(10_000, dtype=torch.float32) * (rank + 1)
+    first = [(0, 3000), (5000, 2500)]
+    rest = GradAllReducer.complement(first, flat2.numel())
+    assert rest == [(3000, 2000), (7500, 2500)]
+    works = red.start(flat2, first)
+    works += red.start(flat2, rest)
+    red.finish(works, [flat2])
+    assert torch.equal(flat, flat2)
     q.put((rank, lin.weight.detach().numpy().copy(), flat[:5].numpy().copy(), flat[-1].item()))
     dist.destroy_process_group()
 

@@ -376,6 +376,12 @@ def main():
             except Exception as e:   # anything unexpected: the plain two-graph step
                 print(f"warning: overlapped all-reduce disabled ({e!r})", file=sys.stderr)
                 step = None
+            if world > 1:   # every rank must issue the same sequence of collectives: one failure -> all fall back
+                flag = torch.tensor([1.0 if step is not None else 0.0], device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                if flag.item() < 0.5:
+                    step = None
+                    info.pop("ar_overlap", None)
             if step is None:
                 model.disable_split_backward()
                 step = capture_plain()

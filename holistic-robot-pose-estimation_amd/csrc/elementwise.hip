@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
     constexpr int U = HRP_EW_APPLY_U;
     const bool bn = d.in.mode == HRP_EW_BN_TRAIN, use_bits = d.relu && V > 1 && d.mask, use_out = d.relu && !use_bits;
     for (; q + (U - 1) * stride < nq; q += U * stride) {
-      float g[U][V], xin[U][V], o[U][V], old[U][V], g2[U][V];
+      // (the rarer operands - saved output instead of the bit mask, accumulation targets - are read where they are
+      // used: keeping them in the batch cost 100 registers on every variant of the kernel)
+      float g[U][V], xin[U][V];
       unsigned bits[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.dout, ((size_t)q + (size_t)u * stride) * d.dout_pitch + c, g[u]);
@@ -396,18 +398,6 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
 #pragma unroll
         for (int u = 0; u < U; ++u) bits[u] = d.mask[((size_t)q + (size_t)u * stride) * d.mask_pitch + c / V];
       }
-      if (use_out) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.out, ((size_t)q + (size_t)u * stride) * d.out_pitch + c, o[u]);
-      }
-      if (d.accumulate) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.din, ((size_t)q + (size_t)u * stride) * d.din_pitch + c, old[u]);
-      }
-      if (d.din2 && d.accumulate2) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) VecIO<T, V>::ld(d.din2, ((size_t)q + (size_t)u * stride) * d.din2_pitch + c, g2[u]);
-      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const size_t p = (size_t)q + (size_t)u * stride;
@@ -415,14 +405,18 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
 #pragma unroll
           for (int i = 0; i < V; ++i) g[u][i] = (bits[u] >> i) & 1u ? g[u][i] : 0.f;
         } else if (use_out) {
+          float o[V];
+          VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] = o[u][i] > 0.f ? g[u][i] : 0.f;
+          for (int i = 0; i < V; ++i) g[u][i] = o[i] > 0.f ? g[u][i] : 0.f;
         }
         if (d.din2) {
           if (d.accumulate2) {
+            float g2[V];
+            VecIO<T, V>::ld(d.din2, p * d.din2_pitch + c, g2);
 #pragma unroll
-            for (int i = 0; i < V; ++i) g2[u][i] += g[u][i];
-            VecIO<T, V>::st(d.din2, p * d.din2_pitch + c, g2[u]);
+            for (int i = 0; i < V; ++i) g2[i] += g[u][i];
+            VecIO<T, V>::st(d.din2, p * d.din2_pitch + c, g2);
           } else {
             VecIO<T, V>::st(d.din2, p * d.din2_pitch + c, g[u]);
           }
@@ -435,8 +429,10 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
           for (int i = 0; i < V; ++i) g[u][i] *= sc[i];
         }
         if (d.accumulate) {
+          float old[V];
+          VecIO<T, V>::ld(d.din, p * d.din_pitch + c, old);
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] += old[u][i];
+          for (int i = 0; i < V; ++i) g[u][i] += old[i];
         }
         VecIO<T, V>::st(d.din, p * d.din_pitch + c, g[u]);
       }

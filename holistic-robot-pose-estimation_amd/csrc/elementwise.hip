@@ -23,6 +23,18 @@ struct VecIO {
     if constexpr (V == 1) Elem<T>::st(p, i, f[0]);
     else *(uint4*)((char*)p + i * Elem<T>::SZ) = Elem<T>::pack(f);
   }
+  // load now, convert at the use: a batch of bf16 vectors waits in half the registers of its fp32 form
+  struct Raw { uint4 q; };
+  __device__ static __forceinline__ Raw ldr(const void* p, size_t i) {
+    Raw r;
+    if constexpr (V == 1) r.q = make_uint4(__float_as_uint(Elem<T>::ld(p, i)), 0, 0, 0);
+    else r.q = *(const uint4*)((const char*)p + i * Elem<T>::SZ);
+    return r;
+  }
+  __device__ static __forceinline__ void cvt(const Raw& r, float* f) {
+    if constexpr (V == 1) f[0] = __uint_as_float(r.q.x);
+    else Elem<T>::unpack(r.q, f);
+  }
 };
 
 // x rotated right by N lanes inside each row of 16 lanes (DPP row_ror)
@@ -73,7 +85,9 @@ __device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int c
   }
 }
 
-template <typename T, int V>
+// MAXIN: inputs this instance can take (2: the blocks' activations, half the channel-constant registers of the
+// 4-input fuse instance - the register count decides how many waves of OTHER lanes' kernels fit next to this one)
+template <typename T, int V, int MAXIN>
 __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
   extern __shared__ float ew_lds[];
   float* tab = ew_lds;
@@ -81,11 +95,11 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
   const int c = cv * V;
   const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;  // pixels per block-iteration
-  float sc[HRP_EW_MAX_IN][V], sh[HRP_EW_MAX_IN][V];
+  float sc[MAXIN][V], sh[MAXIN][V];
   {
     float m[V], iv[V];
 #pragma unroll
-    for (int j = 0; j < HRP_EW_MAX_IN; ++j)
+    for (int j = 0; j < MAXIN; ++j)
       if (j < d.nin) {
         if (d.in[j].mode == HRP_EW_IDENTITY) {
 #pragma unroll
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
   const unsigned npix = (unsigned)d.N * d.H * d.W;
   bool any_up = false;
 #pragma unroll
-  for (int j = 0; j < HRP_EW_MAX_IN; ++j) any_up = any_up || (j < d.nin && d.in[j].up != 1);
+  for (int j = 0; j < MAXIN; ++j) any_up = any_up || (j < d.nin && d.in[j].up != 1);
   const unsigned uW = d.W, uH = d.H;
   const unsigned stride = gridDim.x * ppb;
   unsigned p = blockIdx.x * ppb + threadIdx.x / tpr;
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < HRP_EW_MAX_IN; ++j) {
+    for (int j = 0; j < MAXIN; ++j) {
       if (j >= d.nin) break;
       const hrp_ew_input& in = d.in[j];
       size_t q;
@@ -227,26 +241,30 @@ template <typename T, int V, int RM, int U>
 __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int c, unsigned q, unsigned stride, unsigned nq,
                                                   const float (&mean)[V], const float (&inv)[V], float (&s0)[V], float (&s1)[V]) {
   for (; q + (U - 1) * stride < nq; q += U * stride) {
-    float go[U][V], xin[U][V], o[RM == 2 ? U : 1][V];
+    typename VecIO<T, V>::Raw go[U], xin[U];
     unsigned bits[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t p = (size_t)q + (size_t)u * stride;
-      VecIO<T, V>::ld(d.dout, p * d.dout_pitch + c, go[u]);
-      VecIO<T, V>::ld(d.in.ptr, p * d.in.pitch + c, xin[u]);
+      go[u] = VecIO<T, V>::ldr(d.dout, p * d.dout_pitch + c);
+      xin[u] = VecIO<T, V>::ldr(d.in.ptr, p * d.in.pitch + c);
       if constexpr (RM == 1) bits[u] = d.mask[p * d.mask_pitch + c / V];
-      if constexpr (RM == 2) VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o[u]);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      float gf[V], xf[V], o[V];   // (RM == 2, the rare variant without a bit mask: read where it is used)
+      VecIO<T, V>::cvt(go[u], gf);
+      VecIO<T, V>::cvt(xin[u], xf);
+      if constexpr (RM == 2) VecIO<T, V>::ld(d.out, ((size_t)q + (size_t)u * stride) * d.out_pitch + c, o);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        float g = go[u][i];
+        float g = gf[i];
         if constexpr (RM == 1) g = (bits[u] >> i) & 1u ? g : 0.f;
-        if constexpr (RM == 2) g = o[u][i] > 0.f ? g : 0.f;
+        if constexpr (RM == 2) g = o[i] > 0.f ? g : 0.f;
         s0[i] += g;
-        s1[i] += g * (xin[u][i] - mean[i]) * inv[i];
+        s1[i] += g * (xf[i] - mean[i]) * inv[i];
       }
+    }
   }
   return q;
 }
@@ -518,8 +536,9 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
   const int lds = 4 * tabn * 4;
-  if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
-  else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
+  if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1, HRP_EW_MAX_IN>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
+  else if (d.nin <= 2) hipLaunchKernelGGL((ew_fwd_kernel<T, VEC, 2>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
+  else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC, HRP_EW_MAX_IN>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
   return check_launch("ew_fwd");
 }
 

@@ -626,7 +626,10 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   // persistent workgroups (about two per CU, each walking tiles b, b + grid, ...) when a tile is little MFMA
   // work and there are several tiles per CU; one tile per workgroup otherwise
   const int mfma_per_tile = cdiv(d.Cin * SZ, ROW) * NT * CT * PT * Mma<T>::KSTEPS;
-  static const int persist_max = getenv("HRP_CONV_PERSIST") ? atoi(getenv("HRP_CONV_PERSIST")) : 48;
+  // (off by default since the end of round 1: the persistent instances hold 196-208 registers per lane against 96-132,
+  // so nothing of another lane fits next to their two workgroups on a CU; alone they are 15 % faster on 32->32 @64x64,
+  // in the step they cost 0.55 ms - HRP_CONV_PERSIST=48 restores them)
+  static const int persist_max = getenv("HRP_CONV_PERSIST") ? atoi(getenv("HRP_CONV_PERSIST")) : 0;
   constexpr bool CAN_PERSIST = NT == 9;   // (only 3x3 layers have tiles small enough to profit; keeps the instantiation count down)
   const bool persist = CAN_PERSIST && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256;   // 1x1 layers are store bound: many small workgroups
   const bool fastp = (d.Cin * SZ) % ROW == 0;   // no half-filled last chunk: per-piece advancing pointers

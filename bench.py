@@ -316,11 +316,15 @@ def main():
             def step():
                 g1.replay()
         else:
+            # process-group threads (the RCCL watchdog polls events) keep running while this thread captures: only this
+            # thread's calls are held to the capture rules
+            gmode = dict(capture_error_mode="thread_local")
+
             def capture_plain():
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, **gmode):
                     fwd_bwd()
-                with torch.cuda.graph(g2):
+                with torch.cuda.graph(g2, **gmode):
                     update()
 
                 def step():
@@ -341,11 +345,11 @@ def main():
                 final = [(o, n) for o, n in final if n >= (1 << 18)]
                 rest = GradAllReducer.complement(final, arena.numel())
                 g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1a):
+                with torch.cuda.graph(g1a, **gmode):
                     fwd_bwd()                       # (split active: the backward stops at the split)
-                with torch.cuda.graph(g1b):
+                with torch.cuda.graph(g1b, **gmode):
                     plan.run_backward("rest")
-                with torch.cuda.graph(g2):
+                with torch.cuda.graph(g2, **gmode):
                     update()
                 # self-check on this machine: the second graph must not touch the ranges already handed to RCCL
                 g1a.replay()

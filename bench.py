@@ -158,29 +158,43 @@ def cpu_baseline(B, threads):
                       f"1 warm-up + {n} timed steps, {dt:.1f} s"}
 
 
+def launch_descs(name, args):
+    """-> (family entry point, descriptors) of one launch: a single C-ABI call or one batched launch of n problems."""
+    if name == "hrp_batch_launch":
+        b = args[0]
+        return nv.FAMILY_FN[b.fam], [it.desc for it in b.items]
+    try:
+        return name, [args[0]._obj]
+    except (AttributeError, IndexError):
+        return name, []
+
+
 def conv_flops(name, args):
-    """Algorithmic FLOP of one launch from its descriptor (real channel counts)."""
-    if name == "hrp_conv2d_fwd":
-        d = args[0]._obj
-        return 2.0 * d.N * d.Ho * d.Wo * d.Cout * min(d.Cin, 10 ** 9) * d.ntaps
-    if name == "hrp_conv2d_bwd_weight":
-        d = args[0]._obj
-        return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps
+    """Algorithmic FLOP of one launch from its descriptor(s) (real channel counts)."""
+    fam, descs = launch_descs(name, args)
+    if fam == "hrp_conv2d_fwd":
+        return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps for d in descs)
+    if fam == "hrp_conv2d_bwd_weight":
+        return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps for d in descs)
     return 0.0
 
 
 def conv_bytes(name, args):
     """Algorithmic HBM bytes of one launch: every operand read once, the result written once."""
-    if name not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
+    fam, descs = launch_descs(name, args)
+    if fam not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
         return 0.0
-    d = args[0]._obj
-    esz = 2 if d.dtype == nv.HRP_BF16 else 4
-    if name == "hrp_conv2d_fwd":
-        b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
-        if d.res:
-            b += d.N * d.Ho * d.Wo * d.Cout * esz
-        return float(b)
-    return float((d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout) * esz + d.Cout * d.dw_cin * d.ntaps * 4)
+    tot = 0.0
+    for d in descs:
+        esz = 2 if d.dtype == nv.HRP_BF16 else 4
+        if fam == "hrp_conv2d_fwd":
+            b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
+            if d.res:
+                b += d.N * d.Ho * d.Wo * d.Cout * esz
+            tot += b
+        else:
+            tot += (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout) * esz + d.Cout * d.dw_cin * d.ntaps * 4
+    return float(tot)
 
 
 def main():
@@ -363,7 +377,7 @@ def main():
                     raise RuntimeError("split backward self-check failed")
                 info["ar_overlap"] = {"final_fraction": round(sum(n for _, n in final) / arena.numel(), 3),
                                       "ranges_mb": [round(n * 4 / 2 ** 20, 1) for _, n in final],
-                                      "rest_ranges": len(rest), "split_at": plan.bwd_split, "bwd_ops": len(plan.bwd)}
+                                      "rest_ranges": len(rest), "split_at": plan.bwd_split, "bwd_ops": len(plan.bwd_ops())}
 
                 def step():
                     g1a.replay()
@@ -452,19 +466,22 @@ def main():
     records, records_shape = [], []
 
     def shape_key(name, args):
-        try:
-            dd = args[0]._obj
-        except AttributeError:
+        fam, descs = launch_descs(name, args)
+        if not descs:
             return ""
-        if name == "hrp_conv2d_fwd":
-            return f"{dd.Cin}->{dd.Cout} taps{dd.ntaps} s{dd.in_stride}/{dd.out_stride} @{dd.Ho}x{dd.Wo}"
-        if name == "hrp_conv2d_bwd_weight":
-            return f"{dd.Cin}->{dd.Cout} taps{dd.ntaps} s{dd.in_stride} @{dd.Ho}x{dd.Wo}"
-        if name == "hrp_ew_fwd":
-            return f"C{dd.C} @{dd.H}x{dd.W} nin{dd.nin}"
-        if name.startswith("hrp_ew_bwd"):
-            return f"C{dd.C} @{dd.H}x{dd.W} up{dd.inp.up} mode{dd.inp.mode}"
-        return ""
+        def one(dd):
+            if fam == "hrp_conv2d_fwd":
+                return f"{dd.Cin}->{dd.Cout} taps{dd.ntaps} s{dd.in_stride}/{dd.out_stride} @{dd.Ho}x{dd.Wo}"
+            if fam == "hrp_conv2d_bwd_weight":
+                return f"{dd.Cin}->{dd.Cout} taps{dd.ntaps} s{dd.in_stride} @{dd.Ho}x{dd.Wo}"
+            if fam == "hrp_ew_fwd":
+                return f"C{dd.C} @{dd.H}x{dd.W} nin{dd.nin}"
+            if fam.startswith("hrp_ew_bwd"):
+                return f"C{dd.C} @{dd.H}x{dd.W} up{dd.inp.up} mode{dd.inp.mode}"
+            return ""
+        if len(descs) == 1:
+            return one(descs[0])
+        return f"batch{len(descs)}[" + " | ".join(sorted({one(dd) for dd in descs}))[:100] + "]"
 
     def hook(name, args, launch):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -472,9 +489,10 @@ def main():
         launch()
         e1.record()
         fl = conv_flops(name, args)
-        records.append((name, fl, e0, e1, conv_bytes(name, args)))
+        fam = launch_descs(name, args)[0]      # batched launches count towards their family
+        records.append((fam, fl, e0, e1, conv_bytes(name, args)))
         if os.environ.get("HRP_BENCH_SHAPES"):
-            records_shape.append((name, fl, e0, e1, shape_key(name, args)))
+            records_shape.append((fam, fl, e0, e1, shape_key(name, args)))
 
     # lanes (concurrent graph branches) are folded onto one stream here: a kernel's duration is its own
     from hrpe_amd import plan as plan_mod

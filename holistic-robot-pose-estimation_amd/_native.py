@@ -79,6 +79,18 @@ class BnEntry(C.Structure):
                 ("accumulate", C.c_int32)]
 
 
+# batched launches (include/hrp.h hrp_batch_*)
+BATCH_MAX = 32
+BATCH_CONV, BATCH_WGRAD, BATCH_EW_FWD, BATCH_EW_BWD_REDUCE, BATCH_EW_BWD_APPLY = range(5)
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("family", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("variant", C.c_int32),
+                ("grid", C.c_int32), ("lds_bytes", C.c_int32), ("grid2", C.c_int32),
+                ("blk0", C.c_int32 * (BATCH_MAX + 1)), ("blk2", C.c_int32 * (BATCH_MAX + 1)),
+                ("ws_bytes", C.c_int64 * BATCH_MAX)]
+
+
 OPT_CHUNK = 4096
 
 
@@ -133,6 +145,8 @@ PROTOTYPES = {
     "hrp_mul_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_opt_grad_sumsq": [_P, _P, _I, _P, _P],
     "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
+    "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
+    "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],
     "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],
     "hrp_project_bwd": [_P, _P, _P, _I, _I, _P, _P],
 }
@@ -168,6 +182,8 @@ def lib():
         L.hrp_last_error.argtypes = []
         L.hrp_wgrad_workspace_bytes.restype = C.c_int64
         L.hrp_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
+        L.hrp_batch_table_bytes.restype = C.c_int64
+        L.hrp_batch_table_bytes.argtypes = [C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -196,3 +212,19 @@ def call(name, *args):
         _profile_hook(name, args, lambda: check(getattr(lib(), name)(*args), name))
         return
     check(getattr(lib(), name)(*args), name)
+
+
+def call_batch(batch, stream):
+    """One batched launch (plan.BatchLaunch: .table device tensor, .info BatchInfo, .items the merged launches)."""
+    name = "hrp_batch_launch"
+    if _skip and (name in _skip or FAMILY_FN[batch.fam] in _skip):
+        return
+    fn = lambda: check(lib().hrp_batch_launch(batch.table.data_ptr(), C.byref(batch.info), stream), name)   # noqa: E731
+    if _profile_hook is not None:
+        _profile_hook(name, (batch,), fn)
+        return
+    fn()
+
+
+FAMILY_FN = {"conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
+             "ew_app": "hrp_ew_bwd_apply"}

@@ -1,0 +1,139 @@
+// Batched tile convolution: n problems of one tap count and element type in one launch (hrp_batch_*, include/hrp.h).
+// Every problem keeps its own tile configuration: the kernel is the union of four instances of the tile program of
+// conv_tile.h behind a workgroup-uniform switch (registers / LDS of the launch = the maximum over the four).
+//
+// Tile choice differs from the single-problem launcher: a batch fills the chip by itself (the eight 3x3 problems of
+// a stage-4 layer are 3 000+ workgroups), so every problem takes the LARGEST tile that fits - 256 pixels x 32 or 64
+// output channels - instead of shrinking tiles until one problem alone reaches 256 workgroups; the weight slab of a
+// 128- or 256-channel layer is then staged once per 256 pixels instead of once per 64 or 128.
+#pragma once
+#include "conv_tile.h"
+#include <string.h>
+
+namespace hrp {
+
+struct ConvProblem {
+  hrp_conv_desc d;
+  ConvTiling t;
+  int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64
+  int pad[3];
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_batch_kernel(const ConvProblem* __restrict__ tab, const BatchHdr h) {
+  int base;
+  const int g = batch_find(h, blockIdx.x, base);
+  const ConvProblem& P = tab[g];
+  const int bid = (int)blockIdx.x - base;
+  const int slot = blockIdx.x & (HRP_STAT_SLOTS - 1);
+  switch (P.cfg) {
+    case 0: conv_tile_body<T, 1, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+    case 1: conv_tile_body<T, 1, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+    case 2: conv_tile_body<T, 2, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+    default: conv_tile_body<T, 2, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+  }
+}
+
+template <typename T, int NT>
+static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds) {
+  int rc = -100;
+  static const int budget_kb = getenv("HRP_CONV_BATCH_LDS_KB") ? atoi(getenv("HRP_CONV_BATCH_LDS_KB")) : 76;   // tuning knob
+  g_conv_lds_budget_kb = budget_kb;
+  if (d.Cout <= 32) {
+    rc = plan_cfg<T, 1, 2, 1, 4, NT>(d, P.t, lds, false); P.cfg = 0;
+    if (rc == -100) { rc = plan_cfg<T, 1, 1, 1, 4, NT>(d, P.t, lds, false); P.cfg = 1; }
+  } else {
+    rc = plan_cfg<T, 2, 2, 1, 4, NT>(d, P.t, lds, false); P.cfg = 2;
+    if (rc == -100) { rc = plan_cfg<T, 2, 1, 1, 4, NT>(d, P.t, lds, false); P.cfg = 3; }
+    if (rc == -100) { rc = plan_cfg<T, 1, 2, 1, 4, NT>(d, P.t, lds, false); P.cfg = 0; }
+    if (rc == -100) { rc = plan_cfg<T, 1, 1, 1, 4, NT>(d, P.t, lds, false); P.cfg = 1; }
+  }
+  if (rc == -100) {
+    set_error("conv batch: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
+    return HRP_ERR_ARG;
+  }
+  return rc;
+}
+
+template <typename T, int NT>
+static int conv_batch_prepare_nt(const hrp_conv_desc* descs, int n, ConvProblem* tab, hrp_batch_info* info) {
+  constexpr int SZ = Elem<T>::SZ;
+  ConvProblem probs[HRP_BATCH_MAX];
+  long weight[HRP_BATCH_MAX];
+  int lds_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const hrp_conv_desc& d = descs[i];
+    HRP_REQUIRE((d.Cin * SZ) % ROW == 0, "conv batch: Cin * sizeof(T) must be a multiple of 32 bytes (Cin=%d)", d.Cin);
+    memset(&probs[i], 0, sizeof(ConvProblem));
+    probs[i].d = d;
+    int lds = 0;
+    const int rc = conv_batch_plan_one<T, NT>(d, probs[i], lds);
+    if (rc != HRP_OK) return rc;
+    lds_max = lds > lds_max ? lds : lds_max;
+    // work of one workgroup (MFMA steps): the long-running problems go first so that the launch tail is short
+    const int ct = probs[i].cfg >= 2 ? 2 : 1, pt = (probs[i].cfg & 1) ? 1 : 2;
+    weight[i] = (long)cdiv(d.Cin * SZ, ROW) * NT * ct * pt;
+  }
+  int order[HRP_BATCH_MAX];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)   // stable insertion sort, heaviest first
+    for (int j = i; j > 0 && weight[order[j]] > weight[order[j - 1]]; --j) { int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }
+  int blk = 0;
+  for (int k = 0; k < n; ++k) {
+    info->blk0[k] = blk;
+    blk += probs[order[k]].t.nblocks;
+    if (tab) tab[k] = probs[order[k]];
+  }
+  info->blk0[n] = blk;
+  info->grid = blk;
+  info->lds_bytes = lds_max;
+  info->variant = NT;
+  return HRP_OK;
+}
+
+template <typename T>
+static int conv_batch_prepare_t(const hrp_conv_desc* descs, int n, void* table, hrp_batch_info* info) {
+  for (int i = 0; i < n; ++i) {
+    const int rc = conv_check(&descs[i]);
+    if (rc != HRP_OK) return rc;
+    HRP_REQUIRE(descs[i].ntaps == descs[0].ntaps && descs[i].dtype == descs[0].dtype, "conv batch: mixed tap counts / element types");
+    // skinny fp32 linear layers take the split-K path of the single launcher (memset + atomics): not batched
+    HRP_REQUIRE(!(descs[i].dtype == HRP_F32 && descs[i].H == 1 && descs[i].W == 1 && descs[i].Cin >= 512),
+                "conv batch: linear layers are launched one by one");
+  }
+  ConvProblem* tab = (ConvProblem*)table;
+  switch (descs[0].ntaps) {
+    case 1: return conv_batch_prepare_nt<T, 1>(descs, n, tab, info);
+    case 2: return conv_batch_prepare_nt<T, 2>(descs, n, tab, info);
+    case 4: return conv_batch_prepare_nt<T, 4>(descs, n, tab, info);
+    case 9: return conv_batch_prepare_nt<T, 9>(descs, n, tab, info);
+    default:
+      set_error("conv batch: ntaps=%d is not one of the batched tap counts (1, 2, 4, 9)", descs[0].ntaps);
+      return HRP_ERR_ARG;
+  }
+}
+
+template <typename T, int NT>
+static int conv_batch_launch_nt(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_batch_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const BatchHdr h = make_hdr(info->blk0, info->n);
+  hipLaunchKernelGGL((conv_batch_kernel<T, NT>), dim3(info->grid), dim3(256), info->lds_bytes, s, (const ConvProblem*)table_dev, h);
+  return check_launch("conv_batch_kernel");
+}
+
+template <typename T>
+static int conv_batch_launch_t(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
+  switch (info->variant) {
+    case 1: return conv_batch_launch_nt<T, 1>(table_dev, info, s);
+    case 2: return conv_batch_launch_nt<T, 2>(table_dev, info, s);
+    case 4: return conv_batch_launch_nt<T, 4>(table_dev, info, s);
+    case 9: return conv_batch_launch_nt<T, 9>(table_dev, info, s);
+    default: set_error("conv batch: bad variant %d", info->variant); return HRP_ERR_ARG;
+  }
+}
+
+}  // namespace hrp

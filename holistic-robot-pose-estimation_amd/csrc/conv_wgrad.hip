@@ -17,7 +17,9 @@
 // build one 8-deep MFMA operand; every source lane carries its own pixel address, so tap shifts and
 // stride-2 sampling cost nothing extra.  fp32 needs one 32-bit read per operand.
 #include "hrp_common.h"
+#include "batch.h"
 #include <stdlib.h>
+#include <string.h>
 
 // -DHRP_TIMELINE (tools/bench_kernels.py timeline, never in the shipped library): wave 0 of every workgroup
 // stamps the 100 MHz wall clock at phase boundaries into the last MiB of the workspace.
@@ -48,7 +50,7 @@ struct WgradTiling {
   int x_pieces, dy_pieces, buf_bytes;   // 1 KiB DMA pieces of the X halo tile / dY tile; one stage buffer
   int lds_tab_off, lds_red_off;
   int use_ws, lds_bytes;
-  FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_tx, fd_ty, fd_cib;
+  FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_tx, fd_ty, fd_cib, fd_g;
 };
 
 template <typename T>
@@ -88,8 +90,10 @@ __device__ __forceinline__ void wg_dma16(const char* src, char* lds_wave_base) {
 // NB = 32-channel blocks per workgroup in each of the cout / cin dimensions.  NB = 2 (1x1 layers, bf16): a
 // 64 x 64 block of dW per workgroup = 4 MFMAs per 4 fragment reads instead of 1 per 2, and half the re-reads of
 // X and dY across workgroups (the 32 x 32 version of the 1x1 layers ran at 80 TFLOP/s, LDS-read bound).
+// gxi: which of the t.G pixel-tile shares this workgroup walks; blk: its (cout block, cin block) pair.  The single
+// launch passes (blockIdx.x, blockIdx.y), the batched launch what it decoded from its linear block index.
 template <typename T, int NT, int NKS, int NB>
-__global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgrad_desc d, const WgradTiling t) {
+__device__ __forceinline__ void conv_wgrad_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
   static_assert(NB == 1 || (NT == 1 && Elem<T>::SZ == 2), "NB = 2 is built for 1x1 bf16 only");
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
   constexpr int CB = 32 * NB;       // channels per workgroup block (cout and cin)
@@ -104,14 +108,14 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int blk = blockIdx.y;
+  const int npairs = t.n_cob * t.n_cib;
   const int cob = fdiv(blk, t.fd_cib), cib = blk - cob * t.n_cib;
   const int co0 = cob * CB, ci0 = cib * CB;
   const int IS = d.in_stride;
   const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
 #ifdef HRP_TIMELINE
   unsigned long long* tl = (unsigned long long*)((char*)d.workspace + d.workspace_bytes - (1 << 20)) +
-                           ((size_t)blockIdx.x * gridDim.y + blk) * 16;
+                           ((size_t)gxi * npairs + blk) * 16;
 #endif
   HRP_STAMP(0);
 
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   // hides the LDS latency).
   int it = 0;
   HRP_STAMP(1);
-  if ((int)blockIdx.x < t.ntiles) issue(blockIdx.x, smem);
+  if (gxi < t.ntiles) issue(gxi, smem);
   // (computed here, under the latency of the first tile's DMA)
   // bf16: the LDS offsets of a lane's operands do not depend on the tile -> registers, NKS k-steps of 16 pixels
   constexpr int NKS_ = NKS > 0 ? NKS : 1;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   }
 
   HRP_STAMP(2);
-  for (int tile = blockIdx.x; tile < t.ntiles; tile += t.G, ++it) {
+  for (int tile = gxi; tile < t.ntiles; tile += t.G, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (it < 4) HRP_STAMP(3 + 2 * it);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   float* dump = (float*)smem;
   const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
   // partial slab [g][block][NT*1024], coalesced; a second launch folds the G slabs into dW
-  float* ws = t.use_ws ? (float*)d.workspace + ((size_t)blockIdx.x * gridDim.y + blk) * (NTE * 1024) : nullptr;
+  float* ws = t.use_ws ? (float*)d.workspace + ((size_t)gxi * npairs + blk) * (NTE * 1024) : nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();
@@ -398,10 +402,14 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   }
 }
 
-// dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci]
-template <int NTE, int NB>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc d, int G, int pairs, int n_cib) {
-  const int blk = blockIdx.y;
+template <typename T, int NT, int NKS, int NB>
+__global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgrad_desc d, const WgradTiling t) {
+  conv_wgrad_body<T, NT, NKS, NB>(d, t, blockIdx.x, blockIdx.y);
+}
+
+// dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci].  bx: which 64 consecutive elements of the pair's NTE * 1024.
+__device__ __forceinline__ void wgrad_reduce_body(const hrp_wgrad_desc& d, const int G, const int pairs, const int n_cib,
+                                                  const int NTE, const int NB, const int bx, const int blk) {
   const int cob = blk / n_cib, cib = blk - cob * n_cib;
   const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
   // block = 64 consecutive elements x 4 slab phases; lanes read 256 contiguous bytes of a slab, 8 loads
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc 
   const float* ws = (const float*)d.workspace + (size_t)blk * (NTE * 1024);
   const size_t gstride = (size_t)pairs * (NTE * 1024);
   const int e = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + e;
+  const int i = bx * 64 + e;
   float s = 0.f;
   int g = ph;
   for (; g + 28 < G; g += 32) {
@@ -435,8 +443,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc 
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc d, int G, int pairs, int n_cib, int NTE, int NB) {
+  wgrad_reduce_body(d, G, pairs, n_cib, NTE, NB, blockIdx.x, blockIdx.y);
+}
+
+// wg_total: workgroups this problem may use (0: the single-launch default, about one per CU)
 template <typename T, int NT, int NB>
-static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
+static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget = 0) {
   constexpr int SZ = Elem<T>::SZ;
   constexpr int P = 32 * NB * SZ;
   constexpr int NTE = NT * NB * NB;
@@ -498,10 +511,11 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t) {
   int pairs = t.n_cob * t.n_cib;
   // workgroups per (cout, cin) block: ~2 per CU over the whole launch; each walks ntiles / G pixel tiles
   static const int wg_total = getenv("HRP_WGRAD_WGS") ? atoi(getenv("HRP_WGRAD_WGS")) : 256;   // tuning knob
-  int G = wg_total / pairs;
+  int G = (wg_budget > 0 ? wg_budget : wg_total) / pairs;
   if (G < 1) G = 1;
   if (G > t.ntiles) G = t.ntiles;
   t.G = G;
+  t.fd_g = make_fastdiv(G);
   t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
   t.fd_thw = make_fastdiv(t.TH * t.TW); t.fd_tw = make_fastdiv(t.TW);
   t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y); t.fd_cib = make_fastdiv(t.n_cib);
@@ -558,7 +572,7 @@ static int launch_wgrad_nb(const hrp_wgrad_desc& d, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(t.G, pairs), dim3(256), t.lds_bytes, s, d, t);
   rc = check_launch("conv_wgrad_kernel");
   if (rc != HRP_OK || !t.use_ws) return rc;
-  hipLaunchKernelGGL((wgrad_reduce_kernel<NTE, NB>), dim3(NTE * 1024 / 64, pairs), dim3(256), 0, s, d, t.G, pairs, t.n_cib);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NTE * 1024 / 64, pairs), dim3(256), 0, s, d, t.G, pairs, t.n_cib, NTE, NB);
   return check_launch("wgrad_reduce_kernel");
 }
 template <typename T, int NT>
@@ -569,10 +583,58 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
   return launch_wgrad_nb<T, NT, 1>(d, s);
 }
 
-}  // namespace hrp
 
-extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
-  using namespace hrp;
+// ---- batched launches (hrp_batch_*, include/hrp.h) --------------------------------------------------------------
+// n weight-gradient problems of one tap count and element type in one launch, each with its own tiling; a second
+// launch folds every problem's partial slabs.  The workgroups of the launch (about two per CU) are shared between the
+// problems in proportion to their work, so a problem contributes G = share / pairs slabs instead of the 256 / pairs of
+// a launch of its own: the eight 3x3 layers of a stage-4 step write 8 x 2.3 MB of slabs instead of 8 x 9.4 MB.
+struct WgradProblem {
+  hrp_wgrad_desc d;
+  WgradTiling t;
+  int nks, nb, nte, pairs;
+  FastDiv fd_r;   // division by nte * 16 (blocks per pair of the folding launch)
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) WGRAD_OCC void wgrad_batch_kernel(const WgradProblem* __restrict__ tab, const BatchHdr h) {
+  int base;
+  const int g = batch_find(h, blockIdx.x, base);
+  const WgradProblem& P = tab[g];
+  const int local = (int)blockIdx.x - base;
+  const int blk = fdiv(local, P.t.fd_g);        // consecutive workgroups = the pixel shares of one (cout, cin) pair
+  const int gxi = local - blk * P.t.G;
+  if constexpr (Elem<T>::SZ == 4) {
+    conv_wgrad_body<T, NT, 0, 1>(P.d, P.t, gxi, blk);
+  } else if constexpr (NT == 1) {
+    switch (P.nks * 4 + P.nb) {
+      case 4 * 4 + 1: conv_wgrad_body<T, NT, 4, 1>(P.d, P.t, gxi, blk); break;
+      case 2 * 4 + 1: conv_wgrad_body<T, NT, 2, 1>(P.d, P.t, gxi, blk); break;
+      case 1 * 4 + 1: conv_wgrad_body<T, NT, 1, 1>(P.d, P.t, gxi, blk); break;
+      case 4 * 4 + 2: conv_wgrad_body<T, NT, 4, 2>(P.d, P.t, gxi, blk); break;
+      case 2 * 4 + 2: conv_wgrad_body<T, NT, 2, 2>(P.d, P.t, gxi, blk); break;
+      default: conv_wgrad_body<T, NT, 1, 2>(P.d, P.t, gxi, blk); break;
+    }
+  } else {
+    switch (P.nks) {
+      case 4: conv_wgrad_body<T, NT, 4, 1>(P.d, P.t, gxi, blk); break;
+      case 2: conv_wgrad_body<T, NT, 2, 1>(P.d, P.t, gxi, blk); break;
+      default: conv_wgrad_body<T, NT, 1, 1>(P.d, P.t, gxi, blk); break;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProblem* __restrict__ tab, const BatchHdr h) {
+  int base;
+  const int g = batch_find(h, blockIdx.x, base);
+  const WgradProblem& P = tab[g];
+  const int local = (int)blockIdx.x - base;
+  const int blk = fdiv(local, P.fd_r);
+  const int bx = local - blk * (P.nte * 16);
+  wgrad_reduce_body(P.d, P.t.G, P.pairs, P.t.n_cib, P.nte, P.nb, bx, blk);
+}
+
+static int wgrad_check(const hrp_wgrad_desc* d) {
   HRP_REQUIRE(d && d->x && d->dy && d->dw, "wgrad: null pointer");
   HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16, "wgrad: dtype");
   const int vec = d->dtype == HRP_F32 ? 4 : 8;
@@ -583,6 +645,134 @@ extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
   HRP_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "wgrad: ntaps=%d unsupported", d->ntaps);
   HRP_REQUIRE(d->dw_cin <= d->Cin, "wgrad: dw_cin > Cin");
   HRP_REQUIRE(d->dw_tap_stride == 0 || (d->dw_tap_off >= 0 && d->dw_tap_off + d->ntaps <= d->dw_tap_stride), "wgrad: tap group");
+  return HRP_OK;
+}
+
+template <typename T, int NT>
+static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget) {
+  P.nb = 1;
+  int rc;
+  if constexpr (can_nb2<T, NT>()) {
+    if (want_nb2(d)) P.nb = 2;
+  }
+  if (P.nb == 2) {
+    if constexpr (can_nb2<T, NT>()) rc = wgrad_tiling<T, NT, 2>(d, P.t, budget);
+    else rc = HRP_ERR_ARG;
+  } else {
+    rc = wgrad_tiling<T, NT, 1>(d, P.t, budget);
+  }
+  if (rc != HRP_OK) return rc;
+  P.nks = Elem<T>::SZ == 2 ? P.t.BM / 64 : 0;
+  P.nte = NT * P.nb * P.nb;
+  P.pairs = P.t.n_cob * P.t.n_cib;
+  P.fd_r = make_fastdiv(P.nte * 16);
+  return HRP_OK;
+}
+
+template <typename T, int NT>
+static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProblem* tab, hrp_batch_info* info) {
+  WgradProblem probs[HRP_BATCH_MAX];
+  double work[HRP_BATCH_MAX], total = 0.0;
+  for (int i = 0; i < n; ++i) {
+    memset(&probs[i], 0, sizeof(WgradProblem));
+    probs[i].d = descs[i];
+    const int rc = wgrad_plan_one<T, NT>(descs[i], probs[i], 0);
+    if (rc != HRP_OK) return rc;
+    work[i] = (double)descs[i].N * descs[i].Ho * descs[i].Wo * probs[i].pairs;
+    total += work[i];
+  }
+  // workgroups of the launch: two per CU, shared in proportion to the work (at least one per (cout, cin) pair)
+  static const int wg_launch = getenv("HRP_WGRAD_BATCH_WGS") ? atoi(getenv("HRP_WGRAD_BATCH_WGS")) : 512;
+  int lds_max = 0, blk = 0, blk2 = 0;
+  for (int i = 0; i < n; ++i) {
+    int budget = (int)(wg_launch * work[i] / total + 0.5);
+    if (budget < probs[i].pairs) budget = probs[i].pairs;
+    const int rc = wgrad_plan_one<T, NT>(descs[i], probs[i], budget);
+    if (rc != HRP_OK) return rc;
+    WgradProblem& P = probs[i];
+    const int64_t need = (int64_t)P.t.G * P.pairs * P.nte * 1024 * 4;
+    info->ws_bytes[i] = need;
+    if (tab) {
+      HRP_REQUIRE(descs[i].workspace && descs[i].workspace_bytes >= need,
+                  "wgrad batch: problem %d needs %lld workspace bytes (has %lld)", i, (long long)need, (long long)descs[i].workspace_bytes);
+      HRP_REQUIRE((uintptr_t)descs[i].workspace % 16 == 0, "wgrad batch: workspace alignment");
+    }
+    P.t.use_ws = 1;
+    lds_max = P.t.lds_bytes > lds_max ? P.t.lds_bytes : lds_max;
+    info->blk0[i] = blk;
+    blk += P.t.G * P.pairs;
+    info->blk2[i] = blk2;
+    blk2 += P.nte * 16 * P.pairs;
+    if (tab) tab[i] = P;
+  }
+  info->blk0[n] = blk; info->blk2[n] = blk2;
+  info->grid = blk; info->grid2 = blk2;
+  info->lds_bytes = lds_max;
+  info->variant = NT;
+  return HRP_OK;
+}
+
+template <typename T>
+static int wgrad_batch_prepare_t(const hrp_wgrad_desc* descs, int n, void* table, hrp_batch_info* info) {
+  WgradProblem* tab = (WgradProblem*)table;
+  switch (descs[0].ntaps) {
+    case 1: return wgrad_batch_prepare_nt<T, 1>(descs, n, tab, info);
+    case 4: return wgrad_batch_prepare_nt<T, 4>(descs, n, tab, info);
+    default: return wgrad_batch_prepare_nt<T, 9>(descs, n, tab, info);
+  }
+}
+
+int wgrad_batch_prepare(const hrp_wgrad_desc* descs, int n, void* table, hrp_batch_info* info) {
+  for (int i = 0; i < n; ++i) {
+    const int rc = wgrad_check(&descs[i]);
+    if (rc != HRP_OK) return rc;
+    HRP_REQUIRE(descs[i].ntaps == descs[0].ntaps && descs[i].dtype == descs[0].dtype, "wgrad batch: mixed tap counts / element types");
+  }
+  if (descs[0].dtype == HRP_F32) return wgrad_batch_prepare_t<float>(descs, n, table, info);
+  return wgrad_batch_prepare_t<bf16_t>(descs, n, table, info);
+}
+
+template <typename T, int NT>
+static int wgrad_batch_launch_nt(const WgradProblem* tab, const hrp_batch_info* info, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_batch_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_batch_kernel<T, NT>), dim3(info->grid), dim3(256), info->lds_bytes, s, tab, make_hdr(info->blk0, info->n));
+  int rc = check_launch("wgrad_batch_kernel");
+  if (rc != HRP_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(info->grid2), dim3(256), 0, s, tab, make_hdr(info->blk2, info->n));
+  return check_launch("wgrad_reduce_batch_kernel");
+}
+
+int wgrad_batch_launch(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
+  const WgradProblem* tab = (const WgradProblem*)table_dev;
+  if (info->dtype == HRP_F32) {
+    switch (info->variant) {
+      case 1: return wgrad_batch_launch_nt<float, 1>(tab, info, s);
+      case 4: return wgrad_batch_launch_nt<float, 4>(tab, info, s);
+      case 9: return wgrad_batch_launch_nt<float, 9>(tab, info, s);
+    }
+  } else {
+    switch (info->variant) {
+      case 1: return wgrad_batch_launch_nt<bf16_t, 1>(tab, info, s);
+      case 4: return wgrad_batch_launch_nt<bf16_t, 4>(tab, info, s);
+      case 9: return wgrad_batch_launch_nt<bf16_t, 9>(tab, info, s);
+    }
+  }
+  set_error("wgrad batch: bad variant %d", info->variant);
+  return HRP_ERR_ARG;
+}
+
+int64_t wgrad_batch_table_bytes(int n) { return (int64_t)n * sizeof(WgradProblem); }
+
+}  // namespace hrp
+
+extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
+  using namespace hrp;
+  const int crc = wgrad_check(d);
+  if (crc != HRP_OK) return crc;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == HRP_F32) {
     if (d->ntaps == 1) return launch_wgrad<float, 1>(*d, s);

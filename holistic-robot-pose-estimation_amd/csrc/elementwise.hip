@@ -8,7 +8,9 @@
 // Train-mode BN needs no separate finalize kernel: each workgroup derives scale/shift of its channel slab
 // once (into LDS) from the (sum, sumsq) statistic slots the producing conv accumulated in its epilogue.
 #include "hrp_common.h"
+#include "batch.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace hrp {
 
@@ -87,13 +89,15 @@ __device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int c
 
 // MAXIN: inputs this instance can take (2: the blocks' activations, half the channel-constant registers of the
 // 4-input fuse instance - the register count decides how many waves of OTHER lanes' kernels fit next to this one)
+// (bx, by) of gx x nslab: the block's position in its problem's grid - blockIdx / gridDim in the single launch, decoded
+// from the linear block index in the batched launch
 template <typename T, int V, int MAXIN>
-__global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
+__device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr, const int bx, const int by, const int gx) {
   extern __shared__ float ew_lds[];
   float* tab = ew_lds;
-  const int cv = (blockIdx.y * tpr + threadIdx.x % tpr);
+  const int cv = (by * tpr + threadIdx.x % tpr);
   const int c = cv * V;
-  const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
+  const int cbase = by * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;  // pixels per block-iteration
   float sc[MAXIN][V], sh[MAXIN][V];
   {
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
 #pragma unroll
   for (int j = 0; j < MAXIN; ++j) any_up = any_up || (j < d.nin && d.in[j].up != 1);
   const unsigned uW = d.W, uH = d.H;
-  const unsigned stride = gridDim.x * ppb;
-  unsigned p = blockIdx.x * ppb + threadIdx.x / tpr;
+  const unsigned stride = gx * ppb;
+  unsigned p = bx * ppb + threadIdx.x / tpr;
   if (!any_up && d.nin <= 2) {
     // one or two same-resolution inputs (every activation of the blocks): U pixels per thread and trip, all loads
     // issued before the first use; one block per CU then streams as fast as four with one-pixel trips
@@ -197,6 +201,11 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
   }
 }
 
+template <typename T, int V, int MAXIN>
+__global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
+  ew_fwd_body<T, V, MAXIN>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 // pooled, masked output gradient at input pixel q = (n, qy, qx)
 template <typename T, int V>
 __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q, int c, float* g) {
@@ -270,7 +279,8 @@ __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int 
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_desc d, int tpr) {
+__device__ __forceinline__ void ew_bwd_reduce_body(const hrp_ew_bwd_desc& d, const int tpr, const int bx, const int by, const int gx,
+                                                   const int stat_slot) {
   extern __shared__ float ew_lds[];
   const int tabn = min(tpr * V, TAB_CH);
   float* tab = ew_lds;
@@ -278,9 +288,9 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   float* red0 = ew_lds + 4 * tabn;
   float* red1 = red0 + nred;
   const int lane_c = threadIdx.x % tpr;
-  const int cv = blockIdx.y * tpr + lane_c;
+  const int cv = by * tpr + lane_c;
   const int c = cv * V;
-  const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
+  const int cbase = by * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;
   const int up = d.in.up, Hq = d.H / up, Wq = d.W / up;
   float s0[V], s1[V];
@@ -290,8 +300,8 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   load_consts<V>(d.in, d.C, cbase, nch, c, tab, sc, sh, mean, inv);
   if (c < d.C) {
     const unsigned nq = (unsigned)d.N * Hq * Wq;
-    const unsigned stride = gridDim.x * ppb;
-    unsigned q = blockIdx.x * ppb + threadIdx.x / tpr;
+    const unsigned stride = gx * ppb;
+    unsigned q = bx * ppb + threadIdx.x / tpr;
     if (up == 1) {   // (uniform) batched pixel loop, then its single-pixel tail
       if (!d.relu) { q = reduce_pixels<T, V, 0, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 0, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
       else if (V > 1 && d.mask) { q = reduce_pixels<T, V, 1, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 1, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
@@ -339,32 +349,37 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
   // thread (lane_c, i) -> one channel: tpr * V threads finish the sum and issue the atomics
   for (int e = threadIdx.x; e < tpr * V; e += 256) {
     const int lc = e / V, i = e - lc * V;
-    const int ch = (blockIdx.y * tpr + lc) * V + i;
+    const int ch = (by * tpr + lc) * V + i;
     if (ch >= d.C) continue;
     float a0 = 0.f, a1 = 0.f;
     for (int k = 0; k < nparts; ++k) {
       a0 += red0[(k * tpr + lc) * V + i];
       a1 += red1[(k * tpr + lc) * V + i];
     }
-    float* slot = d.sums + (blockIdx.x & (HRP_STAT_SLOTS - 1)) * 2 * d.C;
+    float* slot = d.sums + stat_slot * 2 * d.C;
     atomicAdd(&slot[ch], a0);
     atomicAdd(&slot[d.C + ch], a1);
   }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_desc d, int tpr) {
+  ew_bwd_reduce_body<T, V>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
 }
 
 #ifndef HRP_EW_APPLY_U
 #define HRP_EW_APPLY_U 4
 #endif
 template <typename T, int V>
-__global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
+__device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, const int tpr, const int bx, const int by, const int gx) {
   extern __shared__ float ew_lds[];
   const int tabn = min(tpr * V, TAB_CH);
   float* tab = ew_lds;
   float* ktab0 = ew_lds + 4 * tabn;
   float* ktab1 = ktab0 + tabn;
-  const int cv = blockIdx.y * tpr + threadIdx.x % tpr;
+  const int cv = by * tpr + threadIdx.x % tpr;
   const int c = cv * V;
-  const int cbase = blockIdx.y * tpr * V, nch = tpr * V;
+  const int cbase = by * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;
   const int up = d.in.up, Hq = d.H / up, Wq = d.W / up;
   float sc[V], sh[V], mean[V], inv[V], k0[V], k1[V];
@@ -395,8 +410,8 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
   }
   if (c >= d.C) return;
   const unsigned nq = (unsigned)d.N * Hq * Wq;
-  const unsigned stride = gridDim.x * ppb;
-  unsigned q = blockIdx.x * ppb + threadIdx.x / tpr;
+  const unsigned stride = gx * ppb;
+  unsigned q = bx * ppb + threadIdx.x / tpr;
   if (up == 1) {
     // U pixels per thread and trip, every load of the trip issued before the first use (the branches are uniform)
     constexpr int U = HRP_EW_APPLY_U;
@@ -492,6 +507,11 @@ __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc
   }
 }
 
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
+  ew_bwd_apply_body<T, V>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 static inline bool aligned16(const void* p, int pitch, int sz) {
   return ((uintptr_t)p % 16 == 0) && (((size_t)pitch * sz) % 16 == 0);
 }
@@ -578,11 +598,176 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   return check_launch(APPLY ? "ew_bwd_apply" : "ew_bwd_reduce");
 }
 
+
+// ---- batched launches (hrp_batch_*, include/hrp.h) --------------------------------------------------------------
+// n element-wise problems in one launch (the activations of every branch of both trunks after the same layer, all
+// BatchNorm backward passes of a lock-step layer ..).  Vector path only.  The launch's workgroups are shared between
+// the problems in proportion to their bytes, so a workgroup of the [64,64,64,32] tensor and one of the [64,8,8,256]
+// tensor stream about the same amount.
+struct EwProblem { hrp_ew_desc d; int tpr, gx, nslab, pad; FastDiv fd_gx; };
+struct EwBwdProblem { hrp_ew_bwd_desc d; int tpr, gx, nslab, pad; FastDiv fd_gx; };
+
+template <typename T, int MAXIN>
+__global__ __launch_bounds__(256) void ew_fwd_batch_kernel(const EwProblem* __restrict__ tab, const BatchHdr h) {
+  int base;
+  const int g = batch_find(h, blockIdx.x, base);
+  const EwProblem& P = tab[g];
+  const int local = (int)blockIdx.x - base;
+  const int by = fdiv(local, P.fd_gx), bx = local - by * P.gx;
+  ew_fwd_body<T, Elem<T>::VEC, MAXIN>(P.d, P.tpr, bx, by, P.gx);
+}
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void ew_bwd_batch_kernel(const EwBwdProblem* __restrict__ tab, const BatchHdr h) {
+  int base;
+  const int g = batch_find(h, blockIdx.x, base);
+  const EwBwdProblem& P = tab[g];
+  const int local = (int)blockIdx.x - base;
+  const int by = fdiv(local, P.fd_gx), bx = local - by * P.gx;
+  if constexpr (APPLY) ew_bwd_apply_body<T, Elem<T>::VEC>(P.d, P.tpr, bx, by, P.gx);
+  else ew_bwd_reduce_body<T, Elem<T>::VEC>(P.d, P.tpr, bx, by, P.gx, blockIdx.x & (HRP_STAT_SLOTS - 1));
+}
+
+static int ew_fwd_check(const hrp_ew_desc* d);
+static int ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply);
+
+// share of `total` workgroups for a problem of `bytes` out of `sum` (at least `lo`)
+static inline int ew_share(int total, double bytes, double sum, int lo) {
+  int b = (int)(total * bytes / sum + 0.5);
+  return b < lo ? lo : b;
+}
+
+template <typename T>
+static int ew_fwd_batch_prepare(const hrp_ew_desc* descs, int n, EwProblem* tab, hrp_batch_info* info) {
+  constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
+  double bytes[HRP_BATCH_MAX], sum = 0.0;
+  int maxin = 2;
+  for (int i = 0; i < n; ++i) {
+    const hrp_ew_desc& d = descs[i];
+    const int rc = ew_fwd_check(&d);
+    if (rc != HRP_OK) return rc;
+    bool ok = aligned16(d.out, d.out_pitch, SZ) && d.C % VEC == 0;
+    for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
+    HRP_REQUIRE(ok, "ew batch: problem %d is not on the 16-byte vector path", i);
+    HRP_REQUIRE(!d.mask || (d.relu && d.mask_pitch >= d.C / VEC), "ew_fwd: the ReLU bit mask needs relu and the 16-byte vector path");
+    if (d.nin > 2) maxin = HRP_EW_MAX_IN;
+    bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
+    sum += bytes[i];
+  }
+  static const int total = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 2048;
+  int blk = 0, lds_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const hrp_ew_desc& d = descs[i];
+    const EwGeom g = geom(d.C, VEC, true, (long)d.N * d.H * d.W, ew_share(n == 1 ? 256 : total, bytes[i], sum, 16));
+    const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
+    lds_max = 4 * tabn * 4 > lds_max ? 4 * tabn * 4 : lds_max;
+    info->blk0[i] = blk;
+    blk += g.gx * g.nslab;
+    if (tab) {
+      memset(&tab[i], 0, sizeof(EwProblem));
+      tab[i].d = d; tab[i].tpr = g.tpr; tab[i].gx = g.gx; tab[i].nslab = g.nslab; tab[i].fd_gx = make_fastdiv(g.gx);
+    }
+  }
+  info->blk0[n] = blk;
+  info->grid = blk; info->lds_bytes = lds_max; info->variant = maxin;
+  return HRP_OK;
+}
+
+template <typename T, bool APPLY>
+static int ew_bwd_batch_prepare(const hrp_ew_bwd_desc* descs, int n, EwBwdProblem* tab, hrp_batch_info* info) {
+  constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
+  double bytes[HRP_BATCH_MAX], sum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const hrp_ew_bwd_desc& d = descs[i];
+    const int rc = ew_bwd_check(&d, APPLY);
+    if (rc != HRP_OK) return rc;
+    bool ok = aligned16(d.dout, d.dout_pitch, SZ) && aligned16(d.in.ptr ? d.in.ptr : d.dout, d.in.pitch ? d.in.pitch : d.dout_pitch, SZ) &&
+              d.C % VEC == 0;
+    if (d.relu) ok = ok && aligned16(d.out, d.out_pitch, SZ);
+    if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
+    if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
+    HRP_REQUIRE(ok, "ew batch: problem %d is not on the 16-byte vector path", i);
+    HRP_REQUIRE(!d.mask || (d.relu && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
+    bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
+    sum += bytes[i];
+  }
+  static const int total_apply = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 2048;
+  static const int total_red = getenv("HRP_EW_BATCH_RED_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_RED_BLOCKS")) : 1024;
+  int blk = 0, lds_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const hrp_ew_bwd_desc& d = descs[i];
+    const int up = d.in.up;
+    const int share = ew_share(n == 1 ? 256 : (APPLY ? total_apply : total_red), bytes[i], sum, 16);
+    const EwGeom g = geom(d.C, VEC, true, (long)d.N * (d.H / up) * (d.W / up), share);
+    const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
+    int lds;
+    if (APPLY) lds = 6 * tabn * 4;
+    else lds = (4 * tabn + 2 * ((g.tpr < 64 ? 4 : 256 / g.tpr) * g.tpr * g.V)) * 4;
+    lds_max = lds > lds_max ? lds : lds_max;
+    info->blk0[i] = blk;
+    blk += g.gx * g.nslab;
+    if (tab) {
+      memset(&tab[i], 0, sizeof(EwBwdProblem));
+      tab[i].d = d; tab[i].tpr = g.tpr; tab[i].gx = g.gx; tab[i].nslab = g.nslab; tab[i].fd_gx = make_fastdiv(g.gx);
+    }
+  }
+  info->blk0[n] = blk;
+  info->grid = blk; info->lds_bytes = lds_max; info->variant = 0;
+  return HRP_OK;
+}
+
+int ew_batch_prepare(int family, const void* descs, int n, void* table, hrp_batch_info* info) {
+  if (family == HRP_BATCH_EW_FWD) {
+    const hrp_ew_desc* d = (const hrp_ew_desc*)descs;
+    for (int i = 0; i < n; ++i) HRP_REQUIRE(d[i].dtype == d[0].dtype, "ew batch: mixed element types");
+    info->dtype = d[0].dtype;
+    return d[0].dtype == HRP_F32 ? ew_fwd_batch_prepare<float>(d, n, (EwProblem*)table, info)
+                                 : ew_fwd_batch_prepare<bf16_t>(d, n, (EwProblem*)table, info);
+  }
+  const hrp_ew_bwd_desc* d = (const hrp_ew_bwd_desc*)descs;
+  for (int i = 0; i < n; ++i) HRP_REQUIRE(d[i].dtype == d[0].dtype, "ew batch: mixed element types");
+  info->dtype = d[0].dtype;
+  const bool f32 = d[0].dtype == HRP_F32;
+  if (family == HRP_BATCH_EW_BWD_APPLY)
+    return f32 ? ew_bwd_batch_prepare<float, true>(d, n, (EwBwdProblem*)table, info) : ew_bwd_batch_prepare<bf16_t, true>(d, n, (EwBwdProblem*)table, info);
+  return f32 ? ew_bwd_batch_prepare<float, false>(d, n, (EwBwdProblem*)table, info) : ew_bwd_batch_prepare<bf16_t, false>(d, n, (EwBwdProblem*)table, info);
+}
+
+int ew_batch_launch(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
+  const BatchHdr h = make_hdr(info->blk0, info->n);
+  const dim3 grid(info->grid), block(256);
+  const bool f32 = info->dtype == HRP_F32;
+  if (info->family == HRP_BATCH_EW_FWD) {
+    const EwProblem* tab = (const EwProblem*)table_dev;
+    if (info->variant <= 2) {
+      if (f32) hipLaunchKernelGGL((ew_fwd_batch_kernel<float, 2>), grid, block, info->lds_bytes, s, tab, h);
+      else hipLaunchKernelGGL((ew_fwd_batch_kernel<bf16_t, 2>), grid, block, info->lds_bytes, s, tab, h);
+    } else {
+      if (f32) hipLaunchKernelGGL((ew_fwd_batch_kernel<float, HRP_EW_MAX_IN>), grid, block, info->lds_bytes, s, tab, h);
+      else hipLaunchKernelGGL((ew_fwd_batch_kernel<bf16_t, HRP_EW_MAX_IN>), grid, block, info->lds_bytes, s, tab, h);
+    }
+    return check_launch("ew_fwd_batch_kernel");
+  }
+  const EwBwdProblem* tab = (const EwBwdProblem*)table_dev;
+  if (info->family == HRP_BATCH_EW_BWD_APPLY) {
+    if (f32) hipLaunchKernelGGL((ew_bwd_batch_kernel<float, true>), grid, block, info->lds_bytes, s, tab, h);
+    else hipLaunchKernelGGL((ew_bwd_batch_kernel<bf16_t, true>), grid, block, info->lds_bytes, s, tab, h);
+  } else {
+    if (f32) hipLaunchKernelGGL((ew_bwd_batch_kernel<float, false>), grid, block, info->lds_bytes, s, tab, h);
+    else hipLaunchKernelGGL((ew_bwd_batch_kernel<bf16_t, false>), grid, block, info->lds_bytes, s, tab, h);
+  }
+  return check_launch("ew_bwd_batch_kernel");
+}
+
+int64_t ew_batch_table_bytes(int family, int n) {
+  return (int64_t)n * (family == HRP_BATCH_EW_FWD ? sizeof(EwProblem) : sizeof(EwBwdProblem));
+}
+
 }  // namespace hrp
 
 using namespace hrp;
 
-extern "C" int hrp_ew_fwd(const hrp_ew_desc* d, void* stream) {
+static int hrp::ew_fwd_check(const hrp_ew_desc* d) {
   HRP_REQUIRE(d && d->out && d->nin >= 1 && d->nin <= HRP_EW_MAX_IN, "ew_fwd: bad descriptor");
   HRP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0, "ew_fwd: empty");
   HRP_REQUIRE((int64_t)d->N * d->H * d->W < (1ll << 31), "ew_fwd: more than 2^31 pixels");
@@ -592,11 +777,17 @@ extern "C" int hrp_ew_fwd(const hrp_ew_desc* d, void* stream) {
     HRP_REQUIRE(in.mode == HRP_EW_IDENTITY || (in.a && in.b), "ew_fwd: input %d needs a/b", j);
     HRP_REQUIRE(in.mode != HRP_EW_BN_TRAIN || (in.stats && in.count > 0.f), "ew_fwd: input %d needs stats", j);
   }
+  return HRP_OK;
+}
+
+extern "C" int hrp_ew_fwd(const hrp_ew_desc* d, void* stream) {
+  const int rc = ew_fwd_check(d);
+  if (rc) return rc;
   if (d->dtype == HRP_F32) return ew_fwd_t<float>(*d, (hipStream_t)stream);
   return ew_fwd_t<bf16_t>(*d, (hipStream_t)stream);
 }
 
-static int ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
+static int hrp::ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
   HRP_REQUIRE(d && d->dout, "ew_bwd: bad descriptor");
   HRP_REQUIRE(!d->relu || d->out, "ew_bwd: relu needs the forward output");
   HRP_REQUIRE(d->in.up >= 1 && d->H % d->in.up == 0 && d->W % d->in.up == 0, "ew_bwd: geometry");

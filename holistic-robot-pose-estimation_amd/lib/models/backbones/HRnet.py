@@ -180,32 +180,43 @@ class HighResolutionModule(PlannedModule):
         return self.num_inchannels
 
     def emit_fuse(self, pb, xs):
-        """All-to-all cross-resolution fuse of the branch outputs (HRnet.py:243-265)."""
+        """All-to-all cross-resolution fuse of the branch outputs (HRnet.py:243-265).
+
+        The paths j -> i are independent until the sums: they are emitted into one virtual lane per SOURCE branch j (all
+        paths out of branch j accumulate into the gradient of xs[j], so they stay in one lane), the sums into one
+        virtual lane per output - the lock-step merge turns same-shaped steps of different lanes into batched launches."""
         if self.num_branches == 1:
             return xs
-        outs = []
-        for i, row in enumerate(self.fuse_layers):
-            terms = []
-            for j in range(self.num_branches):
-                if j == i:
-                    terms.append(Term(xs[j]))
-                elif j > i:
-                    t = conv_bn(pb, xs[j], row[j][0], row[j][1])
-                    t.up = 2 ** (j - i)
-                    terms.append(t)
-                else:
-                    h = xs[j]
-                    steps = list(row[j])
-                    for st in steps[:-1]:
-                        h = pb.act([conv_bn(pb, h, st[0], st[1])], relu=True)
-                    terms.append(conv_bn(pb, h, steps[-1][0], steps[-1][1]))
-            outs.append(pb.act(terms, relu=True))
+        nb, rows = self.num_branches, self.fuse_layers
+        terms = [[None] * nb for _ in rows]
+        with pb.parallel(nb, virtual=True) as par:
+            for j in range(nb):
+                with par.lane(j):
+                    for i in range(len(rows)):
+                        if j > i:      # lower resolution: 1x1 conv + BN, upsampled inside the sum kernel
+                            t = conv_bn(pb, xs[j], rows[i][j][0], rows[i][j][1])
+                            t.up = 2 ** (j - i)
+                            terms[i][j] = t
+                    for i in range(len(rows)):
+                        if j < i:      # higher resolution: (i - j) stride-2 3x3 steps
+                            h = xs[j]
+                            steps = list(rows[i][j])
+                            for st in steps[:-1]:
+                                h = pb.act([conv_bn(pb, h, st[0], st[1])], relu=True)
+                            terms[i][j] = conv_bn(pb, h, steps[-1][0], steps[-1][1])
+        outs = [None] * len(rows)
+        with pb.parallel(len(rows), virtual=True) as par:
+            for i in range(len(rows)):
+                with par.lane(i):
+                    terms[i][i] = Term(xs[i])
+                    outs[i] = pb.act(terms[i], relu=True)
         return outs
 
-    def emit(self, pb, xs):
-        # the branches are independent until the fuse layers: one lane (HIP stream / graph branch) each
+    def emit(self, pb, xs, virtual=False):
+        # the branches are independent until the fuse layers: one lane each (a HIP stream / graph branch, or - virtual -
+        # a lane of the lock-step merge inside the caller's stream)
         xs = list(xs)
-        with pb.parallel(self.num_branches) as par:
+        with pb.parallel(self.num_branches, virtual=virtual) as par:
             for b in range(self.num_branches):
                 with par.lane(b):
                     xs[b] = _emit_seq(pb, self.branches[b], xs[b])
@@ -240,6 +251,33 @@ def _transition(pb, tr, src):
     return src
 
 
+# "nets": one chain (a stream in the plan's hybrid mode) per trunk, the branches of a module are virtual lanes merged
+# into batched launches inside it.  "flat": round 1's structure - every branch of every trunk is a lane of one flat block.
+TRUNK_LANES = os.environ.get("HRP_TRUNK_LANES", "nets")
+
+
+def _trunk_segments(net):
+    """Stem .. stage 4 of ONE net (reference HRnet.py:500-533) as four chain segments: emit_trunks joins the nets'
+    streams between them, which gives the backward top-level positions (between stages) where the data-parallel step
+    may split it, and lets the late weight pack join after the stem."""
+    def stem(pb, x):
+        h = pb.act([conv_bn(pb, x, net.conv1, net.bn1)], relu=True)
+        h = pb.act([conv_bn(pb, h, net.conv2, net.bn2)], relu=True)
+        h = _emit_seq(pb, net.layer1, h)
+        return [h if tr is None else _transition(pb, tr, h) for tr in net.transition1]
+
+    def stage(mods, trans):
+        def seg(pb, ys):
+            for m in mods:
+                ys = m.emit(pb, ys, virtual=True)
+            if trans is not None:
+                # a new branch always starts from the LAST (lowest-resolution) output, HRnet.py:516-529
+                ys = [ys[j] if tr is None else _transition(pb, tr, ys[-1]) for j, tr in enumerate(trans)]
+            return ys
+        return seg
+    return [stem, stage(net.stage2, net.transition2), stage(net.stage3, net.transition3), stage(net.stage4, None)]
+
+
 def emit_trunks(pb, nets, xs, rider=None):
     """Trunks (stem .. stage4, reference HRnet.py:500-533) of one or more HRNets with the same stage layout,
     emitted in lockstep so that every independent chain of every net - stem, each branch of the current
@@ -251,6 +289,15 @@ def emit_trunks(pb, nets, xs, rider=None):
     shipped full.yaml next to the HRNet root trunk); every parallel block gets one more lane that advances it by
     one unit, so the chain overlaps the HRNet branches without nesting blocks."""
     n = len(nets)
+    if TRUNK_LANES == "nets" and rider is None:
+        ys = list(xs)
+        segs = [_trunk_segments(net) for net in nets]
+        for k in range(4):
+            with pb.parallel(n) as par:
+                for i in range(n):
+                    with par.lane(i):
+                        ys[i] = segs[i][k](pb, ys[i])
+        return ys
     alive = [rider is not None]
 
     def ride(par, lane):
@@ -276,8 +323,23 @@ def emit_trunks(pb, nets, xs, rider=None):
     for k in range(3):
         for mi in range(len(stages[0][k])):
             mods = [st[k][mi] for st in stages]
-            nl = sum(m.num_branches for m in mods)
-            with pb.parallel(nl + extra()) as par:
+            if TRUNK_LANES == "flat2":
+                # two lanes per net: the high-resolution branch (HBM-heavy launches) and the other branches as virtual
+                # lanes of one chain (MFMA-heavy batched launches)
+                with pb.parallel(2 * n + extra()) as par:
+                    ride(par, 2 * n)
+                    for i, m in enumerate(mods):
+                        ys[i] = list(ys[i])
+                        with par.lane(2 * i):
+                            ys[i][0] = _emit_seq(pb, m.branches[0], ys[i][0])
+                        with par.lane(2 * i + 1):
+                            with pb.parallel(m.num_branches - 1, virtual=True) as vp:
+                                for b in range(1, m.num_branches):
+                                    with vp.lane(b - 1):
+                                        ys[i][b] = _emit_seq(pb, m.branches[b], ys[i][b])
+            else:
+              nl = sum(m.num_branches for m in mods)
+              with pb.parallel(nl + extra()) as par:
                 ride(par, nl)
                 lane = 0
                 for i, m in enumerate(mods):

@@ -10,6 +10,7 @@ decision of "first writer overwrites / later writers accumulate" for every gradi
 PyTorch is used for device memory (torch.zeros buffers), the stream handle and the public
 ``torch.autograd.Function`` boundary only.
 """
+import collections
 import contextlib
 import ctypes as C
 import math
@@ -118,15 +119,150 @@ SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
 MAX_LANE_DEPTH = int(os.environ.get("HRP_LANE_DEPTH", "1"))
 
 
+# How a plan executes.  "merged" (default): ONE stream; the lanes of every parallel block are walked in lock step and
+# the launches of one kernel family that sit at the same position of their lanes - the same layer of every branch of
+# both trunks - become ONE batched launch (hrp_batch_*, include/hrp.h).  "lanes": every lane is a HIP stream forked
+# from / joined into its parent (round 1; still what the measurements of the batched launches are compared with).
+# "hybrid": parallel blocks that asked for streams keep them (one per trunk), the virtual blocks inside each stream are
+# merged - two chains of batched launches whose ramp-up / tail phases overlap.
+PLAN_MODE = os.environ.get("HRP_PLAN_MODE", "hybrid")
+BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
+
+Entry = collections.namedtuple("Entry", "lane path op")   # lane None: fork / join marker of the lanes mode
+
+
 class _OpList(list):
-    """Launch list; ``append(op)`` tags the op with the lane (HIP stream) the builder is emitting into."""
+    """Launch list; ``append(op)`` tags the op with the lane the builder is emitting into."""
 
     def __init__(self, plan):
         super().__init__()
         self.plan = plan
 
     def append(self, op):
-        list.append(self, (self.plan.cur_lane, op))
+        list.append(self, Entry(self.plan.cur_lane, self.plan.lane_path, op))
+
+
+# kernel family -> (hrp_batch_family, single-launch entry point, descriptor type)
+FAMILIES = {"conv": (nv.BATCH_CONV, "hrp_conv2d_fwd", nv.ConvDesc),
+            "wgrad": (nv.BATCH_WGRAD, "hrp_conv2d_bwd_weight", nv.WgradDesc),
+            "ew_fwd": (nv.BATCH_EW_FWD, "hrp_ew_fwd", nv.EwDesc),
+            "ew_red": (nv.BATCH_EW_BWD_REDUCE, "hrp_ew_bwd_reduce", nv.EwBwdDesc),
+            "ew_app": (nv.BATCH_EW_BWD_APPLY, "hrp_ew_bwd_apply", nv.EwBwdDesc)}
+
+
+class Launch:
+    """One launch of a batchable family: (family, descriptor).  Callable like the plain closures of the launch lists."""
+    __slots__ = ("fam", "desc")
+
+    def __init__(self, fam, desc):
+        self.fam, self.desc = fam, desc
+
+    def __call__(self, s):
+        nv.call(FAMILIES[self.fam][1], C.byref(self.desc), s)
+
+    def launches(self):
+        return [self]
+
+    def merge_key(self):
+        """Launches with equal keys may share a batched launch; None: always alone."""
+        d = self.desc
+        esz = 4 if d.dtype == nv.HRP_F32 else 2
+        if self.fam == "conv":
+            if d.ntaps not in (1, 2, 4, 9) or (d.Cin * esz) % 32 or (d.dtype == nv.HRP_F32 and d.H == 1 and d.W == 1 and d.Cin >= 512):
+                return None
+            return ("conv", d.dtype, d.ntaps)
+        if self.fam == "wgrad":
+            return ("wgrad", d.dtype, d.ntaps)
+        if d.C % (16 // esz):
+            return None
+        return (self.fam, d.dtype)
+
+    def written(self):
+        """Device addresses this launch writes (two launches of one batch must not share any)."""
+        d = self.desc
+        if self.fam == "conv":
+            return (d.y + ((d.out_off_y * d.y_W + d.out_off_x) * d.y_pitch if d.out_stride > 1 else 0),)
+        if self.fam == "wgrad":
+            return (d.dw + 4 * d.dw_tap_off,)
+        if self.fam == "ew_fwd":
+            return (d.out,)
+        if self.fam == "ew_red":
+            return (d.sums,)
+        return tuple(x for x in (d.din, d.din2) if x)
+
+
+class BatchLaunch:
+    """Launches of one family (one per concurrent lane) as ONE launch; built by Plan._flatten, prepared at finalize."""
+
+    def __init__(self, plan, items):
+        self.plan, self.items = plan, list(items)
+        self.fam = items[0].fam
+        self.info, self.table, self.singles = None, None, False
+
+    def launches(self):
+        return self.items
+
+    def merge_key(self):
+        return self.items[0].merge_key()
+
+    def ws_query(self):
+        """-> workspace bytes per problem (weight gradients)."""
+        n = len(self.items)
+        arr = (nv.WgradDesc * n)(*[it.desc for it in self.items])
+        info = nv.BatchInfo()
+        nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, None, C.byref(info)), "hrp_batch_prepare")
+        return [int(info.ws_bytes[i]) for i in range(n)]
+
+    def prepare(self):
+        famid, _, dtype = FAMILIES[self.fam]
+        n = len(self.items)
+        arr = (dtype * n)(*[it.desc for it in self.items])     # copies: every pointer is final by now
+        info = nv.BatchInfo()
+        nbytes = int(nv.lib().hrp_batch_table_bytes(famid, n))
+        host = (C.c_char * nbytes)()
+        try:
+            nv.check(nv.lib().hrp_batch_prepare(famid, arr, n, host, C.byref(info)), "hrp_batch_prepare")
+        except nv.HrpError:
+            if os.environ.get("HRP_PLAN_STATS"):
+                import sys
+                print(f"plan: batch of {n} {self.fam} launches runs one by one ({nv.lib().hrp_last_error().decode()})", file=sys.stderr)
+            self.singles = True      # not batchable after all (scalar path, tile does not fit ..): one by one
+            return
+        self.info = info
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.plan.device)
+        self.plan.keep.append(self.table)
+
+    def __call__(self, s):
+        if self.singles:
+            for it in self.items:
+                it(s)
+        else:
+            nv.call_batch(self, s)
+
+
+def _merge_ops(plan, ops):
+    """Ops of equal merge key -> batched launches of at most BATCH_MAX problems with pairwise distinct outputs."""
+    items = [l for op in ops for l in op.launches()]
+    out, cur, seen = [], [], set()
+    for it in items:
+        w = it.written()
+        if len(cur) == nv.BATCH_MAX or any(a in seen for a in w):
+            out.append(cur)
+            cur, seen = [], set()
+        cur.append(it)
+        seen.update(w)
+    out.append(cur)
+    return [g[0] if len(g) == 1 else BatchLaunch(plan, g) for g in out]
+
+
+class _Seq:
+    def __init__(self):
+        self.items, self.blocks = [], {}
+
+
+class _Par:
+    def __init__(self):
+        self.lanes = {}
 
 
 class _LaneSync:
@@ -152,6 +288,10 @@ class _PackJoin:
     def run(self, streams):
         if self.plan._pack_stream is not None:
             streams[0].wait_stream(self.plan._pack_stream)
+
+    def __call__(self, s):   # merged mode: an ordinary entry of the flat list
+        if self.plan._pack_stream is not None and not SERIAL_LANES:
+            torch.cuda.current_stream(self.plan.device).wait_stream(self.plan._pack_stream)
 
 
 def lanes_concurrent(a, b):
@@ -197,6 +337,8 @@ class Plan:
         self.counters = {}         # build statistics (HRP_PLAN_STATS=1 prints them at finalize)
         self.wgrad_ws_bytes = {}   # lane -> scratch bytes shared by that lane's weight-gradient launches
         self.wgrad_ws = {}
+        self.merged, self.fwd_run, self.bwd_run = False, [], []
+        self._block_lanes = {}     # parallel block id -> stream of each lane (None: virtual block)
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -299,31 +441,141 @@ class Plan:
         self._pack_stream = None
         if self._pack_tables_late:
             self._pack_stream = torch.cuda.Stream(device=dev)
-            list.insert(self.fwd, cut, (None, _PackJoin(self)))
-        self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev)
-                         for lane, nb in self.wgrad_ws_bytes.items()}
-        self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes - 1)]
-        # resolve deferred pointers
+            list.insert(self.fwd, cut, Entry(None, (), _PackJoin(self)))
+        self.merged = PLAN_MODE in ("merged", "hybrid")
+        if not self.merged:
+            self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev)
+                             for lane, nb in self.wgrad_ws_bytes.items()}
+        # resolve deferred pointers (merged: the weight-gradient scratch is assigned below, once the batches are known)
         for fn in self._late:
             fn()
         self._late = []
+        if self.merged:
+            # lock-step merge of the virtual lanes into batched launches; streams only where a block asked for them
+            self.fwd_run, self.bwd_run = self._flatten(self.fwd), self._flatten(self.bwd)
+            ops = [e.op for e in self.fwd_run + self.bwd_run if e.lane is not None]
+            batches = [op for op in ops if isinstance(op, BatchLaunch)]
+            # weight-gradient scratch: one buffer per stream, every launch of that stream uses it in turn
+            need = {}
+            for e in self.fwd_run + self.bwd_run:
+                op = e.op
+                if isinstance(op, BatchLaunch) and op.fam == "wgrad":
+                    op.ws = op.ws_query()
+                    need[e.lane] = max(need.get(e.lane, 0), sum(_rup(b, 256) for b in op.ws))
+                elif isinstance(op, Launch) and op.fam == "wgrad":
+                    need[e.lane] = max(need.get(e.lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(op.desc))))
+            self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev) for lane, nb in need.items()}
+            for e in self.fwd_run + self.bwd_run:
+                op = e.op
+                if isinstance(op, BatchLaunch) and op.fam == "wgrad":   # problems of one launch run concurrently: disjoint regions
+                    off = 0
+                    for it, b in zip(op.items, op.ws):
+                        it.desc.workspace, it.desc.workspace_bytes = self.wgrad_ws[e.lane].data_ptr() + off, b
+                        off += _rup(b, 256)
+                elif isinstance(op, Launch) and op.fam == "wgrad":
+                    op.desc.workspace, op.desc.workspace_bytes = self.wgrad_ws[e.lane].data_ptr(), self.wgrad_ws[e.lane].numel() * 4
+            for op in batches:
+                op.prepare()
+                if op.fam == "wgrad" and op.singles:
+                    lane = next(e.lane for e in self.fwd_run + self.bwd_run if e.op is op)
+                    for it in op.items:
+                        it.desc.workspace, it.desc.workspace_bytes = self.wgrad_ws[lane].data_ptr(), self.wgrad_ws[lane].numel() * 4
+            used = {e.lane for e in self.fwd_run + self.bwd_run if e.lane is not None}
+            self._side_streams = [torch.cuda.Stream(device=dev) if (i + 1) in used else None for i in range(self.n_lanes - 1)]
+        else:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes - 1)]
         self._bn_tables()
         self.built = True
         if os.environ.get("HRP_PLAN_STATS"):
             import sys
-            print(f"plan: {len(self.fwd)} forward / {len(self.bwd)} backward ops, {self.n_lanes} lanes, {self.counters}",
-                  file=sys.stderr)
+            msg = f"plan: {len(self.fwd)} forward / {len(self.bwd)} backward ops, {self.n_lanes} lanes, {self.counters}"
+            if self.merged:
+                ops = [e.op for e in self.fwd_run + self.bwd_run if e.lane is not None]
+                nb = sum(isinstance(op, BatchLaunch) and not op.singles for op in ops)
+                msg += (f"; {PLAN_MODE}: {sum(e.lane is not None for e in self.fwd_run)} / {sum(e.lane is not None for e in self.bwd_run)}"
+                        f" launches, {nb} of them batched, streams {sorted({e.lane for e in self.fwd_run if e.lane is not None})}")
+            print(msg, file=sys.stderr)
+
+    def _flatten(self, entries):
+        """Launch list of the merged / hybrid modes.  The lanes of every VIRTUAL parallel block (all blocks in merged mode)
+        are walked in lock step - position k of every lane before position k + 1 of any - and launches of equal merge
+        key at one position are folded into batched launches.  Lanes of one block are independent by construction
+        (TensorH.check_readable / take_grad_slot), so any interleaving that keeps each lane's own order is a valid
+        serial order.  Blocks that asked for streams (hybrid mode) keep their fork / join markers; the merge happens
+        inside each of their lanes.  -> list of Entry (path unused)."""
+        root = _Seq()
+        for e in entries:
+            if e.lane is None and not isinstance(e.op, _PackJoin):
+                continue        # fork / join markers are re-created below
+            seq = root
+            for blk, idx in (e.path or ()):
+                node = seq.blocks.get(blk)
+                if node is None:
+                    node = _Par()
+                    node.blk = blk
+                    seq.blocks[blk] = node
+                    seq.items.append(node)
+                seq = node.lanes.setdefault(idx, _Seq())
+            seq.items.append(e.op)
+
+        def key_of(op):
+            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch)) else None
+
+        def lockstep(kids):
+            out = []
+            for k in range(max(len(x) for x in kids)):
+                groups = collections.OrderedDict()
+                for x in kids:
+                    if k < len(x):
+                        key = key_of(x[k])
+                        if key is None:
+                            out.append(x[k])
+                        else:
+                            groups.setdefault(key, []).append(x[k])
+                for ops in groups.values():
+                    out += ops if len(ops) == 1 else _merge_ops(self, ops)
+            return out
+
+        def walk(seq, lane):
+            """-> entries of this sequence, running on stream `lane`."""
+            out = []
+            for it in seq.items:
+                if isinstance(it, _PackJoin):
+                    out.append(Entry(None, (), it))
+                elif not isinstance(it, _Par):
+                    out.append(Entry(lane, (), it))
+                else:
+                    real = PLAN_MODE == "hybrid" and self._block_lanes.get(it.blk) is not None
+                    if real:
+                        ids = self._block_lanes[it.blk]
+                        kids = [(ids[idx], walk(sub, ids[idx])) for idx, sub in sorted(it.lanes.items())]
+                        children = [l for l, _ in kids if l != lane]
+                        out.append(Entry(None, (), _LaneSync("fork", lane, children)))
+                        for _, ents in kids:
+                            out += ents
+                        out.append(Entry(None, (), _LaneSync("join", lane, children)))
+                    else:
+                        kids = [walk(sub, lane) for _, sub in sorted(it.lanes.items())]
+                        assert all(e.lane == lane for x in kids for e in x), "a virtual block cannot contain a block with streams"
+                        out += [Entry(lane, (), op) for op in lockstep([[e.op for e in x] for x in kids])]
+            return out
+        return walk(root, 0)
 
     def _late_pack_cut(self):
         """Index in self.fwd right after the first parallel block (the join back into the main lane), or None when the
         plan is not a training plan with at least two parallel blocks and a network's worth of weights."""
         if not self.need_grad or os.environ.get("HRP_NO_LATE_PACK") or len(self.weight_list) < 64:
             return None
-        joins = [i for i, (lane, op) in enumerate(self.fwd) if lane is None and getattr(op, "kind", None) == "join"]
-        forks = [i for i, (lane, op) in enumerate(self.fwd) if lane is None and getattr(op, "kind", None) == "fork"]
+        joins = [i for i, e in enumerate(self.fwd) if e.lane is None and getattr(e.op, "kind", None) == "join"]
+        forks = [i for i, e in enumerate(self.fwd) if e.lane is None and getattr(e.op, "kind", None) == "fork"]
         if len(forks) < 2 or not joins or forks[1] < joins[0]:
             return None           # (nested or single blocks: keep the simple order)
         return joins[0] + 1
+
+    def patch_wgrad_ws(self, g, lane):
+        """lanes mode: the lane's weight-gradient scratch (merged / hybrid modes assign it after the merge)."""
+        if lane in self.wgrad_ws:
+            g.workspace, g.workspace_bytes = self.wgrad_ws[lane].data_ptr(), self.wgrad_ws[lane].numel() * 4
 
     def late(self, fn):
         """Defer pointer patching until the arenas exist (finalize)."""
@@ -401,23 +653,29 @@ class Plan:
     def _run_list(self, ops):
         if SERIAL_LANES:
             h = self._stream()
-            for lane, op in ops:
+            for lane, _, op in ops:
                 if lane is not None:
                     op(h)
             return
         streams = [torch.cuda.current_stream(self.device)] + self._side_streams
-        handles = [st.cuda_stream for st in streams]
-        for lane, op in ops:
+        handles = [st.cuda_stream if st is not None else None for st in streams]
+        for lane, _, op in ops:
             if lane is None:
                 op.run(streams)
             else:
                 op(handles[lane])
 
+    def fwd_ops(self):
+        return self.fwd_run if self.merged else self.fwd
+
+    def bwd_ops(self):
+        return self.bwd_run if self.merged else self.bwd
+
     def run_forward(self):
         s = self._stream()
         if self.stats_floats:
             self.stats.zero_()
-        self._run_list(self.fwd)
+        self._run_list(self.fwd_ops())
         if self._run_tab:
             nv.call("hrp_bn_running_update", self._run_tab[0].data_ptr(), self._run_tab[1], s)
 
@@ -431,12 +689,13 @@ class Plan:
                 self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
             if self.bsums_floats:
                 self.bsums.zero_()
+        ops = self.bwd_ops()
         if part is None:
-            self._run_list(self.bwd)
+            self._run_list(ops)
         elif part == "first":
-            self._run_list(list.__getitem__(self.bwd, slice(0, self.bwd_split)))
+            self._run_list(list.__getitem__(ops, slice(0, self.bwd_split)))
         else:
-            self._run_list(list.__getitem__(self.bwd, slice(self.bwd_split, None)))
+            self._run_list(list.__getitem__(ops, slice(self.bwd_split, None)))
         if part in (None, "rest") and self._pgrad_tab:
             nv.call("hrp_bn_param_grad", self._pgrad_tab[0].data_ptr(), self._pgrad_tab[1], s)
 
@@ -477,7 +736,8 @@ class Plan:
         try:
             nv.call = lambda name, *args: [walk(a) for a in args] and 0
             depth, tops = 0, []
-            for i, (lane, op) in enumerate(self.bwd):
+            for i, e in enumerate(self.bwd_ops()):
+                lane, op = e.lane, e.op
                 if lane is None:
                     if getattr(op, "kind", None) == "fork":
                         if depth == 0:
@@ -489,7 +749,11 @@ class Plan:
                 if depth == 0:
                     tops.append(i)
                 del hits[:]
-                op(0)
+                if isinstance(op, (Launch, BatchLaunch)):
+                    for it in op.launches():     # the descriptors say what a launch touches
+                        walk(it.desc)
+                else:
+                    op(0)
                 for h in hits:
                     last[bisect.bisect_right(starts, h) - 1] = i
         finally:
@@ -503,7 +767,7 @@ class Plan:
                         bn_ptrs.add(g.data_ptr() - base)
             for k, st in enumerate(starts):
                 if st in bn_ptrs:
-                    last[k] = len(self.bwd)
+                    last[k] = len(self.bwd_ops())
         total = sum(n for _, n in self._grad_layout)
         for c in tops:
             if c == 0:
@@ -663,7 +927,7 @@ class PlanBuilder:
             if y.stats is not None:
                 d.stats = p.stats.data_ptr() + 4 * y.stats
         p.late(late)
-        p.fwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+        p.fwd.append(Launch("conv", d))
         y.producer = ("conv", d)
         if p.need_grad and weight.requires_grad:
             def bw():
@@ -680,9 +944,8 @@ class PlanBuilder:
                         g.dy_t[i], g.dx_t[i] = taps[4 * grp + i]
                     g.dw_cin, g.dw_tap_stride, g.dw_tap_off, g.accumulate = xs.C, 16, 4 * grp, 0
                     p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
-                    p.late(lambda g=g, lane=lane: (setattr(g, "workspace", p.wgrad_ws[lane].data_ptr()),
-                                                   setattr(g, "workspace_bytes", p.wgrad_ws[lane].numel() * 4)))
-                    p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
+                    p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
+                    p.bwd.append(Launch("wgrad", g))
                 gp = p.grad_of_param(weight)
                 acc = 1 if p.grad_arena is not None else 0
                 p.bwd.append(lambda s: nv.call("hrp_gather_f32", gw12.data_ptr(), idx_g.data_ptr(), gp.data_ptr(),
@@ -758,7 +1021,7 @@ class PlanBuilder:
                 if y.stats is not None:
                     d.stats = p.stats.data_ptr() + 4 * y.stats
             p.late(late)
-            p.fwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+            p.fwd.append(Launch("conv", d))
         if p.need_grad:
             self.bwd_stack.append(lambda: self._deconv_bwd(x, w, y, dtype))
         return y
@@ -783,9 +1046,8 @@ class PlanBuilder:
                 g.dw_cin, g.dw_tap_stride, g.dw_tap_off = y.C, 16, 4 * grp
                 g.accumulate = 1 if (w.grad_written or p.grad_arena is not None) else 0
                 p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
-                p.late(lambda g=g, lane=lane: (setattr(g, "workspace", p.wgrad_ws[lane].data_ptr()),
-                                               setattr(g, "workspace_bytes", p.wgrad_ws[lane].numel() * 4)))
-                p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
+                p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
+                p.bwd.append(Launch("wgrad", g))
             w.grad_written = True
         if x.requires_grad:
             acc = x.take_grad_slot()
@@ -800,7 +1062,7 @@ class PlanBuilder:
             if acc:
                 d.res = x.gptr()
             p.late(lambda d=d: setattr(d, "w", w.arena.data_ptr() + w.fwd_off * esz))
-            p.bwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+            p.bwd.append(Launch("conv", d))
 
     def constant(self, N, Cc, value):
         t = self.plan.new(N, 1, 1, Cc, torch.float32, pitch=Cc)
@@ -880,7 +1142,7 @@ class PlanBuilder:
             if y.stats is not None:
                 d.stats = p.stats.data_ptr() + 4 * y.stats
         p.late(late)
-        p.fwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+        p.fwd.append(Launch("conv", d))
         y.producer = ("conv", d)
         if p.need_grad:
             self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu))
@@ -920,9 +1182,8 @@ class PlanBuilder:
             w.grad_written = True
             lane = p.cur_lane
             p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
-            p.late(lambda g=g, lane=lane: (setattr(g, "workspace", p.wgrad_ws[lane].data_ptr()),
-                                           setattr(g, "workspace_bytes", p.wgrad_ws[lane].numel() * 4)))
-            p.bwd.append(lambda s, g=g: nv.call("hrp_conv2d_bwd_weight", C.byref(g), s))
+            p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
+            p.bwd.append(Launch("wgrad", g))
         # data gradient
         if x.requires_grad:
             acc = x.take_grad_slot()
@@ -932,7 +1193,11 @@ class PlanBuilder:
                 gb_bytes = x.N * x.H * x.W * x.pitch * esz
                 p.bwd.append(lambda s: nv.call("hrp_fill_zero", x.gptr(), gb_bytes, s))
                 acc = 1
-            for (py, px) in classes:
+            par = None
+            if len(classes) > 1:   # the parity classes write disjoint pixels: virtual lanes, one batched launch per tap count
+                vp = self.parallel(len(classes), virtual=True)
+                par = vp.__enter__()
+            for ci, (py, px) in enumerate(classes):
                 d = nv.ConvDesc()
                 d.x, d.y = y.gptr(), x.gptr()
                 d.dtype = _dt(dtype)
@@ -961,7 +1226,13 @@ class PlanBuilder:
                 if acc:
                     d.res, d.res_pitch = x.gptr(), x.pitch
                 if d.Ho > 0 and d.Wo > 0:
-                    p.bwd.append(lambda s, d=d: nv.call("hrp_conv2d_fwd", C.byref(d), s))
+                    if par is not None:
+                        with par.lane(ci):
+                            p.bwd.append(Launch("conv", d))
+                    else:
+                        p.bwd.append(Launch("conv", d))
+            if par is not None:
+                vp.__exit__(None, None, None)
 
     # ---- element-wise ---------------------------------------------------------------------------------
     def _fold(self, bn):
@@ -1029,7 +1300,7 @@ class PlanBuilder:
             mask = torch.zeros(N * H * W * (Cc // vec), dtype=torch.uint8, device=p.device)
             p.keep.append(mask)
             d.mask, d.mask_pitch = mask.data_ptr(), Cc // vec
-        p.fwd.append(lambda s, d=d: nv.call("hrp_ew_fwd", C.byref(d), s))
+        p.fwd.append(Launch("ew_fwd", d))
         if p.need_grad:
             self.bwd_stack.append(lambda: self._act_bwd(terms, out, relu, d))
         return out
@@ -1069,8 +1340,8 @@ class PlanBuilder:
                 off = p.alloc_bsums(fd.C)
                 p.bn_bwd.append((tm.bn, off))
                 p.late(lambda b=b, off=off: setattr(b, "sums", p.bsums.data_ptr() + 4 * off))
-                p.bwd.append(lambda s, b=b: nv.call("hrp_ew_bwd_reduce", C.byref(b), s))
-            p.bwd.append(lambda s, b=b: nv.call("hrp_ew_bwd_apply", C.byref(b), s))
+                p.bwd.append(Launch("ew_red", b))
+            p.bwd.append(Launch("ew_app", b))
 
     # ---- pooling / heads -----------------------------------------------------------------------------
     def avgpool(self, x, out=None):
@@ -1114,7 +1385,7 @@ class PlanBuilder:
         assert p.cur_lane == 0 and p.lane_path == ()
         for lane, path, emit in reversed(self.bwd_stack):
             if lane is None:
-                list.append(p.bwd, (None, emit))    # lane fork / join marker (already mirrored)
+                list.append(p.bwd, Entry(None, (), emit))    # lane fork / join marker (already mirrored)
                 continue
             p.cur_lane, p.lane_path = lane, path
             emit()
@@ -1122,24 +1393,27 @@ class PlanBuilder:
         p.finalize()
 
     @contextlib.contextmanager
-    def parallel(self, n):
+    def parallel(self, n, virtual=False):
         """``with pb.parallel(n) as par: with par.lane(i): ...`` - emit n independent sub-graphs into n lanes
         (lane 0 stays on the current lane).  Tensors produced before the block may be read by every lane;
-        nothing produced or whose gradient is written inside one lane may be touched by a sibling."""
+        nothing produced or whose gradient is written inside one lane may be touched by a sibling.
+        virtual: the lanes exist for the lock-step merge only (independent launches of ONE chain - the parity classes
+        of a stride-2 data gradient, the paths of a fuse layer); in lanes mode they stay on the parent's stream."""
         p = self.plan
         p._n_blocks += 1
         parent = p.cur_lane
-        if len(p.lane_path) >= MAX_LANE_DEPTH:
+        if len(p.lane_path) >= MAX_LANE_DEPTH or virtual:
             n = 1   # deeper blocks stay on their parent lane
         n = min(n, int(os.environ.get("HRP_LANE_MAXN", "64")))
         children = [p.lane_id(parent, i) for i in range(1, n)]
         par = _Parallel(self, p._n_blocks, ([parent] + children + [parent] * 64) if children else [parent] * 64)
+        p._block_lanes[p._n_blocks] = ([parent] + children) if children else None
         if children:
-            list.append(p.fwd, (None, _LaneSync("fork", parent, children)))
+            list.append(p.fwd, Entry(None, (), _LaneSync("fork", parent, children)))
             list.append(self.bwd_stack, (None, None, _LaneSync("join", parent, children)))
         yield par
         if children:
-            list.append(p.fwd, (None, _LaneSync("join", parent, children)))
+            list.append(p.fwd, Entry(None, (), _LaneSync("join", parent, children)))
             list.append(self.bwd_stack, (None, None, _LaneSync("fork", parent, children)))
 
     # ---- outputs ----------------------------------------------------------------------------------------

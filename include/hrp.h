@@ -16,7 +16,9 @@
  *   hrp_conv2d_fwd            nn.Conv2d forward       lib/models/backbones/HRnet.py:22-25, 65-71, 284-288,
  *                                                     200-204, 218-233, 331-337, 364-368, 377-383;
  *                             nn.Linear forward       lib/models/full_net.py:95-97, 129-131; depth_layer :159-165
- *   hrp_conv2d_bwd_data/_bwd_weight / hrp_colsum      autograd of the above (loss.backward(), scripts/train_full.py:61)
+ *   hrp_conv2d_bwd_weight / hrp_colsum                autograd of the above (loss.backward(), scripts/train_full.py:61);
+ *                             the data gradient is hrp_conv2d_fwd itself on the transposed packing (dst_t of
+ *                             hrp_pack_weights) with mirrored taps - there is no separate hrp_conv2d_bwd_data entry
  *   hrp_ew_fwd                BatchNorm2d + ReLU + residual add + nn.Upsample(nearest) + fuse sum
  *                                                     HRnet.py:45-55, 82-96, 197-208, 256-263, 539-540
  *   hrp_ew_bwd_reduce/_apply  autograd of the above
@@ -266,6 +268,40 @@ int hrp_opt_adam_step(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* ch
 int hrp_ew_fwd(const hrp_ew_desc* d, void* stream);
 int hrp_ew_bwd_reduce(const hrp_ew_bwd_desc* d, void* stream);
 int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream);
+
+/* ---- batched launches ---------------------------------------------------------------------------------------
+ * n <= HRP_BATCH_MAX independent problems of one kernel family in ONE launch (blockIdx -> (problem, tile)).  The
+ * reference runs the 2-4 branches of a HighResolutionModule one after the other (HRnet.py:247-252 `for i in
+ * range(self.num_branches): x[i] = self.branches[i](x[i])`) and its two trunks one after the other
+ * (full_net.py:252-302); they are independent until the fuse layers / the heads, so the same layer of every branch
+ * of both trunks is one launch here.  Problems may differ in shape (each gets its own tile configuration inside
+ * the launch) but share the family, the element type and - convolutions, weight gradients - the tap count.
+ *
+ *   hrp_batch_prepare  host only (no HIP call): validates the n descriptors, chooses tiles, fills `info` and, when
+ *                      table_host != NULL, the launch table (hrp_batch_table_bytes(family, n) bytes of HOST memory).
+ *                      The caller copies the table to device memory it owns - once: descriptors are static - and
+ *                      keeps `info`.  HRP_BATCH_WGRAD: info->ws_bytes[i] is the scratch problem i needs in ITS OWN
+ *                      descriptor's `workspace` (problems of one launch run concurrently: disjoint regions); with
+ *                      table_host == NULL the call only fills ws_bytes (size query).
+ *   hrp_batch_launch   asynchronous on `stream`, hipGraph-capturable.
+ * A group the library cannot batch (split-K linear layers, scalar-path element-wise problems, mixed tap counts ..)
+ * makes prepare return HRP_ERR_ARG: launch those problems one by one. */
+typedef enum {
+  HRP_BATCH_CONV = 0, HRP_BATCH_WGRAD = 1, HRP_BATCH_EW_FWD = 2, HRP_BATCH_EW_BWD_REDUCE = 3, HRP_BATCH_EW_BWD_APPLY = 4
+} hrp_batch_family;
+#define HRP_BATCH_MAX 32
+typedef struct hrp_batch_info {
+  int32_t family, n, dtype;
+  int32_t variant;                  /* library-internal kernel selector (tap count, input count ..) */
+  int32_t grid, lds_bytes;          /* main launch */
+  int32_t grid2;                    /* HRP_BATCH_WGRAD: the launch that folds the partial slabs into dW */
+  int32_t blk0[HRP_BATCH_MAX + 1];  /* first block of problem i (table order) in the main launch */
+  int32_t blk2[HRP_BATCH_MAX + 1];  /* ... in the second launch */
+  int64_t ws_bytes[HRP_BATCH_MAX];  /* HRP_BATCH_WGRAD: workspace bytes problem i (CALLER order) needs */
+} hrp_batch_info;
+int64_t hrp_batch_table_bytes(int family, int n);
+int hrp_batch_prepare(int family, const void* descs, int n, void* table_host, hrp_batch_info* info);
+int hrp_batch_launch(const void* table_dev, const hrp_batch_info* info, void* stream);
 
 int hrp_bn_running_update(const hrp_bn_entry* table_dev, int count, void* stream);
 int hrp_bn_fold(const hrp_bn_entry* table_dev, int count, void* stream);

@@ -41,9 +41,9 @@ def test_ctypes_struct_sizes_match_c():
 #include <stdio.h>
 #include "hrp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
          sizeof(hrp_ew_input), sizeof(hrp_ew_desc), sizeof(hrp_ew_bwd_desc), sizeof(hrp_bn_entry), sizeof(hrp_fk_chain),
-         sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk));
+         sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk), sizeof(hrp_batch_info));
   return 0;
 }'''
     import tempfile
@@ -54,7 +54,7 @@ int main(void) {
         out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
     sizes = [int(v) for v in out]
     mirrors = [nv.ConvDesc, nv.WgradDesc, nv.PackEntry, nv.EwInput, nv.EwDesc, nv.EwBwdDesc, nv.BnEntry, nv.FkChain,
-               nv.OptTensor, nv.OptChunk]
+               nv.OptTensor, nv.OptChunk, nv.BatchInfo]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
@@ -272,9 +272,10 @@ def test_plan_lanes_bookkeeping():
                 pb.bwd_stack.append(lambda i=i: pl.bwd.append(lambda s, i=i: ran.append(f"b{i}")))
                 assert pl.lane_path == ((1, i),)
     pl.fwd.append(lambda s: ran.append("post"))
-    kinds = [(lane, getattr(op, "kind", None)) for lane, op in pl.fwd]
+    kinds = [(e.lane, getattr(e.op, "kind", None)) for e in pl.fwd]
     assert kinds[0] == (0, None) and kinds[1] == (None, "fork") and kinds[-2] == (None, "join") and kinds[-1] == (0, None)
-    assert [lane for lane, _ in pl.fwd[2:5]] == [0, 1, 2] and pl.n_lanes == 3
+    assert [e.lane for e in pl.fwd[2:5]] == [0, 1, 2] and pl.n_lanes == 3
+    assert [e.path for e in pl.fwd[2:5]] == [((1, 0),), ((1, 1),), ((1, 2),)]
     # a tensor whose gradient is written from two concurrent lanes is rejected at build time
     t = P.TensorH(pl, 1, 1, 1, 8, torch.float32, buf=torch.zeros(8))
     with pb.parallel(2) as par:
@@ -286,13 +287,126 @@ def test_plan_lanes_bookkeeping():
     # backward: reverse order, the forward join becomes a fork and vice versa
     for lane, path, emit in reversed(pb.bwd_stack):
         if lane is None:
-            list.append(pl.bwd, (None, emit))
+            list.append(pl.bwd, P.Entry(None, (), emit))
         else:
             pl.cur_lane, pl.lane_path = lane, path
             emit()
-    bk = [(lane, getattr(op, "kind", None)) for lane, op in pl.bwd]
+    bk = [(e.lane, getattr(e.op, "kind", None)) for e in pl.bwd]
     first = next(i for i, (l, k) in enumerate(bk) if k == "fork" and bk[i + 1][0] == 2)
     assert [l for l, _ in bk[first + 1:first + 4]] == [2, 1, 0] and bk[first + 4] == (None, "join")
+
+
+def _fake_conv(y, ntaps=9, cin=32, cout=32, hw=64):
+    d = nv.ConvDesc()
+    d.x, d.w, d.y = 0x10000, 0x20000, y
+    d.dtype, d.N, d.H, d.W, d.Cin, d.x_pitch = nv.HRP_BF16, 2, hw, hw, cin, cin
+    d.Ho, d.Wo, d.Cout, d.y_H, d.y_W, d.y_pitch, d.res_pitch = hw, hw, cout, hw, hw, cout, cout
+    d.out_stride, d.in_stride, d.ntaps, d.w_ntaps, d.w_cout_pad = 1, 1, ntaps, ntaps, (cout + 31) // 32 * 32
+    k = 0
+    for a in range(-1, 2):
+        for b in range(-1, 2):
+            if k < ntaps:
+                d.dy[k], d.dx[k], d.wtap[k] = (a, b, k) if ntaps == 9 else (0, 0, k)
+                k += 1
+    return d
+
+
+def test_plan_lockstep_merge_into_batched_launches():
+    """plan.py merged mode (host logic): the lanes of a parallel block are walked in lock step, launches of one
+    family / tap count at the same position fold into one batched launch, every lane keeps its own order, nested
+    (virtual) blocks merge upwards, and two launches writing the same address never share a batch."""
+    import torch
+    from hrpe_amd import plan as P
+    pl = P.Plan(torch.device("cpu"), torch.bfloat16, True, True)
+    pb = P.PlanBuilder(pl)
+    log = []
+    pl.fwd.append(lambda s: log.append("pre"))
+    with pb.parallel(3) as par:
+        for i in range(3):
+            with par.lane(i):
+                pl.fwd.append(P.Launch("conv", _fake_conv(0x100000 * (i + 1))))                    # position 0: 3x3
+                pl.fwd.append(lambda s, i=i: log.append(f"misc{i}"))                               # position 1: not batchable
+                pl.fwd.append(P.Launch("conv", _fake_conv(0x900000 + 0x100000 * i, ntaps=1 if i else 9)))   # position 2: mixed taps
+                if i == 2:   # a nested virtual block: two independent launches of this lane
+                    with pb.parallel(2, virtual=True) as vp:
+                        for j in range(2):
+                            with vp.lane(j):
+                                pl.fwd.append(P.Launch("conv", _fake_conv(0x2000000 + 0x100000 * j, ntaps=1)))
+    pl.fwd.append(P.Launch("conv", _fake_conv(0x5000000)))
+    mode = P.PLAN_MODE
+    P.PLAN_MODE = "merged"          # every block virtual: one stream
+    flat = [e.op for e in pl._flatten(pl.fwd)]
+    kinds = [type(op).__name__ if not callable(op) or isinstance(op, (P.Launch, P.BatchLaunch)) else "fn" for op in flat]
+    assert kinds == ["fn", "BatchLaunch", "fn", "fn", "fn", "Launch", "BatchLaunch", "BatchLaunch", "Launch"], kinds
+    assert [len(op.items) for op in flat if isinstance(op, P.BatchLaunch)] == [3, 2, 2]
+    assert flat[5].desc.ntaps == 9 and {it.desc.ntaps for it in flat[6].items} == {1}
+    # the same output twice at one position: two launches, not one batch
+    pl2 = P.Plan(torch.device("cpu"), torch.bfloat16, True, True)
+    pb2 = P.PlanBuilder(pl2)
+    with pb2.parallel(2) as par:
+        for i in range(2):
+            with par.lane(i):
+                pl2.fwd.append(P.Launch("conv", _fake_conv(0x100000)))
+    assert [type(e.op).__name__ for e in pl2._flatten(pl2.fwd)] == ["Launch", "Launch"]
+    # batching off: the same order, one by one
+    P.BATCHING = False
+    try:
+        ops = [e.op for e in pl._flatten(pl.fwd)]
+        assert all(not isinstance(op, P.BatchLaunch) for op in ops) and len(ops) == 13
+    finally:
+        P.BATCHING = True
+    # hybrid: the block that asked for streams keeps its three lanes (fork / join markers around them), only the
+    # virtual block inside lane 2 is merged
+    P.PLAN_MODE = "hybrid"
+    try:
+        ents = pl._flatten(pl.fwd)
+    finally:
+        P.PLAN_MODE = mode
+    marks = [getattr(e.op, "kind", None) for e in ents if e.lane is None]
+    assert marks == ["fork", "join"]
+    assert [e.lane for e in ents if e.lane is not None] == [0] + [0] * 3 + [1] * 3 + [2] * 4 + [0]
+    assert sum(isinstance(e.op, P.BatchLaunch) for e in ents) == 1
+
+
+def test_batch_prepare_is_host_only():
+    """hrp_batch_prepare makes no HIP call: block ranges, per-problem tiles and the refusal paths can be checked here."""
+    lib = nv.lib()
+    descs = [_fake_conv(0x100000, cin=32, cout=32, hw=64), _fake_conv(0x200000, cin=256, cout=256, hw=8),
+             _fake_conv(0x300000, cin=64, cout=64, hw=32)]
+    arr = (nv.ConvDesc * 3)(*descs)
+    info = nv.BatchInfo()
+    nb = lib.hrp_batch_table_bytes(nv.BATCH_CONV, 3)
+    assert nb > 0 and lib.hrp_batch_table_bytes(nv.BATCH_CONV, nv.BATCH_MAX + 1) == 0
+    host = (C.c_char * nb)()
+    assert lib.hrp_batch_prepare(nv.BATCH_CONV, arr, 3, host, C.byref(info)) == 0, lib.hrp_last_error()
+    assert info.n == 3 and info.variant == 9 and info.blk0[0] == 0 and info.blk0[3] == info.grid
+    # 2 images: 32 ch @64x64 -> 32 tiles of 256 px; 256 ch @8x8 -> 1 tile x 4 cout blocks; 64 ch @32x32 -> 8 tiles x 1
+    assert sorted(info.blk0[i + 1] - info.blk0[i] for i in range(3)) == [4, 8, 32]
+    assert info.blk0[1] - info.blk0[0] == 4          # the deepest K loop goes first
+    assert 0 < info.lds_bytes <= 160 * 1024
+    # mixed tap counts are refused, and so is a half-filled last channel chunk
+    bad = (nv.ConvDesc * 2)(descs[0], _fake_conv(0x400000, ntaps=1))
+    assert lib.hrp_batch_prepare(nv.BATCH_CONV, bad, 2, host, C.byref(info)) != 0
+    bad = (nv.ConvDesc * 1)(_fake_conv(0x400000, cin=8))
+    assert lib.hrp_batch_prepare(nv.BATCH_CONV, bad, 1, host, C.byref(info)) != 0
+    # weight gradients: the size query (no table) shares the launch's workgroups between the problems
+    gs = []
+    for cin, hw in ((32, 64), (128, 16)):
+        g = nv.WgradDesc()
+        g.x, g.dy, g.dw, g.dtype = 0x10000, 0x20000, 0x30000, nv.HRP_BF16
+        g.N, g.H, g.W, g.Cin, g.x_pitch, g.Ho, g.Wo, g.Cout, g.dy_pitch = 64, hw, hw, cin, cin, hw, hw, cin, cin
+        g.in_stride, g.ntaps, g.dw_cin, g.accumulate = 1, 9, cin, 1
+        k = 0
+        for a in range(-1, 2):
+            for b in range(-1, 2):
+                g.dy_t[k], g.dx_t[k] = a, b
+                k += 1
+        gs.append(g)
+    arr = (nv.WgradDesc * 2)(*gs)
+    assert lib.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, None, C.byref(info)) == 0, lib.hrp_last_error()
+    single = [lib.hrp_wgrad_workspace_bytes(C.byref(g)) for g in gs]
+    assert all(0 < info.ws_bytes[i] <= single[i] for i in range(2))
+    assert info.grid <= 2 * 512 and info.grid2 > 0
 
 
 def test_resnet_full_net_state_dict_keys():

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the batched launches (hrp_batch_*) on the lock-step layers of an HRNet-W32 stage
+(development tool; run on the GPU box).
+
+    python tools/bench_batch.py [conv|wgrad|all] [--batch 64] [--nets 2] [--branches 4]
+
+HRP_TIMELINE=1 (needs `make -C .../csrc timeline`): per-problem phase means of the conv workgroups.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_kernels as bk  # noqa: E402
+from hrpe_amd import _native as nv  # noqa: E402
+
+DEV = bk.DEV
+CLASSES = [(32, 64), (64, 32), (128, 16), (256, 8)]
+
+
+def mk_conv(N, hw, c, dtype, stats=True, k=3):
+    esz = 2
+    x = torch.randn(N * hw * hw * c, device=DEV).to(dtype)
+    w = torch.randn(c, c, k, k, device=DEV) / (c * k * k) ** 0.5
+    wp, _ = bk.pack(w, dtype)
+    y = torch.zeros(N * hw * hw * c, dtype=dtype, device=DEV)
+    st = torch.zeros(16 * c, device=DEV)
+    d = nv.ConvDesc()
+    d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    d.dtype = nv.HRP_BF16
+    d.N, d.H, d.W, d.Cin, d.x_pitch = N, hw, hw, c, c
+    d.Ho, d.Wo, d.Cout = hw, hw, c
+    d.y_H, d.y_W, d.y_pitch, d.res_pitch = hw, hw, c, c
+    d.out_stride, d.in_stride = 1, 1
+    taps = bk.TAPS3 if k == 3 else [(0, 0)]
+    d.ntaps = d.w_ntaps = len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+    d.w_cout_pad = bk.rup(c, 32)
+    if stats:
+        d.stats = st.data_ptr()
+    return d, (x, wp, y, st)
+
+
+class Batch:
+    def __init__(self, fam, descs):
+        famid = {"conv": nv.BATCH_CONV, "wgrad": nv.BATCH_WGRAD}[fam]
+        n = len(descs)
+        self.fam, self.items = fam, descs
+        arr = (type(descs[0]) * n)(*descs)
+        self.info = nv.BatchInfo()
+        nb = int(nv.lib().hrp_batch_table_bytes(famid, n))
+        host = (C.c_char * nb)()
+        nv.check(nv.lib().hrp_batch_prepare(famid, arr, n, host, C.byref(self.info)), "prepare")
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+
+    def __call__(self):
+        nv.check(nv.lib().hrp_batch_launch(self.table.data_ptr(), C.byref(self.info), None), "launch")
+
+
+def conv_batch(N, nets, branches, dtype):
+    keep, descs = [], []
+    for _ in range(nets):
+        for c, hw in CLASSES[:branches]:
+            d, bufs = mk_conv(N, hw, c, dtype)
+            descs.append(d)
+            keep.append(bufs)
+    singles = [bk.timeit(lambda d=d: nv.call("hrp_conv2d_fwd", C.byref(d), None)) for d in descs[:branches]]
+    b = Batch("conv", descs)
+    us = bk.timeit(b)
+    fl = sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * 9 for d in descs)
+    by = sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * 2 for d in descs)
+    print(f"conv batch{len(descs)} (nets {nets} x branches {branches}, B={N}): {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  "
+          f"{by / us / 1e3:6.0f} GB/s  grid {b.info.grid} lds {b.info.lds_bytes}  | one by one: "
+          + " ".join(f"{t:.1f}" for t in singles) + f" (sum x nets {sum(singles) * nets:.1f})")
+    if bk.TIMELINE:
+        L = nv.lib()
+        torch.cuda.synchronize()
+        L.hrp_debug_conv_timeline_batch(None, 0, 1)
+        b()
+        torch.cuda.synchronize()
+        host = torch.zeros(8192 * 8, dtype=torch.int64)
+        L.hrp_debug_conv_timeline_batch(C.c_void_p(host.data_ptr()), 8192, 0)
+        tl = host.view(-1, 8).double()
+        t0 = tl[tl[:, 0] > 0][:, 0].min()
+        names = ["entry", "setup", "issued", "stage0", "loop end", "in lds", "stored", "end"]
+        for i in range(b.info.n):
+            lo, hi = b.info.blk0[i], min(b.info.blk0[i + 1], 8192)
+            if lo >= hi:
+                continue
+            t = tl[lo:hi]
+            t = t[t[:, 0] > 0]
+            print(f"   problem {i}: blocks {lo}..{hi}  start {((t[:, 0] - t0).mean() / 100):6.2f}/{((t[:, 0] - t0).max() / 100):6.2f}  "
+                  f"end {((t[:, 7] - t0).mean() / 100):6.2f}/{((t[:, 7] - t0).max() / 100):6.2f}  phases: "
+                  + "  ".join(f"{names[k + 1]} {((t[:, k + 1] - t[:, k]).mean() / 100):.2f}" for k in range(7))
+                  + f"  total {((t[:, 7] - t[:, 0]).mean() / 100):.2f}")
+    return keep
+
+
+def wgrad_batch(N, nets, branches, dtype):
+    keep, descs = [], []
+    for _ in range(nets):
+        for c, hw in CLASSES[:branches]:
+            d, bufs = mk_conv(N, hw, c, dtype, stats=False)
+            g = nv.WgradDesc()
+            dw = torch.zeros(c, c, 9, device=DEV)
+            g.x, g.dy, g.dw, g.dtype = d.x, d.y, dw.data_ptr(), d.dtype
+            g.N, g.H, g.W, g.Cin, g.x_pitch = N, hw, hw, c, c
+            g.Ho, g.Wo, g.Cout, g.dy_pitch = hw, hw, c, c
+            g.in_stride, g.ntaps = 1, 9
+            for i, (a, b) in enumerate(bk.TAPS3):
+                g.dy_t[i], g.dx_t[i] = a, b
+            g.dw_cin, g.accumulate = c, 1
+            descs.append(g)
+            keep.append((bufs, dw))
+    arr = (nv.WgradDesc * len(descs))(*descs)
+    info = nv.BatchInfo()
+    nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_WGRAD, arr, len(descs), None, C.byref(info)), "query")
+    for i, g in enumerate(descs):
+        ws = torch.zeros(info.ws_bytes[i] // 4 + 4, device=DEV)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        keep.append(ws)
+    singles = []
+    for g in descs[:branches]:
+        g1 = nv.WgradDesc.from_buffer_copy(bytes(g))
+        nb = int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g1)))
+        ws = torch.zeros(nb // 4 + 4, device=DEV)
+        g1.workspace, g1.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        singles.append(bk.timeit(lambda g1=g1: nv.call("hrp_conv2d_bwd_weight", C.byref(g1), None)))
+    b = Batch("wgrad", descs)
+    us = bk.timeit(b)
+    fl = sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * 9 for d in descs)
+    print(f"wgrad batch{len(descs)} (nets {nets} x branches {branches}, B={N}): {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  "
+          f"grid {b.info.grid}+{b.info.grid2} lds {b.info.lds_bytes}  | one by one: " + " ".join(f"{t:.1f}" for t in singles)
+          + f" (sum x nets {sum(singles) * nets:.1f})")
+    return keep
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--nets", type=int, default=2)
+    ap.add_argument("--branches", type=int, default=4)
+    a = ap.parse_args()
+    dt = torch.bfloat16
+    if a.what in ("conv", "all"):
+        conv_batch(a.batch, a.nets, a.branches, dt)
+        conv_batch(a.batch, 1, a.branches, dt)
+        for i in range(4):
+            CLS = CLASSES
+            CLASSES = [CLS[i]]
+            conv_batch(a.batch, 2, 1, dt)
+            CLASSES = CLS
+    if a.what in ("wgrad", "all"):
+        wgrad_batch(a.batch, a.nets, a.branches, dt)
+        wgrad_batch(a.batch, 1, a.branches, dt)

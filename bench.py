@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the HoRoPose image->pose hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one training step of the reference's full network (RootNetwithRegInt with HRNet-W32 as the
-regression AND the root/depth backbone, configs[2] of BASELINE.json) on one synthetic batch of 64
-256x256 images per GPU: forward, loss of lib/core/function.py:191-322, backward, gradient all-reduce
-(N > 1), clip_grad_norm_(5.0) and the Adam update (scripts/train_full.py:53-67).  The convolution trunk
-runs in bf16 on MFMA, heads in fp32.  The whole step is captured once in a HIP graph and replayed.
+N > 1 without a torch.distributed environment: this process (which never touches the GPU) starts N ranks of itself
+through torch.distributed.run and relays rank 0's line; under torch.distributed.run it is one of the ranks.
 
-Prints ONE JSON line (rank 0): images/sec over all GPUs, the roofline entry of the dominant kernel
-family (durations measured with HIP events on the launch stream in an instrumented pass of the same step)
-and a CPU baseline of the same step timed with the oracle on the host cores.
+Workloads (--workload):
+  full   (default, the headline) one training step of the reference's full network (RootNetwithRegInt with HRNet-W32
+         as the regression AND the root/depth backbone, configs[2] of BASELINE.json) on one synthetic batch of 64
+         256x256 images per GPU: forward, loss of lib/core/function.py:191-322, backward, gradient all-reduce (N > 1),
+         clip_grad_norm_(5.0) and the Adam update (scripts/train_full.py:53-67).
+  hrnet  the metric's literal workload: ONE HRNet-W32 (RootNet("hrnet32") = DepthNet, scripts/train_depthnet.py:231-250)
+         forward + L1 loss + backward + clip + Adam, B = 64.
+  --forward-only   BASELINE.json configs[1]: eval-mode forward of the chosen workload (BatchNorm folded).
+The convolution trunk runs in bf16 on MFMA, heads in fp32.  The whole step is captured once in a HIP graph and replayed.
+
+Prints ONE JSON line (rank 0): images/sec over all GPUs, the roofline entry of the dominant kernel family (durations
+measured with HIP events on the launch stream in an instrumented pass of the same step), a CPU baseline of the same
+step timed with the oracle on the host cores, the step time without the optimizer, and the end-to-end key-point error in
+pixels against the reference's fixture.
 """
 import argparse
 import json
@@ -121,31 +129,55 @@ def host_cores():
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(B, threads):
-    """The same training step (forward, loss, backward) on the host with the CPU oracle (fp32)."""
+def cpu_baseline(B, threads, workload="full", forward_only=False):
+    """The same step (forward, loss, backward; or the eval forward) on the host with the CPU oracle (fp32)."""
     from oracle import fk as ofk, heads as oheads
     torch.set_num_threads(threads)
-    m = build_model(0.0)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
-            v.requires_grad_(True)
-    robot = ofk.Robot(os.path.join(ROOT, "holistic-robot-pose-estimation_amd", "assets", "panda_kinematics.urdf"))
     d = {k: torch.tensor(v) for k, v in synthetic_batch(B, 1).items()}
     K = d["K"]
     kv = torch.sqrt(K[:, 0, 0] * K[:, 1, 1] * 1e6 / (d["bbox"][:, 2] - d["bbox"][:, 0]) ** 2)
-    rot6 = ofk.rotmat_to_rot6d(d["R"])
-    with torch.no_grad():
-        kp3d = robot.get_keypoints(d["q"], rot6, d["t"])
-        kp2d = ofk.project(K, kp3d)
-        gt = dict(pose=d["q"], root_rot=robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
-                  root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7))
-    def step():
-        for v in sd.values():
-            v.grad = None
-        pred = oheads.full_forward(sd, robot, d["x_reg"], d["x_root"], kv, K, training=True, reg_backbone=REG_BACKBONE)
-        loss, _ = oheads.full_loss(pred, gt, K)
-        loss.backward()
+    if workload == "hrnet":
+        m = build_depthnet()
+    else:
+        m = build_model(0.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    if not forward_only:
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
+                v.requires_grad_(True)
+    if workload == "hrnet":
+        gt_depth = d["t"][:, 2:3]
+
+        def step():
+            for v in sd.values():
+                v.grad = None
+            if forward_only:
+                with torch.no_grad():
+                    oheads.rootnet_forward(sd, d["x_root"], kv, training=False)
+                return
+            pred = oheads.rootnet_forward(sd, d["x_root"], kv, training=True) / 1000.0
+            torch.nn.functional.l1_loss(pred, gt_depth).backward()
+        what = "DepthNet (one HRNet-W32)"
+    else:
+        robot = ofk.Robot(os.path.join(ROOT, "holistic-robot-pose-estimation_amd", "assets", "panda_kinematics.urdf"))
+        rot6 = ofk.rotmat_to_rot6d(d["R"])
+        with torch.no_grad():
+            kp3d = robot.get_keypoints(d["q"], rot6, d["t"])
+            kp2d = ofk.project(K, kp3d)
+            gt = dict(pose=d["q"], root_rot=robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
+                      root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7))
+
+        def step():
+            for v in sd.values():
+                v.grad = None
+            if forward_only:
+                with torch.no_grad():
+                    oheads.full_forward(sd, robot, d["x_reg"], d["x_root"], kv, K, training=False, reg_backbone=REG_BACKBONE)
+                return
+            pred = oheads.full_forward(sd, robot, d["x_reg"], d["x_root"], kv, K, training=True, reg_backbone=REG_BACKBONE)
+            loss, _ = oheads.full_loss(pred, gt, K)
+            loss.backward()
+        what = "full-network"
 
     step()                      # warm-up: oneDNN primitive creation, allocator
     t0, n = time.time(), 0
@@ -154,8 +186,14 @@ def cpu_baseline(B, threads):
         n += 1
     dt = time.time() - t0
     return {"value": B * n / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch fp32 CPU restatement) full-network forward+loss+backward, B={B}, "
-                      f"1 warm-up + {n} timed steps, {dt:.1f} s"}
+            "sample": f"oracle (torch fp32 CPU restatement) {what} {'eval forward' if forward_only else 'forward+loss+backward'}, "
+                      f"B={B}, 1 warm-up + {n} timed steps, {dt:.1f} s"}
+
+
+def build_depthnet():
+    from hrpe_amd.lib.models.depth_net import get_rootnet
+    torch.manual_seed(808)
+    return get_rootnet("hrnet32")
 
 
 def launch_descs(name, args):
@@ -197,6 +235,50 @@ def conv_bytes(name, args):
     return float(tot)
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks as children of a process that has made no
+    GPU call (never exec from a process that initialised HIP), relay their output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
+def keypoint_px_error(dev, dtypes):
+    """End-to-end key-point error in pixels on the reference's eval fixture (tests/golden/golden_full_eval.npz, written by
+    the reference itself, B = 2): the network's FK key-points and the reference's, both projected with K
+    (lib/utils/transforms.py:17-21).  -> {dtype name: max |uv - uv_ref| in px}"""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    path = os.path.join(gdir, "golden_full_eval.npz")
+    if not os.path.exists(path):
+        return None
+    sys.path.insert(0, gdir)
+    from synth import synth_inputs, synth_state_dict
+    from hrpe_amd.lib.models.full_net import RootNetwithRegInt
+    from hrpe_amd.lib.utils.transforms import point_projection_from_3d_tensor
+    g = np.load(path)
+    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE, "cam_params": np.eye(4), "init_pose_from_mean": True}
+    m = RootNetwithRegInt(init, model_args(0.0))
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m = m.to(dev).eval()
+    x_reg, x_root, kv, K = [t.to(dev) for t in synth_inputs(2)]
+    ref_uv = point_projection_from_3d_tensor(K, torch.tensor(g["xyz_fk"]).to(dev))
+    out = {}
+    for name, dt in dtypes:
+        m.set_compute_dtype(dt)
+        with torch.no_grad():
+            o = m(x_reg, x_root, kv, K)
+        uv = point_projection_from_3d_tensor(K, o[7])
+        out[name] = round(float((uv - ref_uv).abs().max()), 6)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,16 +295,20 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all cores, at most 64)")
     ap.add_argument("--p-dropout", type=float, default=0.5, help="lib/core/config.py:70 default")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--workload", default="full", choices=["full", "hrnet"],
+                    help="full: the full network (headline, BASELINE.json configs[2]); hrnet: one HRNet-W32 (DepthNet), the metric's literal workload")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.cpu_baseline_only:
+        self_launch(a, sys.argv[1:])
 
     if a.cpu_baseline_only:
         cores = host_cores()
-        print(json.dumps(cpu_baseline(a.cpu_batch, a.cpu_threads or cores)))
+        print(json.dumps(cpu_baseline(a.cpu_batch, a.cpu_threads or cores, a.workload, a.forward_only)))
         return
 
     rank, world, local = init_distributed()
-    if world != a.gpus and rank == 0 and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s): the line would be mislabelled")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     if os.environ.get("HRP_BENCH_DEVICE"):   # functional test of the N > 1 structure with all ranks on one GPU (gloo)
@@ -234,79 +320,73 @@ def main():
     B = a.batch
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
-    if a.forward_only:
-        # informational: inference path (BASELINE.json configs[1]); BatchNorm folded into the conv epilogues
-        model = build_model(0.0).to(dev).set_compute_dtype(dtype).eval()
-        d = {k: torch.tensor(v).to(dev) for k, v in synthetic_batch(B, 808 + rank).items()}
-        kv = compute_k_values(d["K"][:, 0, 0], d["K"][:, 1, 1], d["bbox"])
-        with torch.no_grad():
-            model(d["x_reg"], d["x_root"], kv, d["K"])
-            torch.cuda.synchronize(dev)
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                model(d["x_reg"], d["x_root"], kv, d["K"])
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                model(d["x_reg"], d["x_root"], kv, d["K"])
-            for _ in range(a.warmup):
-                g.replay()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                g.replay()
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-        if rank == 0:
-            print(json.dumps({"metric": "images/sec forward-only full network (eval, folded BN), informational",
-                              "value": round(B * a.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": a.steps,
-                              "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "dtype": a.dtype,
-                              "data": "synthetic", "config": {"workload": "BASELINE.json configs[1]: two HRNet-W32 + heads + FK, "
-                                                                          "forward only", "per_gpu_batch": B}}))
-        return
-    model = build_model(a.p_dropout).to(dev).set_compute_dtype(dtype).train()
-    broadcast_module(model)
+    hrnet = a.workload == "hrnet"
+    fwd_only = a.forward_only
+    model = (build_depthnet() if hrnet else build_model(0.0 if fwd_only else a.p_dropout)).to(dev).set_compute_dtype(dtype)
+    model.train(not fwd_only)
+    if not fwd_only:
+        broadcast_module(model)
     params = [p for p in model.parameters() if p.requires_grad]
     # Adam(lr 1e-4) as scripts/train_full.py:42; fused multi-tensor kernels (the default foreach path spends
     # ~3 500 tiny launches per step on the per-parameter step counters)
-    if a.torch_optim:
-        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=not a.no_graph)
-    else:   # clip_grad_norm_(5) + Adam as two table-driven launches (hrpe_amd/optim.py)
-        opt = FusedClipAdam(params, lr=1e-4, max_norm=5.0)
+    opt = None
+    if not fwd_only:
+        if a.torch_optim:
+            opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=not a.no_graph)
+        else:   # clip_grad_norm_(5) + Adam as two table-driven launches (hrpe_amd/optim.py)
+            opt = FusedClipAdam(params, lr=1e-4, max_norm=1.0 if hrnet else 5.0)   # depthnet.yaml clips at 1, full.yaml at 5
     reducer = GradAllReducer(bucket_mb=64)
     info = {}
 
     d = {k: torch.tensor(v).to(dev) for k, v in synthetic_batch(B, 808 + rank).items()}
     K = d["K"]
     kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], d["bbox"])
-    rot6 = rotmat_to_rot6d(d["R"])
-    with torch.no_grad():
-        kp3d, kp2d = model.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
-        gt = dict(pose=d["q"], root_rot=model.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
-                  root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d,
-                  mask=torch.ones(B, 7, device=dev))
     loss_holder = {}
     h2d = os.environ.get("HRP_BENCH_H2D")
     if h2d in ("u8", "u8res"):     # the dataset's bytes: the model's input kernel divides by 255
         for k in ("x_reg", "x_root"):
             d[k] = (d[k] * 255).to(torch.uint8)
+    if hrnet:
+        gt_depth = d["t"][:, 2:3].contiguous()
 
-    def fwd_bwd():
-        pred = model(d["x_reg"], d["x_root"], kv, K)
-        loss, _ = full_loss(pred, gt, K)
-        loss.backward()
-        loss_holder["loss"] = loss.detach()
+        def forward():
+            return model(d["x_root"], kv)
+
+        def fwd_bwd():
+            loss = torch.nn.functional.l1_loss(forward() / 1000.0, gt_depth)   # scripts/train_depthnet.py:231-250
+            loss.backward()
+            loss_holder["loss"] = loss.detach()
+    else:
+        rot6 = rotmat_to_rot6d(d["R"])
+        with torch.no_grad():
+            kp3d, kp2d = model.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
+            gt = dict(pose=d["q"], root_rot=model.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
+                      root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d,
+                      mask=torch.ones(B, 7, device=dev))
+
+        def forward():
+            return model(d["x_reg"], d["x_root"], kv, K)
+
+        def fwd_bwd():
+            loss, _ = full_loss(forward(), gt, K)
+            loss.backward()
+            loss_holder["loss"] = loss.detach()
+    if fwd_only:
+        def fwd_bwd():    # noqa: F811  (the "step" of a forward-only run)
+            with torch.no_grad():
+                loss_holder["loss"] = forward()[0].float().mean()
 
     def update():
+        if fwd_only:
+            return
         if a.torch_optim:
-            torch.nn.utils.clip_grad_norm_(params, 5.0)   # configs/panda/full.yaml:39
+            torch.nn.utils.clip_grad_norm_(params, 1.0 if hrnet else 5.0)   # configs/panda/full.yaml:39, depthnet.yaml
         opt.step()
 
     def step_eager():
         fwd_bwd()
-        reducer(model.flat_grads())
+        if not fwd_only:
+            reducer(model.flat_grads())
         update()
 
     # first step eagerly: builds the plan, allocates gradients / optimizer state
@@ -321,7 +401,7 @@ def main():
             step_eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        if world == 1 and not os.environ.get("HRP_BENCH_TWO_GRAPHS"):   # (the flag exercises the N > 1 structure on one GPU)
+        if fwd_only or (world == 1 and not os.environ.get("HRP_BENCH_TWO_GRAPHS")):   # (the flag exercises the N > 1 structure on one GPU)
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 fwd_bwd()
@@ -457,6 +537,21 @@ def main():
         dt = tt.item()
     final_loss = float(loss_holder["loss"].item())
 
+    # the same step without clip + Adam (SURVEY 8d C3 "Adam excluded and included: report both"), one GPU only
+    ms_no_opt = None
+    if world == 1 and use_graph and not fwd_only and not h2d and not os.environ.get("HRP_BENCH_TWO_GRAPHS"):
+        gno = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gno):
+            fwd_bwd()
+        for _ in range(2):
+            gno.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            gno.replay()
+        torch.cuda.synchronize(dev)
+        ms_no_opt = (time.perf_counter() - t0) / a.steps * 1e3
+
     if rank != 0:
         return
     ms_per_step = dt / a.steps * 1e3
@@ -496,7 +591,8 @@ def main():
 
     # lanes (concurrent graph branches) are folded onto one stream here: a kernel's duration is its own
     from hrpe_amd import plan as plan_mod
-    model.disable_split_backward()      # (N > 1: the timed step ran the backward in two graphs)
+    if not fwd_only:
+        model.disable_split_backward()      # (N > 1: the timed step ran the backward in two graphs)
     plan_mod.SERIAL_LANES = True
     nv.set_profile_hook(hook)
     # park the stream behind a spin kernel while the host enqueues the step: the event intervals then are the
@@ -546,24 +642,31 @@ def main():
                 "traffic": traffic, "launches": dom[1][0], "avg_launch_us": round(dom[1][1] / dom[1][0] * 1e3, 2),
                 "algorithmic_bytes_per_launch": round(dom[1][3] / dom[1][0]), "flop_per_byte": round(intensity, 1),
                 "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4)}
-    step_tflops = 3 * FWD_GFLOP_PER_IMAGE["full"] * 1e9 * B / (ms_per_step * 1e-3) / 1e12
+    gf_img = FWD_GFLOP_PER_IMAGE["depthnet" if hrnet else "full"] * (1 if fwd_only else 3)
+    step_tflops = gf_img * 1e9 * B * world / (ms_per_step * 1e-3) / 1e12 / world     # per GPU
+    passes = 1 if hrnet else 2
+    net = ("one HRNet-W32 (RootNet('hrnet32') = DepthNet, the metric's literal workload)" if hrnet else
+           f"full network ({'HRNet-W32' if REG_BACKBONE.startswith('hrnet') else REG_BACKBONE + ' + deconv head'} reg backbone + "
+           "HRNet-W32 DepthNet + heads + FK loss)")
+    what = (f"{net} eval forward (BatchNorm folded), BASELINE.json configs[1]" if fwd_only else
+            f"{net} fwd+loss+bwd+clip+Adam" + ("" if hrnet else ", BASELINE.json configs[2]"))
+    clip = 1 if hrnet else 5
     out = {
         "metric": "images/sec/GPU fwd+bwd HRNet-W32 256x256 bs=64; 1/2/4/8-GPU scaling",
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"full network ({'HRNet-W32' if REG_BACKBONE.startswith('hrnet') else REG_BACKBONE + ' + deconv head'} "
-                               "reg backbone + HRNet-W32 DepthNet + heads + FK loss) "
-                               "fwd+loss+bwd+clip+Adam, BASELINE.json configs[2]",
+        "config": {"workload": what,
                    "global_batch": B * world, "per_gpu_batch": B, "image": "3x256x256",
-                   "hrnet_w32_passes_per_image": 2, "parallelism": f"dp{world}", "hip_graph": use_graph,
-                   "p_dropout": a.p_dropout,
+                   "hrnet_w32_passes_per_image": passes, "parallelism": f"dp{world}", "rccl_ranks": world, "hip_graph": use_graph,
+                   "plan_mode": plan_mod.PLAN_MODE, "p_dropout": 0.0 if (hrnet or fwd_only) else a.p_dropout,
                    "inputs": {None: "resident in HBM", "u8": "uint8 images from pinned host memory every step (PCIe-inclusive)",
                               "f32": "fp32 images from pinned host memory every step (PCIe-inclusive)",
                               "u8res": "uint8 images resident in HBM"}[h2d],
-                   "optimizer": "clip_grad_norm_(5)+torch.optim.Adam(fused)" if a.torch_optim else
-                                "hrpe_amd.optim.FusedClipAdam (clip 5 + Adam, lr 1e-4)"},
-        "hrnet_w32_passes_per_sec": round(2 * value, 2),
+                   "optimizer": None if fwd_only else (f"clip_grad_norm_({clip})+torch.optim.Adam(fused)" if a.torch_optim else
+                                                      f"hrpe_amd.optim.FusedClipAdam (clip {clip} + Adam, lr 1e-4)")},
+        "hrnet_w32_passes_per_sec": round(passes * value, 2),
+        "ms_per_step_without_optimizer": round(ms_no_opt, 3) if ms_no_opt is not None else None,
         "step_model_tflops": round(step_tflops, 2),
         "step_frac_of_mfma_peak": round(step_tflops / peak, 4),
         "roofline": roofline,
@@ -571,14 +674,18 @@ def main():
         "loss": final_loss,
         **info,
     }
+    try:   # end-to-end key-point error against the reference's own eval fixture (fp32 parity path and the benchmarked bf16)
+        out["max_px_err"] = keypoint_px_error(dev, [("fp32", torch.float32), ("bf16", torch.bfloat16)])
+    except Exception as e:   # the parity tests are the gate; a missing fixture must not take the number down
+        out["max_px_err"] = {"error": repr(e)[:200]}
     if not a.no_cpu_baseline:
         # separate process (own thread pool, hard time limit): the baseline must never take the GPU number
         # down with it
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch",
-                                str(a.cpu_batch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                               timeout=240)
+                                str(a.cpu_batch), "--workload", a.workload] + (["--forward-only"] if fwd_only else []),
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
             out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "images/sec", "error": repr(e)[:200]}

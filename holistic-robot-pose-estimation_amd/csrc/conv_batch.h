@@ -15,22 +15,37 @@ namespace hrp {
 struct ConvProblem {
   hrp_conv_desc d;
   ConvTiling t;
-  int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64
-  int pad[3];
+  int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64, 4: 0 with persistent workgroups
+  int pgrid;      // cfg 4: workgroups of this problem
+  int pad[2];
 };
 
-template <typename T, int NT>
+// LIGHT: the variant for batches of problems with <= 32 output channels only (the high-resolution branch of both
+// trunks).  The union kernel's register allocation is the maximum over its bodies; keeping the 64-channel bodies out
+// lets this one carry the persistent body (plans live across tiles: ~200 registers) and still run two workgroups
+// per CU.
+template <typename T, int NT, bool LIGHT>
 __global__ __launch_bounds__(256) void conv_batch_kernel(const ConvProblem* __restrict__ tab, const BatchHdr h) {
   int base;
   const int g = batch_find(h, blockIdx.x, base);
   const ConvProblem& P = tab[g];
   const int bid = (int)blockIdx.x - base;
   const int slot = blockIdx.x & (HRP_STAT_SLOTS - 1);
-  switch (P.cfg) {
-    case 0: conv_tile_body<T, 1, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
-    case 1: conv_tile_body<T, 1, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
-    case 2: conv_tile_body<T, 2, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
-    default: conv_tile_body<T, 2, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+  if constexpr (LIGHT) {
+    switch (P.cfg) {
+      case 0: conv_tile_body<T, 1, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+      case 1: conv_tile_body<T, 1, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+      default:   // 4: cfg 0 with P.pgrid persistent workgroups walking the problem's tiles
+        if constexpr (NT == 9) conv_tile_body<T, 1, 2, 1, 4, NT, true, true>(P.d, P.t, bid, P.pgrid, slot);
+        break;
+    }
+  } else {
+    switch (P.cfg) {
+      case 0: conv_tile_body<T, 1, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+      case 1: conv_tile_body<T, 1, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+      case 2: conv_tile_body<T, 2, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+      default: conv_tile_body<T, 2, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+    }
   }
 }
 
@@ -78,16 +93,30 @@ static int conv_batch_prepare_nt(const hrp_conv_desc* descs, int n, ConvProblem*
   for (int i = 0; i < n; ++i) order[i] = i;
   for (int i = 1; i < n; ++i)   // stable insertion sort, heaviest first
     for (int j = i; j > 0 && weight[order[j]] > weight[order[j - 1]]; --j) { int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }
+  // A batch of small-channel problems only runs the LIGHT kernel.  Its 3x3 problems with many tiles of two K chunks
+  // (the index arithmetic of such a tile costs more instructions than its MFMAs) get persistent workgroups that keep
+  // their DMA / store plans across tiles: two per CU over the launch.
+  bool light = true;
+  for (int i = 0; i < n; ++i) light = light && probs[i].cfg <= 1;
+  static const int pwgs = getenv("HRP_CONV_BATCH_PERSIST") ? atoi(getenv("HRP_CONV_BATCH_PERSIST")) : 512;
+  const int pcap = light && pwgs > 0 ? (pwgs / n < 32 ? 32 : pwgs / n) : 0;
   int blk = 0;
   for (int k = 0; k < n; ++k) {
+    ConvProblem& P = probs[order[k]];
     info->blk0[k] = blk;
-    blk += probs[order[k]].t.nblocks;
-    if (tab) tab[k] = probs[order[k]];
+    if (NT == 9 && pcap > 0 && P.cfg == 0 && P.t.nblocks >= 2 * pcap && P.d.Cin * SZ <= 2 * ROW) {
+      P.cfg = 4;
+      P.pgrid = pcap;
+      blk += pcap;
+    } else {
+      blk += P.t.nblocks;
+    }
+    if (tab) tab[k] = P;
   }
   info->blk0[n] = blk;
   info->grid = blk;
   info->lds_bytes = lds_max;
-  info->variant = NT;
+  info->variant = NT + (light ? 100 : 0);
   return HRP_OK;
 }
 
@@ -113,25 +142,29 @@ static int conv_batch_prepare_t(const hrp_conv_desc* descs, int n, void* table, 
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, bool LIGHT>
 static int conv_batch_launch_nt(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_batch_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_batch_kernel<T, NT, LIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const BatchHdr h = make_hdr(info->blk0, info->n);
-  hipLaunchKernelGGL((conv_batch_kernel<T, NT>), dim3(info->grid), dim3(256), info->lds_bytes, s, (const ConvProblem*)table_dev, h);
+  hipLaunchKernelGGL((conv_batch_kernel<T, NT, LIGHT>), dim3(info->grid), dim3(256), info->lds_bytes, s, (const ConvProblem*)table_dev, h);
   return check_launch("conv_batch_kernel");
 }
 
 template <typename T>
 static int conv_batch_launch_t(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
   switch (info->variant) {
-    case 1: return conv_batch_launch_nt<T, 1>(table_dev, info, s);
-    case 2: return conv_batch_launch_nt<T, 2>(table_dev, info, s);
-    case 4: return conv_batch_launch_nt<T, 4>(table_dev, info, s);
-    case 9: return conv_batch_launch_nt<T, 9>(table_dev, info, s);
+    case 1: return conv_batch_launch_nt<T, 1, false>(table_dev, info, s);
+    case 2: return conv_batch_launch_nt<T, 2, false>(table_dev, info, s);
+    case 4: return conv_batch_launch_nt<T, 4, false>(table_dev, info, s);
+    case 9: return conv_batch_launch_nt<T, 9, false>(table_dev, info, s);
+    case 101: return conv_batch_launch_nt<T, 1, true>(table_dev, info, s);
+    case 102: return conv_batch_launch_nt<T, 2, true>(table_dev, info, s);
+    case 104: return conv_batch_launch_nt<T, 4, true>(table_dev, info, s);
+    case 109: return conv_batch_launch_nt<T, 9, true>(table_dev, info, s);
     default: set_error("conv batch: bad variant %d", info->variant); return HRP_ERR_ARG;
   }
 }

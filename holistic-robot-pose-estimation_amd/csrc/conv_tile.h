@@ -674,7 +674,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   const int pocc = pgrid > 0 ? pgrid : occ;
   const int grid = persist && t.nblocks > 256 * pocc ? 256 * pocc : t.nblocks;
   if (t.ksplit > 1 && d.res != d.y)
-    (void)hipMemsetAsync(d.y, 0, (size_t)d.N * d.y_H * d.y_W * d.y_pitch * SZ, s);
+    zero_async(d.y, (size_t)d.N * d.y_H * d.y_W * d.y_pitch * SZ, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d, t);
   return check_launch("conv_tile_kernel");
 }

@@ -555,7 +555,7 @@ static int launch_wgrad_nb(const hrp_wgrad_desc& d, hipStream_t s) {
       set_error("wgrad: a tap group without a workspace must accumulate (the caller zeroes dw)");
       return HRP_ERR_ARG;
     }
-    (void)hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
+    zero_async(d.dw, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
   }
   void (*kern)(const hrp_wgrad_desc, const WgradTiling) = nullptr;
   if constexpr (Elem<T>::SZ == 2) {

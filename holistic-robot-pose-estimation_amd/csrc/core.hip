@@ -373,11 +373,8 @@ extern "C" int hrp_nchw_to_nhwc_s2d(const float* src, void* dst, int dtype, int 
 
 extern "C" int hrp_fill_zero(void* p, int64_t bytes, void* stream) {
   HRP_REQUIRE(p && bytes >= 0, "fill_zero: bad args");
-  if (hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
-    set_error("fill_zero: hipMemsetAsync failed");
-    return HRP_ERR_LAUNCH;
-  }
-  return HRP_OK;
+  zero_async(p, (size_t)bytes, (hipStream_t)stream);
+  return check_launch("fill_zero");
 }
 
 extern "C" int hrp_gather_f32(const float* src, const int32_t* idx, float* dst, int n, int accumulate, void* stream) {
@@ -442,7 +439,7 @@ extern "C" int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int 
 
 extern "C" int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream) {
   HRP_REQUIRE(x && out && rows > 0 && C > 0, "colsum: bad args");
-  if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream);
+  if (!accumulate) zero_async(out, sizeof(float) * C, (hipStream_t)stream);
   int gx = (int)((rows + 63) / 64);
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;

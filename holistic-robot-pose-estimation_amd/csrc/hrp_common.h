@@ -114,6 +114,31 @@ __device__ __forceinline__ int fdiv16(int v, const FastDiv& f) { return (int)(((
 // a * b for 0 <= a, b < 2^24 (full-rate v_mul_u32_u24; v_mul_lo_u32 is quarter rate)
 __device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 
+// Stream-ordered zero fill as an ordinary kernel of THIS library (16-byte aligned pointer and size: every caller
+// passes fp32 / bf16 tensors whose byte size is a multiple of 16, the tail loop covers the rest).  Used instead of
+// hipMemsetAsync: a memset node sits outside the kernel queue's in-order dispatch on some paths (round 2 measured lost
+// split-K contributions when a memset on a side stream was followed by the kernel that accumulates into the buffer).
+static __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+static inline void zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (!ptr || bytes == 0) return;
+  unsigned char* b = (unsigned char*)ptr;
+  size_t head = ((uintptr_t)b % 16) ? 16 - ((uintptr_t)b % 16) : 0;
+  if (head > bytes) head = bytes;
+  if (head) hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(64), 0, s, (uint4*)nullptr, (size_t)0, b, (int)head);
+  b += head; bytes -= head;
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)(bytes % 16);
+  if (n16 == 0 && ntail == 0) return;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)b, n16, b + n16 * 16, ntail);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

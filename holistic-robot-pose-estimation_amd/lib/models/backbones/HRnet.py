@@ -323,7 +323,26 @@ def emit_trunks(pb, nets, xs, rider=None):
     for k in range(3):
         for mi in range(len(stages[0][k])):
             mods = [st[k][mi] for st in stages]
-            if TRUNK_LANES == "flat2":
+            if TRUNK_LANES == "flat3":
+                # two lanes per RESOLUTION CLASS: the high-resolution branch of every net (HBM-heavy, small-K launches:
+                # the batch runs the light conv kernel with persistent workgroups) and all other branches of every net
+                # (MFMA-heavy batched launches) - complementary kernels on two streams
+                for i in range(n):
+                    ys[i] = list(ys[i])
+                with pb.parallel(2 + extra()) as par:
+                    ride(par, 2)
+                    with par.lane(0):
+                        with pb.parallel(n, virtual=True) as vp:
+                            for i, m in enumerate(mods):
+                                with vp.lane(i):
+                                    ys[i][0] = _emit_seq(pb, m.branches[0], ys[i][0])
+                    with par.lane(1):
+                        items = [(i, b) for i, m in enumerate(mods) for b in range(1, m.num_branches)]
+                        with pb.parallel(len(items), virtual=True) as vp:
+                            for q, (i, b) in enumerate(items):
+                                with vp.lane(q):
+                                    ys[i][b] = _emit_seq(pb, mods[i].branches[b], ys[i][b])
+            elif TRUNK_LANES == "flat2":
                 # two lanes per net: the high-resolution branch (HBM-heavy launches) and the other branches as virtual
                 # lanes of one chain (MFMA-heavy batched launches)
                 with pb.parallel(2 * n + extra()) as par:

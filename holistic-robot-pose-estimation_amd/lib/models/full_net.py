@@ -6,6 +6,7 @@ pred_xyz_fk)``.  One static plan holds both HRNet-W32 trunks, the depth head, th
 the camera geometry, the iterative joint / rotation regressors and the FK kernel; nothing leaves the GPU
 (the reference copies the depth to the host and back, full_net.py:249, 287)."""
 import math
+import os
 import time
 
 import numpy as np
@@ -239,7 +240,7 @@ class RootNetwithRegInt(PlannedModule):
                     gamma = pb.dense(self.depth_layer.emit(pb, rootd["feat"]))
         else:
             ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])
-            with pb.parallel(2) as par:
+            with pb.parallel(2, virtual="heads" in os.environ.get("HRP_DBG_VIRTUAL", "")) as par:
                 with par.lane(0):
                     heat, xf = self.reg_backbone.emit_heads(pb, ys_reg)
                 with par.lane(1):
@@ -254,7 +255,7 @@ class RootNetwithRegInt(PlannedModule):
         xf_pose, xf_rot = pb.new_like(xf), pb.new_like(xf)
         pb.copy_cols(xf, xf_pose)
         pb.copy_cols(xf, xf_rot)
-        with pb.parallel(2) as par:
+        with pb.parallel(2, virtual="iter" in os.environ.get("HRP_DBG_VIRTUAL", "")) as par:
             with par.lane(0):
                 pose = self._iter_head(pb, xf_pose, self.init_pose, self.init_pose.shape[1], self.fc_pose_1,
                                        self.fc_pose_2, self.decpose)

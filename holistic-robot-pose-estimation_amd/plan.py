@@ -73,6 +73,10 @@ class TensorH:
         """-> accumulate flag for a producer of this tensor's gradient."""
         acc = self.grad_written
         self.grad_written = True
+        # allocate NOW (build time, on the building stream): launch closures call gptr() when they run, and a buffer
+        # first created then would be zero-filled on torch's current stream - unordered against a lane's side stream,
+        # where the fill could land after the first accumulations and wipe them (first step of a plan only)
+        self.grad_buf()
         root = self.base if self.base is not None else self
         here = self.plan.lane_path
         if any(lanes_concurrent(here, q) for q in root._grad_paths):
@@ -127,6 +131,8 @@ MAX_LANE_DEPTH = int(os.environ.get("HRP_LANE_DEPTH", "1"))
 # merged - two chains of batched launches whose ramp-up / tail phases overlap.
 PLAN_MODE = os.environ.get("HRP_PLAN_MODE", "hybrid")
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
+# development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
+BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
 
 Entry = collections.namedtuple("Entry", "lane path op")   # lane None: fork / join marker of the lanes mode
 
@@ -166,6 +172,8 @@ class Launch:
     def merge_key(self):
         """Launches with equal keys may share a batched launch; None: always alone."""
         d = self.desc
+        if BATCH_FAMILIES is not None and self.fam not in BATCH_FAMILIES:
+            return None
         esz = 4 if d.dtype == nv.HRP_F32 else 2
         if self.fam == "conv":
             if d.ntaps not in (1, 2, 4, 9) or (d.Cin * esz) % 32 or (d.dtype == nv.HRP_F32 and d.H == 1 and d.W == 1 and d.Cin >= 512):
@@ -515,6 +523,9 @@ class Plan:
                     node.blk = blk
                     seq.blocks[blk] = node
                     seq.items.append(node)
+                # a block's launches must be contiguous in its parent's sequence: anything emitted after the block
+                # started and before it ended would otherwise be moved behind it
+                assert seq.items[-1] is node, "plan: launches of a parallel block are interleaved with its parent's"
                 seq = node.lanes.setdefault(idx, _Seq())
             seq.items.append(e.op)
 
@@ -659,11 +670,20 @@ class Plan:
             return
         streams = [torch.cuda.current_stream(self.device)] + self._side_streams
         handles = [st.cuda_stream if st is not None else None for st in streams]
+        dbg = os.environ.get("HRP_DBG_SYNC")     # development aid: device-wide sync after every op / every fork and join
         for lane, _, op in ops:
             if lane is None:
                 op.run(streams)
+                if dbg:
+                    torch.cuda.synchronize(self.device)
             else:
+                if dbg == "pre1" and lane == 1:
+                    torch.cuda.synchronize(self.device)
                 op(handles[lane])
+                if dbg == "all" or (dbg == "lane1" and lane == 1) or (dbg == "lane0" and lane == 0):
+                    torch.cuda.synchronize(self.device)
+                elif dbg == "s1" and lane == 1:
+                    streams[1].synchronize()
 
     def fwd_ops(self):
         return self.fwd_run if self.merged else self.fwd

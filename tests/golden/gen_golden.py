@@ -21,6 +21,7 @@ Fixtures (reference call site that produced each):
   golden_metrics.npz     lib/utils/metrics.py compute_metrics_batch (:8-113) and summary_add_pck (:116-162), `metrics`.
   golden_full_train.npz  lib/core/function.py farward_loss(train=True): loss terms + grads + BN
                          running stats after one step.
+  golden_full_train_b8.npz   the same step at B = 8 (`full_train_b8`): tighter gradient tolerance (less BN noise).
 """
 import os
 import sys
@@ -304,7 +305,7 @@ def gen_depthnet_resnet():
                      "backbone.layer4.0.downsample.0.weight", "backbone.layer4.2.bn3.weight", "depth_layer.weight"], out, "")
     args = rh.default_args()
     args.backbone_name = args.rootnet_backbone_name = "resnet50"
-    init = {"robot_type": robot_type, "pose_params": INITIAL_JOINT_ANGLE,
+    init = {"robot_type": "panda", "pose_params": INITIAL_JOINT_ANGLE,
             "cam_params": np.eye(4, dtype=float), "init_pose_from_mean": True}
     full = RootNetwithRegInt(init, args)
     full.load_state_dict(synth_state_dict(full.state_dict()))
@@ -452,10 +453,9 @@ PICK_GRADS_RESNET = [
 ]
 
 
-def gen_full_train(backbone_name=None):
+def gen_full_train(backbone_name=None, B=2):
     function = import_reference_step_function()
     full, margs = build_full(backbone_name)
-    B = 2
     batch, small = make_batch(B, full.robot)
     args = rh._AttrDict(dict(margs))
     args.update(urdf_robot_name="panda", use_origin_bbox=False, use_extended_bbox=True,
@@ -495,8 +495,9 @@ def gen_full_train(backbone_name=None):
     for n, t in zip(NAMES8, o):
         out["fwd:" + n] = t.numpy()
     out["k_values"] = kv.numpy()
-    np.savez_compressed(os.path.join(HERE, "golden_full_train_resnet.npz" if backbone_name else "golden_full_train.npz"), **out)
-    print("full train ok", out["loss"], {k: float(v) for k, v in terms.items()})
+    name = "golden_full_train_resnet.npz" if backbone_name else ("golden_full_train.npz" if B == 2 else f"golden_full_train_b{B}.npz")
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("full train ok", name, out["loss"], {k: float(v) for k, v in terms.items()})
 
 
 if __name__ == "__main__":
@@ -504,5 +505,7 @@ if __name__ == "__main__":
     for w in which:
         if w == "full_train_resnet":
             gen_full_train("resnet50")
+        elif w == "full_train_b8":      # the same step at B = 8: train-mode BatchNorm over >= 512 samples per channel
+            gen_full_train(None, B=8)   # amplifies rounding noise far less than B = 2, so gradients can be held tighter
         else:
             globals()["gen_" + w]()

@@ -137,6 +137,15 @@ def test_full_eval_golden():
         assert err < 3e-4, f"{n}: rel err {err}"
     # key-points in pixels: soft-argmax root uv within 1e-2 px of the reference after ~330 fp32 convs
     assert np.abs(out[3].cpu().numpy() - g["root_uv"]).max() < 1e-2
+    # ... and the END-TO-END FK key-points, projected like the loss does (lib/core/function.py:119-122): the FK kernel is
+    # within 1e-3 px of the reference on identical inputs (test_fk_golden); here its inputs (pose, rotation, translation)
+    # come out of two fp32 trunks whose summation order differs from ATen's, which is what this bound measures
+    from hrpe_amd.lib.utils.transforms import point_projection_from_3d_tensor
+    Kd = K.to(DEV)
+    px = (point_projection_from_3d_tensor(Kd, out[7]) -
+          point_projection_from_3d_tensor(Kd, torch.tensor(g["xyz_fk"]).to(DEV))).abs().max().item()
+    print(f"end-to-end projected FK key-points vs reference: max {px:.2e} px")
+    assert px < 2e-2, px
 
 
 def test_full_eval_baxter_golden():

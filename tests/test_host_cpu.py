@@ -431,3 +431,39 @@ def test_resnet_full_net_state_dict_keys():
     assert tuple(sd["deconv_layers.0.weight"].shape) == (2048, 256, 4, 4)
     assert tuple(sd["deconv_layers.7.running_var"].shape) == (256,)
     assert tuple(sd["final_layer.weight"].shape) == (448, 256, 1, 1)
+
+
+def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` outside torch.distributed.run: the parent starts N ranks through
+    `python -m torch.distributed.run` (127.0.0.1 rendezvous) without having initialised HIP itself, and a rank whose
+    WORLD_SIZE disagrees with --gpus refuses to print a mislabelled line."""
+    import importlib
+    import subprocess as sp
+    import torch
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"], seen["cuda_init"] = cmd, env, torch.cuda.is_initialized()
+        return R()
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    assert cmd[cmd.index("--master-port") + 1].isdigit() and cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert seen["cuda_init"] is False and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # inside a launcher whose world size disagrees with --gpus: no line
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "mislabelled" in str(e.value)

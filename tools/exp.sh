@@ -5,8 +5,5 @@ try:
 except Exception as e: print("$name FAILED", e)
 PY
 }
-run nets_lds40 HRP_CONV_BATCH_LDS_KB=40
-run flat2 HRP_TRUNK_LANES=flat2
-run merged HRP_PLAN_MODE=merged
-run flat HRP_TRUNK_LANES=flat
-run nets_lds56 HRP_CONV_BATCH_LDS_KB=56
+run flat3 HRP_TRUNK_LANES=flat3
+run flat3_np HRP_TRUNK_LANES=flat3 HRP_CONV_BATCH_PERSIST=0

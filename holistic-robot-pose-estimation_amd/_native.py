@@ -147,6 +147,8 @@ PROTOTYPES = {
     "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
     "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
     "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],
+    "hrp_rng_advance": [_P, _P],
+    "hrp_dropout_f32": [_P, _I, _P, _I, _P, _I, _I, _F, _P, C.c_uint32, _P],
     "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],
     "hrp_project_bwd": [_P, _P, _P, _I, _I, _P, _P],
 }

@@ -315,9 +315,66 @@ __global__ void mul_kernel(const float* __restrict__ x, int xp, const float* __r
   *d = acc ? *d + v : v;
 }
 
+// ---- dropout of the regression heads (reference full_net.py:98-99, 132-133 nn.Dropout(p)) -------------------------
+// Philox4x32-10 (Salmon et al., the generator torch / cuRAND use): key = the plan's seed, counter = (element / 4, salt of
+// the dropout op, step).  Everything the kernel needs lives on the device - the seed and a step counter one launch per
+// forward advances - so the mask is drawn on the stream the consumer runs on and a captured HIP graph draws a fresh
+// mask every replay.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void rng_advance_kernel(uint64_t* state) { state[1] += 1; }
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int xp, float* __restrict__ y, int yp,
+                                                      float* __restrict__ mask, int rows, int cols, float keep,
+                                                      const uint64_t* __restrict__ state, uint32_t salt) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;     // 4 consecutive elements of the [rows, cols] mask
+  const size_t n = (size_t)rows * cols;
+  if (q * 4 >= n) return;
+  const uint64_t seed = state[0], step = state[1];
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) ^ salt, (uint32_t)step, (uint32_t)(step >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float scale = 1.0f / keep;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t i = q * 4 + j;
+    if (i >= n) break;
+    const float u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);     // uniform in [0, 1)
+    const float m = u < keep ? scale : 0.f;
+    const int r = (int)(i / cols), cc = (int)(i - (size_t)r * cols);
+    mask[i] = m;
+    y[(size_t)r * yp + cc] = x[(size_t)r * xp + cc] * m;
+  }
+}
+
 }  // namespace hrp
 
 using namespace hrp;
+
+extern "C" int hrp_rng_advance(uint64_t* state_dev, void* stream) {
+  HRP_REQUIRE(state_dev, "rng_advance: null state");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev);
+  return check_launch("rng_advance");
+}
+
+extern "C" int hrp_dropout_f32(const float* x, int x_pitch, float* y, int y_pitch, float* mask, int rows, int cols, float keep,
+                               const uint64_t* state_dev, uint32_t salt, void* stream) {
+  HRP_REQUIRE(x && y && mask && state_dev && rows > 0 && cols > 0, "dropout: bad args");
+  HRP_REQUIRE(keep > 0.f && keep <= 1.f, "dropout: keep probability %f", (double)keep);
+  const size_t quads = ((size_t)rows * cols + 3) / 4;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_pitch, y, y_pitch,
+                     mask, rows, cols, keep, state_dev, salt);
+  return check_launch("dropout");
+}
 
 extern "C" int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,
                            int accumulate, void* stream) {

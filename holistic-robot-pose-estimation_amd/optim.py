@@ -134,6 +134,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         nv.call("hrp_opt_adam_step", self._tensors.data_ptr(), self._chunks.data_ptr(), self._nchunks,
                 self._slots.data_ptr(), self.max_norm, self.step_count.data_ptr(),
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), s)
+        # the parameters changed through raw pointers (no tensor._version bump): inference plans must repack / refold
+        from .plan import bump_param_epoch
+        bump_param_epoch()
 
     def total_norm(self):
         """Gradient norm of the last step (before clipping), as clip_grad_norm_ returns it."""

@@ -134,6 +134,15 @@ BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batchin
 # development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
 BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
 
+# bumped whenever parameters / BatchNorm buffers are modified behind torch's back (see Plan.params_dirty)
+PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
 Entry = collections.namedtuple("Entry", "lane path op")   # lane None: fork / join marker of the lanes mode
 
 
@@ -347,6 +356,7 @@ class Plan:
         self.wgrad_ws = {}
         self.merged, self.fwd_run, self.bwd_run = False, [], []
         self._block_lanes = {}     # parallel block id -> stream of each lane (None: virtual block)
+        self._rng, self.n_dropout = None, 0
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -376,6 +386,7 @@ class Plan:
         self._grad_layout = []     # (offset, numel) in arena order
         for p in params:
             self._grad_views[id(p)] = self.grad_arena[off:off + p.numel()].view(p.shape)
+            self._grad_views[id(p)]._hrp_plan_grad = True
             self._grad_layout.append((off, p.numel()))
             off += _rup(p.numel(), 4)
 
@@ -389,6 +400,14 @@ class Plan:
             self.param_grads[id(p)] = e
             self.keep.append(e[1])
         return e[1]
+
+    def rng_state(self):
+        """Device-side (seed, step) of the plan's dropout masks; the seed comes from torch's generator at build time."""
+        if self._rng is None:
+            seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            self._rng = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+            self.keep.append(self._rng)
+        return self._rng
 
     def alloc_stats(self, Cc):
         off = self.stats_floats
@@ -629,8 +648,11 @@ class Plan:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def params_dirty(self):
+        # tensor versions catch torch-side updates (torch.optim, load_state_dict); PARAM_EPOCH the updates made through
+        # raw pointers (FusedClipAdam.step, hrp_bn_running_update), which do not bump ._version
         v = tuple(w.param._version for w in self.weight_list) + \
-            tuple(t._version for bn, _, _ in self.bn_fold.values() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            tuple(t._version for bn, _, _ in self.bn_fold.values() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+            (PARAM_EPOCH,)
         if v != self._versions:
             self._versions = v
             return True
@@ -692,7 +714,12 @@ class Plan:
         return self.bwd_run if self.merged else self.bwd
 
     def run_forward(self):
+        global PARAM_EPOCH
         s = self._stream()
+        if self._rng is not None:
+            nv.call("hrp_rng_advance", self._rng.data_ptr(), s)
+        if self.training and self._run_tab:
+            PARAM_EPOCH += 1       # running statistics change through raw pointers below: eval plans must refold
         if self.stats_floats:
             self.stats.zero_()
         self._run_list(self.fwd_ops())
@@ -810,7 +837,9 @@ class Plan:
         """Hand the plan-owned gradient buffers to the parameters (torch semantics: .grad holds this
         backward's gradient; an already-present foreign .grad tensor is accumulated into)."""
         for p, g in self.param_grads.values():
-            if p.grad is None or p.grad is g:
+            # (a .grad that is ANOTHER plan's arena view - a trailing partial batch built a second training plan - holds
+            # that plan's last gradient, not something to accumulate onto: this backward's gradient replaces it)
+            if p.grad is None or p.grad is g or getattr(p.grad, "_hrp_plan_grad", False):
                 p.grad = g
             else:
                 p.grad.add_(g)
@@ -1540,7 +1569,8 @@ class PlanBuilder:
         return xyz, uv, rr
 
     def dropout(self, x, prob):
-        """Inverted dropout on an fp32 [N, C] tensor (mask drawn by torch's generator each run)."""
+        """Inverted dropout on an fp32 [N, C] tensor: one launch draws the Philox mask (plan seed, per-op salt, a step
+        counter the forward advances) and applies it, on the lane's own stream (hrp_dropout_f32)."""
         p = self.plan
         if not p.training or prob <= 0.0:
             return x
@@ -1550,11 +1580,11 @@ class PlanBuilder:
         y = p.new(x.N, 1, 1, x.C, torch.float32, pitch=x.pitch)
         y.requires_grad = x.requires_grad
         keep = 1.0 - prob
-
-        def fw(s):
-            mask.bernoulli_(keep).mul_(1.0 / keep)
-            nv.call("hrp_mul_f32", x.ptr(), x.pitch, mask.data_ptr(), cols, y.ptr(), y.pitch, rows, cols, 0, s)
-        p.fwd.append(fw)
+        state = p.rng_state()
+        p.n_dropout += 1
+        salt = p.n_dropout * 0x9E3779B1 & 0xFFFFFFFF
+        p.fwd.append(lambda s: nv.call("hrp_dropout_f32", x.ptr(), x.pitch, y.ptr(), y.pitch, mask.data_ptr(), rows, cols, keep,
+                                       state.data_ptr(), salt, s))
         if p.need_grad:
             def bw():
                 if not y.grad_written or not x.requires_grad:
@@ -1563,6 +1593,7 @@ class PlanBuilder:
                 p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), y.pitch, mask.data_ptr(), cols, x.gptr(), x.pitch,
                                                rows, cols, acc, s))
             self.bwd_stack.append(bw)
+        y.dropout_mask = mask
         return y
 
     def cat_cols(self, parts, width=None):

@@ -340,6 +340,14 @@ int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_sca
 /* y (+)= x * m element-wise on [rows, cols] fp32 (dropout masks of the regression heads, full_net.py:98-99) */
 int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,
                 int accumulate, void* stream);
+/* nn.Dropout of the regression heads (lib/models/full_net.py:98-99, 132-133; p = args.p_dropout, lib/config.py default
+ * 0.5), inverted scaling: mask[r,c] = (u < keep) / keep with u from Philox4x32-10 keyed by state_dev[0] (seed) at counter
+ * (element / 4, salt, state_dev[1] = step); y = x * mask.  `mask` ([rows, cols] dense fp32) is what the backward multiplies
+ * by (hrp_mul_f32).  hrp_rng_advance increments state_dev[1]: one launch per forward, so a captured HIP graph draws a new
+ * mask at every replay, on the stream the consumer runs on. */
+int hrp_rng_advance(uint64_t* state_dev, void* stream);
+int hrp_dropout_f32(const float* x, int x_pitch, float* y, int y_pitch, float* mask, int rows, int cols, float keep,
+                    const uint64_t* state_dev, uint32_t salt, void* stream);
 /* point_projection_from_3d_tensor (lib/utils/transforms.py:17-21): K [B,9], pts [B,P,3] -> uv [B,P,2] */
 int hrp_project_fwd(const float* K, const float* pts, int B, int P, float* uv, void* stream);
 int hrp_project_bwd(const float* K, const float* pts, const float* duv, int B, int P, float* dpts, void* stream);

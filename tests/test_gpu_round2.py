@@ -1,0 +1,227 @@
+"""GPU: round-2 additions - batched launches against the same problems launched one by one, the Philox dropout of the
+regression heads on lane streams, refreshed inference plans after FusedClipAdam / running-statistics updates, the graph
+cache of PlannedModule."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_model import DEV, NAMES8, build_full, load
+from synth import synth_inputs
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+pytestmark = pytest.mark.gpu
+
+
+def _conv_problem(nv, N, hw, cin, cout, k, dtype, seed):
+    import bench_kernels as bk
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(N * hw * hw * cin, generator=g).to(DEV).to(dtype)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(DEV)
+    wp, _ = bk.pack(w, dtype)
+    d = nv.ConvDesc()
+    d.x, d.w = x.data_ptr(), wp.data_ptr()
+    d.dtype = nv.HRP_BF16 if dtype == torch.bfloat16 else nv.HRP_F32
+    d.N, d.H, d.W, d.Cin, d.x_pitch = N, hw, hw, cin, cin
+    d.Ho, d.Wo, d.Cout = hw, hw, cout
+    d.y_H, d.y_W, d.y_pitch, d.res_pitch = hw, hw, cout, cout
+    d.out_stride, d.in_stride = 1, 1
+    taps = bk.TAPS3 if k == 3 else [(0, 0)]
+    d.ntaps = d.w_ntaps = len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+    d.w_cout_pad = bk.rup(cout, 32)
+    return d, (x, wp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [3, 40])
+def test_batched_conv_equals_single_launches(dtype, N):
+    """hrp_batch_* conv: four problems of different shapes in ONE launch give bit-identical outputs to four single
+    launches (a convolution output is one dot product in a fixed K order whatever the tile), and equal batch statistics up
+    to the order of the fp32 atomics.  N = 40 reaches the persistent light kernel and images-per-tile > 1."""
+    from hrpe_amd import _native as nv
+    shapes = [(32, 32, 64), (64, 64, 32), (128, 128, 16), (256, 256, 8)]
+    descs, keep = [], []
+    for i, (cin, cout, hw) in enumerate(shapes):
+        d, bufs = _conv_problem(nv, N, hw, cin, cout, 3, dtype, 100 + i)
+        keep.append(bufs)
+        descs.append(d)
+    outs = {}
+    for mode in ("single", "batch"):
+        ys, sts = [], []
+        for d in descs:
+            y = torch.full((d.N * d.Ho * d.Wo * d.Cout,), 7.0, device=DEV).to(dtype)
+            st = torch.zeros(16 * d.Cout, device=DEV)
+            d.y, d.stats = y.data_ptr(), st.data_ptr()
+            ys.append(y)
+            sts.append(st)
+        if mode == "single":
+            for d in descs:
+                nv.call("hrp_conv2d_fwd", C.byref(d), None)
+        else:
+            arr = (nv.ConvDesc * len(descs))(*descs)
+            info = nv.BatchInfo()
+            host = (C.c_char * int(nv.lib().hrp_batch_table_bytes(nv.BATCH_CONV, len(descs))))()
+            nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_CONV, arr, len(descs), host, C.byref(info)), "prepare")
+            tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+            nv.check(nv.lib().hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+        torch.cuda.synchronize()
+        outs[mode] = (ys, sts)
+    for (ya, sa), (yb, sb), d in zip(zip(*outs["single"]), zip(*outs["batch"]), descs):
+        assert torch.equal(ya, yb), f"conv {d.Cin}->{d.Cout} @{d.Ho}: batched output differs from the single launch"
+        a, b = sa.view(8, -1).sum(0), sb.view(8, -1).sum(0)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(a.abs().max())), "batch statistics"
+    # light-only batch (two 32-channel problems): the LIGHT kernel variant, persistent workgroups when N is large
+    light = [descs[0], _conv_problem(nv, N, 64, 32, 32, 3, dtype, 7)[0]]
+    ref = []
+    for d in light:
+        y = torch.zeros(d.N * d.Ho * d.Wo * d.Cout, device=DEV).to(dtype)
+        d.y, d.stats = y.data_ptr(), None
+        nv.call("hrp_conv2d_fwd", C.byref(d), None)
+        ref.append(y)
+    got = []
+    for d in light:
+        y = torch.zeros(d.N * d.Ho * d.Wo * d.Cout, device=DEV).to(dtype)
+        d.y = y.data_ptr()
+        got.append(y)
+    arr = (nv.ConvDesc * 2)(*light)
+    info = nv.BatchInfo()
+    host = (C.c_char * int(nv.lib().hrp_batch_table_bytes(nv.BATCH_CONV, 2)))()
+    nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_CONV, arr, 2, host, C.byref(info)), "prepare")
+    assert info.variant == 109
+    tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+    nv.check(nv.lib().hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
+def test_grouped_plan_matches_one_by_one_plan():
+    """The same network with batched launches (default), with the launches one by one in the same order (HRP_NO_BATCH),
+    fully merged on one stream and on the round-1 lanes: eval outputs to 2e-6 (split-K atomics of the single-launch
+    path), a training step within the run-to-run noise of the fp32 atomics (BN statistics, weight-gradient slabs)."""
+    from hrpe_amd import plan as P
+    from hrpe_amd.lib.models.backbones import HRnet
+    m = build_full().eval()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    saved = (P.PLAN_MODE, P.BATCHING, HRnet.TRUNK_LANES)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}      # (the train-mode forward moves the running statistics)
+    outs = {}
+    try:
+        for name, mode, batching, lanes in (("batched", "hybrid", True, "nets"), ("one_by_one", "hybrid", False, "nets"),
+                                            ("merged", "merged", True, "nets"), ("lanes", "lanes", False, "flat")):
+            P.PLAN_MODE, P.BATCHING, HRnet.TRUNK_LANES = mode, batching, lanes
+            m.invalidate_plans()
+            m.load_state_dict(sd0)
+            m.eval()
+            with torch.no_grad():
+                ev = [o.clone() for o in m(x_reg, x_root, kv, K)]
+            m.train()
+            m.zero_grad()
+            out = m(x_reg, x_root, kv, K)
+            sum(o.float().square().mean() for o in out).backward()
+            torch.cuda.synchronize()
+            outs[name] = (ev, m.flat_grads()[0].clone())
+            if name == "batched":      # second run of the same plan: the noise floor
+                m.load_state_dict(sd0)
+                m.zero_grad()
+                out = m(x_reg, x_root, kv, K)
+                sum(o.float().square().mean() for o in out).backward()
+                torch.cuda.synchronize()
+                outs["batched_again"] = (ev, m.flat_grads()[0].clone())
+    finally:
+        P.PLAN_MODE, P.BATCHING, HRnet.TRUNK_LANES = saved
+        m.invalidate_plans()
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    noise = rel(outs["batched_again"][1], outs["batched"][1])
+    for name in ("one_by_one", "merged", "lanes"):
+        for n, a, b in zip(NAMES8, outs[name][0], outs["batched"][0]):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (name, n)
+        e = rel(outs[name][1], outs["batched"][1])
+        assert e <= max(10 * noise, 2e-3), (name, e, noise)
+    # (not bit for bit at this batch size: the single-launch path runs the small fp32 1x1 fuse convs split-K with fp32
+    # atomics, the batched path does not; test_batched_conv_equals_single_launches pins bit-identity kernel by kernel)
+
+
+def test_dropout_mask_on_lane_streams():
+    """the dropout mask is drawn by a Philox kernel on the stream of the lane that uses it.  With
+    p_dropout = 0.5 the rotation head runs on a side stream: forward y == x * mask, backward dx == dy * mask with the SAME
+    mask, masks differ between steps and between the two dropout layers, and the keep rate is ~0.5."""
+    from hrpe_amd import plan as P
+    m = build_full(p_dropout=0.5).train()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    masks_seen = []
+    drops = []
+    orig = P.PlanBuilder.dropout
+
+    def spy(self, x, prob):
+        y = orig(self, x, prob)
+        drops.append((x, y, y.dropout_mask))
+        return y
+    P.PlanBuilder.dropout = spy
+    try:
+        for step in range(2):
+            m.zero_grad()
+            out = m(x_reg, x_root, kv, K)
+            sum(o.float().square().mean() for o in out).backward()
+            torch.cuda.synchronize()
+            assert len(drops) == 16          # 2 heads x 4 iterations x 2 layers
+            for x, y, mask in drops:
+                xv = x.buf.view(x.N, x.pitch)[:, :x.C]
+                yv = y.buf.view(y.N, y.pitch)[:, :y.C]
+                assert set(torch.unique(mask).tolist()) <= {0.0, 2.0}
+                assert torch.equal(yv, xv * mask), "forward: y == x * mask"
+                gx = x.grad_buf().view(x.N, x.pitch)[:, :x.C]
+                gy = y.grad_buf().view(y.N, y.pitch)[:, :y.C]
+                assert torch.allclose(gx, gy * mask, rtol=0, atol=0), "backward uses the forward's mask"
+            allm = torch.stack([mk for _, _, mk in drops])
+            assert 0.45 < float((allm > 0).float().mean()) < 0.55
+            assert not torch.equal(drops[0][2], drops[1][2])
+            masks_seen.append(allm.clone())
+    finally:
+        P.PlanBuilder.dropout = orig
+    assert not torch.equal(masks_seen[0], masks_seen[1]), "a new mask every step"
+
+
+def test_eval_plan_follows_fused_optimizer_and_running_stats():
+    """FusedClipAdam and hrp_bn_running_update change parameters / buffers through raw pointers (no
+    tensor._version bump); the cached inference plan must repack and refold anyway.  eval -> train step -> eval equals a
+    freshly built model with the same state dict."""
+    from hrpe_amd.optim import FusedClipAdam
+    m = build_full()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    m.eval()
+    with torch.no_grad():
+        before = [o.clone() for o in m(x_reg, x_root, kv, K)]
+    opt = FusedClipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, max_norm=5.0)
+    m.train()
+    out = m(x_reg, x_root, kv, K)
+    sum(o.float().square().mean() for o in out).backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = [o.clone() for o in m(x_reg, x_root, kv, K)]
+    fresh = build_full()
+    fresh.load_state_dict(m.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(x_reg, x_root, kv, K)
+    assert any(float((a - b).abs().max()) > 1e-4 for a, b in zip(after, before)), "the step must change the outputs"
+    for n, a, w in zip(NAMES8, after, want):
+        assert float((a - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max())), n
+    # running statistics only (a train-mode forward without an optimizer step) also invalidate the folded BatchNorm
+    m.train()
+    with torch.no_grad():
+        m(x_reg, x_root, kv, K)
+    m.eval()
+    with torch.no_grad():
+        after2 = m(x_reg, x_root, kv, K)
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        want2 = fresh(x_reg, x_root, kv, K)
+    for n, a, w in zip(NAMES8, after2, want2):
+        assert float((a - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max())), n

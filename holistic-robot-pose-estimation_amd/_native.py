@@ -156,8 +156,21 @@ PROTOTYPES = {
 _lib = None
 
 
+def source_hash():
+    """sha256[:16] over the library's sources, the way csrc/Makefile computes SRC_HASH."""
+    import glob
+    import hashlib
+    files = [os.path.basename(f) for f in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))]
+    names = sorted(files + ["../../include/hrp.h", "Makefile"])      # GNU make $(sort): byte order
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
-    """Compile csrc/*.hip for gfx950 into libhrp_hip.so (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into libhrp_hip.so (hipcc cross-compiles without a GPU).  force: from scratch."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
     r = subprocess.run(["make", "-C", CSRC, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -182,6 +195,8 @@ def lib():
             fn.restype = C.c_int
         L.hrp_last_error.restype = C.c_char_p
         L.hrp_last_error.argtypes = []
+        L.hrp_source_hash.restype = C.c_char_p
+        L.hrp_source_hash.argtypes = []
         L.hrp_wgrad_workspace_bytes.restype = C.c_int64
         L.hrp_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         L.hrp_batch_table_bytes.restype = C.c_int64

@@ -360,6 +360,11 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 
 using namespace hrp;
 
+#ifndef HRP_SRC_HASH
+#define HRP_SRC_HASH "unknown"
+#endif
+extern "C" const char* hrp_source_hash(void) { return HRP_SRC_HASH; }
+
 extern "C" int hrp_rng_advance(uint64_t* state_dev, void* stream) {
   HRP_REQUIRE(state_dev, "rng_advance: null state");
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev);

@@ -7,6 +7,14 @@
  * e.g. tensor.data_ptr()); the library allocates nothing and keeps no state, so all calls are
  * hipGraph-capturable.
  *
+ * Statelessness vs the handle sketched in SURVEY 8(b) (hrp_create / hrp_destroy, hrp_allreduce_bucket): not built, on
+ * purpose.  Packed weights, workspaces and launch tables are caller-owned buffers, so there is nothing for a handle to
+ * hold; the gradient all-reduce goes through torch.distributed (RCCL) on the caller's flat gradient arena
+ * (hrpe_amd/parallel.py).  What IS process-global: the per-kernel "dynamic LDS limit raised" flags and the tuning
+ * knobs read from the environment on first use (static locals of the launch functions).  They are written once
+ * with idempotent values, so concurrent first calls from several host threads are harmless, but the library is
+ * designed for ONE launching thread per process (one process per GPU); hrp_last_error() is thread-local.
+ *
  * Tensor layout: activations are NHWC ("pixel-major": N, H, W, C with C contiguous), element type
  * hrp_dtype (fp32 for parity runs, bf16 for speed); per-channel parameters and statistics are fp32.
  * Convolution weights are consumed in the packed layout written by hrp_pack_weights.
@@ -206,6 +214,9 @@ typedef struct hrp_fk_chain {
 
 const char* hrp_last_error(void);
 int hrp_version(void);
+/* first 16 hex digits of the sha256 over the library's sources (csrc/*.hip, csrc/*.h, this header, the Makefile, sorted by
+ * name) this binary was compiled from; __graft_entry__.build() compares it with the tree it runs in */
+const char* hrp_source_hash(void);
 int hrp_device_ok(void);  /* 1 when the current HIP device is gfx950 */
 
 int hrp_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream);

@@ -35,6 +35,11 @@ def test_library_exports_every_declared_symbol():
     assert lib.hrp_version() >= 100
 
 
+def test_library_is_built_from_these_sources():
+    """The loaded libhrp_hip.so embeds the sha256 of the sources it was compiled from (csrc/Makefile SRC_HASH)."""
+    assert nv.lib().hrp_source_hash().decode() == nv.source_hash()
+
+
 def test_ctypes_struct_sizes_match_c():
     """Compile a tiny C program against include/hrp.h and compare sizeof() with the ctypes mirrors."""
     prog = r'''

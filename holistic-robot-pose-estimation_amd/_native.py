@@ -218,6 +218,10 @@ def set_profile_hook(fn):
     _profile_hook = fn
 
 
+def profiling():
+    return _profile_hook is not None
+
+
 # development aid (timing ablations only - results are wrong): HRP_SKIP=name1,name2 turns those launches into no-ops
 _skip = frozenset(filter(None, os.environ.get("HRP_SKIP", "").split(",")))
 

@@ -5,6 +5,8 @@ A ``PlannedModule`` keeps one plan per (input shapes, compute dtype, train/eval,
 when gradients are required the call is wrapped in ONE ``torch.autograd.Function`` whose backward runs
 the plan's backward list and publishes parameter gradients into ``param.grad``.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -19,27 +21,93 @@ def require_gpu(device):
     nv.lib()
 
 
+# Graph cache: the reference's loop calls model(...) / loss.backward() eagerly (scripts/train_full.py:53-67).  Walking a
+# plan in Python costs ~10 us per launch (2 200 launches per training step), so after GRAPH_WARMUP eager calls of one
+# plan its forward (weight pack + launch list + running statistics) and its backward are captured in HIP graphs and
+# replayed: the unmodified eager loop then runs at the speed of bench.py's captured step.  Inputs are copied into
+# plan-owned staging tensors first (a captured launch bakes its pointers).  Off: HRP_NO_MODULE_GRAPH=1 or
+# runtime.GRAPH_CACHE = False; never active inside somebody else's capture or with a split backward.
+GRAPH_CACHE = not os.environ.get("HRP_NO_MODULE_GRAPH")
+GRAPH_WARMUP = 2
+
+
 class Runner:
     """A built plan plus its external inputs/outputs."""
 
     def __init__(self, plan, in_names, outs, img_inputs):
         self.plan, self.in_names, self.outs, self.img_inputs = plan, in_names, outs, img_inputs
+        self.calls = self.bwd_calls = 0
+        self.g_fwd = self.g_bwd = self.static_in = None
+        self.graph_failed = False
 
-    def forward(self, tensors):
+    # ---- eager pieces ---------------------------------------------------------------------------------------
+    def _forward_launches(self, prep=True):
         p = self.plan
-        for n, t in zip(self.in_names, tensors):
-            p.dyn[n] = t
-        # training plans repack the weights on every step (they change every step, and a captured HIP graph
-        # must contain the pack launch); inference plans repack only when a parameter version changed
-        p.run_prep(force=p.need_grad)
+        # training plans repack the weights on every step (they change every step, and a captured HIP graph must
+        # contain the pack launch); inference plans repack only when a parameter changed - eagerly, OUTSIDE their graph
+        if prep or p.need_grad:
+            p.run_prep(force=p.need_grad)
         p.run_forward()
+
+    def _results(self):
         res = []
         for kind, h, shape in self.outs:
             if kind == "nchw":
-                res.append(h["out"])
+                res.append(h["out"].clone() if self.g_fwd is not None else h["out"])   # (graph pool memory is reused)
             else:
                 res.append(h.buf.view(-1)[: h.N * h.pitch].view(h.N, h.pitch)[:, : h.C].reshape(shape).clone())
         return tuple(res)
+
+    def _graphs_allowed(self):
+        p = self.plan
+        return (GRAPH_CACHE and not self.graph_failed and not p.split_active and not torch.cuda.is_current_stream_capturing()
+                and not nv.profiling())
+
+    def _capture(self, what):
+        """Capture the forward or the backward launch list of this plan (every kernel has run eagerly before: lazy code
+        loading and one-time function attributes are not capturable)."""
+        p = self.plan
+        try:
+            g = torch.cuda.CUDAGraph()
+            pool = self.g_fwd.pool() if self.g_fwd is not None else None
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                if what == "fwd":
+                    self._forward_launches(prep=False)
+                else:
+                    p.run_backward(None)
+            return g
+        except Exception as e:   # a capture-unsafe op somewhere: stay eager for this plan
+            import sys
+            print(f"hrpe_amd: graph capture of the {what} plan failed ({e!r}); running it eagerly", file=sys.stderr)
+            self.graph_failed = True
+            return None
+
+    # ---- public ---------------------------------------------------------------------------------------------
+    def forward(self, tensors):
+        p = self.plan
+        self.calls += 1
+        if self._graphs_allowed() and self.calls > GRAPH_WARMUP:
+            if self.g_fwd is None:
+                self.static_in = [torch.empty_like(t) for t in tensors]
+                for n, st in zip(self.in_names, self.static_in):
+                    p.dyn[n] = st
+                self.g_fwd = self._capture("fwd")
+            if self.g_fwd is not None and p.need_grad and self.g_bwd is None and self.bwd_calls >= GRAPH_WARMUP:
+                self.g_bwd = self._capture("bwd")
+        if self.g_fwd is not None and self._graphs_allowed():
+            for st, t in zip(self.static_in, tensors):
+                st.copy_(t)
+            if not p.need_grad:
+                p.run_prep(force=False)      # pack / fold only when a parameter changed (not part of the graph)
+            self.g_fwd.replay()
+            if p.training and p._run_tab:
+                from .plan import bump_param_epoch
+                bump_param_epoch()       # running statistics moved (the Python side of run_forward does not run on replay)
+            return self._results()
+        for n, t in zip(self.in_names, tensors):
+            p.dyn[n] = t
+        self._forward_launches()
+        return self._results()
 
     def backward(self, grads):
         p = self.plan
@@ -56,7 +124,11 @@ class Runner:
                 nv.call("hrp_nchw_to_nhwc", g.data_ptr(), t.gptr(), _dt(t.dtype), t.N, t.C, t.H, t.W, t.pitch, s)
             else:
                 gb.view(t.N, t.pitch)[:, : t.C].copy_(g.reshape(t.N, t.C))
-        p.run_backward("first" if p.split_active else None)   # (split: the caller runs plan.run_backward("rest"))
+        self.bwd_calls += 1
+        if self.g_bwd is not None and self._graphs_allowed():
+            self.g_bwd.replay()
+        else:
+            p.run_backward("first" if p.split_active else None)   # (split: the caller runs plan.run_backward("rest"))
         p.publish_param_grads()
         gin = []
         for n in self.in_names:

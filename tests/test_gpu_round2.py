@@ -225,3 +225,98 @@ def test_eval_plan_follows_fused_optimizer_and_running_stats():
         want2 = fresh(x_reg, x_root, kv, K)
     for n, a, w in zip(NAMES8, after2, want2):
         assert float((a - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max())), n
+
+
+def test_module_graph_cache_matches_eager_and_speeds_up_the_plain_loop():
+    """the reference's unmodified loop - model(...), loss.backward(), optimizer.step()
+    (scripts/train_full.py:53-67) - replays captured forward / backward graphs per plan after two eager warm-up steps.
+    Same numbers as the eager walk, and the plain loop at B = 64 costs about what one captured whole-step graph costs."""
+    import time
+    from hrpe_amd import runtime as R
+    from hrpe_amd.lib.core.function import full_loss
+    from hrpe_amd.optim import FusedClipAdam
+    from test_gpu_parity import _train_step_inputs
+    g = load("golden_full_train_b8.npz")
+    m = build_full().train()
+    x_reg, x_root, kv, K, gt = _train_step_inputs(g, m, 8)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def step():
+        m.zero_grad()
+        loss, _ = full_loss(m(x_reg, x_root, kv, K), gt, K)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), m.flat_grads()[0].clone()
+    res = {}
+    for cache in (False, True):
+        R.GRAPH_CACHE = cache
+        m.invalidate_plans()
+        out = []
+        for i in range(5):
+            m.load_state_dict(sd0)
+            out.append(step())
+        res[cache] = out
+        if cache:
+            r = next(iter(m._plans.values()))
+            assert r.g_fwd is not None and r.g_bwd is not None, "forward and backward graphs are captured after the warm-up"
+    R.GRAPH_CACHE = True
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    noise = rel(res[False][1][1], res[False][0][1])
+    for i in range(5):
+        assert abs(res[True][i][0] - res[False][i][0]) < 1e-4 * abs(res[False][i][0])
+        assert rel(res[True][i][1], res[False][i][1]) <= max(10 * noise, 2e-3)
+    # speed at the benchmark's batch size, bf16: plain loop with the graph cache vs ONE captured whole step
+    B = 64
+    m = build_full().train().set_compute_dtype(torch.bfloat16)
+    rng = np.random.Generator(np.random.PCG64(3))
+    xr = torch.tensor(rng.random((B, 3, 256, 256), dtype=np.float32)).to(DEV)
+    xo = torch.tensor(rng.random((B, 3, 256, 256), dtype=np.float32)).to(DEV)
+    Kb, kvb = K[:1].repeat(B, 1, 1).contiguous(), kv[:1].repeat(B).contiguous()
+    gtb = {k: v[:1].repeat(B, *([1] * (v.dim() - 1))).contiguous() for k, v in gt.items()}
+    opt = FusedClipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-5, max_norm=5.0)
+
+    def loop_step():
+        loss, _ = full_loss(m(xr, xo, kvb, Kb), gtb, Kb)
+        loss.backward()
+        opt.step()
+    for _ in range(4):
+        loop_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        loop_step()
+    torch.cuda.synchronize()
+    t_loop = (time.perf_counter() - t0) / 10
+    R.GRAPH_CACHE = False
+    try:
+        m.invalidate_plans()
+        for _ in range(2):
+            loop_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            loop_step()
+        torch.cuda.synchronize()
+        t_eager = (time.perf_counter() - t0) / 5
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            loop_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        whole = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(whole):
+            loop_step()
+        for _ in range(2):
+            whole.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            whole.replay()
+        torch.cuda.synchronize()
+        t_graph = (time.perf_counter() - t0) / 10
+    finally:
+        R.GRAPH_CACHE = True
+    print(f"\nB=64 bf16 step: plain loop with graph cache {t_loop * 1e3:.1f} ms, plain loop eager {t_eager * 1e3:.1f} ms, "
+          f"one captured whole-step graph {t_graph * 1e3:.1f} ms")
+    assert t_loop <= 1.10 * t_graph + 1e-3, (t_loop, t_graph)

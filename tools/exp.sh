@@ -1,9 +1,16 @@
-run() { name=$1; shift; env "$@" HRP_PLAN_STATS=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r02_x_$name.json 2> gpurun_out/r02_x_$name.err; python - <<PY
+# development aid: one gpurun call = tests + the bench lines of every workload
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r02_tests.log
+timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_full.json 2> gpurun_out/r02_bench_full.err
+timeout 300 python bench.py --steps 20 --warmup 5 --workload hrnet > gpurun_out/r02_bench_hrnet.json 2> gpurun_out/r02_bench_hrnet.err
+timeout 300 python bench.py --steps 20 --warmup 5 --forward-only > gpurun_out/r02_bench_fwd.json 2> gpurun_out/r02_bench_fwd.err
+timeout 300 python bench.py --steps 20 --warmup 5 --forward-only --workload hrnet > gpurun_out/r02_bench_fwd_hrnet.json 2> gpurun_out/r02_bench_fwd_hrnet.err
+HRP_BENCH_DEVICE=0 HRP_DIST_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r02_bench_gloo2.json 2> gpurun_out/r02_bench_gloo2.err
+cat gpurun_out/r02_tests.log
+for f in full hrnet fwd fwd_hrnet gloo2; do python - <<PY
 import json
 try:
-    d=json.load(open("gpurun_out/r02_x_$name.json")); print("$name", d["value"], d["ms_per_step"], {k:(v["launches"],v["ms"]) for k,v in list(d["kernels"].items())[:5]})
-except Exception as e: print("$name FAILED", e)
+    d=json.loads(open("gpurun_out/r02_bench_$f.json").read().strip().splitlines()[-1])
+    print("$f", d["value"], d["ms_per_step"], d.get("ms_per_step_without_optimizer"), d["n_gpus"], d.get("max_px_err"), d["roofline"]["kernel"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"))
+except Exception as e: print("$f FAILED", repr(e)[:200])
 PY
-}
-run flat3 HRP_TRUNK_LANES=flat3
-run flat3_np HRP_TRUNK_LANES=flat3 HRP_CONV_BATCH_PERSIST=0
+done

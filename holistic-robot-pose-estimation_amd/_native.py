@@ -91,6 +91,14 @@ class BatchInfo(C.Structure):
                 ("ws_bytes", C.c_int64 * BATCH_MAX)]
 
 
+class PoseLossDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pose", "rot", "trans", "root_uv", "depth", "xyz_int", "xyz_fk",
+                                          "gt_pose", "gt_root_rot", "gt_root_trans", "gt_root_uv", "gt_kp3d", "gt_kp2d", "mask", "K",
+                                          "d_pose", "d_rot", "d_trans", "d_root_uv", "d_depth", "d_xyz_int", "d_xyz_fk", "out")] + \
+               [("weights", C.c_float * 10), ("B", C.c_int32), ("P", C.c_int32), ("J", C.c_int32), ("root", C.c_int32),
+                ("image_size", C.c_float)]
+
+
 OPT_CHUNK = 4096
 
 
@@ -147,6 +155,7 @@ PROTOTYPES = {
     "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
     "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
     "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],
+    "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_rng_advance": [_P, _P],
     "hrp_dropout_f32": [_P, _I, _P, _I, _P, _I, _I, _F, _P, C.c_uint32, _P],
     "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],

@@ -444,9 +444,186 @@ __global__ void project_bwd_kernel(const float* __restrict__ K, const float* __r
   }
 }
 
+// =================================================================================================
+// The training loss of configs/panda/full.yaml in ONE launch, with its analytic gradient
+// (reference lib/core/function.py:191-322: ten terms assembled from ~60 tensor expressions and two
+// per-sample projection loops, :119-122).  One workgroup; a thread walks samples b, b + 256, ...
+//   t0 loss_joint   mean (pose - gt)^2                        t5 loss_error3d      mean_j ||xyz_fk - kp3d||
+//   t1 loss_rot     mean (rot6d - gt)^2                       t6 loss_error2d      sum m ||uv_fk - kp2d|| / S / #m
+//   t2 loss_uv      sum m_root ||root_uv - gt|| / S / #m_root t7 loss_error2d_int  same with uv_int
+//   t3 loss_depth   mean |depth - gt_z|                       t8 loss_error3d_int  mean_j ||xyz_int - kp3d||
+//   t4 loss_trans   mean e c, e = ||trans - gt||,             t9 loss_error3d_align mean_j ||xyz_fk - xyz_int||
+//                   c = exp(-20 e) (no gradient) when mean e > 0.5 else 1        (function.py:245-251)
+// uv = (K p)[:2] / (K p)[2] (transforms.py:17-21).  out[0..9] = the terms, out[10] = sum_k w[k] t_k.  Gradients of
+// out[10] with respect to every prediction are written to the d_* buffers (norm at 0: gradient 0, as torch.norm).
+// =================================================================================================
+struct LossArgs {
+  const float *pose, *rot, *trans, *root_uv, *depth, *xyz_int, *xyz_fk;                    // predictions
+  const float *g_pose, *g_rot, *g_trans, *g_root_uv, *g_kp3d, *g_kp2d, *mask, *K;           // ground truth, intrinsics
+  float *d_pose, *d_rot, *d_trans, *d_root_uv, *d_depth, *d_xyz_int, *d_xyz_fk;            // gradients (may be NULL: none)
+  float* out;                                                                             // [11]
+  float w[10];
+  int B, P, J, root;
+  float S;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void pose_loss_kernel(const LossArgs a) {
+  __shared__ float red[4];
+  const int B = a.B, P = a.P, J = a.J;
+  const float invS = 1.0f / a.S;
+  // ---- pass 1: everything the normalisations need ------------------------------------------------------------
+  float s_e = 0.f, n_root = 0.f, n_valid = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float dx = a.trans[3 * b] - a.g_trans[3 * b], dy = a.trans[3 * b + 1] - a.g_trans[3 * b + 1],
+                dz = a.trans[3 * b + 2] - a.g_trans[3 * b + 2];
+    s_e += sqrtf(dx * dx + dy * dy + dz * dz);
+    n_root += a.mask[b * J + a.root] != 0.f ? 1.f : 0.f;
+    for (int j = 0; j < J; ++j) n_valid += a.mask[b * J + j] != 0.f ? 1.f : 0.f;
+  }
+  const float mean_e = block_sum(s_e, red) / B;
+  n_root = block_sum(n_root, red);
+  n_valid = block_sum(n_valid, red);
+  const bool damp = mean_e > 0.5f;
+  // ---- pass 2: terms and gradients ---------------------------------------------------------------------------
+  float t[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) t[k] = 0.f;
+  const bool grad = a.d_pose != nullptr;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    for (int k = 0; k < P; ++k) {
+      const float d = a.pose[b * P + k] - a.g_pose[b * P + k];
+      t[0] += d * d;
+      if (grad) a.d_pose[b * P + k] = a.w[0] * 2.f * d / (B * P);
+    }
+    for (int k = 0; k < 6; ++k) {
+      const float d = a.rot[b * 6 + k] - a.g_rot[b * 6 + k];
+      t[1] += d * d;
+      if (grad) a.d_rot[b * 6 + k] = a.w[1] * 2.f * d / (B * 6);
+    }
+    {
+      const float m = a.mask[b * J + a.root];
+      const float ux = (a.root_uv[2 * b] - a.g_root_uv[2 * b]) * invS, uy = (a.root_uv[2 * b + 1] - a.g_root_uv[2 * b + 1]) * invS;
+      const float n = sqrtf(ux * ux + uy * uy);
+      t[2] += n * m;
+      if (grad) {
+        const float c = n > 0.f ? a.w[2] * m * invS / (n * n_root) : 0.f;
+        a.d_root_uv[2 * b] = c * ux; a.d_root_uv[2 * b + 1] = c * uy;
+      }
+    }
+    {
+      const float d = a.depth[b] - a.g_trans[3 * b + 2];
+      t[3] += fabsf(d);
+      if (grad) a.d_depth[b] = a.w[3] * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f) / B;
+    }
+    {
+      const float dx = a.trans[3 * b] - a.g_trans[3 * b], dy = a.trans[3 * b + 1] - a.g_trans[3 * b + 1],
+                  dz = a.trans[3 * b + 2] - a.g_trans[3 * b + 2];
+      const float e = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float c = damp ? expf(-20.0f * e) : 1.f;
+      t[4] += e * c;
+      if (grad) {
+        const float g = e > 0.f ? a.w[4] * c / (e * B) : 0.f;
+        a.d_trans[3 * b] = g * dx; a.d_trans[3 * b + 1] = g * dy; a.d_trans[3 * b + 2] = g * dz;
+      }
+    }
+    const float* Kb = a.K + 9 * b;
+    for (int j = 0; j < J; ++j) {
+      const int o = (b * J + j) * 3;
+      const float m = a.mask[b * J + j];
+      const float gx = a.g_kp3d[o], gy = a.g_kp3d[o + 1], gz = a.g_kp3d[o + 2];
+      const float g2x = a.g_kp2d[(b * J + j) * 2] * invS, g2y = a.g_kp2d[(b * J + j) * 2 + 1] * invS;
+      float dfk[3] = {0.f, 0.f, 0.f}, dint[3] = {0.f, 0.f, 0.f};
+      const float* pts[2] = {a.xyz_fk + o, a.xyz_int + o};
+      float* dps[2] = {dfk, dint};
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float* p = pts[which];
+        float* dp = dps[which];
+        // 3-D error
+        const float ex = p[0] - gx, ey = p[1] - gy, ez = p[2] - gz;
+        const float n3 = sqrtf(ex * ex + ey * ey + ez * ez);
+        t[which == 0 ? 5 : 8] += n3;
+        const float w3 = a.w[which == 0 ? 6 : 8];     // weights: see the order at the launch (kp3d, kp3d_int)
+        if (n3 > 0.f) { const float c = w3 / (n3 * B * J); dp[0] += c * ex; dp[1] += c * ey; dp[2] += c * ez; }
+        // projected 2-D error
+        const float h0 = Kb[0] * p[0] + Kb[1] * p[1] + Kb[2] * p[2], h1 = Kb[3] * p[0] + Kb[4] * p[1] + Kb[5] * p[2],
+                    h2 = Kb[6] * p[0] + Kb[7] * p[1] + Kb[8] * p[2];
+        const float u = h0 / h2, v = h1 / h2;
+        const float qx = u * invS - g2x, qy = v * invS - g2y;
+        const float n2 = sqrtf(qx * qx + qy * qy);
+        t[which == 0 ? 6 : 7] += n2 * m;
+        const float w2 = a.w[which == 0 ? 5 : 7];     // kp2d, kp2d_int
+        if (n2 > 0.f && m != 0.f) {
+          const float c = w2 * m * invS / (n2 * n_valid);
+          const float du = c * qx, dv = c * qy;
+          const float dh0 = du / h2, dh1 = dv / h2, dh2 = -(du * h0 + dv * h1) / (h2 * h2);
+          dp[0] += Kb[0] * dh0 + Kb[3] * dh1 + Kb[6] * dh2;
+          dp[1] += Kb[1] * dh0 + Kb[4] * dh1 + Kb[7] * dh2;
+          dp[2] += Kb[2] * dh0 + Kb[5] * dh1 + Kb[8] * dh2;
+        }
+      }
+      {  // alignment of the two key-point estimates (weight 0 in full.yaml)
+        const float ex = a.xyz_fk[o] - a.xyz_int[o], ey = a.xyz_fk[o + 1] - a.xyz_int[o + 1], ez = a.xyz_fk[o + 2] - a.xyz_int[o + 2];
+        const float n = sqrtf(ex * ex + ey * ey + ez * ez);
+        t[9] += n;
+        if (n > 0.f && a.w[9] != 0.f) {
+          const float c = a.w[9] / (n * B * J);
+          dfk[0] += c * ex; dfk[1] += c * ey; dfk[2] += c * ez;
+          dint[0] -= c * ex; dint[1] -= c * ey; dint[2] -= c * ez;
+        }
+      }
+      if (grad) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a.d_xyz_fk[o + k] = dfk[k]; a.d_xyz_int[o + k] = dint[k]; }
+      }
+    }
+  }
+  const float norm[10] = {1.f / (B * P), 1.f / (B * 6), 1.f / n_root, 1.f / B, 1.f / B, 1.f / (B * J), 1.f / n_valid, 1.f / n_valid,
+                          1.f / (B * J), 1.f / (B * J)};
+  // weights in term order: joint, rot, uv, depth, trans, error3d, error2d, error2d_int, error3d_int, align
+  const float wt[10] = {a.w[0], a.w[1], a.w[2], a.w[3], a.w[4], a.w[6], a.w[5], a.w[7], a.w[8], a.w[9]};
+  float total = 0.f;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const float v = block_sum(t[k], red) * norm[k];
+    if (threadIdx.x == 0) a.out[k] = v;
+    total += wt[k] * v;
+  }
+  if (threadIdx.x == 0) a.out[10] = total;
+}
+
 }  // namespace hrp
 
 using namespace hrp;
+
+extern "C" int hrp_pose_loss(const hrp_pose_loss_desc* d, void* stream) {
+  HRP_REQUIRE(d && d->pose && d->rot && d->trans && d->root_uv && d->depth && d->xyz_int && d->xyz_fk, "pose_loss: null prediction");
+  HRP_REQUIRE(d->gt_pose && d->gt_root_rot && d->gt_root_trans && d->gt_root_uv && d->gt_kp3d && d->gt_kp2d && d->mask && d->K && d->out,
+              "pose_loss: null ground truth / output");
+  HRP_REQUIRE(d->B > 0 && d->P > 0 && d->J > 0 && d->root >= 0 && d->root < d->J && d->image_size > 0.f, "pose_loss: sizes");
+  const bool g = d->d_pose != nullptr;
+  HRP_REQUIRE(!g || (d->d_rot && d->d_trans && d->d_root_uv && d->d_depth && d->d_xyz_int && d->d_xyz_fk), "pose_loss: all gradient buffers or none");
+  LossArgs a;
+  a.pose = d->pose; a.rot = d->rot; a.trans = d->trans; a.root_uv = d->root_uv; a.depth = d->depth; a.xyz_int = d->xyz_int; a.xyz_fk = d->xyz_fk;
+  a.g_pose = d->gt_pose; a.g_rot = d->gt_root_rot; a.g_trans = d->gt_root_trans; a.g_root_uv = d->gt_root_uv; a.g_kp3d = d->gt_kp3d;
+  a.g_kp2d = d->gt_kp2d; a.mask = d->mask; a.K = d->K;
+  a.d_pose = d->d_pose; a.d_rot = d->d_rot; a.d_trans = d->d_trans; a.d_root_uv = d->d_root_uv; a.d_depth = d->d_depth;
+  a.d_xyz_int = d->d_xyz_int; a.d_xyz_fk = d->d_xyz_fk;
+  a.out = d->out;
+  for (int k = 0; k < 10; ++k) a.w[k] = d->weights[k];
+  a.B = d->B; a.P = d->P; a.J = d->J; a.root = d->root; a.S = d->image_size;
+  hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("pose_loss");
+}
 
 extern "C" int hrp_project_fwd(const float* K, const float* pts, int B, int P, float* uv, void* stream) {
   HRP_REQUIRE(K && pts && uv && B > 0 && P > 0, "project_fwd: bad args");

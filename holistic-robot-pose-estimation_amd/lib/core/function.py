@@ -72,9 +72,65 @@ def prepare_batch(input_batch, robot, device, reference_keypoint_id=3, use_origi
     return out
 
 
+TERM_NAMES = ("loss_joint", "loss_rot", "loss_uv", "loss_depth", "loss_trans", "loss_error3d", "loss_error2d",
+              "loss_error2d_int", "loss_error3d_int", "loss_error3d_align")          # order of function.py:313-319
+_WEIGHT_KEYS = ("pose", "rot", "uv", "depth", "trans", "kp2d", "kp3d", "kp2d_int", "kp3d_int", "align_3d")
+
+
+class _FusedPoseLoss(torch.autograd.Function):
+    """hrp_pose_loss: the ten terms, their weighted sum and its gradient with respect to the predictions in one launch
+    (the reference builds them from ~60 tensor expressions and two per-sample projection loops)."""
+
+    @staticmethod
+    def forward(ctx, K, root, image_size, wvec, gtt, pose, rot, trans, root_uv, depth, xyz_int, xyz_fk):
+        import ctypes as C
+        from hrpe_amd import _native as nv
+        preds = [t.contiguous().float() for t in (pose, rot, trans, root_uv, depth, xyz_int, xyz_fk)]
+        need = any(t.requires_grad for t in (pose, rot, trans, root_uv, depth, xyz_int, xyz_fk))
+        grads = [torch.empty_like(t) for t in preds] if need else [None] * 7
+        out = torch.empty(11, dtype=torch.float32, device=pose.device)
+        d = nv.PoseLossDesc()
+        for name, t in zip(("pose", "rot", "trans", "root_uv", "depth", "xyz_int", "xyz_fk"), preds):
+            setattr(d, name, t.data_ptr())
+        for name, t in zip(("gt_pose", "gt_root_rot", "gt_root_trans", "gt_root_uv", "gt_kp3d", "gt_kp2d", "mask"), gtt):
+            setattr(d, name, t.data_ptr())
+        d.K = K.data_ptr()
+        if need:
+            for name, t in zip(("d_pose", "d_rot", "d_trans", "d_root_uv", "d_depth", "d_xyz_int", "d_xyz_fk"), grads):
+                setattr(d, name, t.data_ptr())
+        d.out = out.data_ptr()
+        for i, w in enumerate(wvec):
+            d.weights[i] = w
+        d.B, d.P, d.J, d.root, d.image_size = pose.shape[0], pose.shape[1], xyz_fk.shape[1], root, image_size
+        nv.call("hrp_pose_loss", C.byref(d), torch.cuda.current_stream(pose.device).cuda_stream)
+        ctx.grads = grads
+        ctx.mark_non_differentiable(out)
+        return out[10], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        gs = [None if g is None else g * g_loss for g in ctx.grads]
+        return (None, None, None, None, None) + tuple(gs)
+
+
 def full_loss(pred, gt, K, root=3, image_size=256.0, weights=FULL_YAML_WEIGHTS):
     """pred: the model's 8-tuple.  gt: dict(pose, root_rot, root_trans, root_uv, kp3d, kp2d, mask).
-    Returns (loss, dict of the ten terms named as in function.py:313-319)."""
+    Returns (loss, dict of the ten terms named as in function.py:313-319).  Device tensors: one fused launch
+    (hrp_pose_loss, analytic gradient); host tensors: the tensor-expression form below (tests of the harness)."""
+    if pred[0].is_cuda:
+        pose, rot, trans, root_uv, depth, uvd, xyz_int, xyz_fk = pred
+        f32 = lambda t: t.contiguous().float()   # noqa: E731
+        gtt = [f32(gt[k]) for k in ("pose", "root_rot", "root_trans", "root_uv", "kp3d", "kp2d", "mask")]
+        wvec = [float(weights[k]) for k in _WEIGHT_KEYS]
+        loss, out = _FusedPoseLoss.apply(f32(K).reshape(-1, 9), int(root), float(image_size), wvec, gtt, pose, rot, trans,
+                                         root_uv, depth, xyz_int, xyz_fk)
+        return loss, {n: out[i] for i, n in enumerate(TERM_NAMES)}
+    return full_loss_expr(pred, gt, K, root, image_size, weights)
+
+
+def full_loss_expr(pred, gt, K, root=3, image_size=256.0, weights=FULL_YAML_WEIGHTS):
+    """The same loss as tensor expressions (autograd) - the line-by-line restatement of function.py:191-322 the fused
+    kernel is tested against."""
     pose, rot, trans, root_uv, depth, uvd, xyz_int, xyz_fk = pred
     uv_int = point_projection_from_3d_tensor(K, xyz_int)        # function.py:121
     uv_fk = point_projection_from_3d_tensor(K, xyz_fk)          # function.py:122

@@ -351,6 +351,23 @@ int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_sca
 /* y (+)= x * m element-wise on [rows, cols] fp32 (dropout masks of the regression heads, full_net.py:98-99) */
 int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,
                 int accumulate, void* stream);
+/* The training loss of configs/panda/full.yaml (lib/core/function.py:191-322, projections of :119-122) and its gradient
+ * with respect to the model's predictions in one launch.  All tensors dense fp32.  weights: pose, rot, uv, depth, trans,
+ * kp2d, kp3d, kp2d_int, kp3d_int, align_3d (the *_loss_weight keys of the yaml, :57-66).  out[0..9]: loss_joint, loss_rot,
+ * loss_uv, loss_depth, loss_trans, loss_error3d, loss_error2d, loss_error2d_int, loss_error3d_int, loss_error3d_align (the
+ * names of function.py:313-319); out[10]: the weighted total.  d_*: gradient of out[10] (all seven, or all NULL). */
+typedef struct hrp_pose_loss_desc {
+  const float *pose, *rot, *trans, *root_uv, *depth, *xyz_int, *xyz_fk;   /* [B,P] [B,6] [B,3] [B,2] [B,1] [B,J,3] [B,J,3] */
+  const float *gt_pose, *gt_root_rot, *gt_root_trans, *gt_root_uv;       /* [B,P] [B,6] [B,3] [B,2] */
+  const float *gt_kp3d, *gt_kp2d, *mask, *K;                             /* [B,J,3] [B,J,2] [B,J] [B,9] */
+  float *d_pose, *d_rot, *d_trans, *d_root_uv, *d_depth, *d_xyz_int, *d_xyz_fk;
+  float* out;                                                            /* [11] */
+  float weights[10];
+  int32_t B, P, J, root;
+  float image_size;
+} hrp_pose_loss_desc;
+int hrp_pose_loss(const hrp_pose_loss_desc* d, void* stream);
+
 /* nn.Dropout of the regression heads (lib/models/full_net.py:98-99, 132-133; p = args.p_dropout, lib/config.py default
  * 0.5), inverted scaling: mask[r,c] = (u < keep) / keep with u from Philox4x32-10 keyed by state_dev[0] (seed) at counter
  * (element / 4, salt, state_dev[1] = step); y = x * mask.  `mask` ([rows, cols] dense fp32) is what the backward multiplies

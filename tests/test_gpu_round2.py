@@ -320,3 +320,43 @@ def test_module_graph_cache_matches_eager_and_speeds_up_the_plain_loop():
     print(f"\nB=64 bf16 step: plain loop with graph cache {t_loop * 1e3:.1f} ms, plain loop eager {t_eager * 1e3:.1f} ms, "
           f"one captured whole-step graph {t_graph * 1e3:.1f} ms")
     assert t_loop <= 1.10 * t_graph + 1e-3, (t_loop, t_graph)
+
+
+@pytest.mark.parametrize("damped", [False, True])
+def test_fused_pose_loss_matches_tensor_expressions(damped):
+    """hrp_pose_loss (ten terms + analytic gradient, one launch) against the tensor-expression restatement
+    of lib/core/function.py:191-322 with autograd, on random predictions; both branches of the exp(-20 e) damping of the
+    translation term (function.py:245-251), a zero mask entry, a prediction that equals its target (norm at 0)."""
+    from hrpe_amd.lib.core.function import TERM_NAMES, full_loss, full_loss_expr
+    g = torch.Generator(device="cpu").manual_seed(5 + int(damped))
+    B, J, P = 37, 7, 8
+    r = lambda *s: torch.randn(*s, generator=g)   # noqa: E731
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = K[:, 1, 1] = 300.0 + 200.0 * torch.rand(B, generator=g)
+    K[:, 0, 2] = K[:, 1, 2] = 128.0
+    K[:, 2, 2] = 1.0
+    kp3d = r(B, J, 3) * 0.3 + torch.tensor([0.0, 0.0, 1.2])
+    gt = dict(pose=r(B, P), root_rot=r(B, 6), root_trans=kp3d[:, 3].clone(), root_uv=128 + 40 * r(B, 2), kp3d=kp3d,
+              kp2d=128 + 60 * r(B, J, 2), mask=(torch.rand(B, J, generator=g) > 0.2).float())
+    gt["mask"][0, 3] = 0.0
+    pred = [r(B, P), r(B, 6), kp3d[:, 3] + (2.0 if damped else 0.05) * r(B, 3), 128 + 40 * r(B, 2), 1.2 + 0.2 * r(B, 1),
+            r(B, J, 3), kp3d + 0.1 * r(B, J, 3), kp3d + 0.1 * r(B, J, 3)]
+    pred[6][1, 2] = kp3d[1, 2]       # exactly on target: ||.|| = 0 -> gradient 0
+    dev = lambda t: t.to(DEV)        # noqa: E731
+    Kd, gtd = dev(K), {k: dev(v) for k, v in gt.items()}
+    pa = [dev(t).requires_grad_(True) for t in pred]
+    pb = [dev(t).requires_grad_(True) for t in pred]
+    la, ta = full_loss(pa, gtd, Kd)
+    lb, tb = full_loss_expr(pb, gtd, Kd)
+    e_mean = float(torch.norm(pb[2] - gtd["root_trans"], dim=1).mean())
+    assert (e_mean > 0.5) == damped
+    for n in TERM_NAMES:
+        assert abs(float(ta[n]) - float(tb[n])) <= 2e-6 * max(1.0, abs(float(tb[n]))), n
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+    (3.0 * la).backward()
+    (3.0 * lb).backward()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        if i == 5:
+            assert a.grad is None or float(a.grad.abs().max()) == 0.0     # uvd does not enter the loss
+            continue
+        assert torch.allclose(a.grad, b.grad, rtol=2e-5, atol=2e-7 * float(b.grad.abs().max())), i

@@ -156,6 +156,9 @@ PROTOTYPES = {
     "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
     "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
+    "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hrp_linear_bwd_weight": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "hrp_rng_advance": [_P, _P],
     "hrp_dropout_f32": [_P, _I, _P, _I, _P, _I, _I, _F, _P, C.c_uint32, _P],
     "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],

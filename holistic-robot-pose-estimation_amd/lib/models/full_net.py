@@ -27,7 +27,8 @@ _HRNETS = ["hrnet", "hrnet32"]
 
 
 class Linear(PlannedModule):
-    """[out, in] weight + bias container (torch.nn.Linear's initialisation); executed as a 1x1 conv on MFMA."""
+    """[out, in] weight + bias container (torch.nn.Linear's initialisation); executed by the skinny fp32 GEMM kernels
+    hrp_linear_* straight from the PyTorch-shaped weight."""
 
     def __init__(self, in_features, out_features):
         super().__init__()
@@ -39,7 +40,9 @@ class Linear(PlannedModule):
         nn.init.uniform_(self.bias, -bound, bound)
 
     def emit(self, pb, x, residual=None):
-        return pb.conv(x, self.weight, self.bias, residual=residual)
+        if os.environ.get("HRP_LINEAR_AS_CONV"):      # round-1 path (A/B measurements): 1x1 conv with fp32 split-K
+            return pb.conv(x, self.weight, self.bias, residual=residual)
+        return pb.linear(x, self.weight, self.bias, residual=residual)
 
 
 class ConvTranspose2d(PlannedModule):

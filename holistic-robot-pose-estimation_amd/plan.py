@@ -357,6 +357,7 @@ class Plan:
         self.merged, self.fwd_run, self.bwd_run = False, [], []
         self._block_lanes = {}     # parallel block id -> stream of each lane (None: virtual block)
         self._rng, self.n_dropout = None, 0
+        self.linear_grad_written = set()
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -1195,6 +1196,43 @@ class PlanBuilder:
         y.producer = ("conv", d)
         if p.need_grad:
             self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu))
+        return y
+
+    def linear(self, x, weight, bias=None, residual=None):
+        """y = x W^T + b (+ residual) on fp32 [N, C] tensors: nn.Linear of the regression heads as a skinny GEMM that reads
+        the PyTorch-shaped weight directly (hrp_linear_*; no packed copy, no split-K memset + conv launch)."""
+        p = self.plan
+        x.check_readable()
+        assert x.dtype == torch.float32 and x.H == 1 and x.W == 1 and weight.dim() == 2 and weight.shape[1] == x.C
+        M, Kf, Nf = x.N, weight.shape[1], weight.shape[0]
+        y = p.new(M, 1, 1, Nf, torch.float32)
+        y.requires_grad = p.need_grad
+        if residual is not None:
+            residual.check_readable()
+        bp = bias.data_ptr() if bias is not None else None
+        p.fwd.append(lambda s: nv.call("hrp_linear_fwd", x.ptr(), x.pitch, weight.data_ptr(), bp,
+                                       residual.ptr() if residual is not None else None, residual.pitch if residual is not None else 0,
+                                       y.ptr(), y.pitch, M, Kf, Nf, s))
+        if p.need_grad:
+            def bw():
+                if not y.grad_written:
+                    return
+                if residual is not None and residual.requires_grad:
+                    acc = residual.take_grad_slot()
+                    p.bwd.append(lambda s: nv.call("hrp_copy_cols", y.gptr(), y.pitch, residual.gptr(), residual.pitch, M, Nf, acc, s))
+                if weight.requires_grad:
+                    gw = p.grad_of_param(weight)
+                    gb = p.grad_of_param(bias) if bias is not None and bias.requires_grad else None
+                    first = id(weight) not in p.linear_grad_written
+                    p.linear_grad_written.add(id(weight))
+                    accw = 1 if (p.grad_arena is not None or not first) else 0
+                    p.bwd.append(lambda s: nv.call("hrp_linear_bwd_weight", x.ptr(), x.pitch, y.gptr(), y.pitch, gw.data_ptr(),
+                                                   gb.data_ptr() if gb is not None else None, M, Kf, Nf, accw, s))
+                if x.requires_grad:
+                    acc = x.take_grad_slot()
+                    p.bwd.append(lambda s: nv.call("hrp_linear_bwd_data", y.gptr(), y.pitch, weight.data_ptr(), x.gptr(), x.pitch,
+                                                   M, Kf, Nf, acc, s))
+            self.bwd_stack.append(bw)
         return y
 
     def _conv_bwd(self, x, w, y, bias, stride, ksize, dtype, residual, relu):

@@ -351,6 +351,19 @@ int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_sca
 /* y (+)= x * m element-wise on [rows, cols] fp32 (dropout masks of the regression heads, full_net.py:98-99) */
 int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,
                 int accumulate, void* stream);
+/* nn.Linear of the regression heads (lib/models/full_net.py:95-100, 129-134 fc_pose_1/2, decpose, fc_rot_1/2, decrot,
+ * called 4 x 6 times per forward by the iterative regressors :318-331, 365-378) and its autograd, fp32, M = batch rows.
+ * w is the PyTorch-shaped parameter [N][K] itself (no packing), bias [N] / res [M, res_pitch] optional.
+ *   fwd:        y[M,N]  = x[M,K] w^T + bias + res
+ *   bwd_data:   dx[M,K] (+)= dy[M,N] w
+ *   bwd_weight: dw[N,K] (+)= dy^T x ;  dbias[N] (+)= column sums of dy (dbias may be NULL) */
+int hrp_linear_fwd(const float* x, int x_pitch, const float* w, const float* bias, const float* res, int res_pitch,
+                   float* y, int y_pitch, int M, int K, int N, void* stream);
+int hrp_linear_bwd_data(const float* dy, int dy_pitch, const float* w, float* dx, int dx_pitch, int M, int K, int N,
+                        int accumulate, void* stream);
+int hrp_linear_bwd_weight(const float* x, int x_pitch, const float* dy, int dy_pitch, float* dw, float* dbias, int M, int K,
+                          int N, int accumulate, void* stream);
+
 /* The training loss of configs/panda/full.yaml (lib/core/function.py:191-322, projections of :119-122) and its gradient
  * with respect to the model's predictions in one launch.  All tensors dense fp32.  weights: pose, rot, uv, depth, trans,
  * kp2d, kp3d, kp2d_int, kp3d_int, align_3d (the *_loss_weight keys of the yaml, :57-66).  out[0..9]: loss_joint, loss_rot,

@@ -360,3 +360,34 @@ def test_fused_pose_loss_matches_tensor_expressions(damped):
             assert a.grad is None or float(a.grad.abs().max()) == 0.0     # uvd does not enter the loss
             continue
         assert torch.allclose(a.grad, b.grad, rtol=2e-5, atol=2e-7 * float(b.grad.abs().max())), i
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 2056, 1024), (64, 1024, 8), (5, 2054, 1024), (130, 1024, 6), (64, 1024, 1024)])
+def test_linear_kernels_match_torch(M, K, N):
+    """hrp_linear_fwd / _bwd_data / _bwd_weight (nn.Linear of the regression heads, full_net.py:95-100) against torch in
+    fp64; padded pitches, residual, accumulate into existing gradients."""
+    from hrpe_amd import _native as nv
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K + 3, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N + 5, generator=g).to(DEV)
+    y = torch.full((M, N + 2), 9.0, device=DEV)
+    nv.call("hrp_linear_fwd", x.data_ptr(), K + 3, w.data_ptr(), b.data_ptr(), res.data_ptr(), N + 5, y.data_ptr(), N + 2, M, K, N, None)
+    want = (x[:, :K].double() @ w.double().t() + b.double() + res[:, :N].double())
+    assert torch.allclose(y[:, :N].double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    assert float((y[:, N:] - 9.0).abs().max()) == 0.0, "columns beyond N are not touched"
+    dy = torch.randn(M, N + 2, generator=g).to(DEV)
+    for acc in (0, 1):
+        dx = torch.full((M, K + 3), 0.5, device=DEV)
+        nv.call("hrp_linear_bwd_data", dy.data_ptr(), N + 2, w.data_ptr(), dx.data_ptr(), K + 3, M, K, N, acc, None)
+        want = dy[:, :N].double() @ w.double() + (0.5 if acc else 0.0)
+        assert torch.allclose(dx[:, :K].double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max())), acc
+        assert float((dx[:, K:] - 0.5).abs().max()) == 0.0
+        dw = torch.full((N, K), 0.25, device=DEV)
+        db = torch.full((N,), 0.25, device=DEV)
+        nv.call("hrp_linear_bwd_weight", x.data_ptr(), K + 3, dy.data_ptr(), N + 2, dw.data_ptr(), db.data_ptr(), M, K, N, acc, None)
+        want_w = dy[:, :N].double().t() @ x[:, :K].double() + (0.25 if acc else 0.0)
+        want_b = dy[:, :N].double().sum(0) + (0.25 if acc else 0.0)
+        assert torch.allclose(dw.double(), want_w, rtol=1e-5, atol=1e-5 * float(want_w.abs().max())), acc
+        assert torch.allclose(db.double(), want_b, rtol=1e-5, atol=1e-5 * float(want_b.abs().max())), acc

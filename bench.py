@@ -628,13 +628,21 @@ def main():
     # which roof binds the family: its arithmetic intensity against the ridge point peak_flops / peak_bytes
     intensity = dom[1][2] / dom[1][3] if dom[1][3] else float("inf")
     hbm_bound = intensity < peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    # measured HBM bytes per launch of the dominant family: the rocprofv3 PMC passes (FETCH_SIZE doubled, WRITE_SIZE; separate
+    # passes over tools/one_step.py, the same network and batch) summarised in profiles/r02_traffic.json; a family = its
+    # single-problem and its batched kernels together
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    fam_kernel = {"hrp_conv2d_fwd": "conv_tile_kernel", "hrp_conv2d_bwd_weight": "conv_wgrad_kernel", "hrp_ew_fwd": "ew_fwd_kernel",
-                  "hrp_ew_bwd_reduce": "ew_bwd_reduce_kernel", "hrp_ew_bwd_apply": "ew_bwd_apply_kernel"}.get(dom[0])
-    if os.path.exists(tpath) and fam_kernel and B == 64 and a.dtype == "bf16":
-        with open(tpath) as fh:   # PMC passes (FETCH_SIZE x2, WRITE_SIZE) of the same workload, see the file's header
-            traffic = json.load(fh)["families"].get(fam_kernel, {}).get("hbm_bytes_per_launch")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel"),
+                   "hrp_conv2d_bwd_weight": ("conv_wgrad_kernel", "wgrad_batch_kernel", "wgrad_reduce_kernel", "wgrad_reduce_batch_kernel"),
+                   "hrp_ew_fwd": ("ew_fwd_kernel", "ew_fwd_batch_kernel"),
+                   "hrp_ew_bwd_reduce": ("ew_bwd_reduce_kernel",), "hrp_ew_bwd_apply": ("ew_bwd_apply_kernel",)}.get(dom[0])
+    if os.path.exists(tpath) and fam_kernels and B == 64 and a.dtype == "bf16" and not hrnet and not fwd_only:
+        with open(tpath) as fh:
+            fams = json.load(fh)["families"]
+        by = sum(fams.get(k, {}).get("hbm_bytes_per_step", 0.0) for k in fam_kernels)
+        if by > 0:
+            traffic = by / dom[1][0]      # per launch of the family as bench.py counts launches
     roofline = {"kernel": dom[0], "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb if hbm_bound else ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",

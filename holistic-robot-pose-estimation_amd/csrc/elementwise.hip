@@ -654,7 +654,9 @@ static int ew_fwd_batch_prepare(const hrp_ew_desc* descs, int n, EwProblem* tab,
     bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
     sum += bytes[i];
   }
-  static const int total = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 2048;
+  // (block budgets swept 256 .. 8192 on the B=64 step: 768 / 384 is the minimum - 43.1 ms at 2048 / 1024, 41.0-41.8 here;
+  // issuing the first trip's loads before the channel-constant phase was measured 0.5 ms slower)
+  static const int total = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 768;
   int blk = 0, lds_max = 0;
   for (int i = 0; i < n; ++i) {
     const hrp_ew_desc& d = descs[i];
@@ -691,8 +693,8 @@ static int ew_bwd_batch_prepare(const hrp_ew_bwd_desc* descs, int n, EwBwdProble
     bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
     sum += bytes[i];
   }
-  static const int total_apply = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 2048;
-  static const int total_red = getenv("HRP_EW_BATCH_RED_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_RED_BLOCKS")) : 1024;
+  static const int total_apply = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 768;
+  static const int total_red = getenv("HRP_EW_BATCH_RED_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_RED_BLOCKS")) : 384;
   int blk = 0, lds_max = 0;
   for (int i = 0; i < n; ++i) {
     const hrp_ew_bwd_desc& d = descs[i];

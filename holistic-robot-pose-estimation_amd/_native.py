@@ -42,7 +42,15 @@ class WgradDesc(C.Structure):
                 ("in_stride", C.c_int32), ("ntaps", C.c_int32),
                 ("dy_t", C.c_int32 * MAX_TAPS), ("dx_t", C.c_int32 * MAX_TAPS),
                 ("dw_cin", C.c_int32), ("dw_tap_stride", C.c_int32), ("dw_tap_off", C.c_int32), ("accumulate", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("phase", C.c_int32), ("reserved", C.c_int32)]
+
+
+class WgradFoldDesc(C.Structure):
+    _fields_ = [("workspace", C.c_void_p), ("dw", C.c_void_p),
+                ("G", C.c_int32), ("pairs", C.c_int32), ("n_cib", C.c_int32), ("nte", C.c_int32), ("nb", C.c_int32),
+                ("Cout", C.c_int32), ("dw_cin", C.c_int32), ("ntaps", C.c_int32), ("dw_tap_stride", C.c_int32),
+                ("dw_tap_off", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PackEntry(C.Structure):
@@ -81,7 +89,7 @@ class BnEntry(C.Structure):
 
 # batched launches (include/hrp.h hrp_batch_*)
 BATCH_MAX = 32
-BATCH_CONV, BATCH_WGRAD, BATCH_EW_FWD, BATCH_EW_BWD_REDUCE, BATCH_EW_BWD_APPLY = range(5)
+BATCH_CONV, BATCH_WGRAD, BATCH_EW_FWD, BATCH_EW_BWD_REDUCE, BATCH_EW_BWD_APPLY, BATCH_WGRAD_FOLD = range(6)
 
 
 class BatchInfo(C.Structure):
@@ -155,6 +163,8 @@ PROTOTYPES = {
     "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
     "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
     "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],
+    "hrp_wgrad_fold_desc_of": [C.POINTER(WgradDesc), C.POINTER(WgradFoldDesc)],
+    "hrp_batch_wgrad_fold_descs": [_P, C.POINTER(BatchInfo), C.POINTER(WgradFoldDesc)],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -259,5 +269,5 @@ def call_batch(batch, stream):
     fn()
 
 
-FAMILY_FN = {"conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
+FAMILY_FN = {"conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
              "ew_app": "hrp_ew_bwd_apply"}

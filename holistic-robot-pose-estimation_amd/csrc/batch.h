@@ -43,6 +43,9 @@ int conv_check(const hrp_conv_desc* d);
 int wgrad_batch_prepare(const hrp_wgrad_desc* descs, int n, void* table, hrp_batch_info* info);
 int wgrad_batch_launch(const void* table_dev, const hrp_batch_info* info, hipStream_t s);
 int64_t wgrad_batch_table_bytes(int n);
+int wgrad_fold_prepare(const hrp_wgrad_fold_desc* descs, int n, void* table, hrp_batch_info* info);
+int wgrad_fold_launch(const void* table_dev, const hrp_batch_info* info, hipStream_t s);
+int64_t wgrad_fold_table_bytes(int n);
 
 int ew_batch_prepare(int family, const void* descs, int n, void* table, hrp_batch_info* info);
 int ew_batch_launch(const void* table_dev, const hrp_batch_info* info, hipStream_t s);

@@ -9,6 +9,7 @@ extern "C" int64_t hrp_batch_table_bytes(int family, int n) {
   switch (family) {
     case HRP_BATCH_CONV: return conv_batch_table_bytes(n);
     case HRP_BATCH_WGRAD: return wgrad_batch_table_bytes(n);
+    case HRP_BATCH_WGRAD_FOLD: return wgrad_fold_table_bytes(n);
     case HRP_BATCH_EW_FWD: case HRP_BATCH_EW_BWD_REDUCE: case HRP_BATCH_EW_BWD_APPLY: return ew_batch_table_bytes(family, n);
     default: return 0;
   }
@@ -30,6 +31,9 @@ extern "C" int hrp_batch_prepare(int family, const void* descs, int n, void* tab
     case HRP_BATCH_WGRAD:
       info->dtype = ((const hrp_wgrad_desc*)descs)[0].dtype;
       return wgrad_batch_prepare((const hrp_wgrad_desc*)descs, n, table_host, info);
+    case HRP_BATCH_WGRAD_FOLD:
+      HRP_REQUIRE(table_host, "wgrad fold: table_host is required");
+      return wgrad_fold_prepare((const hrp_wgrad_fold_desc*)descs, n, table_host, info);
     case HRP_BATCH_EW_FWD: case HRP_BATCH_EW_BWD_REDUCE: case HRP_BATCH_EW_BWD_APPLY:
       HRP_REQUIRE(table_host, "ew batch: table_host is required");
       return ew_batch_prepare(family, descs, n, table_host, info);
@@ -45,6 +49,7 @@ extern "C" int hrp_batch_launch(const void* table_dev, const hrp_batch_info* inf
   switch (info->family) {
     case HRP_BATCH_CONV: return info->dtype == HRP_F32 ? conv_batch_launch_f32(table_dev, info, s) : conv_batch_launch_bf16(table_dev, info, s);
     case HRP_BATCH_WGRAD: return wgrad_batch_launch(table_dev, info, s);
+    case HRP_BATCH_WGRAD_FOLD: return wgrad_fold_launch(table_dev, info, s);
     case HRP_BATCH_EW_FWD: case HRP_BATCH_EW_BWD_REDUCE: case HRP_BATCH_EW_BWD_APPLY: return ew_batch_launch(table_dev, info, s);
     default:
       set_error("batch launch: unknown family %d", info->family);

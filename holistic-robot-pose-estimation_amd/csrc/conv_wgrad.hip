@@ -407,44 +407,61 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   conv_wgrad_body<T, NT, NKS, NB>(d, t, blockIdx.x, blockIdx.y);
 }
 
-// dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci].  bx: which 64 consecutive elements of the pair's NTE * 1024.
-__device__ __forceinline__ void wgrad_reduce_body(const hrp_wgrad_desc& d, const int G, const int pairs, const int n_cib,
-                                                  const int NTE, const int NB, const int bx, const int blk) {
-  const int cob = blk / n_cib, cib = blk - cob * n_cib;
-  const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
-  // block = 64 consecutive elements x 4 slab phases; lanes read 256 contiguous bytes of a slab, 8 loads
-  // in flight per thread
-  __shared__ float part[4][64];
-  const float* ws = (const float*)d.workspace + (size_t)blk * (NTE * 1024);
-  const size_t gstride = (size_t)pairs * (NTE * 1024);
+// dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci].  bx: which 256 consecutive elements of the pair's NTE * 1024.
+constexpr int FOLD_ELEMS = 256;   // per block: 64 lanes x float4, the 4 waves take every fourth slab
+__device__ __forceinline__ void wgrad_fold_body(const hrp_wgrad_fold_desc& f, const int bx, const int blk) {
+  const int G = f.G, NTE = f.nte, NB = f.nb;
+  const int cob = blk / f.n_cib, cib = blk - cob * f.n_cib;
+  const int tstride = f.dw_tap_stride > 0 ? f.dw_tap_stride : f.ntaps;
+  __shared__ float4 part[4][64];
+  const float* ws = f.workspace + (size_t)blk * (NTE * 1024);
+  const size_t gstride = (size_t)f.pairs * (NTE * 1024);
   const int e = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int i = bx * 64 + e;
-  float s = 0.f;
+  const int i = bx * FOLD_ELEMS + 4 * e;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   int g = ph;
-  for (; g + 28 < G; g += 32) {
-    float v[8];
+  for (; g + 28 < G; g += 32) {   // 8 slabs in flight per thread
+    float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + 4 * u) * gstride + i];
+    for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(ws + (size_t)(g + 4 * u) * gstride + i);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
   }
-  for (; g < G; g += 4) s += ws[(size_t)g * gstride + i];
+  for (; g < G; g += 4) {
+    const float4 v = *(const float4*)(ws + (size_t)g * gstride + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
   part[ph][e] = s;
   __syncthreads();
-  if (ph == 0) {
-    s = part[0][e] + part[1][e] + part[2][e] + part[3][e];
-    const int ci = i & 31, row = (i >> 5) & 31, tp = i >> 10;
+  // thread (ph, e) finishes element 4 e + ph: the four phases' partial sums in slab order
+  {
+    const float* p0 = (const float*)&part[0][e];
+    const float* p1 = (const float*)&part[1][e];
+    const float* p2 = (const float*)&part[2][e];
+    const float* p3 = (const float*)&part[3][e];
+    const float r = p0[ph] + p1[ph] + p2[ph] + p3[ph];
+    const int ii = i + ph;
+    const int ci = ii & 31, row = (ii >> 5) & 31, tp = ii >> 10;
     const int tap = tp / (NB * NB), cbk = (tp % (NB * NB)) / NB, ibk = tp % NB;
     const int co = (cob * NB + cbk) * 32 + row, cin = (cib * NB + ibk) * 32 + ci;
-    if (co < d.Cout && cin < d.dw_cin) {
-      float* o = &d.dw[((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tap];
-      *o = d.accumulate ? *o + s : s;
+    if (co < f.Cout && cin < f.dw_cin) {
+      float* o = &f.dw[((size_t)co * f.dw_cin + cin) * tstride + f.dw_tap_off + tap];
+      *o = f.accumulate ? *o + r : r;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_desc d, int G, int pairs, int n_cib, int NTE, int NB) {
-  wgrad_reduce_body(d, G, pairs, n_cib, NTE, NB, blockIdx.x, blockIdx.y);
+static inline hrp_wgrad_fold_desc make_fold_desc(const hrp_wgrad_desc& d, int G, int pairs, int n_cib, int NTE, int NB) {
+  hrp_wgrad_fold_desc f{};
+  f.workspace = (const float*)d.workspace; f.dw = d.dw;
+  f.G = G; f.pairs = pairs; f.n_cib = n_cib; f.nte = NTE; f.nb = NB;
+  f.Cout = d.Cout; f.dw_cin = d.dw_cin; f.ntaps = d.ntaps; f.dw_tap_stride = d.dw_tap_stride; f.dw_tap_off = d.dw_tap_off;
+  f.accumulate = d.accumulate;
+  return f;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const hrp_wgrad_fold_desc f) {
+  wgrad_fold_body(f, blockIdx.x, blockIdx.y);
 }
 
 // wg_total: workgroups this problem may use (0: the single-launch default, about one per CU)
@@ -571,8 +588,8 @@ static int launch_wgrad_nb(const hrp_wgrad_desc& d, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3(t.G, pairs), dim3(256), t.lds_bytes, s, d, t);
   rc = check_launch("conv_wgrad_kernel");
-  if (rc != HRP_OK || !t.use_ws) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NTE * 1024 / 64, pairs), dim3(256), 0, s, d, t.G, pairs, t.n_cib, NTE, NB);
+  if (rc != HRP_OK || !t.use_ws || d.phase == 1) return rc;   // phase 1: the caller folds the slabs later
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NTE * 1024 / FOLD_ELEMS, pairs), dim3(256), 0, s, make_fold_desc(d, t.G, pairs, t.n_cib, NTE, NB));
   return check_launch("wgrad_reduce_kernel");
 }
 template <typename T, int NT>
@@ -593,7 +610,7 @@ struct WgradProblem {
   hrp_wgrad_desc d;
   WgradTiling t;
   int nks, nb, nte, pairs;
-  FastDiv fd_r;   // division by nte * 16 (blocks per pair of the folding launch)
+  FastDiv fd_r;   // division by nte * 4 (blocks per pair of the folding launch)
 };
 
 template <typename T, int NT>
@@ -630,8 +647,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProb
   const WgradProblem& P = tab[g];
   const int local = (int)blockIdx.x - base;
   const int blk = fdiv(local, P.fd_r);
-  const int bx = local - blk * (P.nte * 16);
-  wgrad_reduce_body(P.d, P.t.G, P.pairs, P.t.n_cib, P.nte, P.nb, bx, blk);
+  const int bx = local - blk * (P.nte * 4);
+  hrp_wgrad_fold_desc f;
+  f.workspace = (const float*)P.d.workspace; f.dw = P.d.dw;
+  f.G = P.t.G; f.pairs = P.pairs; f.n_cib = P.t.n_cib; f.nte = P.nte; f.nb = P.nb;
+  f.Cout = P.d.Cout; f.dw_cin = P.d.dw_cin; f.ntaps = P.d.ntaps; f.dw_tap_stride = P.d.dw_tap_stride; f.dw_tap_off = P.d.dw_tap_off;
+  f.accumulate = P.d.accumulate;
+  wgrad_fold_body(f, bx, blk);
+}
+
+// ---- the deferred fold of up to HRP_BATCH_MAX phase-1 problems in one launch (any tap counts / element types) ----
+struct FoldProblem {
+  hrp_wgrad_fold_desc f;
+  FastDiv fd_r;   // division by nte * 4
+  int pad[2];
+};
+
+__global__ __launch_bounds__(256) void wgrad_fold_batch_kernel(const FoldProblem* __restrict__ tab, const BatchHdr h) {
+  int base;
+  const int g = batch_find(h, blockIdx.x, base);
+  const FoldProblem& P = tab[g];
+  const int local = (int)blockIdx.x - base;
+  const int blk = fdiv(local, P.fd_r);
+  const int bx = local - blk * (P.f.nte * 4);
+  wgrad_fold_body(P.f, bx, blk);
 }
 
 static int wgrad_check(const hrp_wgrad_desc* d) {
@@ -665,7 +704,7 @@ static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget) 
   P.nks = Elem<T>::SZ == 2 ? P.t.BM / 64 : 0;
   P.nte = NT * P.nb * P.nb;
   P.pairs = P.t.n_cob * P.t.n_cib;
-  P.fd_r = make_fastdiv(P.nte * 16);
+  P.fd_r = make_fastdiv(P.nte * 4);
   return HRP_OK;
 }
 
@@ -702,11 +741,12 @@ static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProbl
     info->blk0[i] = blk;
     blk += P.t.G * P.pairs;
     info->blk2[i] = blk2;
-    blk2 += P.nte * 16 * P.pairs;
+    blk2 += P.nte * 4 * P.pairs;
     if (tab) tab[i] = P;
   }
   info->blk0[n] = blk; info->blk2[n] = blk2;
-  info->grid = blk; info->grid2 = blk2;
+  // phase 1 (all problems or none): the caller folds the slabs with a HRP_BATCH_WGRAD_FOLD launch of its own
+  info->grid = blk; info->grid2 = descs[0].phase == 1 ? 0 : blk2;
   info->lds_bytes = lds_max;
   info->variant = NT;
   return HRP_OK;
@@ -727,6 +767,7 @@ int wgrad_batch_prepare(const hrp_wgrad_desc* descs, int n, void* table, hrp_bat
     const int rc = wgrad_check(&descs[i]);
     if (rc != HRP_OK) return rc;
     HRP_REQUIRE(descs[i].ntaps == descs[0].ntaps && descs[i].dtype == descs[0].dtype, "wgrad batch: mixed tap counts / element types");
+    HRP_REQUIRE(descs[i].phase == descs[0].phase, "wgrad batch: mixed phases");
   }
   if (descs[0].dtype == HRP_F32) return wgrad_batch_prepare_t<float>(descs, n, table, info);
   return wgrad_batch_prepare_t<bf16_t>(descs, n, table, info);
@@ -741,7 +782,7 @@ static int wgrad_batch_launch_nt(const WgradProblem* tab, const hrp_batch_info* 
   }
   hipLaunchKernelGGL((wgrad_batch_kernel<T, NT>), dim3(info->grid), dim3(256), info->lds_bytes, s, tab, make_hdr(info->blk0, info->n));
   int rc = check_launch("wgrad_batch_kernel");
-  if (rc != HRP_OK) return rc;
+  if (rc != HRP_OK || info->grid2 == 0) return rc;
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(info->grid2), dim3(256), 0, s, tab, make_hdr(info->blk2, info->n));
   return check_launch("wgrad_reduce_batch_kernel");
 }
@@ -767,7 +808,79 @@ int wgrad_batch_launch(const void* table_dev, const hrp_batch_info* info, hipStr
 
 int64_t wgrad_batch_table_bytes(int n) { return (int64_t)n * sizeof(WgradProblem); }
 
+// ---- deferred folds ---------------------------------------------------------------------------------------------
+int64_t wgrad_fold_table_bytes(int n) { return (int64_t)n * sizeof(FoldProblem); }
+
+int wgrad_fold_prepare(const hrp_wgrad_fold_desc* descs, int n, void* table, hrp_batch_info* info) {
+  FoldProblem* tab = (FoldProblem*)table;
+  int blk = 0;
+  for (int i = 0; i < n; ++i) {
+    const hrp_wgrad_fold_desc& f = descs[i];
+    HRP_REQUIRE(f.workspace && f.dw && f.G >= 1 && f.pairs >= 1 && f.n_cib >= 1 && f.pairs % f.n_cib == 0, "wgrad fold: problem %d: bad descriptor", i);
+    HRP_REQUIRE((f.nb == 1 || f.nb == 2) && f.nte >= 1 && f.nte % (f.nb * f.nb) == 0 && f.nte / (f.nb * f.nb) == f.ntaps, "wgrad fold: problem %d: tile elements", i);
+    HRP_REQUIRE(f.dw_tap_stride == 0 || (f.dw_tap_off >= 0 && f.dw_tap_off + f.ntaps <= f.dw_tap_stride), "wgrad fold: tap group");
+    info->blk0[i] = blk;
+    blk += f.nte * 4 * f.pairs;
+    if (tab) {
+      memset(&tab[i], 0, sizeof(FoldProblem));
+      tab[i].f = f;
+      tab[i].fd_r = make_fastdiv(f.nte * 4);
+    }
+  }
+  info->blk0[n] = blk;
+  info->grid = blk; info->grid2 = 0; info->lds_bytes = 0; info->variant = 0; info->dtype = HRP_F32;
+  return HRP_OK;
+}
+
+int wgrad_fold_launch(const void* table_dev, const hrp_batch_info* info, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_fold_batch_kernel, dim3(info->grid), dim3(256), 0, s, (const FoldProblem*)table_dev, make_hdr(info->blk0, info->n));
+  return check_launch("wgrad_fold_batch_kernel");
+}
+
+template <typename T, int NT, int NB>
+static int fold_desc_nb(const hrp_wgrad_desc& d, hrp_wgrad_fold_desc* out) {
+  WgradTiling t{};
+  const int rc = wgrad_tiling<T, NT, NB>(d, t);
+  if (rc != HRP_OK) return rc;
+  const int pairs = t.n_cob * t.n_cib;
+  const int64_t need = (int64_t)t.G * pairs * (NT * NB * NB) * 1024 * 4;
+  const bool use_ws = d.workspace && d.workspace_bytes >= need;   // (as launch_wgrad_nb decides)
+  *out = make_fold_desc(d, use_ws ? t.G : 0, pairs, t.n_cib, NT * NB * NB, NB);
+  return HRP_OK;
+}
+template <typename T, int NT>
+static int fold_desc_t(const hrp_wgrad_desc& d, hrp_wgrad_fold_desc* out) {
+  if constexpr (can_nb2<T, NT>()) {
+    if (want_nb2(d)) return fold_desc_nb<T, NT, 2>(d, out);
+  }
+  return fold_desc_nb<T, NT, 1>(d, out);
+}
+
 }  // namespace hrp
+
+extern "C" int hrp_wgrad_fold_desc_of(const hrp_wgrad_desc* d, hrp_wgrad_fold_desc* out) {
+  using namespace hrp;
+  HRP_REQUIRE(out, "wgrad fold: null pointer");
+  const int crc = wgrad_check(d);
+  if (crc != HRP_OK) return crc;
+  if (d->dtype == HRP_F32) {
+    if (d->ntaps == 1) return fold_desc_t<float, 1>(*d, out);
+    if (d->ntaps == 4) return fold_desc_t<float, 4>(*d, out);
+    return fold_desc_t<float, 9>(*d, out);
+  }
+  if (d->ntaps == 1) return fold_desc_t<bf16_t, 1>(*d, out);
+  if (d->ntaps == 4) return fold_desc_t<bf16_t, 4>(*d, out);
+  return fold_desc_t<bf16_t, 9>(*d, out);
+}
+
+extern "C" int hrp_batch_wgrad_fold_descs(const void* table_host, const hrp_batch_info* info, hrp_wgrad_fold_desc* out) {
+  using namespace hrp;
+  HRP_REQUIRE(table_host && info && out && info->family == HRP_BATCH_WGRAD, "wgrad fold: needs a prepared HRP_BATCH_WGRAD table");
+  const WgradProblem* tab = (const WgradProblem*)table_host;
+  for (int i = 0; i < info->n; ++i)
+    out[i] = make_fold_desc(tab[i].d, tab[i].t.G, tab[i].pairs, tab[i].t.n_cib, tab[i].nte, tab[i].nb);
+  return HRP_OK;
+}
 
 extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
   using namespace hrp;

@@ -130,6 +130,11 @@ MAX_LANE_DEPTH = int(os.environ.get("HRP_LANE_DEPTH", "1"))
 # "hybrid": parallel blocks that asked for streams keep them (one per trunk), the virtual blocks inside each stream are
 # merged - two chains of batched launches whose ramp-up / tail phases overlap.
 PLAN_MODE = os.environ.get("HRP_PLAN_MODE", "hybrid")
+# merged / hybrid: weight-gradient launches write their partial slabs only (descriptor phase 1); the slabs of up to 32
+# layers are folded into the gradients by ONE launch at the end of their lane (or every WGRAD_FOLD_EVERY problems)
+# instead of a 6-10 us launch behind every weight-gradient launch (~660 per step of the benchmark network)
+WGRAD_DEFER = not os.environ.get("HRP_NO_WGRAD_DEFER")
+WGRAD_FOLD_EVERY = int(os.environ.get("HRP_WGRAD_FOLD_EVERY", "32"))
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
 # development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
 BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
@@ -162,7 +167,8 @@ FAMILIES = {"conv": (nv.BATCH_CONV, "hrp_conv2d_fwd", nv.ConvDesc),
             "wgrad": (nv.BATCH_WGRAD, "hrp_conv2d_bwd_weight", nv.WgradDesc),
             "ew_fwd": (nv.BATCH_EW_FWD, "hrp_ew_fwd", nv.EwDesc),
             "ew_red": (nv.BATCH_EW_BWD_REDUCE, "hrp_ew_bwd_reduce", nv.EwBwdDesc),
-            "ew_app": (nv.BATCH_EW_BWD_APPLY, "hrp_ew_bwd_apply", nv.EwBwdDesc)}
+            "ew_app": (nv.BATCH_EW_BWD_APPLY, "hrp_ew_bwd_apply", nv.EwBwdDesc),
+            "wgrad_fold": (nv.BATCH_WGRAD_FOLD, None, nv.WgradFoldDesc)}
 
 
 class Launch:
@@ -178,6 +184,15 @@ class Launch:
     def launches(self):
         return [self]
 
+    def fold_desc(self):
+        """Phase-1 weight gradient launched on its own: the fold descriptor of the tiling the launcher will choose."""
+        f = nv.WgradFoldDesc()
+        nv.check(nv.lib().hrp_wgrad_fold_desc_of(C.byref(self.desc), C.byref(f)), "hrp_wgrad_fold_desc_of")
+        return f
+
+    def fold_descs(self):
+        return [self.fold_desc()]
+
     def merge_key(self):
         """Launches with equal keys may share a batched launch; None: always alone."""
         d = self.desc
@@ -189,7 +204,7 @@ class Launch:
                 return None
             return ("conv", d.dtype, d.ntaps)
         if self.fam == "wgrad":
-            return ("wgrad", d.dtype, d.ntaps)
+            return ("wgrad", d.dtype, d.ntaps, d.reserved)
         if d.C % (16 // esz):
             return None
         return (self.fam, d.dtype)
@@ -199,7 +214,7 @@ class Launch:
         d = self.desc
         if self.fam == "conv":
             return (d.y + ((d.out_off_y * d.y_W + d.out_off_x) * d.y_pitch if d.out_stride > 1 else 0),)
-        if self.fam == "wgrad":
+        if self.fam in ("wgrad", "wgrad_fold"):
             return (d.dw + 4 * d.dw_tap_off,)
         if self.fam == "ew_fwd":
             return (d.out,)
@@ -214,7 +229,7 @@ class BatchLaunch:
     def __init__(self, plan, items):
         self.plan, self.items = plan, list(items)
         self.fam = items[0].fam
-        self.info, self.table, self.singles = None, None, False
+        self.info, self.table, self.singles, self.folds = None, None, False, None
 
     def launches(self):
         return self.items
@@ -240,14 +255,26 @@ class BatchLaunch:
         try:
             nv.check(nv.lib().hrp_batch_prepare(famid, arr, n, host, C.byref(info)), "hrp_batch_prepare")
         except nv.HrpError:
+            if self.fam == "wgrad_fold":
+                raise
             if os.environ.get("HRP_PLAN_STATS"):
                 import sys
                 print(f"plan: batch of {n} {self.fam} launches runs one by one ({nv.lib().hrp_last_error().decode()})", file=sys.stderr)
             self.singles = True      # not batchable after all (scalar path, tile does not fit ..): one by one
             return
         self.info = info
+        if self.fam == "wgrad" and self.items[0].desc.phase == 1:
+            folds = (nv.WgradFoldDesc * n)()
+            nv.check(nv.lib().hrp_batch_wgrad_fold_descs(host, C.byref(info), folds), "hrp_batch_wgrad_fold_descs")
+            self.folds = list(folds)
         self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.plan.device)
         self.plan.keep.append(self.table)
+
+    def fold_descs(self):
+        """Phase-1 weight gradients: the fold descriptors of the problems (after prepare)."""
+        if not self.singles:
+            return self.folds
+        return [it.fold_desc() for it in self.items]
 
     def __call__(self, s):
         if self.singles:
@@ -483,31 +510,64 @@ class Plan:
             self.fwd_run, self.bwd_run = self._flatten(self.fwd), self._flatten(self.bwd)
             ops = [e.op for e in self.fwd_run + self.bwd_run if e.lane is not None]
             batches = [op for op in ops if isinstance(op, BatchLaunch)]
-            # weight-gradient scratch: one buffer per stream, every launch of that stream uses it in turn
-            need = {}
-            for e in self.fwd_run + self.bwd_run:
-                op = e.op
-                if isinstance(op, BatchLaunch) and op.fam == "wgrad":
-                    op.ws = op.ws_query()
-                    need[e.lane] = max(need.get(e.lane, 0), sum(_rup(b, 256) for b in op.ws))
-                elif isinstance(op, Launch) and op.fam == "wgrad":
-                    need[e.lane] = max(need.get(e.lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(op.desc))))
-            self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev) for lane, nb in need.items()}
-            for e in self.fwd_run + self.bwd_run:
-                op = e.op
-                if isinstance(op, BatchLaunch) and op.fam == "wgrad":   # problems of one launch run concurrently: disjoint regions
-                    off = 0
-                    for it, b in zip(op.items, op.ws):
-                        it.desc.workspace, it.desc.workspace_bytes = self.wgrad_ws[e.lane].data_ptr() + off, b
-                        off += _rup(b, 256)
-                elif isinstance(op, Launch) and op.fam == "wgrad":
-                    op.desc.workspace, op.desc.workspace_bytes = self.wgrad_ws[e.lane].data_ptr(), self.wgrad_ws[e.lane].numel() * 4
-            for op in batches:
-                op.prepare()
-                if op.fam == "wgrad" and op.singles:
-                    lane = next(e.lane for e in self.fwd_run + self.bwd_run if e.op is op)
-                    for it in op.items:
-                        it.desc.workspace, it.desc.workspace_bytes = self.wgrad_ws[lane].data_ptr(), self.wgrad_ws[lane].numel() * 4
+            wg_ops = [e for e in self.bwd_run if isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad"]
+            defer = WGRAD_DEFER and bool(wg_ops)
+            # (descriptor.reserved == 1: a gradient some later launch of the list reads - folded on the spot)
+            now = {id(e.op) for e in wg_ops if any(it.desc.reserved for it in e.op.launches())}
+            if defer:
+                # deferred folds: every launch keeps its slabs until its lane folds them, so every problem gets its own
+                # scratch region (one bump allocation over the whole backward: ~4 GB for the benchmark network at B=64)
+                total, ws_off = 0, {}
+                for e in wg_ops:
+                    op = e.op
+                    for it in op.launches():
+                        it.desc.phase = 0 if id(op) in now else 1
+                    if isinstance(op, BatchLaunch):
+                        op.ws = op.ws_query()
+                    else:
+                        op_need = int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(op.desc)))
+                        op.desc.workspace_bytes = op_need
+                    sizes = op.ws if isinstance(op, BatchLaunch) else [op.desc.workspace_bytes]
+                    # (a batch that falls back to single launches: each item then wants its single-launch size)
+                    singles = [int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(it.desc))) for it in op.launches()]
+                    ws_off[id(op)] = []
+                    for b, b1 in zip(sizes, singles):
+                        ws_off[id(op)].append((total, max(b, b1)))
+                        total += _rup(max(b, b1), 256)
+                self.wgrad_ws = {0: torch.zeros(max(total // 4, 4), dtype=torch.float32, device=dev)}
+                base = self.wgrad_ws[0].data_ptr()
+                for e in wg_ops:
+                    for it, (off, b) in zip(e.op.launches(), ws_off[id(e.op)]):
+                        it.desc.workspace, it.desc.workspace_bytes = (base + off, b) if b else (None, 0)
+                for op in batches:
+                    op.prepare()
+                self.bwd_run = self._insert_folds(self.bwd_run)
+            else:
+                # weight-gradient scratch: one buffer per stream, every launch of that stream uses it in turn
+                need = {}
+                for e in self.fwd_run + self.bwd_run:
+                    op = e.op
+                    if isinstance(op, BatchLaunch) and op.fam == "wgrad":
+                        op.ws = op.ws_query()
+                        need[e.lane] = max(need.get(e.lane, 0), sum(_rup(b, 256) for b in op.ws))
+                    elif isinstance(op, Launch) and op.fam == "wgrad":
+                        need[e.lane] = max(need.get(e.lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(op.desc))))
+                self.wgrad_ws = {lane: torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=dev) for lane, nb in need.items()}
+                for e in self.fwd_run + self.bwd_run:
+                    op = e.op
+                    if isinstance(op, BatchLaunch) and op.fam == "wgrad":   # problems of one launch run concurrently: disjoint regions
+                        off = 0
+                        for it, b in zip(op.items, op.ws):
+                            it.desc.workspace, it.desc.workspace_bytes = self.wgrad_ws[e.lane].data_ptr() + off, b
+                            off += _rup(b, 256)
+                    elif isinstance(op, Launch) and op.fam == "wgrad":
+                        op.desc.workspace, op.desc.workspace_bytes = self.wgrad_ws[e.lane].data_ptr(), self.wgrad_ws[e.lane].numel() * 4
+                for op in batches:
+                    op.prepare()
+                    if op.fam == "wgrad" and op.singles:
+                        lane = next(e.lane for e in self.fwd_run + self.bwd_run if e.op is op)
+                        for it in op.items:
+                            it.desc.workspace, it.desc.workspace_bytes = self.wgrad_ws[lane].data_ptr(), self.wgrad_ws[lane].numel() * 4
             used = {e.lane for e in self.fwd_run + self.bwd_run if e.lane is not None}
             self._side_streams = [torch.cuda.Stream(device=dev) if (i + 1) in used else None for i in range(self.n_lanes - 1)]
         else:
@@ -591,6 +651,34 @@ class Plan:
                         out += [Entry(lane, (), op) for op in lockstep([[e.op for e in x] for x in kids])]
             return out
         return walk(root, 0)
+
+    def _insert_folds(self, entries):
+        """Deferred weight-gradient folds: after every WGRAD_FOLD_EVERY phase-1 problems of a lane, before the lane
+        joins its parent and at the end of the list, one HRP_BATCH_WGRAD_FOLD launch folds the lane's pending slabs."""
+        out, pending = [], {}
+
+        def flush(lane, path, everything=True):
+            descs = pending.pop(lane, [])
+            while descs and (everything or len(descs) >= nv.BATCH_MAX):
+                b = BatchLaunch(self, [Launch("wgrad_fold", f) for f in descs[:nv.BATCH_MAX]])
+                b.prepare()
+                out.append(Entry(lane, path, b))
+                descs = descs[nv.BATCH_MAX:]
+            if descs:
+                pending[lane] = descs
+
+        for e in entries:
+            if e.lane is None and getattr(e.op, "kind", None) == "join":
+                for c in e.op.children:
+                    flush(c, e.path)
+            out.append(e)
+            if e.lane is not None and isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1:
+                pending.setdefault(e.lane, []).extend(f for f in e.op.fold_descs() if f.G > 0)
+                if len(pending[e.lane]) >= max(WGRAD_FOLD_EVERY, nv.BATCH_MAX):
+                    flush(e.lane, e.path, everything=False)
+        for lane in sorted(pending):
+            flush(lane, ())
+        return out
 
     def _late_pack_cut(self):
         """Index in self.fwd right after the first parallel block (the join back into the main lane), or None when the
@@ -993,6 +1081,7 @@ class PlanBuilder:
                     for i in range(4):
                         g.dy_t[i], g.dx_t[i] = taps[4 * grp + i]
                     g.dw_cin, g.dw_tap_stride, g.dw_tap_off, g.accumulate = xs.C, 16, 4 * grp, 0
+                    g.reserved = 1    # (plan-side mark: the gather below reads gw12 right away - never a deferred fold)
                     p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
                     p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
                     p.bwd.append(Launch("wgrad", g))

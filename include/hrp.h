@@ -113,7 +113,23 @@ typedef struct hrp_wgrad_desc {
   void* workspace;     /* optional scratch of hrp_wgrad_workspace_bytes(): partial sums are written there
                           and reduced by a second launch instead of fp32 atomics into dw */
   int64_t workspace_bytes;
+  int32_t phase;       /* 0: the whole gradient.  1 (needs the workspace): partial sums only - the caller folds them
+                          later with a HRP_BATCH_WGRAD_FOLD launch (the workspace must stay untouched until then) */
+  int32_t reserved;
 } hrp_wgrad_desc;
+
+/* The deferred second half of a weight gradient (phase 1 above): dw (+)= sum over the G partial slabs.  Filled by
+ * hrp_wgrad_fold_desc_of (single launches) / hrp_batch_wgrad_fold_descs (batched launches); G == 0: nothing to fold
+ * (the launch took the atomics path).  One HRP_BATCH_WGRAD_FOLD launch folds up to HRP_BATCH_MAX problems of ANY tap
+ * count / element type: a training step folds all its ~600 weight gradients in ~20 launches at the end of the lanes
+ * instead of one 6-10 us launch behind every weight-gradient launch. */
+typedef struct hrp_wgrad_fold_desc {
+  const float* workspace;  /* [G][pairs][nte * 1024] */
+  float* dw;
+  int32_t G, pairs, n_cib, nte, nb;
+  int32_t Cout, dw_cin, ntaps, dw_tap_stride, dw_tap_off, accumulate;
+  int32_t reserved;
+} hrp_wgrad_fold_desc;
 
 /* Weight packing table entry (one launch packs every conv / linear weight of a network).
  * src: fp32 [Cout][Cin][ntaps] (PyTorch [Cout][Cin][KH][KW]).  CK = 32 bytes / sizeof(elem).
@@ -298,7 +314,8 @@ int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream);
  * A group the library cannot batch (split-K linear layers, scalar-path element-wise problems, mixed tap counts ..)
  * makes prepare return HRP_ERR_ARG: launch those problems one by one. */
 typedef enum {
-  HRP_BATCH_CONV = 0, HRP_BATCH_WGRAD = 1, HRP_BATCH_EW_FWD = 2, HRP_BATCH_EW_BWD_REDUCE = 3, HRP_BATCH_EW_BWD_APPLY = 4
+  HRP_BATCH_CONV = 0, HRP_BATCH_WGRAD = 1, HRP_BATCH_EW_FWD = 2, HRP_BATCH_EW_BWD_REDUCE = 3, HRP_BATCH_EW_BWD_APPLY = 4,
+  HRP_BATCH_WGRAD_FOLD = 5   /* descriptors: hrp_wgrad_fold_desc */
 } hrp_batch_family;
 #define HRP_BATCH_MAX 32
 typedef struct hrp_batch_info {
@@ -313,6 +330,10 @@ typedef struct hrp_batch_info {
 int64_t hrp_batch_table_bytes(int family, int n);
 int hrp_batch_prepare(int family, const void* descs, int n, void* table_host, hrp_batch_info* info);
 int hrp_batch_launch(const void* table_dev, const hrp_batch_info* info, void* stream);
+/* fold descriptors of a phase-1 weight-gradient launch: of a single launch (the tiling hrp_conv2d_bwd_weight will
+ * choose for d) / of the n problems of a prepared HRP_BATCH_WGRAD table (host copy), in the CALLER's order */
+int hrp_wgrad_fold_desc_of(const hrp_wgrad_desc* d, hrp_wgrad_fold_desc* out);
+int hrp_batch_wgrad_fold_descs(const void* table_host, const hrp_batch_info* info, hrp_wgrad_fold_desc* out);
 
 int hrp_bn_running_update(const hrp_bn_entry* table_dev, int count, void* stream);
 int hrp_bn_fold(const hrp_bn_entry* table_dev, int count, void* stream);

@@ -100,6 +100,119 @@ def test_batched_conv_equals_single_launches(dtype, N):
         assert torch.equal(a, b)
 
 
+def _wgrad_problem(nv, N, hw, cin, cout, k, dtype, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(N * hw * hw * cin, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(N * hw * hw * cout, generator=g).to(DEV).to(dtype)
+    d = nv.WgradDesc()
+    d.x, d.dy, d.dtype = x.data_ptr(), dy.data_ptr(), nv.HRP_BF16 if dtype == torch.bfloat16 else nv.HRP_F32
+    d.N, d.H, d.W, d.Cin, d.x_pitch = N, hw, hw, cin, cin
+    d.Ho, d.Wo, d.Cout, d.dy_pitch = hw, hw, cout, cout
+    d.in_stride, d.ntaps = 1, k * k
+    for i, (a, b) in enumerate([(ky - k // 2, kx - k // 2) for ky in range(k) for kx in range(k)]):
+        d.dy_t[i], d.dx_t[i] = a, b
+    d.dw_cin = cin
+    return d, (x, dy)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_wgrad_fold_equals_immediate(dtype):
+    """Weight gradients in two phases (descriptor phase 1 + ONE HRP_BATCH_WGRAD_FOLD launch over problems of different
+    tap counts, batched and single) are bit-identical to the one-call form: same slabs, same fold order."""
+    from hrpe_amd import _native as nv
+    L = nv.lib()
+    shapes = [(32, 32, 32, 3), (64, 64, 16, 3), (128, 128, 8, 3), (64, 128, 16, 1)]
+    probs = [_wgrad_problem(nv, 6, hw, cin, cout, k, dtype, 50 + i) for i, (cin, cout, hw, k) in enumerate(shapes)]
+    descs = [p[0] for p in probs]
+
+    def run(phase):
+        dws, wss, folds = [], [], []
+        # the three 3x3 problems as one batched launch, the 1x1 problem as a single launch
+        arr = (nv.WgradDesc * 3)(*descs[:3])
+        for d in arr:
+            d.phase, d.accumulate = phase, 0
+            dws.append(torch.full((d.Cout * d.dw_cin * d.ntaps,), 3.0, device=DEV))
+            d.dw = dws[-1].data_ptr()
+        info = nv.BatchInfo()
+        nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 3, None, C.byref(info)), "query")
+        for i, d in enumerate(arr):
+            ws = torch.zeros(int(info.ws_bytes[i]) // 4 + 4, device=DEV)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), int(info.ws_bytes[i])
+            wss.append(ws)
+        host = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD, 3)))()
+        nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 3, host, C.byref(info)), "prepare")
+        assert (info.grid2 == 0) == (phase == 1)
+        tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+        nv.check(L.hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+        if phase == 1:
+            f3 = (nv.WgradFoldDesc * 3)()
+            nv.check(L.hrp_batch_wgrad_fold_descs(host, C.byref(info), f3), "fold descs")
+            folds += list(f3)
+        d = descs[3]
+        d.phase, d.accumulate = phase, 0
+        dw = torch.full((d.Cout * d.dw_cin * d.ntaps,), 3.0, device=DEV)
+        d.dw = dw.data_ptr()
+        need = int(L.hrp_wgrad_workspace_bytes(C.byref(d)))
+        assert need > 0
+        ws = torch.zeros(need // 4 + 4, device=DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+        nv.call("hrp_conv2d_bwd_weight", C.byref(d), None)
+        wss.append(ws)
+        dws.append(dw)
+        if phase == 1:
+            f = nv.WgradFoldDesc()
+            nv.check(L.hrp_wgrad_fold_desc_of(C.byref(d), C.byref(f)), "fold desc")
+            folds.append(f)
+            torch.cuda.synchronize()
+            assert all(float(dw.min()) == 3.0 == float(dw.max()) for dw in dws), "phase 1 must not touch dw"
+            assert all(f.G > 0 for f in folds)
+            farr = (nv.WgradFoldDesc * 4)(*folds)
+            finfo = nv.BatchInfo()
+            fhost = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD_FOLD, 4)))()
+            nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD_FOLD, farr, 4, fhost, C.byref(finfo)), "fold prepare")
+            ftab = torch.frombuffer(bytearray(bytes(fhost)), dtype=torch.uint8).to(DEV)
+            nv.check(L.hrp_batch_launch(ftab.data_ptr(), C.byref(finfo), None), "fold launch")
+        torch.cuda.synchronize()
+        return dws
+
+    a, b = run(0), run(1)
+    for x, y, (cin, cout, hw, k) in zip(a, b, shapes):
+        assert float(x.abs().max()) > 0 and float((x - 3.0).abs().max()) > 0
+        assert torch.equal(x, y), f"wgrad {cin}->{cout} k{k} @{hw}: deferred fold differs"
+
+
+def test_plan_with_deferred_folds_matches_immediate_folds():
+    """One training step of the full network with the weight-gradient folds deferred (default) and folded on the spot
+    (HRP_NO_WGRAD_DEFER): the same gradients (the slab sums are identical; the BN-statistic atomics are the noise)."""
+    from hrpe_amd import plan as P
+    m = build_full().train()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    saved = P.WGRAD_DEFER
+    grads = {}
+    try:
+        for name, defer in (("deferred", True), ("deferred_again", True), ("immediate", False)):
+            P.WGRAD_DEFER = defer
+            if name != "deferred_again":
+                m.invalidate_plans()
+            m.load_state_dict(sd0)
+            m.zero_grad()
+            out = m(x_reg, x_root, kv, K)
+            sum(o.float().square().mean() for o in out).backward()
+            torch.cuda.synchronize()
+            grads[name] = m.flat_grads()[0].clone()
+            if defer:
+                tp = [r.plan for r in m._plans.values() if r.plan.need_grad][-1]
+                assert any(isinstance(e.op, P.BatchLaunch) and e.op.fam == "wgrad_fold" for e in tp.bwd_ops())
+    finally:
+        P.WGRAD_DEFER = saved
+        m.invalidate_plans()
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    noise = rel(grads["deferred_again"], grads["deferred"])
+    assert float(grads["deferred"].abs().max()) > 0
+    assert rel(grads["immediate"], grads["deferred"]) <= max(10 * noise, 1e-4), (rel(grads["immediate"], grads["deferred"]), noise)
+
+
 def test_grouped_plan_matches_one_by_one_plan():
     """The same network with batched launches (default), with the launches one by one in the same order (HRP_NO_BATCH),
     fully merged on one stream and on the round-1 lanes: eval outputs to 2e-6 (split-K atomics of the single-launch

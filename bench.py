@@ -229,6 +229,8 @@ def conv_bytes(name, args):
             b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
             if d.res:
                 b += d.N * d.Ho * d.Wo * d.Cout * esz
+            if d.bnb_x:      # BatchNorm-backward reduce in the epilogue: reads the BatchNorm input once (+ 1/16 mask)
+                b += d.N * d.Ho * d.Wo * d.Cout * esz
             tot += b
         else:
             tot += (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout) * esz + d.Cout * d.dw_cin * d.ntaps * 4

@@ -31,7 +31,9 @@ class ConvDesc(C.Structure):
                 ("out_stride", C.c_int32), ("out_off_y", C.c_int32), ("out_off_x", C.c_int32),
                 ("in_stride", C.c_int32), ("ntaps", C.c_int32),
                 ("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wtap", C.c_int32 * MAX_TAPS),
-                ("w_ntaps", C.c_int32), ("w_cout_pad", C.c_int32), ("relu", C.c_int32)]
+                ("w_ntaps", C.c_int32), ("w_cout_pad", C.c_int32), ("relu", C.c_int32),
+                ("bnb_x", C.c_void_p), ("bnb_mask", C.c_void_p), ("bnb_consts", C.c_void_p),
+                ("bnb_x_pitch", C.c_int32), ("bnb_mask_pitch", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -68,7 +70,7 @@ class EwDesc(C.Structure):
     _fields_ = [("inp", EwInput * EW_MAX_IN), ("nin", C.c_int32), ("out", C.c_void_p),
                 ("out_pitch", C.c_int32), ("dtype", C.c_int32),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("relu", C.c_int32),
-                ("mask", C.c_void_p), ("mask_pitch", C.c_int32)]
+                ("mask", C.c_void_p), ("mask_pitch", C.c_int32), ("consts_out", C.c_void_p)]
 
 
 class EwBwdDesc(C.Structure):

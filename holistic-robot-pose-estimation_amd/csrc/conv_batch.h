@@ -104,7 +104,7 @@ static int conv_batch_prepare_nt(const hrp_conv_desc* descs, int n, ConvProblem*
   for (int k = 0; k < n; ++k) {
     ConvProblem& P = probs[order[k]];
     info->blk0[k] = blk;
-    if (NT == 9 && pcap > 0 && P.cfg == 0 && P.t.nblocks >= 2 * pcap && P.d.Cin * SZ <= 2 * ROW) {
+    if (NT == 9 && pcap > 0 && P.cfg == 0 && P.t.nblocks >= 2 * pcap && P.d.Cin * SZ <= 2 * ROW && !P.d.bnb_x) {
       P.cfg = 4;
       P.pgrid = pcap;
       blk += pcap;

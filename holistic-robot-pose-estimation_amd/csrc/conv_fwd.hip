@@ -19,6 +19,15 @@ int conv_check(const hrp_conv_desc* d) {
   HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
   HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
   HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
+  if (d->bnb_x) {   // BatchNorm-backward reduce in the epilogue: only the plain vector store path computes it
+    const int sz = d->dtype == HRP_F32 ? 4 : 2;
+    HRP_REQUIRE(d->stats && d->bnb_mask && d->bnb_consts, "conv: bnb_x needs stats, bnb_mask and bnb_consts");
+    HRP_REQUIRE(!d->res && !d->relu && !d->bias && !d->scale, "conv: bnb_x excludes res / relu / bias / scale");
+    HRP_REQUIRE(d->out_stride == 1 && d->y_H == d->Ho && d->y_W == d->Wo, "conv: bnb_x needs a launch that covers y");
+    HRP_REQUIRE(d->Cout % vec == 0 && d->bnb_mask_pitch >= d->Cout / vec, "conv: bnb_x needs whole vectors (Cout=%d)", d->Cout);
+    HRP_REQUIRE((uintptr_t)d->y % 16 == 0 && ((size_t)d->y_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_x % 16 == 0 &&
+                ((size_t)d->bnb_x_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_consts % 16 == 0, "conv: bnb_x alignment");
+  }
   return HRP_OK;
 }
 

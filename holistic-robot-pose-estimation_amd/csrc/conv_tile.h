@@ -440,6 +440,32 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
     const char* rg = (const char*)d.res;
     const long long ybase = ((long long)n0 * d.y_H + (oy0 * d.out_stride + d.out_off_y)) * d.y_W +
                             (ox0 * d.out_stride + d.out_off_x);
+    // BatchNorm-backward reduce folded into a data-gradient launch (hrp_conv_desc.bnb_*): mean / invstd of the
+    // thread's channels, and every row's BatchNorm input + mask byte requested up front (issued between the stores
+    // they would wait for the store queue one by one: +4 us per launch)
+    // (not in the persistent instance: its plans live across tiles and 40 more registers would halve its occupancy -
+    // the launchers never pick it for such a problem)
+    const char* bxg = PERSIST ? nullptr : (const char*)d.bnb_x;
+    float bmean[VEC], binv[VEC];
+    uint4 bx_pre[KST];
+    unsigned bits_pre[KST];
+    if (bxg && co < d.Cout) {
+#pragma unroll
+      for (int q = 0; q < VEC; q += 4) {
+        const float4 m4 = *(const float4*)(d.bnb_consts + co + q), i4 = *(const float4*)(d.bnb_consts + d.Cout + co + q);
+        bmean[q] = m4.x; bmean[q + 1] = m4.y; bmean[q + 2] = m4.z; bmean[q + 3] = m4.w;
+        binv[q] = i4.x; binv[q + 1] = i4.y; binv[q + 2] = i4.z; binv[q + 3] = i4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < KST; ++k) {
+        bx_pre[k] = make_uint4(0, 0, 0, 0);
+        bits_pre[k] = 0;
+        if (out_code[k] & cls) continue;
+        const size_t opix = (size_t)(ybase + out_rel[k]);
+        bx_pre[k] = *(const uint4*)(bxg + (opix * d.bnb_x_pitch + co) * SZ);
+        bits_pre[k] = d.bnb_mask[opix * d.bnb_mask_pitch + co / VEC];
+      }
+    }
     if (co < d.Cout) {
       const bool full = t.vec_ok && (co + VEC <= d.Cout);
 #pragma unroll
@@ -468,7 +494,18 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
         if (full && !rg && !d.relu) {
           // plain conv output (the train-mode case): the LDS image is already the stored value
           *(uint4*)(yg + (opix * d.y_pitch + co) * SZ) = raw;
-          if (d.stats) {
+          if (bxg) {
+            // sum g, sum g * xhat over the masked gradient (the values as stored, like the separate reduce pass)
+            const unsigned bits = bits_pre[k];
+            float xf[VEC];
+            Elem<T>::unpack(bx_pre[k], xf);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const float g = (bits >> i) & 1u ? f[i] : 0.f;
+              s1[i] += g;
+              s2[i] += g * (xf[i] - bmean[i]) * binv[i];
+            }
+          } else if (d.stats) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
           }
@@ -656,7 +693,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   // in the step they cost 0.55 ms - HRP_CONV_PERSIST=48 restores them)
   static const int persist_max = getenv("HRP_CONV_PERSIST") ? atoi(getenv("HRP_CONV_PERSIST")) : 0;
   constexpr bool CAN_PERSIST = NT == 9;   // (only 3x3 layers have tiles small enough to profit; keeps the instantiation count down)
-  const bool persist = CAN_PERSIST && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256;   // 1x1 layers are store bound: many small workgroups
+  const bool persist = CAN_PERSIST && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256 && !d.bnb_x;   // 1x1 layers are store bound: many small workgroups
   const bool fastp = (d.Cin * SZ) % ROW == 0;   // no half-filled last chunk: per-piece advancing pointers
   void (*kern)(const hrp_conv_desc, const ConvTiling) =
       fastp ? conv_tile_kernel<T, CT, PT, WC, WP, NT, false, true> : conv_tile_kernel<T, CT, PT, WC, WP, NT, false, false>;

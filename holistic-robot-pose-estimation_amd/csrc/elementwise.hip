@@ -110,6 +110,12 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
           for (int i = 0; i < V; ++i) { sc[j][i] = 1.f; sh[j][i] = 0.f; }
         } else {
           load_consts<V>(d.in[j], d.C, cbase, nch, c, tab, sc[j], sh[j], m, iv);
+          // mean / invstd of input 0 for the backward pass (hrp_conv_desc.bnb_consts): the first pixel row of the
+          // first block of every channel slab publishes them
+          if (j == 0 && d.consts_out && bx == 0 && (int)threadIdx.x < tpr && c < d.C && d.in[0].mode == HRP_EW_BN_TRAIN) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { d.consts_out[c + i] = m[i]; d.consts_out[d.C + c + i] = iv[i]; }
+          }
         }
       }
   }
@@ -779,6 +785,7 @@ static int hrp::ew_fwd_check(const hrp_ew_desc* d) {
     HRP_REQUIRE(in.mode == HRP_EW_IDENTITY || (in.a && in.b), "ew_fwd: input %d needs a/b", j);
     HRP_REQUIRE(in.mode != HRP_EW_BN_TRAIN || (in.stats && in.count > 0.f), "ew_fwd: input %d needs stats", j);
   }
+  HRP_REQUIRE(!d->consts_out || d->in[0].mode == HRP_EW_BN_TRAIN, "ew_fwd: consts_out needs a train-mode BatchNorm as input 0");
   return HRP_OK;
 }
 

@@ -133,6 +133,9 @@ PLAN_MODE = os.environ.get("HRP_PLAN_MODE", "hybrid")
 # merged / hybrid: weight-gradient launches write their partial slabs only (descriptor phase 1); the slabs of up to 32
 # layers are folded into the gradients by ONE launch at the end of their lane (or every WGRAD_FOLD_EVERY problems)
 # instead of a 6-10 us launch behind every weight-gradient launch (~660 per step of the benchmark network)
+# the BatchNorm-backward reduce pass of an activation whose gradient has ONE producer, a data-gradient convolution, runs in
+# that convolution's epilogue (hrp_conv_desc.bnb_*) instead of as a launch of its own over the same two tensors
+FUSE_BN_REDUCE = not os.environ.get("HRP_NO_FUSE_BN_REDUCE")
 WGRAD_DEFER = not os.environ.get("HRP_NO_WGRAD_DEFER")
 WGRAD_FOLD_EVERY = int(os.environ.get("HRP_WGRAD_FOLD_EVERY", "32"))
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
@@ -505,6 +508,8 @@ class Plan:
         for fn in self._late:
             fn()
         self._late = []
+        if FUSE_BN_REDUCE and self.need_grad:
+            self._fuse_bn_reduce()
         if self.merged:
             # lock-step merge of the virtual lanes into batched launches; streams only where a block asked for them
             self.fwd_run, self.bwd_run = self._flatten(self.fwd), self._flatten(self.bwd)
@@ -651,6 +656,54 @@ class Plan:
                         out += [Entry(lane, (), op) for op in lockstep([[e.op for e in x] for x in kids])]
             return out
         return walk(root, 0)
+
+    def _fuse_bn_reduce(self):
+        """conv -> BN -> ReLU -> conv (the interior of BasicBlock / Bottleneck, HRnet.py:41-57): the gradient of the
+        activation comes from exactly one data-gradient launch; its epilogue then also accumulates the two BatchNorm
+        backward sums (sum g, sum g * xhat) and the separate hrp_ew_bwd_reduce launch over the same tensors goes away."""
+        is_l = lambda e, fam: isinstance(e.op, Launch) and e.op.fam == fam   # noqa: E731
+        convs, other = {}, set()
+        for i, e in enumerate(self.bwd):
+            if is_l(e, "conv"):
+                convs.setdefault(e.op.desc.y, []).append((i, e))
+            elif is_l(e, "ew_app"):
+                other.update(x for x in (e.op.desc.din, e.op.desc.din2) if x)
+        fwd_by_mask = {e.op.desc.mask: e.op for e in self.fwd if is_l(e, "ew_fwd") and e.op.desc.mask}
+        drop = set()
+        for i, e in enumerate(self.bwd):
+            if not is_l(e, "ew_red"):
+                continue
+            b = e.op.desc
+            if b.inp.mode != nv.EW_BN_TRAIN or b.inp.up != 1 or not b.relu or not b.mask or b.dout in other:
+                continue
+            cands = convs.get(b.dout, [])
+            fw = fwd_by_mask.get(b.mask)
+            if len(cands) != 1 or fw is None or fw.desc.nin != 1:
+                continue
+            j, ce = cands[0]
+            d = ce.op.desc
+            esz = 4 if d.dtype == nv.HRP_F32 else 2
+            vec = 16 // esz
+            if j > i or ce.lane != e.lane or ce.path != e.path:
+                continue
+            if d.res or d.relu or d.bias or d.scale or d.stats or d.out_stride != 1 or (d.y_H, d.y_W) != (d.Ho, d.Wo):
+                continue
+            if (d.N, d.Ho, d.Wo, d.Cout, d.y_pitch, d.dtype) != (b.N, b.H, b.W, b.C, b.dout_pitch, b.dtype) or d.Cout % vec:
+                continue
+            if d.y % 16 or (d.y_pitch * esz) % 16 or b.inp.ptr % 16 or (b.inp.pitch * esz) % 16:
+                continue
+            consts = torch.zeros(2 * b.C, dtype=torch.float32, device=self.device)
+            self.keep.append(consts)
+            fw.desc.consts_out = consts.data_ptr()
+            d.bnb_x, d.bnb_x_pitch = b.inp.ptr, b.inp.pitch
+            d.bnb_mask, d.bnb_mask_pitch = b.mask, b.mask_pitch
+            d.bnb_consts, d.stats = consts.data_ptr(), b.sums
+            drop.add(i)
+        if drop:
+            kept = [e for i, e in enumerate(self.bwd) if i not in drop]
+            del self.bwd[:]
+            list.extend(self.bwd, kept)
+        self.counters["bn_reduce_fused"] = len(drop)
 
     def _insert_folds(self, entries):
         """Deferred weight-gradient folds: after every WGRAD_FOLD_EVERY phase-1 problems of a lane, before the lane

@@ -92,6 +92,16 @@ typedef struct hrp_conv_desc {
   int32_t w_ntaps;     /* tap slots per chunk in the packed weights                               */
   int32_t w_cout_pad;  /* Cout rounded up to 32 (row count per tap in the packed weights)         */
   int32_t relu;
+  /* Data-gradient launches only (all NULL / 0 otherwise): the BatchNorm-backward REDUCE pass of the activation whose
+   * gradient this launch produces, folded into the epilogue.  y is the gradient of act = relu(bn(bnb_x)); with these
+   * set, `stats` receives  sum(g), sum(g * (bnb_x - mean) * invstd)  with g = y masked by the ReLU bit mask - exactly
+   * what hrp_ew_bwd_reduce would compute from y in a separate pass over y and bnb_x (the reference runs it inside
+   * autograd's native_batch_norm_backward, HRnet.py:41-57).  Needs: no res / relu / bias / scale, out_stride 1,
+   * Cout a multiple of the 16-byte vector, 16-byte aligned rows; y itself is stored unmasked. */
+  const void* bnb_x;        /* forward input of the BatchNorm [N, Ho, Wo, bnb_x_pitch], dtype of y             */
+  const uint8_t* bnb_mask;  /* ReLU bit mask of the activation (hrp_ew_desc.mask), one byte per vector          */
+  const float* bnb_consts;  /* [2 * Cout]: mean, invstd of the BatchNorm input (hrp_ew_desc.consts_out)        */
+  int32_t bnb_x_pitch, bnb_mask_pitch;
 } hrp_conv_desc;
 
 /* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],
@@ -172,6 +182,8 @@ typedef struct hrp_ew_desc {
   int32_t mask_pitch;  /* bit i = (channel i of the vector > 0); [N*H*W][mask_pitch] bytes.  The backward then  */
                        /* reads 1/16 of the bytes of `out` for the ReLU mask.  Vector path only (C, pitches and */
                        /* pointers 16-byte aligned), an error otherwise.                                        */
+  float* consts_out;   /* optional, in[0].mode == HRP_EW_BN_TRAIN: [2C] mean, invstd of input 0 as this launch  */
+                       /* derived them from the statistic slots (read by hrp_conv_desc.bnb_consts in backward) */
 } hrp_ew_desc;
 
 /* Backward of one input j of an ew op.  g = dOut * (out > 0 if relu), pooled (summed) over the

@@ -100,6 +100,63 @@ def test_batched_conv_equals_single_launches(dtype, N):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("batched", [False, True])
+def test_conv_epilogue_bn_backward_reduce(dtype, batched):
+    """hrp_conv_desc.bnb_*: a (data-gradient) convolution that also accumulates the two BatchNorm-backward sums of the
+    activation whose gradient it writes - sum g and sum g * (x - mean) * invstd with g = y masked by the ReLU bit
+    mask - gives the sums a separate pass over the stored y computes, and leaves y itself untouched."""
+    from hrpe_amd import _native as nv
+    vec = 4 if dtype == torch.float32 else 8
+    shapes = [(32, 32, 32, 3), (64, 64, 16, 3), (64, 32, 16, 1)]
+    N = 5
+    probs = []
+    for i, (cin, cout, hw, k) in enumerate(shapes):
+        d, keep = _conv_problem(nv, N, hw, cin, cout, k, dtype, 300 + i)
+        g = torch.Generator(device="cpu").manual_seed(400 + i)
+        npx = N * hw * hw
+        bx = torch.randn(npx, cout, generator=g).to(DEV).to(dtype)
+        mask = torch.randint(0, 1 << vec, (npx, cout // vec), generator=g, dtype=torch.int32).to(torch.uint8).to(DEV)
+        consts = torch.cat([torch.randn(cout, generator=g) * 0.3, torch.rand(cout, generator=g) + 0.5]).to(DEV)
+        y0 = torch.zeros(npx * cout, device=DEV).to(dtype)
+        y1 = torch.zeros(npx * cout, device=DEV).to(dtype)
+        sums = torch.zeros(8 * 2 * cout, device=DEV)
+        probs.append((d, keep, bx, mask, consts, y0, y1, sums, cout))
+    plain, fused = [], []
+    for d, keep, bx, mask, consts, y0, y1, sums, cout in probs:
+        d.y, d.stats = y0.data_ptr(), None
+        nv.call("hrp_conv2d_fwd", C.byref(d), None)
+        f = nv.ConvDesc.from_buffer_copy(d)
+        f.y, f.stats = y1.data_ptr(), sums.data_ptr()
+        f.bnb_x, f.bnb_x_pitch, f.bnb_mask, f.bnb_mask_pitch, f.bnb_consts = bx.data_ptr(), cout, mask.data_ptr(), cout // vec, consts.data_ptr()
+        fused.append(f)
+    if batched:
+        for grp in (fused[:2], fused[2:]):     # (one tap count per batch)
+            arr = (nv.ConvDesc * len(grp))(*grp)
+            info = nv.BatchInfo()
+            host = (C.c_char * int(nv.lib().hrp_batch_table_bytes(nv.BATCH_CONV, len(grp))))()
+            nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_CONV, arr, len(grp), host, C.byref(info)), "prepare")
+            tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+            nv.check(nv.lib().hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+    else:
+        for f in fused:
+            nv.call("hrp_conv2d_fwd", C.byref(f), None)
+    torch.cuda.synchronize()
+    for (d, keep, bx, mask, consts, y0, y1, sums, cout), (cin, _, hw, k) in zip(probs, shapes):
+        assert torch.equal(y0, y1), "the fused launch must store the same y"
+        yv = y0.float().view(-1, cout)
+        bits = ((mask.to(torch.int32).unsqueeze(-1) >> torch.arange(vec, device=DEV)) & 1).reshape(-1, cout).float()
+        gm = yv * bits
+        xh = (bx.float() - consts[:cout]) * consts[cout:]
+        want = torch.cat([gm.sum(0), (gm * xh).sum(0)]).double()
+        got = sums.view(8, 2 * cout).sum(0).double()
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 2e-5, f"conv {cin}->{cout} k{k} @{hw}: BatchNorm backward sums differ by {err}"
+    bad = nv.ConvDesc.from_buffer_copy(fused[0])
+    bad.relu = 1
+    assert nv.lib().hrp_conv2d_fwd(C.byref(bad), None) == -1 and b"bnb_x" in nv.lib().hrp_last_error()
+
+
 def _wgrad_problem(nv, N, hw, cin, cout, k, dtype, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(N * hw * hw * cin, generator=g).to(DEV).to(dtype)

@@ -138,6 +138,10 @@ PLAN_MODE = os.environ.get("HRP_PLAN_MODE", "hybrid")
 FUSE_BN_REDUCE = not os.environ.get("HRP_NO_FUSE_BN_REDUCE")
 WGRAD_DEFER = not os.environ.get("HRP_NO_WGRAD_DEFER")
 WGRAD_FOLD_EVERY = int(os.environ.get("HRP_WGRAD_FOLD_EVERY", "32"))
+# weight gradients feed nothing before the optimizer: the launches of a lane are held back until WGRAD_SINK problems of one
+# tap count are pending (or the lane ends) and then run as ONE batched launch - also the layers that have no lock-step
+# partner (stem, layer1, transitions, the fuse convolutions).  0: every launch stays where the layer's backward put it.
+WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "8"))
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
 # development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
 BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
@@ -513,6 +517,8 @@ class Plan:
         if self.merged:
             # lock-step merge of the virtual lanes into batched launches; streams only where a block asked for them
             self.fwd_run, self.bwd_run = self._flatten(self.fwd), self._flatten(self.bwd)
+            if WGRAD_SINK > 1 and WGRAD_DEFER and BATCHING:
+                self.bwd_run = self._sink_wgrads(self.bwd_run)
             ops = [e.op for e in self.fwd_run + self.bwd_run if e.lane is not None]
             batches = [op for op in ops if isinstance(op, BatchLaunch)]
             wg_ops = [e for e in self.bwd_run if isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad"]
@@ -704,6 +710,53 @@ class Plan:
             del self.bwd[:]
             list.extend(self.bwd, kept)
         self.counters["bn_reduce_fused"] = len(drop)
+
+    def _sink_wgrads(self, entries):
+        """Regroup the weight-gradient launches of every lane into batches of WGRAD_SINK problems of one tap count (their
+        inputs - the layer's forward input and its output gradient - stay untouched for the rest of the step)."""
+        out, pend = [], {}
+
+        def emit(lane, key, path, force):
+            items = pend[lane][key]
+            while items and (force or len(items) >= WGRAD_SINK):
+                grp, rest, seen = [], [], set()
+                for it in items:
+                    w = it.written()
+                    if len(grp) < WGRAD_SINK and not any(a in seen for a in w):
+                        grp.append(it)
+                        seen.update(w)
+                    else:
+                        rest.append(it)
+                out.append(Entry(lane, path, grp[0] if len(grp) == 1 else BatchLaunch(self, grp)))
+                items = rest
+            pend[lane][key] = items
+
+        def flush(lane, path):
+            for key in list(pend.get(lane, {})):
+                emit(lane, key, path, True)
+
+        for e in entries:
+            if e.lane is None:
+                if getattr(e.op, "kind", None) == "join":
+                    for c in e.op.children:
+                        flush(c, e.path)
+                out.append(e)
+                continue
+            op = e.op
+            if isinstance(op, (Launch, BatchLaunch)) and op.fam == "wgrad" and not any(it.desc.reserved for it in op.launches()):
+                for it in op.launches():
+                    key = it.merge_key()
+                    if key is None:
+                        out.append(Entry(e.lane, e.path, it))
+                        continue
+                    pend.setdefault(e.lane, {}).setdefault(key, []).append(it)
+                    if len(pend[e.lane][key]) >= WGRAD_SINK:
+                        emit(e.lane, key, e.path, False)
+            else:
+                out.append(e)
+        for lane in sorted(pend):
+            flush(lane, ())
+        return out
 
     def _insert_folds(self, entries):
         """Deferred weight-gradient folds: after every WGRAD_FOLD_EVERY phase-1 problems of a lane, before the lane

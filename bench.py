@@ -181,7 +181,7 @@ def cpu_baseline(B, threads, workload="full", forward_only=False):
 
     step()                      # warm-up: oneDNN primitive creation, allocator
     t0, n = time.time(), 0
-    while n < 3 or (time.time() - t0 < 10.0 and n < 8):     # a bounded sample: >= 3 steps, about 10-20 s
+    while n < 3 or (time.time() - t0 < 12.0 and n < 200):   # a bounded sample: >= 3 steps, about 12-15 s of CPU work
         step()
         n += 1
     dt = time.time() - t0

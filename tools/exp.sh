@@ -1,5 +1,5 @@
 # development aid: one gpurun call = tests + the bench lines of every workload (written under gpurun_out/)
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r02_tests.log
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r02_tests_full.log 2>&1; grep -E "^E  |passed|failed|^FAILED" gpurun_out/r02_tests_full.log | cut -c1-300 | head -20 > gpurun_out/r02_tests.log
 timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_r02_full.json 2> gpurun_out/bench_r02_full.err
 timeout 300 python bench.py --steps 20 --warmup 5 --workload hrnet > gpurun_out/bench_r02_hrnet.json 2> gpurun_out/bench_r02_hrnet.err
 timeout 300 python bench.py --steps 20 --warmup 5 --forward-only > gpurun_out/bench_r02_fwd.json 2> gpurun_out/bench_r02_fwd.err

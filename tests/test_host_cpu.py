@@ -373,6 +373,134 @@ def test_plan_lockstep_merge_into_batched_launches():
     assert sum(isinstance(e.op, P.BatchLaunch) for e in ents) == 1
 
 
+def _fake_wgrad(dw, ntaps=9, cin=32, cout=32, hw=32, N=4):
+    g = nv.WgradDesc()
+    g.x, g.dy, g.dw, g.dtype = 0x10000, 0x20000, dw, nv.HRP_BF16
+    g.N, g.H, g.W, g.Cin, g.x_pitch = N, hw, hw, cin, cin
+    g.Ho, g.Wo, g.Cout, g.dy_pitch = hw, hw, cout, cout
+    g.in_stride, g.ntaps, g.dw_cin, g.accumulate = 1, ntaps, cin, 1
+    k = 0
+    for a in range(-1, 2):
+        for b in range(-1, 2):
+            if k < ntaps:
+                g.dy_t[k], g.dx_t[k] = (a, b) if ntaps == 9 else (0, 0)
+                k += 1
+    return g
+
+
+def test_plan_regroups_weight_gradients_and_defers_their_folds():
+    """plan.py host logic of round 2: the weight-gradient launches of a lane are regrouped into batches of one tap count
+    wherever they sit (_sink_wgrads), run in phase 1 and are folded by HRP_BATCH_WGRAD_FOLD launches before the lane
+    joins / at the end (_insert_folds); a launch marked `reserved` (its gradient is read right away) stays put."""
+    import torch
+    from hrpe_amd import plan as P
+    pl = P.Plan(torch.device("cpu"), torch.bfloat16, True, True)
+    P.PlanBuilder(pl)
+    log = []
+    ents = []
+    for i in range(5):
+        ents.append(P.Entry(0, (), P.Launch("wgrad", _fake_wgrad(0x100000 * (i + 1), ntaps=9 if i != 2 else 1))))
+        ents.append(P.Entry(0, (), lambda s, i=i: log.append(i)))
+    stay = _fake_wgrad(0x900000)
+    stay.reserved = 1
+    ents.insert(4, P.Entry(0, (), P.Launch("wgrad", stay)))
+    saved = P.WGRAD_SINK
+    P.WGRAD_SINK = 3
+    try:
+        out = pl._sink_wgrads(ents)
+    finally:
+        P.WGRAD_SINK = saved
+    kinds = ["B%d" % len(e.op.items) if isinstance(e.op, P.BatchLaunch) else ("W" if isinstance(e.op, P.Launch) else "f") for e in out]
+    # fn, fn, [reserved wgrad in place], fn, the batch of three 3x3 problems where the third arrived, fn, fn, then the rest
+    assert kinds == ["f", "f", "W", "f", "B3", "f", "f", "W", "W"], kinds
+    assert out[2].op.desc.reserved == 1 and {it.desc.ntaps for it in out[4].op.items} == {9}
+    assert sorted(e.op.desc.ntaps for e in out[-2:]) == [1, 9]
+    # phase 1 + deferred folds: a fold launch of the four deferred problems at the end, none for the reserved one
+    for e in out:
+        if isinstance(e.op, (P.Launch, P.BatchLaunch)):
+            for it in e.op.launches():
+                it.desc.phase = 0 if it.desc.reserved else 1
+                need = int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(it.desc)))
+                it.desc.workspace, it.desc.workspace_bytes = 0x40000000, 1 << 30
+                assert need > 0
+    for e in out:
+        if isinstance(e.op, P.BatchLaunch):
+            e.op.prepare()
+            assert e.op.info.grid2 == 0 and len(e.op.fold_descs()) == 3
+    folded = pl._insert_folds(out)
+    fam = [e.op.fam if isinstance(e.op, (P.Launch, P.BatchLaunch)) else "f" for e in folded]
+    assert fam[:-1] == ["f" if k == "f" else "wgrad" for k in kinds] and fam[-1] == "wgrad_fold"
+    fold = folded[-1].op
+    assert len(fold.items) == 5 and fold.info.family == nv.BATCH_WGRAD_FOLD and fold.info.grid > 0
+    assert {it.desc.dw for it in fold.items} == {0x100000 * (i + 1) for i in range(5)}
+
+
+def test_wgrad_fold_descriptor_and_refusals_are_host_only():
+    lib = nv.lib()
+    g = _fake_wgrad(0x100000, cin=64, cout=64, hw=16, N=8)
+    need = int(lib.hrp_wgrad_workspace_bytes(C.byref(g)))
+    g.workspace, g.workspace_bytes, g.phase = 0x40000000, need, 1
+    f = nv.WgradFoldDesc()
+    assert lib.hrp_wgrad_fold_desc_of(C.byref(g), C.byref(f)) == 0
+    assert f.G >= 1 and f.pairs == 4 and f.nte == 9 and f.nb == 1 and f.dw == 0x100000 and f.accumulate == 1
+    assert f.G * f.pairs * f.nte * 1024 * 4 == need
+    g.workspace_bytes = need - 4            # too small: the launch takes the atomics path, nothing to fold
+    assert lib.hrp_wgrad_fold_desc_of(C.byref(g), C.byref(f)) == 0 and f.G == 0
+    info = nv.BatchInfo()
+    arr = (nv.WgradFoldDesc * 1)(f)
+    host = (C.c_char * int(lib.hrp_batch_table_bytes(nv.BATCH_WGRAD_FOLD, 1)))()
+    assert lib.hrp_batch_prepare(nv.BATCH_WGRAD_FOLD, arr, 1, host, C.byref(info)) == -1      # G == 0 is not foldable
+    assert b"wgrad fold" in lib.hrp_last_error()
+    # mixed phases in one batched weight-gradient launch are refused
+    a, b = _fake_wgrad(0x100000), _fake_wgrad(0x200000)
+    for d in (a, b):
+        d.workspace, d.workspace_bytes = 0x40000000, 1 << 30
+    a.phase = 1
+    arr = (nv.WgradDesc * 2)(a, b)
+    host = (C.c_char * int(lib.hrp_batch_table_bytes(nv.BATCH_WGRAD, 2)))()
+    assert lib.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, host, C.byref(info)) == -1 and b"mixed phases" in lib.hrp_last_error()
+
+
+def test_plan_folds_bn_backward_reduce_into_the_data_gradient():
+    """_fuse_bn_reduce (host logic): conv -> BN -> ReLU -> conv gives the data-gradient launch the BatchNorm operands
+    and drops the reduce launch; an activation gradient with a second writer keeps its reduce pass."""
+    import torch
+    from hrpe_amd import plan as P
+    pl = P.Plan(torch.device("cpu"), torch.bfloat16, True, True)
+    P.PlanBuilder(pl)
+
+    def act(out, mask, raw, nin=1):
+        d = nv.EwDesc()
+        d.nin, d.out, d.out_pitch, d.dtype = nin, out, 32, nv.HRP_BF16
+        d.N, d.H, d.W, d.C, d.relu, d.mask, d.mask_pitch = 2, 64, 64, 32, 1, mask, 4
+        d.inp[0].ptr, d.inp[0].pitch, d.inp[0].up, d.inp[0].mode = raw, 32, 1, nv.EW_BN_TRAIN
+        return d
+
+    def red(gout, mask, raw, sums):
+        b = nv.EwBwdDesc()
+        b.dout, b.dout_pitch, b.mask, b.mask_pitch, b.sums, b.dtype = gout, 32, mask, 4, sums, nv.HRP_BF16
+        b.N, b.H, b.W, b.C, b.relu = 2, 64, 64, 32, 1
+        b.inp.ptr, b.inp.pitch, b.inp.up, b.inp.mode = raw, 32, 1, nv.EW_BN_TRAIN
+        return b
+
+    # activation 1: gradient written by ONE conv -> fused.  activation 2: the conv accumulates onto an ew_app output.
+    list.append(pl.fwd, P.Entry(0, (), P.Launch("ew_fwd", act(0x1000000, 0x1100000, 0x1200000))))
+    list.append(pl.fwd, P.Entry(0, (), P.Launch("ew_fwd", act(0x2000000, 0x2100000, 0x2200000))))
+    c1, c2 = _fake_conv(0x1300000), _fake_conv(0x2300000)
+    r1, r2 = red(0x1300000, 0x1100000, 0x1200000, 0x1400000), red(0x2300000, 0x2100000, 0x2200000, 0x2400000)
+    other = nv.EwBwdDesc()
+    other.din2 = 0x2300000
+    for op in (P.Launch("ew_app", other), P.Launch("conv", c1), P.Launch("ew_red", r1), P.Launch("ew_app", r1),
+               P.Launch("conv", c2), P.Launch("ew_red", r2), P.Launch("ew_app", r2)):
+        list.append(pl.bwd, P.Entry(0, (), op))
+    pl._fuse_bn_reduce()
+    fams = [e.op.fam for e in pl.bwd]
+    assert fams == ["ew_app", "conv", "ew_app", "conv", "ew_red", "ew_app"] and pl.counters["bn_reduce_fused"] == 1
+    assert c1.bnb_x == 0x1200000 and c1.bnb_mask == 0x1100000 and c1.stats == 0x1400000 and c1.bnb_consts
+    assert pl.fwd[0].op.desc.consts_out == c1.bnb_consts and not pl.fwd[1].op.desc.consts_out
+    assert not c2.bnb_x and not c2.stats
+
+
 def test_batch_prepare_is_host_only():
     """hrp_batch_prepare makes no HIP call: block ranges, per-problem tiles and the refusal paths can be checked here."""
     lib = nv.lib()

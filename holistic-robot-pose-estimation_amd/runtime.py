@@ -28,6 +28,7 @@ def require_gpu(device):
 # plan-owned staging tensors first (a captured launch bakes its pointers).  Off: HRP_NO_MODULE_GRAPH=1 or
 # runtime.GRAPH_CACHE = False; never active inside somebody else's capture or with a split backward.
 GRAPH_CACHE = not os.environ.get("HRP_NO_MODULE_GRAPH")
+PLAN_CACHE_MAX = int(os.environ.get("HRP_PLAN_CACHE", "6"))   # plans kept per module (train / eval x a few input shapes)
 GRAPH_WARMUP = 2
 
 
@@ -230,8 +231,14 @@ class PlannedModule(nn.Module):
         key = (tuple(tuple(t.shape) for t in tensors), self._compute_dtype, self.training, need_grad,
                tuple(bool(t.requires_grad) for t in tensors) if need_grad else (),
                tuple(t.dtype == torch.uint8 for t in tensors))
-        runner = self._plans.get(key)
+        runner = self._plans.pop(key, None)
+        if runner is not None:
+            self._plans[key] = runner        # most recently used last
         if runner is None:
+            # bounded cache: a plan owns its activation / gradient / scratch arenas (tens of GB at B = 64), and a
+            # loader with a ragged last batch or varying crops would otherwise keep one set per shape alive for ever
+            while len(self._plans) >= PLAN_CACHE_MAX:
+                self._plans.pop(next(iter(self._plans)))
             plan = Plan(dev, self._compute_dtype, self.training, need_grad)
             if need_grad:
                 plan.preallocate_param_grads(list(self.parameters()))

@@ -1871,13 +1871,15 @@ class PlanBuilder:
         self.copy_cols(x, out)
         return out
 
-    def row_scale(self, x, kvec, scale=1.0):
-        """y[n, :] = x[n, :] * k[n] * scale  (fp32, C == 1 use: depth = gamma * k_value)."""
+    def row_scale(self, x, kvec, into=None):
+        """y[n, :] = x[n, :] * k[n]  (fp32, C == 1 use: depth = gamma * k_value); into: y += x * k on an existing
+        row_scale result (depth += 1000 * offset, depth_net.py:127-131)."""
         p = self.plan
         assert x.C == 1 and kvec.pitch == 1
-        y = p.new(x.N, 1, 1, 1, torch.float32, pitch=1)
-        y.requires_grad = x.requires_grad
-        p.fwd.append(lambda s: nv.call("hrp_mul_f32", x.ptr(), x.pitch, kvec.ptr(), 1, y.ptr(), 1, x.N, 1, 0, s))
+        y = into if into is not None else p.new(x.N, 1, 1, 1, torch.float32, pitch=1)
+        facc = 1 if into is not None else 0
+        y.requires_grad = x.requires_grad or (into is not None and into.requires_grad)
+        p.fwd.append(lambda s: nv.call("hrp_mul_f32", x.ptr(), x.pitch, kvec.ptr(), 1, y.ptr(), 1, x.N, 1, facc, s))
         if p.need_grad:
             def bw():
                 if not y.grad_written or not x.requires_grad:

@@ -58,9 +58,10 @@ def uvz2xyz_singlepoint(uv, z, K):
     return torch.matmul(inv_intrinsics(K), v.unsqueeze(-1)).squeeze(-1)
 
 
-def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32"):
-    """RootNet(backbone).forward, depth_net.py:92-137 (pred_xy/use_offset/add_fc off); a ResNet trunk is followed by
-    global average pooling (:93-95)."""
+def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32", use_offset=False, add_fc=False):
+    """RootNet(backbone).forward, depth_net.py:92-137 (pred_xy off); a ResNet trunk is followed by global average
+    pooling (:93-95).  add_fc: the residual MLP on the pooled feature (:113-120, four Linear + BatchNorm1d + ReLU and a
+    fifth Linear added back); use_offset: depth += 1000 * offset_layer(feature) (:127-131)."""
     if backbone.startswith("resnet"):
         from .resnet import resnet_forward
         fm = resnet_forward(sd, x, prefix="backbone.", name="resnet50" if backbone == "resnet" else backbone, training=training)
@@ -68,8 +69,18 @@ def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32"):
     else:
         feat = hrnet_w32_forward(sd, x, prefix="backbone.", generate_hm=False, generate_feat=True,
                                  training=training)
+    if add_fc:
+        h = feat
+        for i in range(1, 5):
+            h = F.linear(h, sd[f"depth_fc{i}.weight"], sd[f"depth_fc{i}.bias"])
+            h = F.relu(F.batch_norm(h, sd[f"depth_bn{i}.running_mean"], sd[f"depth_bn{i}.running_var"], sd[f"depth_bn{i}.weight"],
+                                    sd[f"depth_bn{i}.bias"], training, 0.1, 1e-5))
+        feat = feat + F.linear(h, sd["depth_fc5.weight"], sd["depth_fc5.bias"])
     gamma = F.conv2d(feat[:, :, None, None], sd["depth_layer.weight"], sd["depth_layer.bias"])
-    return gamma.view(-1, 1) * k_value.view(-1, 1)
+    depth = gamma.view(-1, 1) * k_value.view(-1, 1)
+    if use_offset:
+        depth = depth + 1000.0 * F.conv2d(feat[:, :, None, None], sd["offset_layer.weight"], sd["offset_layer.bias"]).view(-1, 1)
+    return depth
 
 
 def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):

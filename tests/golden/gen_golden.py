@@ -283,6 +283,32 @@ def gen_depthnet():
     print("depthnet ok", out["depth_eval"].ravel(), out["loss"])
 
 
+def gen_depthnet_variants():
+    """RootNet('hrnet32', use_offset=True, add_fc=True) (depth_net.py:44-70, 113-131): eval and one training step."""
+    m = get_rootnet("hrnet32", use_offset=True, add_fc=True)
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    # B = 8: with two samples a BatchNorm1d output is sign(a - b) wherever |a - b| >> sqrt(eps) and anything in between
+    # elsewhere - a 1e-5 relative perturbation of the pooled feature moved the B = 2 prediction by 4 %
+    x, _, kv, _ = synth_inputs(8)
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        out["depth_eval"] = m(x, kv).numpy()
+    m.train()
+    gt = torch.linspace(0.7, 1.4, 8).reshape(8, 1)
+    pred = m(x, kv) / 1000.0
+    loss = torch.nn.L1Loss()(pred, gt)
+    loss.backward()
+    out["depth_train"], out["loss"], out["gt_depth"] = pred.detach().numpy(), np.array(loss.item()), gt.numpy()
+    grad_fixture(m, ["depth_fc1.weight", "depth_fc3.bias", "depth_bn2.weight", "depth_fc5.weight", "offset_layer.weight",
+                     "depth_layer.weight", "backbone.final_feat_layer.0.weight", "backbone.conv1.weight"], out, "")
+    sd = m.state_dict()
+    for n in ["depth_bn1.running_mean", "depth_bn4.running_var"]:
+        out["buf:" + n] = sd[n][:64].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_depthnet_variants.npz"), **out)
+    print("depthnet variants ok", out["depth_eval"].ravel(), out["depth_train"].ravel(), out["loss"])
+
+
 def gen_depthnet_resnet():
     """DepthNet with a ResNet-50 trunk (depth_net.py:16-18, 93-95) and the full network with ResNet-50 for BOTH
     trunks, eval; one DepthNet training step (train_depthnet.py:231-250)."""

@@ -120,6 +120,43 @@ def test_depthnet_golden_eval_and_train_step():
             np.testing.assert_allclose(sd[key[4:]][:64].cpu().numpy(), g[key], rtol=1e-3, atol=1e-6)
 
 
+def test_depthnet_variants_golden_eval_and_train_step():
+    """RootNet('hrnet32', use_offset=True, add_fc=True) (depth_net.py:44-70, 113-131): the residual MLP with BatchNorm1d on
+    the pooled feature and the offset head, eval + one training step against the reference's outputs.  (B = 2: the
+    BatchNorm1d layers normalise over two samples, the most noise-amplifying case there is.)"""
+    from hrpe_amd.lib.models.depth_net import get_rootnet
+    g = load("golden_depthnet_variants.npz")
+    m = get_rootnet("hrnet32", use_offset=True, add_fc=True)
+    ref_keys = set(m.state_dict().keys())
+    assert {"depth_fc1.weight", "depth_fc5.bias", "depth_bn4.running_var", "depth_bn1.num_batches_tracked",
+            "offset_layer.weight", "depth_layer.bias"} <= ref_keys
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m = m.to(DEV)
+    x, _, kv, _ = synth_inputs(8)
+    m.eval()
+    with torch.no_grad():
+        d = m(x.to(DEV), kv.to(DEV))
+    np.testing.assert_allclose(d.cpu().numpy(), g["depth_eval"], rtol=3e-4)
+    m.train()
+    pred = m(x.to(DEV), kv.to(DEV)) / 1000.0
+    loss = torch.nn.functional.l1_loss(pred, torch.tensor(g["gt_depth"]).to(DEV))
+    loss.backward()
+    print("\nvariants: pred", pred.detach().cpu().numpy().ravel(), "ref", g["depth_train"].ravel())
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["depth_train"], rtol=2e-3)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-3)
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            summary_check(params[name].grad, g, f"grad:{name}:", GRAD_TOL, what="depthnet variants ")
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("buf:"):
+            np.testing.assert_allclose(sd[key[4:]][:64].cpu().numpy(), g[key], rtol=2e-3, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        get_rootnet("hrnet32", pred_xy=True)
+
+
 NAMES8 = ["pose", "rot", "trans", "root_uv", "depth", "uvd", "xyz_int", "xyz_fk"]
 
 

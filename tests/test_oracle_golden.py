@@ -159,6 +159,43 @@ def test_depthnet_golden():
             np.testing.assert_allclose(sd[key[4:]][:64].detach().numpy(), g[key], rtol=1e-5, atol=1e-7)
 
 
+def depthnet_variants_sd():
+    shapes = hrnet_shapes("backbone.", hm=False, feat=True)
+    for i, (o, c) in enumerate([(1024, 2048), (512, 1024), (512, 512), (1024, 512), (2048, 1024)], 1):
+        shapes[f"depth_fc{i}.weight"], shapes[f"depth_fc{i}.bias"] = torch.empty(o, c), torch.empty(o)
+        if i < 5:
+            for leaf in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"depth_bn{i}.{leaf}"] = torch.empty(o)
+            shapes[f"depth_bn{i}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    for n in ("depth_layer", "offset_layer"):
+        shapes[n + ".weight"], shapes[n + ".bias"] = torch.empty(1, 2048, 1, 1), torch.empty(1)
+    return synth_state_dict(shapes)
+
+
+def test_depthnet_variants_golden():
+    """RootNet(use_offset=True, add_fc=True) (depth_net.py:44-70, 113-131): oracle against the reference's outputs."""
+    g = load("golden_depthnet_variants.npz")
+    sd = depthnet_variants_sd()
+    x, _, kv, _ = synth_inputs(8)
+    with torch.no_grad():
+        d = heads.rootnet_forward(sd, x, kv, use_offset=True, add_fc=True)
+    np.testing.assert_allclose(d.numpy(), g["depth_eval"], rtol=1e-6)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    pred = heads.rootnet_forward(sd, x, kv, training=True, use_offset=True, add_fc=True) / 1000.0
+    loss = torch.nn.functional.l1_loss(pred, torch.tensor(g["gt_depth"]))
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().numpy(), g["depth_train"], rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            check_summary(sd[name].grad, g, f"grad:{name}:", rtol=2e-3, atol=1e-9)
+        if key.startswith("buf:"):
+            np.testing.assert_allclose(sd[key[4:]][:64].detach().numpy(), g[key], rtol=1e-5, atol=1e-7)
+
+
 def full_sd(dof=8, nkp=7, init_pose=(0.0, 0.0, 0.0, -1.52715, 0.0, 1.8675, 0.0, 0.02)):
     shapes = {}
     shapes.update(hrnet_shapes("reg_backbone.", hm=True, feat=True, num_joints=nkp))

@@ -101,18 +101,24 @@ class RootNetwithRegInt(PlannedModule):
         self.reg_joint_map = args.reg_joint_map
         self.direct_reg_rot = args.direct_reg_rot
         self.rot_iterative_matmul = args.rot_iterative_matmul
-        if self.reg_joint_map or self.direct_reg_rot or self.rot_iterative_matmul:
-            raise NotImplementedError("reg_joint_map / direct_reg_rot / rot_iterative_matmul variants are off in every "
-                                      "shipped config and not built")
+        if self.reg_joint_map or self.rot_iterative_matmul:
+            raise NotImplementedError("reg_joint_map / rot_iterative_matmul variants are off in every shipped config and "
+                                      "not built")
         if self.rotation_dim != 6:
             raise NotImplementedError("only rotation_dim == 6")
         self.fc_pose_1 = Linear(self.feature_channel + npose, 1024)
         self.fc_pose_2 = Linear(1024, 1024)
         self.decpose = Linear(1024, npose)
         nn.init.xavier_uniform_(self.decpose.weight, gain=0.01)
-        self.fc_rot_1 = Linear(self.feature_channel + self.rotation_dim, 1024)
-        self.fc_rot_2 = Linear(1024, 1024)
-        self.decrot = Linear(1024, self.rotation_dim)
+        if self.direct_reg_rot:      # full_net.py:108-115: six stacked layers on the feature, one skip, decrot -> 6
+            self.fc_rot_1 = Linear(self.feature_channel, 1024)
+            for i in range(2, 7):
+                setattr(self, f"fc_rot_{i}", Linear(1024, 1024))
+            self.decrot = Linear(1024, 6)
+        else:
+            self.fc_rot_1 = Linear(self.feature_channel + self.rotation_dim, 1024)
+            self.fc_rot_2 = Linear(1024, 1024)
+            self.decrot = Linear(1024, self.rotation_dim)
         nn.init.xavier_uniform_(self.decrot.weight, gain=0.01)
         if self.rootnet_backbone_name in _HRNETS:
             self.rootnet_backbone = get_hrnet(type_name=32, num_joints=nkpt, depth_dim=self.depth_dim,
@@ -263,8 +269,15 @@ class RootNetwithRegInt(PlannedModule):
                 pose = self._iter_head(pb, xf_pose, self.init_pose, self.init_pose.shape[1], self.fc_pose_1,
                                        self.fc_pose_2, self.decpose)
             with par.lane(1):
-                rot = self._iter_head(pb, xf_rot, self.init_rot, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
-                                      self.decrot)
+                if self.direct_reg_rot:      # full_net.py:333-345
+                    xc1 = self.fc_rot_1.emit(pb, xf_rot)
+                    xc = xc1
+                    for i in range(2, 6):
+                        xc = getattr(self, f"fc_rot_{i}").emit(pb, xc)
+                    rot = self.decrot.emit(pb, self.fc_rot_6.emit(pb, xc, residual=xc1))
+                else:
+                    rot = self._iter_head(pb, xf_rot, self.init_rot, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
+                                          self.decrot)
         pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
         outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, 6)), ("dense", trans, (N, 3)),

@@ -94,7 +94,8 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
-                 fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32"):
+                 fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32",
+                 direct_reg_rot=False):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
@@ -120,7 +121,15 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
     root_uv = (uvd[:, root, :2] + 0.5) * image_size                                  # :302
     trans = uvz2xyz_singlepoint(root_uv, pred_depth, K)                               # :305
     pose = _iter_reg(sd, xf, sd["init_pose"].expand(B, -1), n_iter, "fc_pose_1", "fc_pose_2", "decpose")
-    rot = _iter_reg(sd, xf, sd["init_rot"].expand(B, -1), n_iter, "fc_rot_1", "fc_rot_2", "decrot")
+    if direct_reg_rot:      # full_net.py:333-345: six stacked Linear layers with one skip, no iteration, no init_rot
+        lin = lambda n, v: F.linear(v, sd[n + ".weight"], sd[n + ".bias"])   # noqa: E731
+        xc1 = lin("fc_rot_1", xf)
+        xc = xc1
+        for i in range(2, 7):
+            xc = lin(f"fc_rot_{i}", xc)
+        rot = lin("decrot", xc + xc1)
+    else:
+        rot = _iter_reg(sd, xf, sd["init_rot"].expand(B, -1), n_iter, "fc_rot_1", "fc_rot_2", "decrot")
     xyz_fk = robot.get_keypoints_root(pose, rot, trans, root=root)                    # :380-383
     return pose, rot, trans, root_uv, pred_depth, uvd, xyz_int, xyz_fk
 

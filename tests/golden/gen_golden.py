@@ -345,8 +345,8 @@ def gen_depthnet_resnet():
     print("depthnet resnet ok", out["depth_eval"].ravel(), out["loss"])
 
 
-def build_full(backbone_name=None, robot_type="panda"):
-    args = rh.default_args()
+def build_full(backbone_name=None, robot_type="panda", **over):
+    args = rh.default_args(**over)
     if backbone_name is not None:
         # the shipped full.yaml pairs a ResNet regression trunk (+ deconv head) with the HRNet root trunk;
         # get_resnet() copies torchvision's ImageNet weights, which do not exist here and are overwritten anyway
@@ -372,6 +372,18 @@ def gen_full_eval():
     np.savez_compressed(os.path.join(HERE, "golden_full_eval.npz"),
                         **{n: t.numpy() for n, t in zip(NAMES8, o)})
     print("full eval ok", o[0][0, :3])
+
+
+def gen_full_eval_direct_rot():
+    """direct_reg_rot = True (full_net.py:105-127, 333-345): the rotation comes from six stacked Linear layers."""
+    full, _ = build_full(direct_reg_rot=True)
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_direct_rot.npz"),
+                        **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval (direct_reg_rot) ok", o[1][0])
 
 
 def gen_full_eval_baxter():

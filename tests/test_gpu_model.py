@@ -160,6 +160,42 @@ def test_depthnet_variants_golden_eval_and_train_step():
 NAMES8 = ["pose", "rot", "trans", "root_uv", "depth", "uvd", "xyz_int", "xyz_fk"]
 
 
+def test_full_direct_reg_rot_golden_and_gradients():
+    """direct_reg_rot = True (full_net.py:105-127, 333-345): eval 8-tuple against the reference's output; gradients of the
+    six stacked rotation layers against the oracle on the host (train mode, B = 2)."""
+    from oracle import fk as ofk, heads as oheads
+    g = load("golden_full_eval_direct_rot.npz")
+    m = build_full(direct_reg_rot=True).eval()
+    assert "fc_rot_6.weight" in m.state_dict() and tuple(m.fc_rot_1.weight.shape) == (1024, 2048)
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    for n, t in zip(NAMES8, out):
+        ref = g[n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    m.train()
+    m.zero_grad()
+    out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    (out[1].square().sum() + out[7].square().sum()).backward()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    names = [f"fc_rot_{i}.weight" for i in (1, 3, 6)] + ["decrot.weight", "decrot.bias", "fc_pose_1.weight"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    robot = ofk.Robot(PANDA_URDF)
+    sd0 = {k: v.clone() for k, v in synth_state_dict(m.state_dict()).items()}    # (running statistics before the step)
+    for k in sd:
+        if "running" in k or k.endswith("num_batches_tracked"):
+            sd[k] = sd0[k]
+    o = oheads.full_forward(sd, robot, x_reg, x_root, kv, K, training=True, direct_reg_rot=True)
+    (o[1].square().sum() + o[7].square().sum()).backward()
+    params = dict(m.named_parameters())
+    for k in names:
+        a, b = params[k].grad.detach().cpu(), sd[k].grad
+        e = float((a - b).norm() / (b.norm() + 1e-30))
+        assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
+
+
 def test_full_eval_golden():
     g = load("golden_full_eval.npz")
     m = build_full().eval()

@@ -291,6 +291,22 @@ def test_full_eval_golden(robot):
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
+def test_full_eval_direct_rot_golden(robot):
+    """direct_reg_rot = True (full_net.py:105-127, 333-345)."""
+    g = load("golden_full_eval_direct_rot.npz")
+    sd = {k: v for k, v in full_sd().items() if not k.startswith(("fc_rot_", "decrot"))}
+    shapes = {"fc_rot_1.weight": torch.empty(1024, 2048), "fc_rot_1.bias": torch.empty(1024),
+              "decrot.weight": torch.empty(6, 1024), "decrot.bias": torch.empty(6)}
+    for i in range(2, 7):
+        shapes[f"fc_rot_{i}.weight"], shapes[f"fc_rot_{i}.bias"] = torch.empty(1024, 1024), torch.empty(1024)
+    sd.update(synth_state_dict(shapes))
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K, direct_reg_rot=True)
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
 def test_full_eval_baxter_golden():
     """robot_type = 'baxter' (full_net.py:48-50): 15 DoF, 17 key-points -> 1088 heat-map channels, tree FK with
     key-point offsets; init pose = const.py:183-199 mean."""

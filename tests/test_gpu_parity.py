@@ -19,7 +19,7 @@ from synth import synth_inputs
 from test_gpu_model import DEV, NAMES8, build_full, load, summary_check
 
 pytestmark = pytest.mark.gpu
-GRAD_TOL_B8 = 2e-2
+GRAD_TOL_B8 = 2.5e-2
 # Measured on MI355X (round 2) with the bf16 trunk against the reference's fp32 fixtures / the fp32 HIP path; the bounds are
 # ~3x the measurement.  Eval mode (running statistics) is tight.  Train mode normalises with the statistics of 8 (or 64)
 # images of a randomly weighted 330-layer network: the soft-argmax over 262 144 nearly flat heat-map bins turns bf16
@@ -76,7 +76,8 @@ def test_full_train_step_golden_b8():
     channel amplifies rounding less than the B = 2 fixture (gate 3e-2 there): measured over repeated runs on MI355X the
     l2 error of the sampled gradients is <= 1e-5 for the heads, 5e-3 .. 9e-3 for most trunk tensors and 1.0e-2 .. 1.6e-2
     for the two deepest ones (stem conv1, stage3.0 - the end of a 330-layer backward chain whose run-to-run spread from
-    the fp32 atomics alone is 5e-3 .. 1e-2, see test_grouped_plan_matches_one_by_one_plan).  Gate: 2e-2."""
+    the fp32 atomics alone is 5e-3 .. 1e-2, see test_grouped_plan_matches_one_by_one_plan).  Gate: 2.5e-2 on the l2 error,
+    with summary_check's allowance for the few elements a ReLU tie moves."""
     from hrpe_amd.lib.core.function import full_loss
     g = load("golden_full_train_b8.npz")
     m = build_full().train()

@@ -113,10 +113,19 @@ class _FusedPoseLoss(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(gs)
 
 
-def full_loss(pred, gt, K, root=3, image_size=256.0, weights=FULL_YAML_WEIGHTS):
+def full_loss(pred, gt, K, root=3, image_size=256.0, weights=FULL_YAML_WEIGHTS, kps_need_depth=None):
     """pred: the model's 8-tuple.  gt: dict(pose, root_rot, root_trans, root_uv, kp3d, kp2d, mask).
     Returns (loss, dict of the ten terms named as in function.py:313-319).  Device tensors: one fused launch
-    (hrp_pose_loss, analytic gradient); host tensors: the tensor-expression form below (tests of the harness)."""
+    (hrp_pose_loss, analytic gradient); host tensors: the tensor-expression form below (tests of the harness).
+    multi_kp (a 9-tuple with pred_depths after pred_depth, function.py:115-117): pass kps_need_depth; the L1 term
+    over the listed key-points' depths is added with weight 1 (function.py:300-311) and is not in the dict, as there."""
+    if len(pred) == 9:
+        assert kps_need_depth is not None, "a multi_kp prediction needs kps_need_depth"
+        depths = pred[5]
+        loss, terms = full_loss(pred[:5] + pred[6:], gt, K, root, image_size, weights)
+        gt_depths = gt["kp3d"][:, list(kps_need_depth), 2]
+        assert gt_depths.shape == depths.shape, (gt_depths.shape, depths.shape)
+        return loss + torch.nn.functional.l1_loss(depths, gt_depths), terms
     if pred[0].is_cuda:
         pose, rot, trans, root_uv, depth, uvd, xyz_int, xyz_fk = pred
         f32 = lambda t: t.contiguous().float()   # noqa: E731

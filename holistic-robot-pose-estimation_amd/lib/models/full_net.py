@@ -131,10 +131,11 @@ class RootNetwithRegInt(PlannedModule):
             raise NotImplementedError
         self.multi_kp = args.multi_kp
         self.add_fc = args.add_fc
-        if self.multi_kp or self.add_fc:
-            raise NotImplementedError("multi_kp / add_fc are off in every shipped config and not built")
-        self.kps_need_depth = [args.reference_keypoint_id]
-        self.depth_num = 1
+        if self.add_fc:
+            raise NotImplementedError("add_fc (LeakyReLU MLP on the depth feature) is off in every shipped config and not built")
+        # full_net.py:146-148: with multi_kp the depth layer predicts one gamma per listed key-point
+        self.kps_need_depth = list(args.kps_need_depth) if self.multi_kp else [args.reference_keypoint_id]
+        self.depth_num = len(self.kps_need_depth)
         self.depth_layer = Conv2d(self.inplanes, self.depth_num, 1, bias=True)
         # reference full_net.py:167-177: every conv ~ N(0, sqrt(2/n)), BN = (1, 0), depth layer N(0, 0.001)
         for m in self.modules():
@@ -255,6 +256,18 @@ class RootNetwithRegInt(PlannedModule):
                 with par.lane(1):
                     _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
                     gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+        depths = None
+        if self.multi_kp:      # full_net.py:275-279: pred_depths = gamma * k / 1000 per listed key-point; the root's feeds the rest
+            from hrpe_amd.plan import TensorH
+            gamma_all = gamma
+            kvn = pb.cat_cols([kv] * self.depth_num)
+            depths = pb.row_scale(pb.row_scale(gamma_all, kvn), pb.constant(N, self.depth_num, 1e-3))
+            ri = self.kps_need_depth.index(root)
+            col = TensorH(pb.plan, N, 1, 1, 1, torch.float32, buf=gamma_all.buf, offset=gamma_all.offset + ri,
+                          pitch=gamma_all.pitch, base=gamma_all.base if gamma_all.base is not None else gamma_all)
+            col.requires_grad = gamma_all.requires_grad
+            gamma = pb.plan.new(N, 1, 1, 1, torch.float32, pitch=1)
+            pb.copy_cols(col, gamma)
         il = self.integral_layer
         uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
         depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,
@@ -283,6 +296,8 @@ class RootNetwithRegInt(PlannedModule):
         outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, 6)), ("dense", trans, (N, 3)),
                 ("dense", root_uv, (N, 2)), ("dense", depth, (N, 1)), ("dense", uvd, (N, J, 3)),
                 ("dense", xyz_int, (N, J, 3)), ("dense", xyz_fk, (N, J, 3))]
+        if depths is not None:      # full_net.py:392-395: the 9-tuple carries pred_depths after pred_depth
+            outs.insert(5, ("dense", depths, (N, self.depth_num)))
         return ["x_reg", "x_root", "k_value", "K"], outs, {"x_reg": xr, "x_root": xo}
 
     def forward(self, x_reg_input, x_root_input, k_value, K, init_pose=None, init_rot=None, test_fps=False):

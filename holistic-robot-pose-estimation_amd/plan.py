@@ -1872,19 +1872,21 @@ class PlanBuilder:
         return out
 
     def row_scale(self, x, kvec, into=None):
-        """y[n, :] = x[n, :] * k[n]  (fp32, C == 1 use: depth = gamma * k_value); into: y += x * k on an existing
-        row_scale result (depth += 1000 * offset, depth_net.py:127-131)."""
+        """y[n, c] = x[n, c] * k[n, c]  (fp32; C == 1: depth = gamma * k_value, C > 1: the multi_kp depths); into: y += x * k
+        on an existing row_scale result (depth += 1000 * offset, depth_net.py:127-131)."""
         p = self.plan
-        assert x.C == 1 and kvec.pitch == 1
-        y = into if into is not None else p.new(x.N, 1, 1, 1, torch.float32, pitch=1)
+        Cc = x.C
+        assert kvec.C == Cc
+        y = into if into is not None else p.new(x.N, 1, 1, Cc, torch.float32, pitch=Cc)
         facc = 1 if into is not None else 0
         y.requires_grad = x.requires_grad or (into is not None and into.requires_grad)
-        p.fwd.append(lambda s: nv.call("hrp_mul_f32", x.ptr(), x.pitch, kvec.ptr(), 1, y.ptr(), 1, x.N, 1, facc, s))
+        p.fwd.append(lambda s: nv.call("hrp_mul_f32", x.ptr(), x.pitch, kvec.ptr(), kvec.pitch, y.ptr(), y.pitch, x.N, Cc, facc, s))
         if p.need_grad:
             def bw():
                 if not y.grad_written or not x.requires_grad:
                     return
                 acc = x.take_grad_slot()
-                p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), 1, kvec.ptr(), 1, x.gptr(), x.pitch, x.N, 1, acc, s))
+                p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), y.pitch, kvec.ptr(), kvec.pitch, x.gptr(), x.pitch, x.N, Cc,
+                                               acc, s))
             self.bwd_stack.append(bw)
         return y

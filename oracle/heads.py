@@ -95,7 +95,7 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
                  fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32",
-                 direct_reg_rot=False):
+                 direct_reg_rot=False, kps_need_depth=None):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
@@ -107,7 +107,13 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
         feat_root = hrnet_w32_forward(sd, x_root, prefix="rootnet_backbone.", generate_hm=False,
                                       generate_feat=True, training=training)
     gamma = F.conv2d(feat_root[:, :, None, None], sd["depth_layer.weight"], sd["depth_layer.bias"])
-    pred_depth = (gamma.view(-1, 1) * k_value.view(-1, 1)).reshape(B, 1) / 1000.0   # :281-282
+    pred_depths = None
+    if kps_need_depth is not None:                                                    # multi_kp, :275-279
+        n = len(kps_need_depth)
+        pred_depths = gamma.view(-1, n) * k_value.view(-1, 1).expand(-1, n) / 1000.0
+        pred_depth = pred_depths[:, kps_need_depth.index(root)].reshape(-1, 1)
+    else:
+        pred_depth = (gamma.view(-1, 1) * k_value.view(-1, 1)).reshape(B, 1) / 1000.0   # :281-282
     if reg_backbone.startswith("resnet"):                                             # :293-296
         from .resnet import deconv_head_forward, resnet_forward
         x_out = resnet_forward(sd, x_reg, prefix="reg_backbone.", name="resnet50" if reg_backbone == "resnet" else reg_backbone,
@@ -131,6 +137,8 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
     else:
         rot = _iter_reg(sd, xf, sd["init_rot"].expand(B, -1), n_iter, "fc_rot_1", "fc_rot_2", "decrot")
     xyz_fk = robot.get_keypoints_root(pose, rot, trans, root=root)                    # :380-383
+    if pred_depths is not None:                                                       # :392-393
+        return pose, rot, trans, root_uv, pred_depth, pred_depths, uvd, xyz_int, xyz_fk
     return pose, rot, trans, root_uv, pred_depth, uvd, xyz_int, xyz_fk
 
 

@@ -386,6 +386,19 @@ def gen_full_eval_direct_rot():
     print("full eval (direct_reg_rot) ok", o[1][0])
 
 
+def gen_full_eval_multi_kp():
+    """multi_kp = True, kps_need_depth = [0, 3, 6] (full_net.py:146-148, 275-279, 392-393): the 9-tuple."""
+    full, _ = build_full(multi_kp=True, kps_need_depth=[0, 3, 6])
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    assert len(o) == 9
+    names = NAMES8[:5] + ["depths"] + NAMES8[5:]
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_multi_kp.npz"), **{n: t.numpy() for n, t in zip(names, o)})
+    print("full eval (multi_kp) ok", o[4].ravel(), o[5])
+
+
 def gen_full_eval_baxter():
     """15 DoF / 17 key-points: 1088 heat-map channels, 2063-wide pose regressor, tree FK with key-point offsets."""
     full, _ = build_full(robot_type="baxter")

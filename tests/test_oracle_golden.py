@@ -307,6 +307,19 @@ def test_full_eval_direct_rot_golden(robot):
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
+def test_full_eval_multi_kp_golden(robot):
+    """multi_kp = True, kps_need_depth = [0, 3, 6] (full_net.py:146-148, 275-279, 392-393): the 9-tuple."""
+    g = load("golden_full_eval_multi_kp.npz")
+    sd = {k: v for k, v in full_sd().items() if not k.startswith("depth_layer")}
+    sd.update(synth_state_dict({"depth_layer.weight": torch.empty(3, 2048, 1, 1), "depth_layer.bias": torch.empty(3)}))
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K, kps_need_depth=[0, 3, 6])
+    assert len(out) == 9
+    for n, t in zip(NAMES8[:5] + ["depths"] + NAMES8[5:], out):
+        np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
 def test_full_eval_baxter_golden():
     """robot_type = 'baxter' (full_net.py:48-50): 15 DoF, 17 key-points -> 1088 heat-map channels, tree FK with
     key-point offsets; init pose = const.py:183-199 mean."""

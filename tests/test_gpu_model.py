@@ -201,6 +201,23 @@ def test_full_direct_reg_rot_golden_and_gradients():
         assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
 
 
+def test_full_test_fps_split_timers():
+    """test_fps = True (full_net.py:253-286, 385-392): the 8-tuple plus (time_root, time_other, time_whole); the root part
+    is timed as its own plan (root trunk + depth layer), the rest is the remainder."""
+    m = build_full().eval()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    with torch.no_grad():
+        ref = m(x_reg, x_root, kv, K)
+        m(x_reg, x_root, kv, K, test_fps=True)          # (first call builds the timing plan)
+        out = m(x_reg, x_root, kv, K, test_fps=True)
+    assert len(out) == 9 and len(out[8]) == 3
+    t_root, t_other, t_whole = out[8]
+    assert 0 < t_root < t_whole and t_other >= 0 and abs(t_root + t_other - t_whole) < 1e-9
+    assert t_root > 0.15 * t_whole, (t_root, t_whole)       # one of two equally sized trunks: not a token number
+    for a, b in zip(ref, out[:8]):     # (not bit for bit: the eval plan's fp32 split-K layers sum with atomics)
+        assert float((a - b).abs().max()) <= 5e-5 * max(1.0, float(a.abs().max()))
+
+
 def test_full_multi_kp_golden_and_loss():
     """multi_kp = True (full_net.py:146-148, 275-279, 392-393): the 9-tuple against the reference's output; the loss with
     the extra L1 term over the listed key-points' depths (function.py:300-311) and its gradient into depth_layer

@@ -682,6 +682,61 @@ extern "C" int hrp_pose_geometry_bwd(const float* gamma, const float* k_value, c
   return check_launch("pose_geometry_bwd");
 }
 
+// ---- rot6d composition (rot_iterative_matmul, full_net.py:346-362): out = rot6d(R(a) R(b)) ---------------------------
+// forward: one thread per sample; backward: the same templated code on dual numbers, one evaluation per input (12).
+template <class S>
+__device__ __forceinline__ void rot6d_compose(const S* a, const S* b, S* out) {
+  const S z3[3] = {lift<S>(0.f), lift<S>(0.f), lift<S>(0.f)};
+  const Rigid<S> A = base_to_cam<S>(a, z3), B = base_to_cam<S>(b, z3);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)      // geometries.py:117-131: the first two rows of the product
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[3 * i + j] = A.r[i][0] * B.r[0][j] + A.r[i][1] * B.r[1][j] + A.r[i][2] * B.r[2][j];
+}
+
+__global__ void rot6d_compose_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float av[6], bv[6], o[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { av[i] = a[n * 6 + i]; bv[i] = b[n * 6 + i]; }
+  rot6d_compose<float>(av, bv, o);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[n * 6 + i] = o[i];
+}
+
+__global__ void rot6d_compose_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dout,
+                                         float* __restrict__ da, float* __restrict__ db, int N, int acc_a, int acc_b) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  Dual av[6], bv[6], o[6];
+  float g[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { av[i] = {a[n * 6 + i], 0.f}; bv[i] = {b[n * 6 + i], 0.f}; g[i] = dout[n * 6 + i]; }
+  for (int k = 0; k < 12; ++k) {
+    if (k < 6) av[k].d = 1.f; else bv[k - 6].d = 1.f;
+    rot6d_compose<Dual>(av, bv, o);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t += o[i].d * g[i];
+    if (k < 6) { av[k].d = 0.f; if (da) da[n * 6 + k] = acc_a ? da[n * 6 + k] + t : t; }
+    else { bv[k - 6].d = 0.f; if (db) db[n * 6 + k - 6] = acc_b ? db[n * 6 + k - 6] + t : t; }
+  }
+}
+
+extern "C" int hrp_rot6d_compose_fwd(const float* a, const float* b, float* out, int N, void* stream) {
+  HRP_REQUIRE(a && b && out && N > 0, "rot6d_compose_fwd: bad args");
+  hipLaunchKernelGGL(rot6d_compose_fwd_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, a, b, out, N);
+  return check_launch("rot6d_compose_fwd");
+}
+
+extern "C" int hrp_rot6d_compose_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int N, int acc_a,
+                                     int acc_b, void* stream) {
+  HRP_REQUIRE(a && b && dout && (da || db) && N > 0, "rot6d_compose_bwd: bad args");
+  hipLaunchKernelGGL(rot6d_compose_bwd_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, a, b, dout, da, db, N, acc_a, acc_b);
+  return check_launch("rot6d_compose_bwd");
+}
+
 extern "C" int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
                                   const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream) {
   HRP_REQUIRE(chain_dev && q && rot6d && trans && xyz && B > 0, "fk_project_fwd: bad args");

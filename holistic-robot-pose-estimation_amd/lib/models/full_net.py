@@ -101,9 +101,8 @@ class RootNetwithRegInt(PlannedModule):
         self.reg_joint_map = args.reg_joint_map
         self.direct_reg_rot = args.direct_reg_rot
         self.rot_iterative_matmul = args.rot_iterative_matmul
-        if self.reg_joint_map or self.rot_iterative_matmul:
-            raise NotImplementedError("reg_joint_map / rot_iterative_matmul variants are off in every shipped config and "
-                                      "not built")
+        if self.reg_joint_map:
+            raise NotImplementedError("the reg_joint_map variant is off in every shipped config and not built")
         if self.rotation_dim != 6:
             raise NotImplementedError("only rotation_dim == 6")
         self.fc_pose_1 = Linear(self.feature_channel + npose, 1024)
@@ -194,15 +193,19 @@ class RootNetwithRegInt(PlannedModule):
                 yield
         out["feat"] = pb.avgpool(h)
 
-    def _iter_head(self, pb, xf, init_buf, np_, fc1, fc2, dec):
-        """full_net.py:318-331: p <- p + dec(drop(fc2(drop(fc1([xf; p])))))  x n_iter."""
+    def _iter_head(self, pb, xf, init_buf, np_, fc1, fc2, dec, matmul=False):
+        """full_net.py:318-331: p <- p + dec(drop(fc2(drop(fc1([xf; p])))))  x n_iter; matmul (rot_iterative_matmul,
+        :346-362): p <- rot6d(R(dec(..)) @ R(p)) instead of the sum."""
         N = xf.N
         pred = pb.broadcast_row(init_buf, N, np_)
         for _ in range(self.n_iter):
             xc = pb.cat_cols([xf, pred])
             h = pb.dropout(fc1.emit(pb, xc), self.p_dropout)
             h = pb.dropout(fc2.emit(pb, h), self.p_dropout)
-            pred = dec.emit(pb, h, residual=pred)
+            if matmul:
+                pred = pb.rot6d_compose(pb.dense(dec.emit(pb, h)), pb.dense(pred))
+            else:
+                pred = dec.emit(pb, h, residual=pred)
         return pred
 
     def _build(self, pb, x_reg, x_root, k_value, K):
@@ -290,7 +293,7 @@ class RootNetwithRegInt(PlannedModule):
                     rot = self.decrot.emit(pb, self.fc_rot_6.emit(pb, xc, residual=xc1))
                 else:
                     rot = self._iter_head(pb, xf_rot, self.init_rot, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
-                                          self.decrot)
+                                          self.decrot, matmul=self.rot_iterative_matmul)
         pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
         outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, 6)), ("dense", trans, (N, 3)),

@@ -1871,6 +1871,26 @@ class PlanBuilder:
         self.copy_cols(x, out)
         return out
 
+    def rot6d_compose(self, a, b):
+        """out = rotmat_to_rot6d(R(a) @ R(b)) on dense fp32 [N, 6] tensors (full_net.py:362)."""
+        p = self.plan
+        assert a.C == 6 and b.C == 6 and a.pitch == 6 and b.pitch == 6
+        N = a.N
+        out = p.new(N, 1, 1, 6, torch.float32, pitch=6)
+        out.requires_grad = p.need_grad and (a.requires_grad or b.requires_grad)
+        p.fwd.append(lambda s: nv.call("hrp_rot6d_compose_fwd", a.ptr(), b.ptr(), out.ptr(), N, s))
+        if p.need_grad:
+            def bw():
+                if not out.grad_written or not out.requires_grad:
+                    return
+                acc_a = a.take_grad_slot() if a.requires_grad else 0
+                acc_b = b.take_grad_slot() if b.requires_grad else 0
+                p.bwd.append(lambda s: nv.call("hrp_rot6d_compose_bwd", a.ptr(), b.ptr(), out.gptr(),
+                                               a.gptr() if a.requires_grad else None, b.gptr() if b.requires_grad else None,
+                                               N, acc_a, acc_b, s))
+            self.bwd_stack.append(bw)
+        return out
+
     def row_scale(self, x, kvec, into=None):
         """y[n, c] = x[n, c] * k[n, c]  (fp32; C == 1: depth = gamma * k_value, C > 1: the multi_kp depths); into: y += x * k
         on an existing row_scale result (depth += 1000 * offset, depth_net.py:127-131)."""

@@ -370,6 +370,13 @@ int hrp_pose_geometry_bwd(const float* gamma, const float* k_value, const float*
                           const float* d_depth, const float* d_xyz, const float* d_root_uv, const float* d_trans,
                           float* d_gamma, float* d_uvd, void* stream);
 
+/* out[n] = rotmat_to_rot6d(rot6d_to_rotmat(a[n]) @ rot6d_to_rotmat(b[n]))  (dense fp32 [N, 6]): the update of the
+ * rot_iterative_matmul regressor (reference full_net.py:346-362, lib/utils/geometries.py:100-131).  Backward: exact, by
+ * forward-mode differentiation of the same code; da / db may be NULL; acc_*: add to the existing gradient. */
+int hrp_rot6d_compose_fwd(const float* a, const float* b, float* out, int N, void* stream);
+int hrp_rot6d_compose_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int N, int acc_a, int acc_b,
+                          void* stream);
+
 /* q [B,dof], rot6d [B,6], trans [B,3], K [B,9] (may be NULL -> no uv) -> xyz [B,nkp,3], uv [B,nkp,2].
  * root > 0 re-roots the chain at keypoint `root` (urdf_robot.py:194-198). One wavefront per sample. */
 int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,

@@ -95,7 +95,7 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
                  fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32",
-                 direct_reg_rot=False, kps_need_depth=None):
+                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
@@ -134,6 +134,13 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
         for i in range(2, 7):
             xc = lin(f"fc_rot_{i}", xc)
         rot = lin("decrot", xc + xc1)
+    elif rot_iterative_matmul:      # full_net.py:346-362: the decoded 6-vector is composed onto the estimate as a rotation
+        from .fk import rot6d_to_rotmat, rotmat_to_rot6d
+        rot = sd["init_rot"].expand(B, -1)
+        for _ in range(n_iter):
+            h = F.linear(torch.cat([xf, rot], 1), sd["fc_rot_1.weight"], sd["fc_rot_1.bias"])
+            h = F.linear(h, sd["fc_rot_2.weight"], sd["fc_rot_2.bias"])
+            rot = rotmat_to_rot6d(rot6d_to_rotmat(F.linear(h, sd["decrot.weight"], sd["decrot.bias"])) @ rot6d_to_rotmat(rot))
     else:
         rot = _iter_reg(sd, xf, sd["init_rot"].expand(B, -1), n_iter, "fc_rot_1", "fc_rot_2", "decrot")
     xyz_fk = robot.get_keypoints_root(pose, rot, trans, root=root)                    # :380-383

@@ -399,6 +399,17 @@ def gen_full_eval_multi_kp():
     print("full eval (multi_kp) ok", o[4].ravel(), o[5])
 
 
+def gen_full_eval_rot_matmul():
+    """rot_iterative_matmul = True (full_net.py:346-362): the rotation estimate is updated by composing rotations."""
+    full, _ = build_full(rot_iterative_matmul=True)
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_rot_matmul.npz"), **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval (rot_iterative_matmul) ok", o[1][0])
+
+
 def gen_full_eval_baxter():
     """15 DoF / 17 key-points: 1088 heat-map channels, 2063-wide pose regressor, tree FK with key-point offsets."""
     full, _ = build_full(robot_type="baxter")

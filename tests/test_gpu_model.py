@@ -201,6 +201,49 @@ def test_full_direct_reg_rot_golden_and_gradients():
         assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
 
 
+def test_rot6d_compose_kernel_and_rot_iterative_matmul_golden():
+    """hrp_rot6d_compose_* against torch (forward and both gradients), then rot_iterative_matmul = True
+    (full_net.py:346-362) against the reference's 8-tuple and the oracle's gradients of the rotation head."""
+    from hrpe_amd import _native as nv
+    from oracle import fk as ofk, heads as oheads
+    gen = torch.Generator().manual_seed(11)
+    a, b, go = [torch.randn(37, 6, generator=gen) for _ in range(3)]
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    want = ofk.rotmat_to_rot6d(ofk.rot6d_to_rotmat(ar) @ ofk.rot6d_to_rotmat(br))
+    (want * go).sum().backward()
+    ad, bd, god = a.to(DEV), b.to(DEV), go.to(DEV)
+    out, da, db = torch.zeros(37, 6, device=DEV), torch.full((37, 6), 2.0, device=DEV), torch.zeros(37, 6, device=DEV)
+    nv.call("hrp_rot6d_compose_fwd", ad.data_ptr(), bd.data_ptr(), out.data_ptr(), 37, None)
+    nv.call("hrp_rot6d_compose_bwd", ad.data_ptr(), bd.data_ptr(), god.data_ptr(), da.data_ptr(), db.data_ptr(), 37, 1, 0, None)
+    torch.cuda.synchronize()
+    assert float((out.cpu() - want.detach()).abs().max()) < 2e-6
+    assert float((da.cpu() - 2.0 - ar.grad).abs().max()) < 1e-4 * float(ar.grad.abs().max())      # (accumulated onto 2.0)
+    assert float((db.cpu() - br.grad).abs().max()) < 1e-4 * float(br.grad.abs().max())
+    g = load("golden_full_eval_rot_matmul.npz")
+    m = build_full(rot_iterative_matmul=True).eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    for n, t in zip(NAMES8, o):
+        ref = g[n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    m.train()
+    m.zero_grad()
+    o = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    (o[1].square().sum() + o[7].square().sum()).backward()
+    sd = {k: v.detach().cpu().clone() for k, v in synth_state_dict(m.state_dict()).items()}
+    names = ["fc_rot_1.weight", "fc_rot_2.weight", "decrot.weight", "decrot.bias"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    oo = oheads.full_forward(sd, ofk.Robot(PANDA_URDF), x_reg, x_root, kv, K, training=True, rot_iterative_matmul=True)
+    (oo[1].square().sum() + oo[7].square().sum()).backward()
+    params = dict(m.named_parameters())
+    for k in names:
+        e = float((params[k].grad.detach().cpu() - sd[k].grad).norm() / (sd[k].grad.norm() + 1e-30))
+        assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
+
+
 def test_full_test_fps_split_timers():
     """test_fps = True (full_net.py:253-286, 385-392): the 8-tuple plus (time_root, time_other, time_whole); the root part
     is timed as its own plan (root trunk + depth layer), the rest is the remainder."""

@@ -320,6 +320,17 @@ def test_full_eval_multi_kp_golden(robot):
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
+def test_full_eval_rot_matmul_golden(robot):
+    """rot_iterative_matmul = True (full_net.py:346-362)."""
+    g = load("golden_full_eval_rot_matmul.npz")
+    sd = full_sd()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K, rot_iterative_matmul=True)
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
 def test_full_eval_baxter_golden():
     """robot_type = 'baxter' (full_net.py:48-50): 15 DoF, 17 key-points -> 1088 heat-map channels, tree FK with
     key-point offsets; init pose = const.py:183-199 mean."""

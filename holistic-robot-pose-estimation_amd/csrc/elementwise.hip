@@ -99,6 +99,7 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
   const int c = cv * V;
   const int cbase = by * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;  // pixels per block-iteration
+  const float neg = d.relu == 2 ? 0.01f : 0.f;   // relu 2 = nn.LeakyReLU() (slope 0.01): the mask / sign logic is ReLU's
   float sc[MAXIN][V], sh[MAXIN][V];
   {
     float m[V], iv[V];
@@ -160,7 +161,7 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
             d.mask[pu * d.mask_pitch + cv] = (uint8_t)bits;
           }
 #pragma unroll
-          for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+          for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : neg * acc[i];
         }
         VecIO<T, V>::st(d.out, pu * d.out_pitch + c, acc);
       }
@@ -201,7 +202,7 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
         d.mask[(size_t)p * d.mask_pitch + cv] = (uint8_t)bits;
       }
 #pragma unroll
-      for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+      for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : neg * acc[i];
     }
     VecIO<T, V>::st(d.out, (size_t)p * d.out_pitch + c, acc);
   }
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tp
 // pooled, masked output gradient at input pixel q = (n, qy, qx)
 template <typename T, int V>
 __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q, int c, float* g) {
+  const float neg = d.relu == 2 ? 0.01f : 0.f;
 #pragma unroll
   for (int i = 0; i < V; ++i) g[i] = 0.f;
   const int up = d.in.up;
@@ -235,12 +237,12 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q
         if (V > 1 && d.mask) {
           const unsigned bits = d.mask[p * d.mask_pitch + c / V];
 #pragma unroll
-          for (int i = 0; i < V; ++i) go[i] = (bits >> i) & 1u ? go[i] : 0.f;
+          for (int i = 0; i < V; ++i) go[i] = (bits >> i) & 1u ? go[i] : neg * go[i];
         } else {
           float o[V];
           VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
 #pragma unroll
-          for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : 0.f;
+          for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : neg * go[i];
         }
       }
 #pragma unroll
@@ -255,6 +257,7 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q
 template <typename T, int V, int RM, int U>
 __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int c, unsigned q, unsigned stride, unsigned nq,
                                                   const float (&mean)[V], const float (&inv)[V], float (&s0)[V], float (&s1)[V]) {
+  const float neg = d.relu == 2 ? 0.01f : 0.f;
   for (; q + (U - 1) * stride < nq; q += U * stride) {
     typename VecIO<T, V>::Raw go[U], xin[U];
     unsigned bits[U];
@@ -274,8 +277,8 @@ __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int 
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         float g = gf[i];
-        if constexpr (RM == 1) g = (bits[u] >> i) & 1u ? g : 0.f;
-        if constexpr (RM == 2) g = o[i] > 0.f ? g : 0.f;
+        if constexpr (RM == 1) g = (bits[u] >> i) & 1u ? g : neg * g;
+        if constexpr (RM == 2) g = o[i] > 0.f ? g : neg * g;
         s0[i] += g;
         s1[i] += g * (xf[i] - mean[i]) * inv[i];
       }
@@ -422,6 +425,7 @@ __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, cons
     // U pixels per thread and trip, every load of the trip issued before the first use (the branches are uniform)
     constexpr int U = HRP_EW_APPLY_U;
     const bool bn = d.in.mode == HRP_EW_BN_TRAIN, use_bits = d.relu && V > 1 && d.mask, use_out = d.relu && !use_bits;
+    const float neg = d.relu == 2 ? 0.01f : 0.f;
     for (; q + (U - 1) * stride < nq; q += U * stride) {
       // (the rarer operands - saved output instead of the bit mask, accumulation targets - are read where they are
       // used: keeping them in the batch cost 100 registers on every variant of the kernel)
@@ -442,12 +446,12 @@ __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, cons
         const size_t p = (size_t)q + (size_t)u * stride;
         if (use_bits) {
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] = (bits[u] >> i) & 1u ? g[u][i] : 0.f;
+          for (int i = 0; i < V; ++i) g[u][i] = (bits[u] >> i) & 1u ? g[u][i] : neg * g[u][i];
         } else if (use_out) {
           float o[V];
           VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] = o[i] > 0.f ? g[u][i] : 0.f;
+          for (int i = 0; i < V; ++i) g[u][i] = o[i] > 0.f ? g[u][i] : neg * g[u][i];
         }
         if (d.din2) {
           if (d.accumulate2) {

@@ -130,8 +130,13 @@ class RootNetwithRegInt(PlannedModule):
             raise NotImplementedError
         self.multi_kp = args.multi_kp
         self.add_fc = args.add_fc
-        if self.add_fc:
-            raise NotImplementedError("add_fc (LeakyReLU MLP on the depth feature) is off in every shipped config and not built")
+        if self.add_fc:      # full_net.py:150-157 (depth_dropout is constructed there but never applied)
+            from .depth_net import _Linear1x1
+            self.depth_fc_d1 = _Linear1x1(self.inplanes, 1024)
+            self.depth_fc_d2 = _Linear1x1(1024, 512)
+            self.depth_bn = BatchNorm2d(512)                 # BatchNorm1d: the same parameters / buffers
+            self.depth_fc_u2 = _Linear1x1(512, 1024)
+            self.depth_fc_u1 = _Linear1x1(1024, self.inplanes)
         # full_net.py:146-148: with multi_kp the depth layer predicts one gamma per listed key-point
         self.kps_need_depth = list(args.kps_need_depth) if self.multi_kp else [args.reference_keypoint_id]
         self.depth_num = len(self.kps_need_depth)
@@ -208,6 +213,19 @@ class RootNetwithRegInt(PlannedModule):
                 pred = dec.emit(pb, h, residual=pred)
         return pred
 
+    def _depth_gamma(self, pb, feat):
+        """depth_layer on the pooled root feature (full_net.py:271-274); add_fc: the hour-glass MLP of :261-270 first
+        (fc_d1 -> fc_d2 -> BatchNorm1d -> LeakyReLU -> fc_u2, 0.5 (. + d1), fc_u1, 0.5 (. + feature))."""
+        if self.add_fc:
+            N = feat.N
+            half = lambda t: pb.row_scale(pb.dense(t), pb.constant(N, t.C, 0.5))      # noqa: E731
+            f1 = pb.conv(feat, self.depth_fc_d1.weight, self.depth_fc_d1.bias)
+            f2 = pb.conv(f1, self.depth_fc_d2.weight, self.depth_fc_d2.bias, want_stats=pb.plan.training)
+            mid = pb.act([Term(f2, self.depth_bn)], relu="leaky")
+            f3 = half(pb.conv(mid, self.depth_fc_u2.weight, self.depth_fc_u2.bias, residual=f1))
+            feat = half(pb.conv(f3, self.depth_fc_u1.weight, self.depth_fc_u1.bias, residual=feat))
+        return pb.dense(self.depth_layer.emit(pb, feat))
+
     def _build(self, pb, x_reg, x_root, k_value, K):
         N = x_reg.shape[0]
         J, root = self.num_joints, self.reference_keypoint_id
@@ -231,7 +249,7 @@ class RootNetwithRegInt(PlannedModule):
                     for _ in root_units:
                         pass
             heat, xf, feat_root = res["heat"], res["xf"], rootd["feat"]
-            gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+            gamma = self._depth_gamma(pb, feat_root)
         elif resnet_reg:
             (ys_root,) = emit_trunks(pb, [self.rootnet_backbone], [xo], rider=reg_units)
             with pb.parallel(2) as par:
@@ -241,7 +259,7 @@ class RootNetwithRegInt(PlannedModule):
                     heat, xf = res["heat"], res["xf"]
                 with par.lane(1):
                     _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
-                    gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+                    gamma = self._depth_gamma(pb, feat_root)
         elif resnet_root:
             (ys_reg,) = emit_trunks(pb, [self.reg_backbone], [xr], rider=root_units)
             with pb.parallel(2) as par:
@@ -250,7 +268,7 @@ class RootNetwithRegInt(PlannedModule):
                 with par.lane(1):
                     for _ in root_units:
                         pass
-                    gamma = pb.dense(self.depth_layer.emit(pb, rootd["feat"]))
+                    gamma = self._depth_gamma(pb, rootd["feat"])
         else:
             ys_reg, ys_root = emit_trunks(pb, [self.reg_backbone, self.rootnet_backbone], [xr, xo])
             with pb.parallel(2, virtual="heads" in os.environ.get("HRP_DBG_VIRTUAL", "")) as par:
@@ -258,7 +276,7 @@ class RootNetwithRegInt(PlannedModule):
                     heat, xf = self.reg_backbone.emit_heads(pb, ys_reg)
                 with par.lane(1):
                     _, feat_root = self.rootnet_backbone.emit_heads(pb, ys_root)
-                    gamma = pb.dense(self.depth_layer.emit(pb, feat_root))
+                    gamma = self._depth_gamma(pb, feat_root)
         depths = None
         if self.multi_kp:      # full_net.py:275-279: pred_depths = gamma * k / 1000 per listed key-point; the root's feeds the rest
             from hrpe_amd.plan import TensorH

@@ -680,7 +680,7 @@ class Plan:
             if not is_l(e, "ew_red"):
                 continue
             b = e.op.desc
-            if b.inp.mode != nv.EW_BN_TRAIN or b.inp.up != 1 or not b.relu or not b.mask or b.dout in other:
+            if b.inp.mode != nv.EW_BN_TRAIN or b.inp.up != 1 or b.relu != 1 or not b.mask or b.dout in other:
                 continue
             cands = convs.get(b.dout, [])
             fw = fwd_by_mask.get(b.mask)
@@ -1538,7 +1538,8 @@ class PlanBuilder:
         H = max(tm.t.H * tm.up for tm in terms)
         W = max(tm.t.W * tm.up for tm in terms)
         Cc, N, dtype = t0.t.C, t0.t.N, t0.t.dtype
-        if self.fuse_inference and t0.bn is not None and t0.up == 1 and t0.t.producer is not None \
+        leaky = relu == "leaky"      # nn.LeakyReLU() (slope 0.01): descriptor relu = 2, element-wise kernels only
+        if self.fuse_inference and not leaky and t0.bn is not None and t0.up == 1 and t0.t.producer is not None \
                 and t0.t.producer[0] == "conv" and not getattr(t0.t, "consumed", False) \
                 and len(terms) <= 2 and all(tm.bn is None and tm.up == 1 for tm in terms[1:]):
             d = t0.t.producer[1]
@@ -1555,7 +1556,7 @@ class PlanBuilder:
         d = nv.EwDesc()
         d.nin = len(terms)
         d.out, d.out_pitch, d.dtype = out.ptr(), out.pitch, _dt(dtype)
-        d.N, d.H, d.W, d.C, d.relu = N, H, W, Cc, 1 if relu else 0
+        d.N, d.H, d.W, d.C, d.relu = N, H, W, Cc, 2 if leaky else (1 if relu else 0)
         ins = []
         for j, tm in enumerate(terms):
             e = d.inp[j]

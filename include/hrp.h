@@ -177,7 +177,7 @@ typedef struct hrp_ew_desc {
   int32_t out_pitch;
   int32_t dtype;
   int32_t N, H, W, C;
-  int32_t relu;
+  int32_t relu;        /* 0: none, 1: ReLU, 2: LeakyReLU with slope 0.01 (nn.LeakyReLU(); the backward descriptor carries it on) */
   uint8_t* mask;       /* optional with relu: one byte per 16-byte output vector (8 bf16 / 4 fp32 channels),   */
   int32_t mask_pitch;  /* bit i = (channel i of the vector > 0); [N*H*W][mask_pitch] bytes.  The backward then  */
                        /* reads 1/16 of the bytes of `out` for the ReLU mask.  Vector path only (C, pitches and */

@@ -95,7 +95,7 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
                  fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32",
-                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False):
+                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False, add_fc=False):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
@@ -106,6 +106,13 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
     else:
         feat_root = hrnet_w32_forward(sd, x_root, prefix="rootnet_backbone.", generate_hm=False,
                                       generate_feat=True, training=training)
+    if add_fc:                                                                        # :261-270
+        lin = lambda n, v: F.linear(v, sd[n + ".weight"], sd[n + ".bias"])   # noqa: E731
+        f1 = lin("depth_fc_d1", feat_root)
+        mid = F.leaky_relu(F.batch_norm(lin("depth_fc_d2", f1), sd["depth_bn.running_mean"], sd["depth_bn.running_var"],
+                                        sd["depth_bn.weight"], sd["depth_bn.bias"], training, 0.1, 1e-5))
+        f3 = 0.5 * (lin("depth_fc_u2", mid) + f1)
+        feat_root = 0.5 * (lin("depth_fc_u1", f3) + feat_root)
     gamma = F.conv2d(feat_root[:, :, None, None], sd["depth_layer.weight"], sd["depth_layer.bias"])
     pred_depths = None
     if kps_need_depth is not None:                                                    # multi_kp, :275-279

@@ -410,6 +410,27 @@ def gen_full_eval_rot_matmul():
     print("full eval (rot_iterative_matmul) ok", o[1][0])
 
 
+def gen_full_add_fc():
+    """add_fc = True (full_net.py:150-157, 261-270): eval 8-tuple at B = 2; one train-mode forward at B = 8 (the
+    BatchNorm1d of the hour-glass MLP normalises over the batch: two samples would be a sign function)."""
+    full, _ = build_full(add_fc=True)
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    out = {}
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    for n, t in zip(NAMES8, o):
+        out["eval:" + n] = t.numpy()
+    full.train()
+    x_reg, x_root, kv, K = synth_inputs(8)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    out["train:depth"], out["train:trans"] = o[4].numpy(), o[2].numpy()
+    out["buf:depth_bn.running_mean"] = full.state_dict()["depth_bn.running_mean"][:64].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_full_add_fc.npz"), **out)
+    print("full add_fc ok", out["eval:depth"].ravel(), out["train:depth"].ravel())
+
+
 def gen_full_eval_baxter():
     """15 DoF / 17 key-points: 1088 heat-map channels, 2063-wide pose regressor, tree FK with key-point offsets."""
     full, _ = build_full(robot_type="baxter")

@@ -244,6 +244,41 @@ def test_rot6d_compose_kernel_and_rot_iterative_matmul_golden():
         assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
 
 
+def test_full_add_fc_golden_and_gradients():
+    """add_fc = True (full_net.py:150-157, 261-270): the hour-glass MLP (BatchNorm1d + LeakyReLU, two 0.5-weighted skips)
+    in front of the depth layer.  Eval 8-tuple at B = 2 and the train-mode depth at B = 8 against the reference; the
+    MLP's gradients (LeakyReLU backward in the element-wise kernels) against the oracle at B = 8."""
+    from oracle import fk as ofk, heads as oheads
+    g = load("golden_full_add_fc.npz")
+    m = build_full(add_fc=True).eval()
+    assert "depth_fc_u1.weight" in m.state_dict() and "depth_bn.running_var" in m.state_dict()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    for n, t in zip(NAMES8, out):
+        ref = g["eval:" + n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    sd = {k: v.detach().cpu().clone() for k, v in synth_state_dict(m.state_dict()).items()}
+    m.train()
+    m.zero_grad()
+    x_reg, x_root, kv, K = synth_inputs(8)
+    out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    np.testing.assert_allclose(out[4].detach().cpu().numpy(), g["train:depth"], rtol=5e-3)
+    np.testing.assert_allclose(m.state_dict()["depth_bn.running_mean"][:64].cpu().numpy(), g["buf:depth_bn.running_mean"], rtol=2e-3, atol=1e-5)
+    (out[4].square().sum() + out[2].square().sum()).backward()
+    names = ["depth_fc_d1.weight", "depth_fc_d2.weight", "depth_bn.weight", "depth_bn.bias", "depth_fc_u2.weight", "depth_fc_u1.bias",
+             "depth_layer.weight"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    oo = oheads.full_forward(sd, ofk.Robot(PANDA_URDF), x_reg, x_root, kv, K, training=True, add_fc=True)
+    (oo[4].square().sum() + oo[2].square().sum()).backward()
+    params = dict(m.named_parameters())
+    for k in names:
+        e = float((params[k].grad.detach().cpu() - sd[k].grad).norm() / (sd[k].grad.norm() + 1e-30))
+        assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
+
+
 def test_full_test_fps_split_timers():
     """test_fps = True (full_net.py:253-286, 385-392): the 8-tuple plus (time_root, time_other, time_whole); the root part
     is timed as its own plan (root trunk + depth layer), the rest is the remainder."""

@@ -331,6 +331,34 @@ def test_full_eval_rot_matmul_golden(robot):
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
+def _add_fc_sd():
+    sd = full_sd()
+    shapes = {}
+    for n, (o, i) in {"depth_fc_d1": (1024, 2048), "depth_fc_d2": (512, 1024), "depth_fc_u2": (1024, 512), "depth_fc_u1": (2048, 1024)}.items():
+        shapes[n + ".weight"], shapes[n + ".bias"] = torch.empty(o, i), torch.empty(o)
+    for leaf in ("weight", "bias", "running_mean", "running_var"):
+        shapes["depth_bn." + leaf] = torch.empty(512)
+    shapes["depth_bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    sd.update(synth_state_dict(shapes))
+    return sd
+
+
+def test_full_add_fc_golden(robot):
+    """add_fc = True (full_net.py:150-157, 261-270): eval at B = 2, a train-mode forward at B = 8."""
+    g = load("golden_full_add_fc.npz")
+    sd = _add_fc_sd()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K, add_fc=True)
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g["eval:" + n], atol=1e-5, rtol=1e-5, err_msg=n)
+    x_reg, x_root, kv, K = synth_inputs(8)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=True, add_fc=True)
+    np.testing.assert_allclose(out[4].numpy(), g["train:depth"], rtol=2e-4)
+    np.testing.assert_allclose(sd["depth_bn.running_mean"][:64].numpy(), g["buf:depth_bn.running_mean"], rtol=1e-4, atol=1e-6)
+
+
 def test_full_eval_baxter_golden():
     """robot_type = 'baxter' (full_net.py:48-50): 15 DoF, 17 key-points -> 1088 heat-map channels, tree FK with
     key-point offsets; init pose = const.py:183-199 mean."""

@@ -91,7 +91,8 @@ __device__ __forceinline__ void load_consts(const hrp_ew_input& in, int C, int c
 // 4-input fuse instance - the register count decides how many waves of OTHER lanes' kernels fit next to this one)
 // (bx, by) of gx x nslab: the block's position in its problem's grid - blockIdx / gridDim in the single launch, decoded
 // from the linear block index in the batched launch
-template <typename T, int V, int MAXIN>
+// LEAKY: relu == 2 (nn.LeakyReLU(), slope 0.01) - single launches only, so that the ReLU instances stay as they were
+template <typename T, int V, int MAXIN, bool LEAKY = false>
 __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr, const int bx, const int by, const int gx) {
   extern __shared__ float ew_lds[];
   float* tab = ew_lds;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
   const int c = cv * V;
   const int cbase = by * tpr * V, nch = tpr * V;
   const int ppb = 256 / tpr;  // pixels per block-iteration
-  const float neg = d.relu == 2 ? 0.01f : 0.f;   // relu 2 = nn.LeakyReLU() (slope 0.01): the mask / sign logic is ReLU's
+  constexpr float neg = LEAKY ? 0.01f : 0.f;     // the mask / sign logic is ReLU's
   float sc[MAXIN][V], sh[MAXIN][V];
   {
     float m[V], iv[V];
@@ -160,8 +161,13 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
             for (int i = 0; i < V; ++i) bits |= (acc[i] > 0.f ? 1u : 0u) << i;
             d.mask[pu * d.mask_pitch + cv] = (uint8_t)bits;
           }
+          if constexpr (!LEAKY) {
 #pragma unroll
-          for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : neg * acc[i];
+            for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+          } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : neg * acc[i];
+          }
         }
         VecIO<T, V>::st(d.out, pu * d.out_pitch + c, acc);
       }
@@ -201,22 +207,26 @@ __device__ __forceinline__ void ew_fwd_body(const hrp_ew_desc& d, const int tpr,
         for (int i = 0; i < V; ++i) bits |= (acc[i] > 0.f ? 1u : 0u) << i;
         d.mask[(size_t)p * d.mask_pitch + cv] = (uint8_t)bits;
       }
+      if constexpr (!LEAKY) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : neg * acc[i];
+        for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : neg * acc[i];
+      }
     }
     VecIO<T, V>::st(d.out, (size_t)p * d.out_pitch + c, acc);
   }
 }
 
-template <typename T, int V, int MAXIN>
+template <typename T, int V, int MAXIN, bool LEAKY = false>
 __global__ __launch_bounds__(256) void ew_fwd_kernel(const hrp_ew_desc d, int tpr, int nslab) {
-  ew_fwd_body<T, V, MAXIN>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x);
+  ew_fwd_body<T, V, MAXIN, LEAKY>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // pooled, masked output gradient at input pixel q = (n, qy, qx)
-template <typename T, int V>
+template <typename T, int V, bool LEAKY = false>
 __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q, int c, float* g) {
-  const float neg = d.relu == 2 ? 0.01f : 0.f;
 #pragma unroll
   for (int i = 0; i < V; ++i) g[i] = 0.f;
   const int up = d.in.up;
@@ -237,12 +247,12 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q
         if (V > 1 && d.mask) {
           const unsigned bits = d.mask[p * d.mask_pitch + c / V];
 #pragma unroll
-          for (int i = 0; i < V; ++i) go[i] = (bits >> i) & 1u ? go[i] : neg * go[i];
+          for (int i = 0; i < V; ++i) go[i] = (bits >> i) & 1u ? go[i] : (LEAKY ? 0.01f * go[i] : 0.f);
         } else {
           float o[V];
           VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
 #pragma unroll
-          for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : neg * go[i];
+          for (int i = 0; i < V; ++i) go[i] = o[i] > 0.f ? go[i] : (LEAKY ? 0.01f * go[i] : 0.f);
         }
       }
 #pragma unroll
@@ -254,10 +264,10 @@ __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q
 // thread and trip, all loads issued before the first use.  One pixel per trip kept a single round of loads in flight
 // per thread - 8 dependent HBM latencies on a [64,64,64,32] tensor, 1.6 TB/s.
 // RM: 0 = no ReLU, 1 = ReLU through the bit mask, 2 = ReLU by comparing the saved output.
-template <typename T, int V, int RM, int U>
+// LEAKY: relu == 2 (the slope multiply stays out of the ReLU instances: the reduce is VALU sensitive, +14 % measured)
+template <typename T, int V, int RM, int U, bool LEAKY = false>
 __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int c, unsigned q, unsigned stride, unsigned nq,
                                                   const float (&mean)[V], const float (&inv)[V], float (&s0)[V], float (&s1)[V]) {
-  const float neg = d.relu == 2 ? 0.01f : 0.f;
   for (; q + (U - 1) * stride < nq; q += U * stride) {
     typename VecIO<T, V>::Raw go[U], xin[U];
     unsigned bits[U];
@@ -277,8 +287,8 @@ __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int 
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         float g = gf[i];
-        if constexpr (RM == 1) g = (bits[u] >> i) & 1u ? g : neg * g;
-        if constexpr (RM == 2) g = o[i] > 0.f ? g : neg * g;
+        if constexpr (RM == 1) g = (bits[u] >> i) & 1u ? g : (LEAKY ? 0.01f * g : 0.f);
+        if constexpr (RM == 2) g = o[i] > 0.f ? g : (LEAKY ? 0.01f * g : 0.f);
         s0[i] += g;
         s1[i] += g * (xf[i] - mean[i]) * inv[i];
       }
@@ -313,12 +323,17 @@ __device__ __forceinline__ void ew_bwd_reduce_body(const hrp_ew_bwd_desc& d, con
     unsigned q = bx * ppb + threadIdx.x / tpr;
     if (up == 1) {   // (uniform) batched pixel loop, then its single-pixel tail
       if (!d.relu) { q = reduce_pixels<T, V, 0, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 0, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
+      else if (d.relu == 2) {   // LeakyReLU (rare: the add_fc MLP): one-pixel trips, mask or saved output
+        if (V > 1 && d.mask) q = reduce_pixels<T, V, 1, 1, true>(d, c, q, stride, nq, mean, inv, s0, s1);
+        else q = reduce_pixels<T, V, 2, 1, true>(d, c, q, stride, nq, mean, inv, s0, s1);
+      }
       else if (V > 1 && d.mask) { q = reduce_pixels<T, V, 1, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 1, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
       else { q = reduce_pixels<T, V, 2, 4>(d, c, q, stride, nq, mean, inv, s0, s1); q = reduce_pixels<T, V, 2, 1>(d, c, q, stride, nq, mean, inv, s0, s1); }
     }
     for (; q < nq; q += stride) {
       float g[V], xin[V];
-      pooled_grad<T, V>(d, q, c, g);
+      if (d.relu == 2) pooled_grad<T, V, true>(d, q, c, g);
+      else pooled_grad<T, V>(d, q, c, g);
       VecIO<T, V>::ld(d.in.ptr, (size_t)q * d.in.pitch + c, xin);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(256) void ew_bwd_reduce_kernel(const hrp_ew_bwd_des
 #ifndef HRP_EW_APPLY_U
 #define HRP_EW_APPLY_U 4
 #endif
-template <typename T, int V>
+template <typename T, int V, bool LEAKY = false>
 __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, const int tpr, const int bx, const int by, const int gx) {
   extern __shared__ float ew_lds[];
   const int tabn = min(tpr * V, TAB_CH);
@@ -425,7 +440,7 @@ __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, cons
     // U pixels per thread and trip, every load of the trip issued before the first use (the branches are uniform)
     constexpr int U = HRP_EW_APPLY_U;
     const bool bn = d.in.mode == HRP_EW_BN_TRAIN, use_bits = d.relu && V > 1 && d.mask, use_out = d.relu && !use_bits;
-    const float neg = d.relu == 2 ? 0.01f : 0.f;
+    constexpr float neg = LEAKY ? 0.01f : 0.f;
     for (; q + (U - 1) * stride < nq; q += U * stride) {
       // (the rarer operands - saved output instead of the bit mask, accumulation targets - are read where they are
       // used: keeping them in the batch cost 100 registers on every variant of the kernel)
@@ -446,12 +461,12 @@ __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, cons
         const size_t p = (size_t)q + (size_t)u * stride;
         if (use_bits) {
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] = (bits[u] >> i) & 1u ? g[u][i] : neg * g[u][i];
+          for (int i = 0; i < V; ++i) g[u][i] = (bits[u] >> i) & 1u ? g[u][i] : (LEAKY ? neg * g[u][i] : 0.f);
         } else if (use_out) {
           float o[V];
           VecIO<T, V>::ld(d.out, p * d.out_pitch + c, o);
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] = o[i] > 0.f ? g[u][i] : neg * g[u][i];
+          for (int i = 0; i < V; ++i) g[u][i] = o[i] > 0.f ? g[u][i] : (LEAKY ? neg * g[u][i] : 0.f);
         }
         if (d.din2) {
           if (d.accumulate2) {
@@ -483,7 +498,7 @@ __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, cons
   }
   for (; q < nq; q += stride) {
     float g[V];
-    pooled_grad<T, V>(d, q, c, g);
+    pooled_grad<T, V, LEAKY>(d, q, c, g);
     if (d.din2) {   // identity sibling of the same activation (up == 1): its gradient is g itself
       float g2[V];
       const size_t o2 = (size_t)q * d.din2_pitch + c;
@@ -517,9 +532,9 @@ __device__ __forceinline__ void ew_bwd_apply_body(const hrp_ew_bwd_desc& d, cons
   }
 }
 
-template <typename T, int V>
+template <typename T, int V, bool LEAKY = false>
 __global__ __launch_bounds__(256) void ew_bwd_apply_kernel(const hrp_ew_bwd_desc d, int tpr) {
-  ew_bwd_apply_body<T, V>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x);
+  ew_bwd_apply_body<T, V, LEAKY>(d, tpr, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 static inline bool aligned16(const void* p, int pitch, int sz) {
@@ -566,6 +581,11 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   dim3 grid(g.gx, g.nslab);
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
   const int lds = 4 * tabn * 4;
+  if (d.relu == 2) {      // LeakyReLU: its own instances (rare)
+    if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1, HRP_EW_MAX_IN, true>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
+    else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC, HRP_EW_MAX_IN, true>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
+    return check_launch("ew_fwd");
+  }
   if (g.V == 1) hipLaunchKernelGGL((ew_fwd_kernel<T, 1, HRP_EW_MAX_IN>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
   else if (d.nin <= 2) hipLaunchKernelGGL((ew_fwd_kernel<T, VEC, 2>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
   else hipLaunchKernelGGL((ew_fwd_kernel<T, VEC, HRP_EW_MAX_IN>), grid, dim3(256), lds, s, d, g.tpr, g.nslab);
@@ -597,7 +617,10 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   const int tabn = g.tpr * g.V < TAB_CH ? g.tpr * g.V : TAB_CH;
   if (APPLY) {
     const int lds = 6 * tabn * 4;
-    if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), lds, s, d, g.tpr);
+    if (d.relu == 2) {
+      if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1, true>), grid, dim3(256), lds, s, d, g.tpr);
+      else hipLaunchKernelGGL((ew_bwd_apply_kernel<T, VEC, true>), grid, dim3(256), lds, s, d, g.tpr);
+    } else if (g.V == 1) hipLaunchKernelGGL((ew_bwd_apply_kernel<T, 1>), grid, dim3(256), lds, s, d, g.tpr);
     else hipLaunchKernelGGL((ew_bwd_apply_kernel<T, VEC>), grid, dim3(256), lds, s, d, g.tpr);
   } else {
     const int nred = (g.tpr < 64 ? 4 : 256 / g.tpr) * g.tpr * g.V;
@@ -659,6 +682,7 @@ static int ew_fwd_batch_prepare(const hrp_ew_desc* descs, int n, EwProblem* tab,
     bool ok = aligned16(d.out, d.out_pitch, SZ) && d.C % VEC == 0;
     for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
     HRP_REQUIRE(ok, "ew batch: problem %d is not on the 16-byte vector path", i);
+    HRP_REQUIRE(d.relu != 2, "ew batch: LeakyReLU problems are launched one by one");
     HRP_REQUIRE(!d.mask || (d.relu && d.mask_pitch >= d.C / VEC), "ew_fwd: the ReLU bit mask needs relu and the 16-byte vector path");
     if (d.nin > 2) maxin = HRP_EW_MAX_IN;
     bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
@@ -699,6 +723,7 @@ static int ew_bwd_batch_prepare(const hrp_ew_bwd_desc* descs, int n, EwBwdProble
     if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
     if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
     HRP_REQUIRE(ok, "ew batch: problem %d is not on the 16-byte vector path", i);
+    HRP_REQUIRE(d.relu != 2, "ew batch: LeakyReLU problems are launched one by one");
     HRP_REQUIRE(!d.mask || (d.relu && d.mask_pitch >= d.C / VEC), "ew_bwd: the ReLU bit mask needs relu and the 16-byte vector path");
     bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
     sum += bytes[i];

@@ -291,7 +291,9 @@ def test_full_test_fps_split_timers():
         out = m(x_reg, x_root, kv, K, test_fps=True)
     assert len(out) == 9 and len(out[8]) == 3
     t_root, t_other, t_whole = out[8]
-    assert 0 < t_root < t_whole and t_other >= 0 and abs(t_root + t_other - t_whole) < 1e-9
+    # (no ordering claims beyond the definitions: one plan may replay a captured graph while the other still walks its
+    # launches - wall times of single calls)
+    assert 0 < t_root <= t_whole and t_other >= 0 and abs(t_root + t_other - t_whole) < 1e-9
     assert t_root > 1e-4, (t_root, t_whole)                 # a whole HRNet-W32 forward: not a token number
     for a, b in zip(ref, out[:8]):     # (not bit for bit: the eval plan's fp32 split-K layers sum with atomics)
         assert float((a - b).abs().max()) <= 5e-5 * max(1.0, float(a.abs().max()))

@@ -579,7 +579,7 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
         }
       }
     }
-    __syncthreads();   // the next tile's DMA overwrites the output image / statistics partials
+    if constexpr (PERSIST) __syncthreads();   // the next tile's DMA overwrites the output image / statistics partials
     HRP_CSTAMP(7);
   }
 }

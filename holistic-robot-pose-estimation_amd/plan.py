@@ -78,6 +78,7 @@ class TensorH:
         # where the fill could land after the first accumulations and wipe them (first step of a plan only)
         self.grad_buf()
         root = self.base if self.base is not None else self
+        root.grad_written = True     # (a column slice's gradient lives in its root's buffer: the root's producer must run)
         here = self.plan.lane_path
         if any(lanes_concurrent(here, q) for q in root._grad_paths):
             raise RuntimeError("plan: a gradient is accumulated from two concurrent lanes")

@@ -58,14 +58,25 @@ def uvz2xyz_singlepoint(uv, z, K):
     return torch.matmul(inv_intrinsics(K), v.unsqueeze(-1)).squeeze(-1)
 
 
-def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32", use_offset=False, add_fc=False):
+def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32", use_offset=False, add_fc=False, pred_xy=False):
     """RootNet(backbone).forward, depth_net.py:92-137 (pred_xy off); a ResNet trunk is followed by global average
-    pooling (:93-95).  add_fc: the residual MLP on the pooled feature (:113-120, four Linear + BatchNorm1d + ReLU and a
+    pooling (:93-95).  pred_xy (ResNet trunks only, as in the reference): three deconv + BN + ReLU layers and a 1x1
+    conv on the feature map, softmax over the 64 x 64 map, expected column / row (:98-110); returns [x, y, depth].  add_fc: the residual MLP on the pooled feature (:113-120, four Linear + BatchNorm1d + ReLU and a
     fifth Linear added back); use_offset: depth += 1000 * offset_layer(feature) (:127-131)."""
     if backbone.startswith("resnet"):
         from .resnet import resnet_forward
         fm = resnet_forward(sd, x, prefix="backbone.", name="resnet50" if backbone == "resnet" else backbone, training=training)
         feat = fm.flatten(2).mean(2)
+        if pred_xy:
+            from .hrnet import _Ctx, _bn
+            c, h = _Ctx(sd, "", training), fm
+            for i in (0, 3, 6):
+                h = F.relu(_bn(c, f"deconv_layers.{i + 1}", F.conv_transpose2d(h, sd[f"deconv_layers.{i}.weight"], None, stride=2, padding=1)))
+            xy = F.conv2d(h, sd["xy_layer.weight"], sd["xy_layer.bias"])
+            B, _, H, W = xy.shape
+            p = F.softmax(xy.reshape(B, 1, H * W), 2).reshape(B, 1, H, W)
+            coord_x = (p.sum(2) * torch.arange(W).float()).sum(2)
+            coord_y = (p.sum(3) * torch.arange(H).float()).sum(2)
     else:
         feat = hrnet_w32_forward(sd, x, prefix="backbone.", generate_hm=False, generate_feat=True,
                                  training=training)
@@ -80,6 +91,8 @@ def rootnet_forward(sd, x, k_value, training=False, backbone="hrnet32", use_offs
     depth = gamma.view(-1, 1) * k_value.view(-1, 1)
     if use_offset:
         depth = depth + 1000.0 * F.conv2d(feat[:, :, None, None], sd["offset_layer.weight"], sd["offset_layer.bias"]).view(-1, 1)
+    if pred_xy:
+        return torch.cat((coord_x, coord_y, depth), dim=1)
     return depth
 
 

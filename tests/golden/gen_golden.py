@@ -309,6 +309,31 @@ def gen_depthnet_variants():
     print("depthnet variants ok", out["depth_eval"].ravel(), out["depth_train"].ravel(), out["loss"])
 
 
+def gen_depthnet_pred_xy():
+    """RootNet('resnet50', pred_xy=True) (depth_net.py:33-43, 98-110, 133-135): [x, y, depth], eval + train forward
+    at B = 4 and the gradients of a sum-of-squares loss on the x / y columns.  (The reference moves its index ramps to
+    the GPU inside forward: .cuda() is a no-op for this CPU run.)"""
+    from lib.models.backbones import Resnet as ref_resnet
+    ref_resnet.ResNet.init_weights = lambda self, name: None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    m = get_rootnet("resnet50", pred_xy=True)
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    x, _, kv, _ = synth_inputs(4)
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        out["coord_eval"] = m(x, kv).numpy()
+    m.train()
+    pred = m(x, kv)
+    loss = (pred[:, :2] / 64.0).square().sum() + (pred[:, 2:] / 1000.0).square().sum()
+    loss.backward()
+    out["coord_train"], out["loss"] = pred.detach().numpy(), np.array(loss.item())
+    grad_fixture(m, ["xy_layer.weight", "deconv_layers.0.weight", "deconv_layers.4.weight", "deconv_layers.6.weight",
+                     "backbone.layer4.2.conv3.weight", "depth_layer.weight"], out, "")
+    np.savez_compressed(os.path.join(HERE, "golden_depthnet_pred_xy.npz"), **out)
+    print("depthnet pred_xy ok", out["coord_eval"], out["loss"])
+
+
 def gen_depthnet_resnet():
     """DepthNet with a ResNet-50 trunk (depth_net.py:16-18, 93-95) and the full network with ResNet-50 for BOTH
     trunks, eval; one DepthNet training step (train_depthnet.py:231-250)."""

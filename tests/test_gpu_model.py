@@ -159,7 +159,32 @@ def test_depthnet_variants_golden_eval_and_train_step():
         if key.startswith("buf:"):
             np.testing.assert_allclose(sd[key[4:]][:64].cpu().numpy(), g[key], rtol=2e-3, atol=1e-5)
     with pytest.raises(NotImplementedError):
-        get_rootnet("hrnet32", pred_xy=True)
+        get_rootnet("hrnet32", pred_xy=True)      # (the reference's HRNet branch has no feature map for that head either)
+
+
+def test_depthnet_pred_xy_golden():
+    """RootNet('resnet50', pred_xy=True) (depth_net.py:33-43, 98-110, 133-135): [x, y, depth] from three deconv layers, a
+    1x1 conv and a 2-D soft-argmax; eval + train forward and sampled gradients against the reference (B = 4)."""
+    from hrpe_amd.lib.models.depth_net import get_rootnet
+    g = load("golden_depthnet_pred_xy.npz")
+    m = get_rootnet("resnet50", pred_xy=True)
+    assert {"deconv_layers.0.weight", "deconv_layers.7.running_var", "xy_layer.bias"} <= set(m.state_dict().keys())
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m = m.to(DEV).eval()
+    x, _, kv, _ = synth_inputs(4)
+    with torch.no_grad():
+        d = m(x.to(DEV), kv.to(DEV))
+    np.testing.assert_allclose(d.cpu().numpy(), g["coord_eval"], rtol=3e-4)
+    m.train()
+    pred = m(x.to(DEV), kv.to(DEV))
+    loss = (pred[:, :2] / 64.0).square().sum() + (pred[:, 2:] / 1000.0).square().sum()
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["coord_train"], rtol=1e-3)
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            summary_check(params[name].grad, g, f"grad:{name}:", GRAD_TOL, what="depthnet pred_xy ")
 
 
 NAMES8 = ["pose", "rot", "trans", "root_uv", "depth", "uvd", "xyz_int", "xyz_fk"]

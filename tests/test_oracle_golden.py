@@ -359,6 +359,38 @@ def test_full_add_fc_golden(robot):
     np.testing.assert_allclose(sd["depth_bn.running_mean"][:64].numpy(), g["buf:depth_bn.running_mean"], rtol=1e-4, atol=1e-6)
 
 
+def test_depthnet_pred_xy_golden():
+    """RootNet('resnet50', pred_xy=True) (depth_net.py:33-43, 98-110, 133-135)."""
+    from hrpe_amd.lib.models.backbones.Resnet import get_resnet
+    g = load("golden_depthnet_pred_xy.npz")
+    shapes = {"backbone." + k: v for k, v in get_resnet("resnet50", pretrain=False).state_dict().items()}
+    cin = 2048
+    for i in (0, 3, 6):
+        shapes[f"deconv_layers.{i}.weight"] = torch.empty(cin, 256, 4, 4)
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            shapes[f"deconv_layers.{i + 1}.{leaf}"] = torch.empty(256)
+        shapes[f"deconv_layers.{i + 1}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+        cin = 256
+    shapes["xy_layer.weight"], shapes["xy_layer.bias"] = torch.empty(1, 256, 1, 1), torch.empty(1)
+    shapes["depth_layer.weight"], shapes["depth_layer.bias"] = torch.empty(1, 2048, 1, 1), torch.empty(1)
+    sd = synth_state_dict(shapes)
+    x, _, kv, _ = synth_inputs(4)
+    with torch.no_grad():
+        d = heads.rootnet_forward(sd, x, kv, backbone="resnet50", pred_xy=True)
+    np.testing.assert_allclose(d.numpy(), g["coord_eval"], rtol=1e-5)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    pred = heads.rootnet_forward(sd, x, kv, training=True, backbone="resnet50", pred_xy=True)
+    loss = (pred[:, :2] / 64.0).square().sum() + (pred[:, 2:] / 1000.0).square().sum()
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().numpy(), g["coord_train"], rtol=1e-5)
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            check_summary(sd[name].grad, g, f"grad:{name}:", rtol=5e-3, atol=1e-8)
+
+
 def test_full_eval_baxter_golden():
     """robot_type = 'baxter' (full_net.py:48-50): 15 DoF, 17 key-points -> 1088 heat-map channels, tree FK with
     key-point offsets; init pose = const.py:183-199 mean."""

@@ -283,7 +283,8 @@ def test_grouped_plan_matches_one_by_one_plan():
     outs = {}
     try:
         for name, mode, batching, lanes in (("batched", "hybrid", True, "nets"), ("one_by_one", "hybrid", False, "nets"),
-                                            ("merged", "merged", True, "nets"), ("lanes", "lanes", False, "flat")):
+                                            ("merged", "merged", True, "nets"), ("lanes", "lanes", False, "flat"),
+                                            ("flat2", "hybrid", True, "flat2")):
             P.PLAN_MODE, P.BATCHING, HRnet.TRUNK_LANES = mode, batching, lanes
             m.invalidate_plans()
             m.load_state_dict(sd0)
@@ -308,7 +309,7 @@ def test_grouped_plan_matches_one_by_one_plan():
         m.invalidate_plans()
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
     noise = rel(outs["batched_again"][1], outs["batched"][1])
-    for name in ("one_by_one", "merged", "lanes"):
+    for name in ("one_by_one", "merged", "lanes", "flat2"):
         for n, a, b in zip(NAMES8, outs[name][0], outs["batched"][0]):
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (name, n)
         e = rel(outs[name][1], outs["batched"][1])

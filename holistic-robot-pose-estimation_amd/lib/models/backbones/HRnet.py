@@ -252,11 +252,12 @@ def _transition(pb, tr, src):
 
 
 # "nets": one chain (a stream in the plan's hybrid mode) per trunk, the branches of a module are virtual lanes merged
-# into batched launches inside it.  "flat2" (default since the end of round 2): two streams per trunk - the high-resolution
-# branch (HBM-heavy, small-K launches) and the other branches batched - measured 39.7 ms against 40.4 ms for "nets" once
-# the weight gradients had left the dependency chain (before that: 44.0 against 42.8).  "flat": round 1's structure - every
-# branch of every trunk is a lane of one flat block.
-TRUNK_LANES = os.environ.get("HRP_TRUNK_LANES", "flat2")
+# into batched launches inside it (default).  "flat2": two streams per trunk - the high-resolution branch (HBM-heavy,
+# small-K launches) and the other branches batched - 1.7 % faster on the step at the end of round 2 (39.7 against 40.4 ms on
+# one box, inside the box-to-box spread) for 600 more launches and a less efficient conv family (27.9 against 25.4 ms of
+# kernel time, roofline fraction 0.177 against 0.197): not the default.  "flat": round 1's structure - every branch of
+# every trunk is a lane of one flat block.
+TRUNK_LANES = os.environ.get("HRP_TRUNK_LANES", "nets")
 
 
 def _trunk_segments(net):

@@ -165,6 +165,8 @@ PROTOTYPES = {
     "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
     "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
     "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],
+    "hrp_softargmax_flat_fwd": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "hrp_softargmax_flat_bwd": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "hrp_rot6d_compose_fwd": [_P, _P, _P, _I, _P],
     "hrp_rot6d_compose_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "hrp_wgrad_fold_desc_of": [C.POINTER(WgradDesc), C.POINTER(WgradFoldDesc)],

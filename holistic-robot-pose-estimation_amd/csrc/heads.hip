@@ -636,6 +636,55 @@ extern "C" int hrp_project_bwd(const float* K, const float* pts, const float* du
   return check_launch("project_bwd");
 }
 
+// ---- flat soft-argmax (HeatmapIntegralJoint, integral.py:206-232): per (sample, channel) softmax over the H*W positions
+// of a small map, coord = E[flat index] / (H*W) in [0, 1).  One wave per (channel, sample); ms keeps (max, sum).
+template <typename T>
+__global__ __launch_bounds__(64) void softargmax_flat_fwd_kernel(const void* __restrict__ logits, int HW, int pitch,
+                                                                 float* __restrict__ coord, float* __restrict__ ms) {
+  const int j = blockIdx.x, b = blockIdx.y, J = gridDim.x, lane = threadIdx.x;
+  float m = -INFINITY;
+  for (int p = lane; p < HW; p += 64) m = fmaxf(m, Elem<T>::ld(logits, ((size_t)b * HW + p) * pitch + j));
+  m = wave_max(m);
+  float s = 0.f, sx = 0.f;
+  for (int p = lane; p < HW; p += 64) {
+    const float e = __expf(Elem<T>::ld(logits, ((size_t)b * HW + p) * pitch + j) - m);
+    s += e; sx += e * (float)p;
+  }
+  s = wave_sum(s); sx = wave_sum(sx);
+  if (lane == 0) {
+    coord[b * J + j] = sx / s / (float)HW;
+    ms[(b * J + j) * 2] = m; ms[(b * J + j) * 2 + 1] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void softargmax_flat_bwd_kernel(const void* __restrict__ logits, int HW, int pitch,
+                                                                 const float* __restrict__ coord, const float* __restrict__ ms,
+                                                                 const float* __restrict__ dcoord, void* __restrict__ dlogits, int dpitch) {
+  const int j = blockIdx.x, b = blockIdx.y, J = gridDim.x, lane = threadIdx.x;
+  const float m = ms[(b * J + j) * 2], s = ms[(b * J + j) * 2 + 1], c = coord[b * J + j], g = dcoord[b * J + j];
+  for (int p = lane; p < HW; p += 64) {
+    const float pr = __expf(Elem<T>::ld(logits, ((size_t)b * HW + p) * pitch + j) - m) / s;
+    Elem<T>::st(dlogits, ((size_t)b * HW + p) * dpitch + j, pr * ((float)p / (float)HW - c) * g);
+  }
+}
+
+extern "C" int hrp_softargmax_flat_fwd(const void* logits, int dtype, int B, int J, int HW, int pitch, float* coord, float* ms,
+                                       void* stream) {
+  HRP_REQUIRE(logits && coord && ms && B > 0 && J > 0 && HW > 0 && pitch >= J, "softargmax_flat_fwd: bad args");
+  if (dtype == HRP_F32) hipLaunchKernelGGL(softargmax_flat_fwd_kernel<float>, dim3(J, B), dim3(64), 0, (hipStream_t)stream, logits, HW, pitch, coord, ms);
+  else hipLaunchKernelGGL(softargmax_flat_fwd_kernel<bf16_t>, dim3(J, B), dim3(64), 0, (hipStream_t)stream, logits, HW, pitch, coord, ms);
+  return check_launch("softargmax_flat_fwd");
+}
+
+extern "C" int hrp_softargmax_flat_bwd(const void* logits, int dtype, int B, int J, int HW, int pitch, const float* coord,
+                                       const float* ms, const float* dcoord, void* dlogits, int dpitch, void* stream) {
+  HRP_REQUIRE(logits && coord && ms && dcoord && dlogits && B > 0 && J > 0 && HW > 0, "softargmax_flat_bwd: bad args");
+  if (dtype == HRP_F32) hipLaunchKernelGGL(softargmax_flat_bwd_kernel<float>, dim3(J, B), dim3(64), 0, (hipStream_t)stream, logits, HW, pitch, coord, ms, dcoord, dlogits, dpitch);
+  else hipLaunchKernelGGL(softargmax_flat_bwd_kernel<bf16_t>, dim3(J, B), dim3(64), 0, (hipStream_t)stream, logits, HW, pitch, coord, ms, dcoord, dlogits, dpitch);
+  return check_launch("softargmax_flat_bwd");
+}
+
 extern "C" int hrp_softargmax3d_fwd(const void* logits, int dtype, int B, int J, int D, int H, int W, int pitch,
                                     int root, int fix_root, float* uvd, float* ms, void* stream) {
   HRP_REQUIRE(logits && uvd && ms && B > 0 && J > 0, "softargmax_fwd: bad args");

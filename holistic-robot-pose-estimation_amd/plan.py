@@ -1873,6 +1873,27 @@ class PlanBuilder:
         self.copy_cols(x, out)
         return out
 
+    def softargmax_flat(self, heat, J):
+        """HeatmapIntegralJoint's core (integral.py:206-224): per channel softmax over the H*W positions of NHWC logits
+        [N, H, W, J] -> E[flat index] / (H*W), fp32 [N, J] dense."""
+        p = self.plan
+        N, HW = heat.N, heat.H * heat.W
+        coord = p.new(N, 1, 1, J, torch.float32, pitch=J)
+        ms = p.new(N, 1, 1, J * 2, torch.float32, pitch=J * 2)
+        coord.requires_grad = p.need_grad and heat.requires_grad
+        dt = _dt(heat.dtype)
+        p.fwd.append(lambda s: nv.call("hrp_softargmax_flat_fwd", heat.ptr(), dt, N, J, HW, heat.pitch, coord.ptr(), ms.ptr(), s))
+        if p.need_grad:
+            def bw():
+                if not coord.grad_written or not heat.requires_grad:
+                    return
+                assert not heat.grad_written, "joint-map gradient has a single producer"
+                heat.take_grad_slot()
+                p.bwd.append(lambda s: nv.call("hrp_softargmax_flat_bwd", heat.ptr(), dt, N, J, HW, heat.pitch, coord.ptr(), ms.ptr(),
+                                               coord.gptr(), heat.gptr(), heat.pitch, s))
+            self.bwd_stack.append(bw)
+        return coord
+
     def rot6d_compose(self, a, b):
         """out = rotmat_to_rot6d(R(a) @ R(b)) on dense fp32 [N, 6] tensors (full_net.py:362)."""
         p = self.plan

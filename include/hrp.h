@@ -370,6 +370,13 @@ int hrp_pose_geometry_bwd(const float* gamma, const float* k_value, const float*
                           const float* d_depth, const float* d_xyz, const float* d_root_uv, const float* d_trans,
                           float* d_gamma, float* d_uvd, void* stream);
 
+/* HeatmapIntegralJoint (reference lib/utils/integral.py:206-232): per (sample, channel j < J) softmax over the HW
+ * positions of logits [B, HW, pitch], coord[b, j] = E[flat index] / HW in [0, 1); ms [B, J, 2] keeps (max, sum) for the
+ * backward pass, which overwrites dlogits[b, p, j] = softmax * (p / HW - coord) * dcoord. */
+int hrp_softargmax_flat_fwd(const void* logits, int dtype, int B, int J, int HW, int pitch, float* coord, float* ms, void* stream);
+int hrp_softargmax_flat_bwd(const void* logits, int dtype, int B, int J, int HW, int pitch, const float* coord, const float* ms,
+                            const float* dcoord, void* dlogits, int dpitch, void* stream);
+
 /* out[n] = rotmat_to_rot6d(rot6d_to_rotmat(a[n]) @ rot6d_to_rotmat(b[n]))  (dense fp32 [N, 6]): the update of the
  * rot_iterative_matmul regressor (reference full_net.py:346-362, lib/utils/geometries.py:100-131).  Backward: exact, by
  * forward-mode differentiation of the same code; da / db may be NULL; acc_*: add to the existing gradient. */

@@ -108,7 +108,7 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
                  fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32",
-                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False, add_fc=False):
+                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False, add_fc=False, joint_bounds=None):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
@@ -146,7 +146,18 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
     xyz_int = uvd_to_xyz(uvd, K, pred_depth, image_size, depth_factor)
     root_uv = (uvd[:, root, :2] + 0.5) * image_size                                  # :302
     trans = uvz2xyz_singlepoint(root_uv, pred_depth, K)                               # :305
-    pose = _iter_reg(sd, xf, sd["init_pose"].expand(B, -1), n_iter, "fc_pose_1", "fc_pose_2", "decpose")
+    if joint_bounds is not None:    # reg_joint_map (full_net.py:313-316; HeatmapIntegralJoint, integral.py:206-232)
+        from .hrnet import _Ctx, _bn
+        c, j = _Ctx(sd, "", training), x_out
+        for i in (0, 3, 6):
+            j = F.relu(_bn(c, f"joint_conv_layers.{i + 1}", F.conv2d(j, sd[f"joint_conv_layers.{i}.weight"], sd[f"joint_conv_layers.{i}.bias"], padding=1)))
+        jm = F.conv2d(j, sd["joint_final_layer.weight"], sd["joint_final_layer.bias"])
+        hm = F.softmax(jm.reshape(B, jm.shape[1], -1), 2)
+        coord = (hm * torch.arange(hm.shape[-1], dtype=torch.float32)).sum(2) / float(hm.shape[-1])
+        jb = torch.as_tensor(joint_bounds, dtype=torch.float32)
+        pose = coord * (jb[:, 1] - jb[:, 0]) + jb[:, 0]
+    else:
+        pose = _iter_reg(sd, xf, sd["init_pose"].expand(B, -1), n_iter, "fc_pose_1", "fc_pose_2", "decpose")
     if direct_reg_rot:      # full_net.py:333-345: six stacked Linear layers with one skip, no iteration, no init_rot
         lin = lambda n, v: F.linear(v, sd[n + ".weight"], sd[n + ".bias"])   # noqa: E731
         xc1 = lin("fc_rot_1", xf)

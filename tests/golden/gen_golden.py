@@ -456,6 +456,20 @@ def gen_full_add_fc():
     print("full add_fc ok", out["eval:depth"].ravel(), out["train:depth"].ravel())
 
 
+def gen_full_eval_joint_map():
+    """reg_joint_map = True, joint_conv_dim = [128, 128, 128], ResNet-50 regression trunk (full_net.py:87-93, 218-237,
+    313-316; HeatmapIntegralJoint, integral.py:186-232).  (The integral layer moves the joint bounds to the GPU inside
+    forward: .cuda() is a no-op for this CPU run.)"""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    full, _ = build_full("resnet50", reg_joint_map=True, joint_conv_dim=[128, 128, 128])
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_joint_map.npz"), **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval (reg_joint_map) ok", o[0][0])
+
+
 def gen_full_eval_baxter():
     """15 DoF / 17 key-points: 1088 heat-map channels, 2063-wide pose regressor, tree FK with key-point offsets."""
     full, _ = build_full(robot_type="baxter")

@@ -304,6 +304,59 @@ def test_full_add_fc_golden_and_gradients():
         assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
 
 
+def test_full_reg_joint_map_golden_and_gradients():
+    """reg_joint_map = True (ResNet-50 regression trunk; full_net.py:87-93, 218-237, 313-316, integral.py:186-232): the
+    joint angles come from a flat soft-argmax over one 8 x 8 map per joint, scaled into the joint bounds.  hrp_softargmax_flat_*
+    against torch, the eval 8-tuple against the reference, the joint head's gradients against the oracle."""
+    from hrpe_amd import _native as nv
+    from hrpe_amd.lib.dataset.const import JOINT_BOUNDS
+    from oracle import fk as ofk, heads as oheads
+    gen = torch.Generator().manual_seed(5)
+    lg = torch.randn(3, 64, 8, generator=gen) * 3
+    lr = lg.clone().requires_grad_(True)
+    hm = torch.softmax(lr.permute(0, 2, 1), 2)
+    want = (hm * torch.arange(64.0)).sum(2) / 64.0
+    gc = torch.randn(3, 8, generator=gen)
+    (want * gc).sum().backward()
+    ld, coord, ms, dl = lg.to(DEV), torch.zeros(3, 8, device=DEV), torch.zeros(3, 16, device=DEV), torch.zeros(3, 64, 8, device=DEV)
+    nv.call("hrp_softargmax_flat_fwd", ld.data_ptr(), nv.HRP_F32, 3, 8, 64, 8, coord.data_ptr(), ms.data_ptr(), None)
+    nv.call("hrp_softargmax_flat_bwd", ld.data_ptr(), nv.HRP_F32, 3, 8, 64, 8, coord.data_ptr(), ms.data_ptr(), gc.to(DEV).data_ptr(),
+            dl.data_ptr(), 8, None)
+    torch.cuda.synchronize()
+    assert float((coord.cpu() - want.detach()).abs().max()) < 2e-6
+    assert float((dl.cpu() - lr.grad).abs().max()) < 1e-5 * max(1.0, float(lr.grad.abs().max()))
+    g = load("golden_full_eval_joint_map.npz")
+    m = build_full(backbone_name="resnet50", reg_joint_map=True, joint_conv_dim=[128, 128, 128]).eval()
+    keys = set(m.state_dict().keys())
+    assert "joint_conv_layers.6.bias" in keys and "joint_final_layer.weight" in keys and "fc_pose_1.weight" not in keys
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    for n, t in zip(NAMES8, o):
+        ref = g[n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    m.train()
+    m.zero_grad()
+    o = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    (o[0].square().sum() + o[7].square().sum()).backward()
+    sd = {k: v.detach().cpu().clone() for k, v in synth_state_dict(m.state_dict()).items()}
+    # (not joint_final_layer.bias: a per-channel shift of the logits leaves the softmax unchanged - its gradient is rounding noise)
+    names = ["joint_final_layer.weight", "joint_conv_layers.7.weight", "joint_conv_layers.6.weight", "joint_conv_layers.4.weight",
+             "joint_conv_layers.1.bias"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    oo = oheads.full_forward(sd, ofk.Robot(PANDA_URDF), x_reg, x_root, kv, K, training=True, reg_backbone="resnet50",
+                             joint_bounds=JOINT_BOUNDS["panda"])
+    (oo[0].square().sum() + oo[7].square().sum()).backward()
+    params = dict(m.named_parameters())
+    for k in names:
+        if float(sd[k].grad.norm()) < 1e-12:      # (a conv bias in front of a train-mode BatchNorm has no gradient)
+            continue
+        e = float((params[k].grad.detach().cpu() - sd[k].grad).norm() / (sd[k].grad.norm() + 1e-30))
+        assert e < GRAD_TOL, f"grad {k}: L2 rel {e}"
+
+
 def test_full_test_fps_split_timers():
     """test_fps = True (full_net.py:253-286, 385-392): the 8-tuple plus (time_root, time_other, time_whole); the root part
     is timed as its own plan (root trunk + depth layer), the rest is the remainder."""

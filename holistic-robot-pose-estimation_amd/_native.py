@@ -33,7 +33,13 @@ class ConvDesc(C.Structure):
                 ("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wtap", C.c_int32 * MAX_TAPS),
                 ("w_ntaps", C.c_int32), ("w_cout_pad", C.c_int32), ("relu", C.c_int32),
                 ("bnb_x", C.c_void_p), ("bnb_mask", C.c_void_p), ("bnb_consts", C.c_void_p),
-                ("bnb_x_pitch", C.c_int32), ("bnb_mask_pitch", C.c_int32)]
+                ("bnb_x_pitch", C.c_int32), ("bnb_mask_pitch", C.c_int32),
+                ("bnb_stats", C.c_void_p), ("bnb_gamma", C.c_void_p), ("bnb_beta", C.c_void_p),
+                ("bnb_count", C.c_float), ("bnb_eps", C.c_float),
+                ("pro_mode", C.c_int32), ("pro_reserved", C.c_int32),
+                ("pro_x2", C.c_void_p), ("pro_stats", C.c_void_p), ("pro_bsums", C.c_void_p),
+                ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p),
+                ("pro_count", C.c_float), ("pro_eps", C.c_float), ("pro_side", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -144,6 +150,7 @@ PROTOTYPES = {
     "hrp_maxpool3x3s2_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "hrp_maxpool3x3s2_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hrp_conv2d_fwd": [C.POINTER(ConvDesc), _P],
+    "hrp_conv_rowstrip_channels": [C.POINTER(ConvDesc)],
     "hrp_conv2d_bwd_weight": [C.POINTER(WgradDesc), _P],
     "hrp_colsum": [_P, _I, _L, _I, _I, _P, _I, _P],
     "hrp_ew_fwd": [C.POINTER(EwDesc), _P],

@@ -7,7 +7,7 @@
 // output channels - instead of shrinking tiles until one problem alone reaches 256 workgroups; the weight slab of a
 // 128- or 256-channel layer is then staged once per 256 pixels instead of once per 64 or 128.
 #pragma once
-#include "conv_tile.h"
+#include "conv_row.h"
 #include <string.h>
 
 namespace hrp {
@@ -15,9 +15,11 @@ namespace hrp {
 struct ConvProblem {
   hrp_conv_desc d;
   ConvTiling t;
-  int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64, 4: 0 with persistent workgroups
+  int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64, 4: 0 with persistent workgroups,
+                  // 5 / 6: row-strip kernel (conv_row.h) for 32 / 64 channels
   int pgrid;      // cfg 4: workgroups of this problem
   int pad[2];
+  RowPlan r;      // cfg 5 / 6
 };
 
 // LIGHT: the variant for batches of problems with <= 32 output channels only (the high-resolution branch of both
@@ -25,7 +27,7 @@ struct ConvProblem {
 // lets this one carry the persistent body (plans live across tiles: ~200 registers) and still run two workgroups
 // per CU.
 template <typename T, int NT, bool LIGHT>
-__global__ __launch_bounds__(256) void conv_batch_kernel(const ConvProblem* __restrict__ tab, const BatchHdr h) {
+__global__ __launch_bounds__(256, LIGHT ? 1 : 2) void conv_batch_kernel(const ConvProblem* __restrict__ tab, const BatchHdr h) {
   int base;
   const int g = batch_find(h, blockIdx.x, base);
   const ConvProblem& P = tab[g];
@@ -44,6 +46,8 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(const ConvProblem* __re
       case 0: conv_tile_body<T, 1, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
       case 1: conv_tile_body<T, 1, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
       case 2: conv_tile_body<T, 2, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
+      case 5: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_row_body<32>(P.d, P.r, bid, slot); break;
+      case 6: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_row_body<64>(P.d, P.r, bid, slot); break;
       default: conv_tile_body<T, 2, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
     }
   }
@@ -52,6 +56,17 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(const ConvProblem* __re
 template <typename T, int NT>
 static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds) {
   int rc = -100;
+  if constexpr (NT == 9 && Elem<T>::SZ == 2) {
+    const int rc_ = hrp_conv_rowstrip_channels(&d);
+    if (rc_) {   // the lean kernel of the high-resolution BasicBlock layers
+      row_plan(d, P.r);
+      P.t = ConvTiling{};
+      P.t.nblocks = P.r.nstrips;
+      P.cfg = rc_ == 32 ? 5 : 6;
+      lds = row_lds_bytes(rc_);
+      return HRP_OK;
+    }
+  }
   static const int budget_kb = getenv("HRP_CONV_BATCH_LDS_KB") ? atoi(getenv("HRP_CONV_BATCH_LDS_KB")) : 76;   // tuning knob
   g_conv_lds_budget_kb = budget_kb;
   if (d.Cout <= 32) {
@@ -88,6 +103,7 @@ static int conv_batch_prepare_nt(const hrp_conv_desc* descs, int n, ConvProblem*
     // work of one workgroup (MFMA steps): the long-running problems go first so that the launch tail is short
     const int ct = probs[i].cfg >= 2 ? 2 : 1, pt = (probs[i].cfg & 1) ? 1 : 2;
     weight[i] = (long)cdiv(d.Cin * SZ, ROW) * NT * ct * pt;
+    if (probs[i].cfg >= 5) weight[i] = (long)cdiv(d.Cin * SZ, ROW) * NT * 4;     // 4 tiles per wave
   }
   int order[HRP_BATCH_MAX];
   for (int i = 0; i < n; ++i) order[i] = i;

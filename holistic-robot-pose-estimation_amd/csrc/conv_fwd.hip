@@ -1,7 +1,7 @@
 // bf16 instantiations of the tile convolution (conv_tile.h) and the C entry point hrp_conv2d_fwd.
 // (The fp32 kernels live in conv_fwd_f32.hip, the batched kernels in conv_batch_{bf16,f32}.hip: four translation
 // units, for build time only.)
-#include "conv_tile.h"
+#include "conv_row.h"
 
 namespace hrp {
 
@@ -19,7 +19,7 @@ int conv_check(const hrp_conv_desc* d) {
   HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
   HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
   HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
-  if (d->bnb_x) {   // BatchNorm-backward reduce in the epilogue: only the plain vector store path computes it
+  if (d->bnb_x && d->bnb_mask) {   // BatchNorm-backward reduce in the epilogue: only the plain vector store path computes it
     const int sz = d->dtype == HRP_F32 ? 4 : 2;
     HRP_REQUIRE(d->stats && d->bnb_mask && d->bnb_consts, "conv: bnb_x needs stats, bnb_mask and bnb_consts");
     HRP_REQUIRE(!d->res && !d->relu && !d->bias && !d->scale, "conv: bnb_x excludes res / relu / bias / scale");
@@ -28,16 +28,25 @@ int conv_check(const hrp_conv_desc* d) {
     HRP_REQUIRE((uintptr_t)d->y % 16 == 0 && ((size_t)d->y_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_x % 16 == 0 &&
                 ((size_t)d->bnb_x_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_consts % 16 == 0, "conv: bnb_x alignment");
   }
+  // input transforms / the mask-less epilogue reduce exist in the row-strip kernel only (conv_row.h)
+  if (d->pro_mode != 0 || d->pro_side || (d->bnb_x && !d->bnb_mask))
+    HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / mask-less bnb_x need a row-strip problem (hrp_conv_rowstrip_channels)");
   return HRP_OK;
 }
 
 }  // namespace hrp
+
+extern "C" int hrp_conv_rowstrip_channels(const hrp_conv_desc* d) {
+  static const bool off = getenv("HRP_NO_ROWCONV") != nullptr;     // A/B switch: everything on the general tile program
+  return (d && !off) ? hrp::row_channels(*d) : 0;
+}
 
 extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   using namespace hrp;
   const int rc = conv_check(d);
   if (rc != HRP_OK) return rc;
   if (d->dtype == HRP_F32) return launch_conv_f32(*d, (hipStream_t)stream);
+  if (hrp_conv_rowstrip_channels(d)) return launch_conv_row(*d, (hipStream_t)stream);
   return launch_conv<bf16_t>(*d, (hipStream_t)stream);
 }
 

@@ -1,0 +1,483 @@
+// Row-strip 3x3 convolution for the high-resolution branches of HRNet (gfx950, bf16): the lean kernel of the
+// BasicBlock layers conv3x3 C -> C with C = 32 @ W = 64 and C = 64 @ W = 32 (reference HRnet.py:28-57; 130 of the 326
+// convolutions of an HRNet-W32 forward and as many data gradients).  In both shapes an image row is exactly 4 KiB.
+//
+// Why a second kernel: the general tile program (conv_tile.h) spends ~2 100 instructions per wave on a 256-pixel tile of
+// these layers (index arithmetic of its DMA / store plans, LDS round trip of the epilogue) for 36 MFMAs; here the shape
+// is a template constant and everything is affine in the lane id:
+//   workgroup (4 waves) -> one strip of TH = 8 full-width output rows of one image, all output channels
+//   staging   : the TH + 2 input rows are CONTIGUOUS in NHWC memory: 10 x 4 direct-to-LDS DMA pieces of 1 KiB, source =
+//               row base + lane constant (no bounds logic: rows outside the image are zero-filled, the left / right
+//               padding is ONE zero pixel between consecutive LDS rows, shared by x = W of row r and x = -1 of row r + 1)
+//   weights   : the wave's 32 output channels x all taps x all input channels live in REGISTERS as MFMA A fragments
+//               (72 VGPRs for C = 32, 144 for C = 64), read once per workgroup from the packed layout of hrp_pack_weights
+//   MFMA loop : a wave owns 4 vertically adjacent 32-pixel tiles; every B fragment (one ds_read_b128 of 32 pixels x 16
+//               channels at a tap-shifted address) feeds up to three accumulators (the taps dy = -1, 0, +1 of the three
+//               output rows that see this input row): 0.5 LDS reads per MFMA, no weight reads in the loop
+//   epilogue  : the MFMA row -> output channel assignment is permuted (a free choice: it is just which weight row a lane
+//               loads) so that a lane's 16 accumulators are 16 CONSECUTIVE channels of one pixel: two 16-byte stores per
+//               tile straight from registers, no LDS round trip; per-channel statistics are reduced across lanes with a
+//               reduce-scatter butterfly (31 shuffles for 32 values) once per workgroup
+//   LDS bank conflicts: a 16-lane group of ds_read_b128 reads the same 16-byte slot of 16 different pixels (pixel stride
+//               64 / 128 bytes = 4 / 2 pixels per 256-byte bank row); slot' = slot ^ g(x) with g = (x >> 2) & 3 resp.
+//               (x >> 1) & 7 of the IMAGE column x spreads them over all 16 slots.  The DMA writes lane-linear, so the
+//               permutation is applied on the per-lane source address (a constant) and again on the read address.
+//
+// Fused BatchNorm work (train mode; what takes the element-wise passes of a BasicBlock interior off HBM):
+//   pro_mode 1   the staged rows are x' = relu(bn(x)) (statistics of x from its producer's epilogue): every lane
+//                transforms, in place, exactly the 16 bytes it DMA'd itself (no extra barrier), and also stores them to
+//                pro_side (the activation the weight gradient of this layer reads) - replaces hrp_ew_fwd
+//   pro_mode 2   the staged rows are the BatchNorm + ReLU BACKWARD of (x = gradient of the activation, pro_x2 = BatchNorm
+//                input, same lane-constant addressing, through registers) - replaces hrp_ew_bwd_apply
+//   bnb_x        epilogue: sum g, sum g * xhat of the stored gradient (mask recomputed from bnb_x) - replaces
+//                hrp_ew_bwd_reduce (as conv_tile.h's bnb_*, but without the separate mask tensor)
+#pragma once
+#include "conv_tile.h"
+
+namespace hrp {
+
+template <int C>
+struct RowCfg {
+  static constexpr int W = 2048 / C;        // 64, 32
+  static constexpr int P = 2 * C;           // bytes per pixel
+  static constexpr int S = P / 16;          // 16-byte slots per pixel
+  static constexpr int KS = C / 16;         // MFMA k-steps per tap
+  static constexpr int MT = C / 32;         // 32-channel output tiles
+  static constexpr int NCOL = W / 32;       // 32-pixel tiles per image row
+  static constexpr int TH = 8;              // output rows per workgroup
+  static constexpr int PXP = 1024 / P;      // pixels per 1 KiB DMA piece
+  static constexpr int ROWB = (W + 1) * P;  // LDS row pitch: the row + one zero pixel
+  static constexpr int NROWS = TH + 2;
+  static constexpr int TILE_BYTES = P + NROWS * ROWB;               // leading zero pixel + rows
+  static constexpr int CTAB_OFF = (TILE_BYTES + 255) & ~255;        // per-channel constants [8][C] floats
+  static constexpr int STAT_OFF = CTAB_OFF + 8 * C * 4;             // [4 waves][64] floats
+  static constexpr int LDS_BYTES = STAT_OFF + 4 * 64 * 4;
+  static_assert(MT * NCOL == 2, "two waves side by side (columns or channel tiles), two on top of each other");
+  __device__ static __forceinline__ int g(int x) { return C == 32 ? (x >> 2) & 3 : (x >> 1) & 7; }
+};
+
+struct RowPlan {
+  int wslot[9];        // packed-weight tap slot of the canonical tap (dy + 1) * 3 + (dx + 1)
+  int nstrips, spi;    // workgroups = N * H / TH; strips per image
+  FastDiv fd_spi;
+  int pad[2];
+};
+
+// mean / invstd / scale / shift of one channel from the statistic slots (the arithmetic of elementwise.hip's
+// channel_consts: m = sum / n, var = max(sumsq / n - m^2, 0), invstd = rsqrt(var + eps), sc = gamma * invstd, sh = beta - m * sc)
+__device__ __forceinline__ void row_bn_consts(const float* stats, const float* gamma, const float* beta, float count, float eps,
+                                              int c, int C, float& mean, float& inv, float& sc, float& sh) {
+  const float m = slot_sum(stats, c, 2 * C) / count;
+  const float var = fmaxf(slot_sum(stats, C + c, 2 * C) / count - m * m, 0.f);
+  inv = rsqrtf(var + eps);
+  mean = m;
+  sc = gamma[c] * inv;
+  sh = beta[c] - m * sc;
+}
+
+// the relu(bn(.)) of the forward prologue and the mask of both backward uses: ONE expression, so that the three agree bit for bit
+__device__ __forceinline__ float row_bn_act(float x, float sc, float sh) { return fmaf(x, sc, sh); }
+
+// Host: is this problem one the row-strip kernel takes?  (Everything else runs the general tile program.)
+static inline int row_channels(const hrp_conv_desc& d) {
+  if (d.dtype != HRP_BF16 || d.ntaps != 9 || d.in_stride != 1 || d.out_stride != 1) return 0;
+  if (d.Cin != d.Cout || (d.Cin != 32 && d.Cin != 64)) return 0;
+  const int C = d.Cin;
+  if (d.W != 2048 / C || d.Wo != d.W || d.Ho != d.H || d.H % 8 || d.y_H != d.Ho || d.y_W != d.Wo) return 0;
+  if (d.x_pitch != C || d.y_pitch != C || d.w_cout_pad != C || (d.res && d.res_pitch != C)) return 0;
+  if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.w | (uintptr_t)d.res) % 16) return 0;
+  if (d.bias) return 0;
+  if (d.bnb_x && (d.bnb_mask || d.bnb_x_pitch != C || !d.bnb_stats || !d.bnb_gamma || !d.bnb_beta || !d.stats ||
+                  d.res || d.relu || d.scale || (uintptr_t)d.bnb_x % 16)) return 0;
+  if (d.pro_mode < 0 || d.pro_mode > 2) return 0;
+  if (d.pro_mode && (!d.pro_stats || !d.pro_gamma || !d.pro_beta)) return 0;
+  if (d.pro_mode == 2 && (!d.pro_x2 || !d.pro_bsums || (uintptr_t)d.pro_x2 % 16 || d.bnb_x)) return 0;
+  if (d.pro_side && (uintptr_t)d.pro_side % 16) return 0;
+  if ((long long)d.N * d.H * d.W * C * 2 >= (1ll << 31)) return 0;     // 32-bit byte offsets inside the tensors
+  unsigned seen = 0;
+  for (int i = 0; i < 9; ++i) {
+    if (d.dy[i] < -1 || d.dy[i] > 1 || d.dx[i] < -1 || d.dx[i] > 1) return 0;
+    seen |= 1u << ((d.dy[i] + 1) * 3 + d.dx[i] + 1);
+  }
+  return seen == 0x1ff ? C : 0;
+}
+
+static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
+  for (int i = 0; i < 9; ++i) rp.wslot[(d.dy[i] + 1) * 3 + d.dx[i] + 1] = d.wtap[i];
+  rp.spi = d.H / 8;
+  rp.nstrips = d.N * rp.spi;
+  rp.fd_spi = make_fastdiv(rp.spi);
+  rp.pad[0] = rp.pad[1] = 0;
+}
+
+template <int C>
+__device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
+  using R = RowCfg<C>;
+  constexpr int W = R::W, P = R::P, S = R::S, KS = R::KS, TH = R::TH, ROWB = R::ROWB, NROWS = R::NROWS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ctab = (float*)(smem + R::CTAB_OFF);
+  float* stat_lds = (float*)(smem + R::STAT_OFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int sel = wave & 1, rg = wave >> 1;
+  const int col = R::NCOL == 2 ? sel : 0;     // which 32-pixel column block of the rows
+  const int m = R::MT == 2 ? sel : 0;         // which 32-channel output tile
+  HRP_CSTAMP(0);
+
+  if ((rp.nstrips & 7) == 0) bid = (bid & 7) * (rp.nstrips >> 3) + (bid >> 3);   // strips of one image on one XCD
+  const int n = fdiv(bid, rp.fd_spi);
+  const int y0 = (bid - n * rp.spi) * TH;
+  const int H = d.H;
+  const int pro = d.pro_mode;
+
+  // ---- weights: A fragments of this wave's 32 output channels.  MFMA row rho = 8 q + 4 h + i carries output channel
+  // 16 h + 4 q + i, so that accumulator register 4 q + i of a lane (half h) is channel 16 h + 4 q + i: consecutive.
+  bf16x8 wf[9][KS];
+  auto load_weights = [&]() {
+    const int rho = l31;
+    const int co = m * 32 + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+    const char* wl = (const char*)d.w + co * ROW + half * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+        wf[t][kk] = *(const bf16x8*)(wl + (size_t)((kk * d.w_ntaps + rp.wslot[t]) * C) * ROW);
+  };
+  if (pro == 0) load_weights();
+
+  // ---- staging: piece `wave` of every row; the lane's 16 bytes = (pixel lane / S of the piece, slot lane % S), holding
+  // the LOGICAL slot (lane % S) ^ g(x)
+  const int px_in_piece = lane / S;
+  const int xcol = wave * R::PXP + px_in_piece;
+  const int lslot = (lane % S) ^ R::g(xcol);
+  const unsigned lane_off = (unsigned)(wave * 1024 + px_in_piece * P + lslot * 16);
+  const unsigned img_off = (unsigned)n * (unsigned)(H * W * P);
+  char* lds_rows = smem + P;
+  {
+    const char* xg = (const char*)d.x + img_off + lane_off;
+#pragma unroll
+    for (int rs = 0; rs < NROWS; ++rs) {
+      const int y = y0 - 1 + rs;
+      char* dst = lds_rows + rs * ROWB + wave * 1024;
+      if (y >= 0 && y < H) dma16(xg + y * (W * P), dst);
+      else *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // second operand of the backward prologue: same bytes of the BatchNorm input, through registers
+  uint4 x2[NROWS];
+  if (pro == 2) {
+    const char* x2g = (const char*)d.pro_x2 + img_off + lane_off;
+#pragma unroll
+    for (int rs = 0; rs < NROWS; ++rs) {
+      const int y = y0 - 1 + rs;
+      x2[rs] = make_uint4(0, 0, 0, 0);
+      if (y >= 0 && y < H) x2[rs] = *(const uint4*)(x2g + y * (W * P));
+    }
+  }
+  // the zero pixels: one in front of row slot 0, one behind every row slot
+  if (tid < (NROWS + 1) * S) {
+    const int k = tid / S, j = tid - k * S;
+    *(uint4*)(smem + (k == 0 ? 0 : P + (k - 1) * ROWB + W * P) + j * 16) = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- per-channel constants (LDS table [8][C]):
+  //   0 sc, 1 sh        of pro_stats  (prologue 1 / 2: act = fma(x, sc, sh))
+  //   2 a = invstd, 3 b = -mean * invstd, 4 k0, 5 k1     (prologue 2)
+  //   4 sc, 5 sh, 6 a, 7 b   of bnb_stats (epilogue reduce) - prologue 2 and the epilogue reduce never meet in one launch
+  const bool bnb = d.bnb_x != nullptr;
+  if (pro != 0 && tid < C) {
+    float mean, inv, sc, sh;
+    row_bn_consts(d.pro_stats, d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps, tid, C, mean, inv, sc, sh);
+    ctab[0 * C + tid] = sc; ctab[1 * C + tid] = sh;
+    if (pro == 2) {
+      ctab[2 * C + tid] = inv; ctab[3 * C + tid] = -mean * inv;
+      ctab[4 * C + tid] = slot_sum(d.pro_bsums, tid, 2 * C) / d.pro_count;
+      ctab[5 * C + tid] = slot_sum(d.pro_bsums, C + tid, 2 * C) / d.pro_count;
+    }
+  }
+  if (bnb && tid >= 64 && tid < 64 + C) {
+    const int c = tid - 64;
+    float mean, inv, sc, sh;
+    row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
+    ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+  }
+  HRP_CSTAMP(1);
+
+  // ---- prologue: transform the bytes this lane staged, in place
+  if (pro != 0) {
+    __syncthreads();                                          // the constant table
+    const int cb = lslot * 8;                                 // the lane's 8 channels
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; i += 4) {
+      const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this lane's DMA pieces (and x2) have landed
+    char* side = (char*)d.pro_side;
+    if (pro == 1) {
+#pragma unroll
+      for (int rs = 0; rs < NROWS; ++rs) {
+        const int y = y0 - 1 + rs;
+        if (y < 0 || y >= H) continue;
+        char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+        float f[8];
+        Elem<bf16_t>::unpack(*(const uint4*)p, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
+        const uint4 o = Elem<bf16_t>::pack(f);
+        *(uint4*)p = o;
+        if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
+      }
+    } else {
+      float a[8], b[8], k0[8], k1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
+        const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
+        a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
+        b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
+        k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
+        k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+      }
+#pragma unroll
+      for (int rs = 0; rs < NROWS; ++rs) {
+        const int y = y0 - 1 + rs;
+        if (y < 0 || y >= H) continue;
+        char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+        float gq[8], xv[8];
+        Elem<bf16_t>::unpack(*(const uint4*)p, gq);
+        Elem<bf16_t>::unpack(x2[rs], xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float g = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
+          const float xh = fmaf(xv[i], a[i], b[i]);
+          gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
+        }
+        const uint4 o = Elem<bf16_t>::pack(gq);
+        *(uint4*)p = o;
+        if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
+      }
+    }
+    load_weights();
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  HRP_CSTAMP(2);
+
+  // ---- MFMA loop: input rows rg*4 - 1 .. rg*4 + 4 of the strip (LDS row slots rg*4 .. rg*4 + 5)
+  f32x16 acc[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[o][i] = 0.f;
+  {
+    // read address of (dx, kk) for row slot rg*4: pixel x = col*32 + l31 + dx (x = -1 / W are the shared zero pixels)
+    int baddr[3][KS];
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int xq = col * 32 + l31 + dxi - 1;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+        baddr[dxi][kk] = P + rg * 4 * ROWB + xq * P + (((2 * kk + half) ^ R::g(xq)) << 4);
+    }
+    constexpr int NSTEP = 6 * 3 * KS, RING = 4, AHEAD = 3;
+    bf16x8 bq[RING];
+    auto rd = [&](int s) -> bf16x8 {   // s is a constant after unrolling
+      const int irel = s / (3 * KS), dxi = (s / KS) % 3, kk = s % KS;
+      return *(const bf16x8*)(smem + baddr[dxi][kk] + irel * ROWB);
+    };
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) bq[s % RING] = rd(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + AHEAD < NSTEP) bq[(s + AHEAD) % RING] = rd(s + AHEAD);
+      const int irel = s / (3 * KS), dxi = (s / KS) % 3, kk = s % KS;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int dyi = irel - o;                 // input row (rg*4 - 1 + irel) = output row (rg*4 + o) + dy, dy = dyi - 1
+        if (dyi >= 0 && dyi <= 2)
+          acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[dyi * 3 + dxi][kk], bq[s % RING], acc[o], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // keep the read-ahead where it is
+    }
+  }
+  HRP_CSTAMP(4);
+
+  // ---- epilogue: lane = pixel (row y0 + rg*4 + o, x = col*32 + l31), channels m*32 + 16*half .. +15
+  const unsigned out_off = img_off + (unsigned)((y0 + rg * 4) * W + col * 32 + l31) * P + (m * 32 + 16 * half) * 2;
+  const int cl = m * 32 + 16 * half;      // first channel of the lane
+  char* yg = (char*)d.y;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+  if (bnb) {
+    // y = gradient of act = relu(bn(bnb_x)), stored unmasked; sums of g = y * [act > 0] and g * bnb_x (finished to
+    // sum g * xhat = a * S2 + b * S1 per workgroup below)
+    const char* bx = (const char*)d.bnb_x + out_off;
+    uint4 xr[4][2];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { xr[o][0] = *(const uint4*)(bx + o * (W * P)); xr[o][1] = *(const uint4*)(bx + o * (W * P) + 16); }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      const float4 a = *(const float4*)(ctab + 4 * C + cl + i), b = *(const float4*)(ctab + 5 * C + cl + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float v[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = acc[o][8 * hh + i];
+        const uint4 pk = Elem<bf16_t>::pack(v);
+        *(uint4*)(yg + out_off + o * (W * P) + 16 * hh) = pk;
+        Elem<bf16_t>::unpack(pk, v);            // the values as stored
+        Elem<bf16_t>::unpack(xr[o][hh], xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
+          s1[8 * hh + i] += g;
+          s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
+        }
+      }
+    }
+  } else {
+    const char* rg_ = (const char*)d.res;
+    uint4 rr[4][2];
+    if (rg_) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) { rr[o][0] = *(const uint4*)(rg_ + out_off + o * (W * P)); rr[o][1] = *(const uint4*)(rg_ + out_off + o * (W * P) + 16); }
+    }
+    float sc[16], sh[16];
+    const bool aff = d.scale != nullptr;
+    if (aff) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const float4 a = *(const float4*)(d.scale + cl + i), b = *(const float4*)(d.shift + cl + i);
+        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = acc[o][8 * hh + i];
+        if (aff) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[8 * hh + i] + sh[8 * hh + i];
+        }
+        if (rg_) {
+          float r[8];
+          Elem<bf16_t>::unpack(rr[o][hh], r);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += r[i];
+        }
+        if (d.relu) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        const uint4 pk = Elem<bf16_t>::pack(v);
+        *(uint4*)(yg + out_off + o * (W * P) + 16 * hh) = pk;
+        if (d.stats) {
+          Elem<bf16_t>::unpack(pk, v);          // statistics of the values as stored
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { s1[8 * hh + i] += v[i]; s2[8 * hh + i] = fmaf(v[i], v[i], s2[8 * hh + i]); }
+        }
+      }
+    }
+  }
+  HRP_CSTAMP(5);
+  if (d.stats) {
+    // reduce-scatter over the 32 lanes of a half wave (they hold the same 16 channels): after the step with lane
+    // distance D a lane keeps the half of its values selected by its bit D; 31 shuffles instead of 32 x 5, and lane l31
+    // ends with the total of value l31 (s1[0..15], s2[0..15])
+    float v16[16];
+    {
+      const bool up = (l31 & 16) != 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float keep = up ? s2[j] : s1[j], send = up ? s1[j] : s2[j];
+        v16[j] = keep + __shfl_xor(send, 16, 64);
+      }
+    }
+    float v8[8], v4[4], v2[2], v1;
+    {
+      const bool up = (l31 & 8) != 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float keep = up ? v16[8 + j] : v16[j], send = up ? v16[j] : v16[8 + j];
+        v8[j] = keep + __shfl_xor(send, 8, 64);
+      }
+    }
+    {
+      const bool up = (l31 & 4) != 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float keep = up ? v8[4 + j] : v8[j], send = up ? v8[j] : v8[4 + j];
+        v4[j] = keep + __shfl_xor(send, 4, 64);
+      }
+    }
+    {
+      const bool up = (l31 & 2) != 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float keep = up ? v4[2 + j] : v4[j], send = up ? v4[j] : v4[2 + j];
+        v2[j] = keep + __shfl_xor(send, 2, 64);
+      }
+    }
+    {
+      const bool up = (l31 & 1) != 0;
+      const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
+      v1 = keep + __shfl_xor(send, 1, 64);
+    }
+    // lane l31 < 16: sum 1 of channel cl + l31; l31 >= 16: sum 2 of channel cl + l31 - 16
+    stat_lds[wave * 64 + lane] = v1;
+    __syncthreads();
+    if (tid < 2 * C) {
+      const int which = tid / C, c = tid - which * C;
+      const int mc = c >> 5, hq = (c >> 4) & 1, j = c & 15;
+      auto tot = [&](int wh) {
+        const int li = hq * 32 + wh * 16 + j;
+        float t = 0.f;
+        if (R::MT == 1) t = (stat_lds[0 * 64 + li] + stat_lds[1 * 64 + li]) + (stat_lds[2 * 64 + li] + stat_lds[3 * 64 + li]);
+        else t = stat_lds[mc * 64 + li] + stat_lds[(mc + 2) * 64 + li];
+        return t;
+      };
+      float t = tot(which);
+      if (bnb && which == 1) t = fmaf(ctab[6 * C + c], t, ctab[7 * C + c] * tot(0));     // sum g * xhat = a * sum g x + b * sum g
+      atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, t);
+    }
+  }
+  HRP_CSTAMP(6);
+  HRP_CSTAMP(7);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void conv_row_kernel(const hrp_conv_desc d, const RowPlan rp) {
+  conv_row_body<C>(d, rp, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
+}
+
+static inline int row_lds_bytes(int C) { return C == 32 ? RowCfg<32>::LDS_BYTES : RowCfg<64>::LDS_BYTES; }
+
+// -> HRP_OK when launched, -100 when the problem is not a row-strip problem
+static int launch_conv_row(const hrp_conv_desc& d, hipStream_t s) {
+  const int C = row_channels(d);
+  if (!C) return -100;
+  RowPlan rp;
+  row_plan(d, rp);
+  if (C == 32) hipLaunchKernelGGL(conv_row_kernel<32>, dim3(rp.nstrips), dim3(256), RowCfg<32>::LDS_BYTES, s, d, rp);
+  else hipLaunchKernelGGL(conv_row_kernel<64>, dim3(rp.nstrips), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
+  return check_launch("conv_row_kernel");
+}
+
+}  // namespace hrp

@@ -143,6 +143,9 @@ WGRAD_FOLD_EVERY = int(os.environ.get("HRP_WGRAD_FOLD_EVERY", "32"))
 # tap count are pending (or the lane ends) and then run as ONE batched launch - also the layers that have no lock-step
 # partner (stem, layer1, transitions, the fuse convolutions).  0: every launch stays where the layer's backward put it.
 WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "8"))
+# train-mode BasicBlock interiors conv -> BN -> ReLU -> conv on the row-strip kernel (csrc/conv_row.h): the BatchNorm + ReLU
+# runs in the second convolution's staging path, its backward in the staging path of the first convolution's data gradient
+ROWCONV_FUSE = not os.environ.get("HRP_NO_ROWCONV_FUSE")
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
 # development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
 BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
@@ -221,7 +224,8 @@ class Launch:
         """Device addresses this launch writes (two launches of one batch must not share any)."""
         d = self.desc
         if self.fam == "conv":
-            return (d.y + ((d.out_off_y * d.y_W + d.out_off_x) * d.y_pitch if d.out_stride > 1 else 0),)
+            main = d.y + ((d.out_off_y * d.y_W + d.out_off_x) * d.y_pitch if d.out_stride > 1 else 0)
+            return (main, d.pro_side) if d.pro_side else (main,)
         if self.fam in ("wgrad", "wgrad_fold"):
             return (d.dw + 4 * d.dw_tap_off,)
         if self.fam == "ew_fwd":
@@ -693,7 +697,7 @@ class Plan:
             vec = 16 // esz
             if j > i or ce.lane != e.lane or ce.path != e.path:
                 continue
-            if d.res or d.relu or d.bias or d.scale or d.stats or d.out_stride != 1 or (d.y_H, d.y_W) != (d.Ho, d.Wo):
+            if d.res or d.relu or d.bias or d.scale or d.stats or d.out_stride != 1 or (d.y_H, d.y_W) != (d.Ho, d.Wo) or d.pro_mode or d.bnb_x:
                 continue
             if (d.N, d.Ho, d.Wo, d.Cout, d.y_pitch, d.dtype) != (b.N, b.H, b.W, b.C, b.dout_pitch, b.dtype) or d.Cout % vec:
                 continue
@@ -1393,6 +1397,118 @@ class PlanBuilder:
         if p.need_grad:
             self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu))
         return y
+
+    def _wgrad_launch(self, x, w, y, ksize=3, stride=1):
+        """Weight-gradient launch of conv(x) -> y for parameter holder w (dW (+)= x^T * y.grad)."""
+        p = self.plan
+        dtype = x.dtype
+        vec = 8 if dtype == torch.bfloat16 else 4
+        taps = _TAPS3 if ksize == 3 else [(0, 0)]
+        g = nv.WgradDesc()
+        g.x, g.dy, g.dw = x.ptr(), y.gptr(), p.grad_of_param(w.param).data_ptr()
+        g.dtype = _dt(dtype)
+        g.N, g.H, g.W, g.Cin, g.x_pitch = x.N, x.H, x.W, _rup(x.C, vec), x.pitch
+        g.Ho, g.Wo, g.Cout, g.dy_pitch = y.H, y.W, y.C, y.pitch
+        g.in_stride, g.ntaps = stride, len(taps)
+        for i, (a, b) in enumerate(taps):
+            g.dy_t[i], g.dx_t[i] = a, b
+        g.dw_cin = w.cin
+        g.accumulate = 1 if (w.grad_written or p.grad_arena is not None) else 0
+        w.grad_written = True
+        lane = p.cur_lane
+        p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
+        p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
+        p.bwd.append(Launch("wgrad", g))
+
+    def conv_bn_relu_conv(self, x, conv1_w, bn1, conv2_w):
+        """y2 = conv2(relu(bn1(conv1(x)))), the interior of a BasicBlock (reference HRnet.py:41-50), in a TRAINING plan on the
+        row-strip kernel: conv1 as usual (statistics in its epilogue), conv2 with the BatchNorm + ReLU applied while its
+        input rows are staged (the activation leaves as a side output, the operand of conv2's weight gradient) - no
+        hrp_ew_fwd pass.  Backward: conv2's data gradient accumulates the BatchNorm-backward sums in its epilogue, conv1's
+        data gradient applies the BatchNorm + ReLU backward while IT stages (side output: the gradient of conv1's output,
+        the operand of conv1's weight gradient) - no hrp_ew_bwd_reduce / hrp_ew_bwd_apply passes.
+        -> y2 (raw, with statistics), or None when the shapes / mode are not the row-strip kernel's (caller: general path)."""
+        p = self.plan
+        if not (ROWCONV_FUSE and p.training and x.dtype == torch.bfloat16):
+            return None
+        Cc = x.C
+        if tuple(conv1_w.shape) != (Cc, Cc, 3, 3) or tuple(conv2_w.shape) != (Cc, Cc, 3, 3) or x.pitch != Cc or x.offset:
+            return None
+        if p.need_grad and not x.requires_grad:
+            return None
+        x.check_readable()
+        dtype = x.dtype
+        w1 = p.weight(conv1_w, Cc, Cc, 9)
+        probe = self._conv_desc(x, w1, x, 1, 3, dtype)       # geometry only; dummy aligned pointers
+        probe.w = probe.x
+        probe.pro_mode, probe.pro_stats, probe.pro_gamma, probe.pro_beta = 1, probe.x, probe.x, probe.x
+        if nv.lib().hrp_conv_rowstrip_channels(C.byref(probe)) != Cc:
+            return None
+        w2 = p.weight(conv2_w, Cc, Cc, 9)
+        for w in (w1, w2):
+            w.dtype, w.cin_used = dtype, Cc
+            w.need_t = getattr(w, "need_t", False) or p.need_grad
+        esz = 2
+        cnt = float(x.N * x.H * x.W)
+        y1, h, y2 = p.new(x.N, x.H, x.W, Cc, dtype), p.new(x.N, x.H, x.W, Cc, dtype), p.new(x.N, x.H, x.W, Cc, dtype)
+        for t in (y1, h, y2):
+            t.requires_grad = p.need_grad
+        y1.stats, y2.stats = p.alloc_stats(Cc), p.alloc_stats(Cc)
+        p.bn_train.append((bn1, y1.stats, x.N * x.H * x.W))
+        gam, bet = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+        d1 = self._conv_desc(x, w1, y1, 1, 3, dtype)
+        d2 = self._conv_desc(y1, w2, y2, 1, 3, dtype)
+        d2.pro_mode, d2.pro_gamma, d2.pro_beta, d2.pro_count, d2.pro_eps, d2.pro_side = 1, gam, bet, cnt, bn1.eps, h.ptr()
+
+        def late():
+            d1.w, d2.w = w1.arena.data_ptr() + w1.fwd_off * esz, w2.arena.data_ptr() + w2.fwd_off * esz
+            d1.stats, d2.stats = p.stats.data_ptr() + 4 * y1.stats, p.stats.data_ptr() + 4 * y2.stats
+            d2.pro_stats = d1.stats
+        p.late(late)
+        p.fwd.append(Launch("conv", d1))
+        p.fwd.append(Launch("conv", d2))
+        y1.producer, y2.producer = None, ("conv", d2)
+        p.counters["rowconv_fused_blocks"] = p.counters.get("rowconv_fused_blocks", 0) + 1
+        if p.need_grad:
+            def bw():
+                if not y2.grad_written:
+                    return
+                if conv2_w.requires_grad:
+                    self._wgrad_launch(h, w2, y2)
+                # data gradient of conv2 -> gradient of the activation h (raw), BatchNorm-backward sums in the epilogue
+                h.take_grad_slot()
+                boff = p.alloc_bsums(Cc)
+                p.bn_bwd.append((bn1, boff))
+                g2 = self._conv_desc(y2, w2, h, 1, 3, dtype)
+                g2.x, g2.y = y2.gptr(), h.gptr()
+                for i, (a, b) in enumerate(_TAPS3):
+                    g2.dy[i], g2.dx[i], g2.wtap[i] = -a, -b, i
+                g2.bnb_x, g2.bnb_x_pitch = y1.ptr(), y1.pitch
+                g2.bnb_gamma, g2.bnb_beta, g2.bnb_count, g2.bnb_eps = gam, bet, cnt, bn1.eps
+                # data gradient of conv1 -> x.grad; its staged operand is the BatchNorm + ReLU backward of (h.grad, y1)
+                y1.take_grad_slot()
+                acc = x.take_grad_slot()
+                g1 = self._conv_desc(h, w1, x, 1, 3, dtype)
+                g1.x, g1.y = h.gptr(), x.gptr()
+                for i, (a, b) in enumerate(_TAPS3):
+                    g1.dy[i], g1.dx[i], g1.wtap[i] = -a, -b, i
+                if acc:
+                    g1.res, g1.res_pitch = x.gptr(), x.pitch
+                g1.pro_mode, g1.pro_x2, g1.pro_gamma, g1.pro_beta, g1.pro_count, g1.pro_eps = 2, y1.ptr(), gam, bet, cnt, bn1.eps
+                g1.pro_side = y1.gptr()
+
+                def late_b():
+                    g2.w, g1.w = w2.arena.data_ptr() + w2.bwd_off * esz, w1.arena.data_ptr() + w1.bwd_off * esz
+                    g2.stats = p.bsums.data_ptr() + 4 * boff
+                    g2.bnb_stats = g1.pro_stats = p.stats.data_ptr() + 4 * y1.stats
+                    g1.pro_bsums = g2.stats
+                p.late(late_b)
+                p.bwd.append(Launch("conv", g2))
+                p.bwd.append(Launch("conv", g1))
+                if conv1_w.requires_grad:
+                    self._wgrad_launch(x, w1, y1)
+            self.bwd_stack.append(bw)
+        return y2
 
     def linear(self, x, weight, bias=None, residual=None):
         """y = x W^T + b (+ residual) on fp32 [N, C] tensors: nn.Linear of the regression heads as a skinny GEMM that reads

@@ -102,6 +102,33 @@ typedef struct hrp_conv_desc {
   const uint8_t* bnb_mask;  /* ReLU bit mask of the activation (hrp_ew_desc.mask), one byte per vector          */
   const float* bnb_consts;  /* [2 * Cout]: mean, invstd of the BatchNorm input (hrp_ew_desc.consts_out)        */
   int32_t bnb_x_pitch, bnb_mask_pitch;
+  /* ---- fields below: row-strip kernels only (hrp_conv_rowstrip_channels(d) != 0: the 3x3 stride-1 C -> C layers of the
+   * HRNet branches, bf16, dense NHWC rows of 4 KiB: C = 32 @ W = 64, C = 64 @ W = 32).  Any other problem that sets them
+   * is HRP_ERR_ARG: callers ask hrp_conv_rowstrip_channels first.
+   * bnb_x with bnb_mask == NULL: the ReLU mask of the epilogue reduce is recomputed from bnb_x itself,
+   * mask = (bn(bnb_x) > 0), BatchNorm constants derived in the kernel from bnb_stats (the forward sum / sum-of-squares
+   * slots of bnb_x), bnb_gamma, bnb_beta, bnb_count, bnb_eps - the arithmetic the forward prologue (pro_mode 1) applied. */
+  const float* bnb_stats;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  float bnb_count, bnb_eps;
+  /* Input transform applied while x is staged (reference HRnet.py:41-50: conv2(relu(bn1(conv1(x)))) and its autograd):
+   *   pro_mode 1: x' = relu(gamma * (x - mean) * invstd + beta) - train-mode BatchNorm of x from pro_stats (the sum /
+   *               sum-of-squares slots written by the epilogue of x's producer): the activation is never materialised
+   *               for this layer's forward (replaces an hrp_ew_fwd pass);
+   *   pro_mode 2: x' = gamma * invstd * (g - k0 - xhat * k1),  g = x * [bn(pro_x2) > 0],  xhat = (pro_x2 - mean) * invstd,
+   *               k0 / k1 = slot sums of pro_bsums / count: x is the gradient of relu(bn(pro_x2)), x' the gradient of
+   *               pro_x2 - what hrp_ew_bwd_apply computes in a pass of its own;
+   *   pro_side  (optional, geometry of x): x' is also written there, every pixel once - the operand the weight gradient
+   *               of the neighbouring layer reads (forward: the activation; backward: the BatchNorm input gradient). */
+  int32_t pro_mode, pro_reserved;
+  const void* pro_x2;
+  const float* pro_stats;
+  const float* pro_bsums;
+  const float* pro_gamma;
+  const float* pro_beta;
+  float pro_count, pro_eps;
+  void* pro_side;
 } hrp_conv_desc;
 
 /* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],
@@ -272,6 +299,9 @@ int hrp_maxpool3x3s2_bwd(const void* dy, int dy_pitch, const uint8_t* argmax, vo
                          int C, int pitch, int accumulate, void* stream);
 
 int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream);
+/* 32 / 64 when hrp_conv2d_fwd (and a HRP_BATCH_CONV launch) will run problem d on the row-strip kernel - the only one that
+ * honours pro_mode / pro_side / a mask-less bnb_x - else 0.  Host only. */
+int hrp_conv_rowstrip_channels(const hrp_conv_desc* d);
 int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream);
 /* scratch bytes hrp_conv2d_bwd_weight wants for this problem (0 is never returned for a valid problem) */
 int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d);

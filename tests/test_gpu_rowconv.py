@@ -1,0 +1,328 @@
+"""GPU parity tests of the row-strip convolution kernel (csrc/conv_row.h) through the C ABI: the lean 3x3 kernel of the
+HRNet branch BasicBlocks (reference HRnet.py:28-57) with its fused BatchNorm prologues / epilogues, against plain torch
+fp32 on the CPU.
+
+Tolerance: bf16 operands, fp32 accumulation - 2e-2 of the tensor's scale on outputs (one bf16 ulp is 2^-8), 2e-3 on fp32
+statistics (which are compared with sums over the kernel's OWN stored output, so only the summation order differs)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EPS = 1e-5
+SLOTS = 8
+TAPS3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+
+
+def nvmod():
+    import hrpe_amd  # noqa: F401
+    from hrpe_amd import _native as nv
+    return nv
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def pack(nv, w):
+    """fp32 [Cout, Cin, 3, 3] -> (forward packing, transposed packing) in bf16 (hrp_pack_weights)."""
+    cout, cin = w.shape[0], w.shape[1]
+    nf = -(-cin // 16) * 9 * rup(cout, 32) * 16
+    nb = -(-cout // 16) * 9 * rup(cin, 32) * 16
+    dst = torch.zeros(nf, dtype=torch.bfloat16, device=DEV)
+    dst_t = torch.zeros(nb, dtype=torch.bfloat16, device=DEV)
+    tab = (nv.PackEntry * 1)()
+    wd = w.to(DEV).contiguous()
+    tab[0].src, tab[0].dst, tab[0].dst_t = wd.data_ptr(), dst.data_ptr(), dst_t.data_ptr()
+    tab[0].Cout, tab[0].Cin, tab[0].ntaps = cout, cin, 9
+    tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(DEV)
+    nv.call("hrp_pack_weights", tdev.data_ptr(), 1, nv.HRP_BF16, max(nf, nb), None)
+    torch.cuda.synchronize()
+    return dst, dst_t
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def nhwc(x_nchw_bf):
+    """fp32 NCHW values (already bf16-representable) -> dense NHWC bf16 device tensor."""
+    return x_nchw_bf.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def from_nhwc(t, N, H, W, Cc):
+    return t.float().cpu().view(N, H, W, Cc).permute(0, 3, 1, 2)
+
+
+def desc(nv, x, wp, y, N, H, W, Cc, transposed=False):
+    d = nv.ConvDesc()
+    d.x, d.w, d.y, d.dtype = x.data_ptr(), wp.data_ptr(), y.data_ptr(), nv.HRP_BF16
+    d.N, d.H, d.W, d.Cin, d.x_pitch = N, H, W, Cc, Cc
+    d.Ho, d.Wo, d.Cout = H, W, Cc
+    d.y_H, d.y_W, d.y_pitch, d.res_pitch = H, W, Cc, Cc
+    d.out_stride, d.in_stride, d.ntaps, d.w_ntaps, d.w_cout_pad = 1, 1, 9, 9, Cc
+    for i, (a, b) in enumerate(TAPS3):
+        if transposed:      # data gradient: mirrored taps on the transposed packing
+            d.dy[i], d.dx[i], d.wtap[i] = -a, -b, i
+        else:
+            d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+    return d
+
+
+def slots_of(total, g):
+    """Split per-channel totals [2C] over the 8 statistic slots at random (the kernel must add the slots)."""
+    r = torch.rand(SLOTS, total.numel(), generator=g)
+    r = r / r.sum(0, keepdim=True)
+    return (r * total[None]).float().contiguous().to(DEV)
+
+
+def bn_consts(x, gamma, beta):
+    """fp32 per-channel train-mode BatchNorm constants of NCHW x: mean, invstd, sc, sh."""
+    cnt = x.numel() / x.shape[1]
+    s1, s2 = x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))
+    m = s1 / cnt
+    var = (s2 / cnt - m * m).clamp_min(0)
+    inv = torch.rsqrt(var + EPS)
+    sc = gamma * inv
+    return m, inv, sc, beta - m * sc, torch.cat([s1, s2]), cnt
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+SHAPES = [(32, 3, 64), (64, 2, 32), (32, 1, 16), (64, 5, 8)]     # (C, N, H); W = 2048 / C
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_rowconv_plain_and_eval_epilogue(shape):
+    nv = nvmod()
+    Cc, N, H = shape
+    W = 2048 // Cc
+    g = torch.Generator().manual_seed(Cc * 131 + N)
+    x = bf(torch.randn(N, Cc, H, W, generator=g))
+    w = bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc))
+    wp, _ = pack(nv, w)
+    xd = nhwc(x)
+    y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
+    st = torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    d = desc(nv, xd, wp, y, N, H, W, Cc)
+    d.stats = st.data_ptr()
+    assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), w.double(), padding=1).float()
+    got = from_nhwc(y, N, H, W, Cc)
+    assert rel(got, ref) < 2e-2, rel(got, ref)
+    s = st.view(SLOTS, 2 * Cc).sum(0).cpu()
+    own = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
+    assert rel(s, own) < 2e-3, rel(s, own)
+    # eval-mode epilogue: folded BatchNorm affine + residual + ReLU (HRnet.py:52-56 in an inference plan)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    r = bf(torch.randn(N, Cc, H, W, generator=g))
+    rd = nhwc(r)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    d.stats, d.scale, d.shift, d.res, d.relu = None, scd.data_ptr(), shd.data_ptr(), rd.data_ptr(), 1
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    ref2 = torch.relu(ref * sc[None, :, None, None] + sh[None, :, None, None] + r)
+    got2 = from_nhwc(y, N, H, W, Cc)
+    assert rel(got2, ref2) < 2e-2, rel(got2, ref2)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_rowconv_bn_relu_prologue(shape):
+    """conv(relu(bn(x))) with the activation as a side output (pro_mode 1) == hrp_ew_fwd followed by the conv."""
+    nv = nvmod()
+    Cc, N, H = shape
+    W = 2048 // Cc
+    g = torch.Generator().manual_seed(Cc * 17 + N)
+    x = bf(torch.randn(N, Cc, H, W, generator=g) * 1.5 + 0.3)
+    w = bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc))
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    m, inv, sc, sh, tot, cnt = bn_consts(x, gamma, beta)
+    a = bf(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]))
+    ref = F.conv2d(a.double(), w.double(), padding=1).float()
+    wp, _ = pack(nv, w)
+    xd = nhwc(x)
+    y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
+    side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
+    st_in, st = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    d = desc(nv, xd, wp, y, N, H, W, Cc)
+    d.stats = st.data_ptr()
+    d.pro_mode, d.pro_stats, d.pro_gamma, d.pro_beta = 1, st_in.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    d.pro_count, d.pro_eps, d.pro_side = float(cnt), EPS, side.data_ptr()
+    assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    got, gside = from_nhwc(y, N, H, W, Cc), from_nhwc(side, N, H, W, Cc)
+    assert rel(gside, a) < 1e-2, rel(gside, a)           # (one bf16 ulp where the fp32 affine rounds the other way)
+    assert ((gside > 0) != (a > 0)).float().mean().item() < 1e-4
+    assert rel(got, ref) < 2e-2, rel(got, ref)
+    s = st.view(SLOTS, 2 * Cc).sum(0).cpu()
+    own = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
+    assert rel(s, own) < 2e-3, rel(s, own)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_rowconv_bn_backward_reduce_epilogue(shape):
+    """Data gradient whose epilogue accumulates sum g, sum g * xhat of the stored gradient (mask recomputed from the
+    BatchNorm input) == the conv followed by hrp_ew_bwd_reduce."""
+    nv = nvmod()
+    Cc, N, H = shape
+    W = 2048 // Cc
+    g = torch.Generator().manual_seed(Cc * 29 + N)
+    dy = bf(torch.randn(N, Cc, H, W, generator=g))
+    w = bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc))
+    x1 = bf(torch.randn(N, Cc, H, W, generator=g) * 2.0 - 0.4)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    m, inv, sc, sh, tot, cnt = bn_consts(x1, gamma, beta)
+    _, wpt = pack(nv, w)
+    dyd, x1d = nhwc(dy), nhwc(x1)
+    y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
+    st_in, bs = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    d = desc(nv, dyd, wpt, y, N, H, W, Cc, transposed=True)
+    d.stats, d.bnb_x, d.bnb_x_pitch = bs.data_ptr(), x1d.data_ptr(), Cc
+    d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps = st_in.data_ptr(), gd.data_ptr(), bd.data_ptr(), float(cnt), EPS
+    assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()      # the data gradient of conv2d(., w, padding=1)
+    got = from_nhwc(y, N, H, W, Cc)
+    assert rel(got, ref) < 2e-2, rel(got, ref)
+    act = x1 * sc[None, :, None, None] + sh[None, :, None, None]
+    sure = act.abs() > 1e-4                                   # (elements whose mask could fall either way are left out of both sides)
+    gm = got * (act > 0) * sure
+    xh = (x1 - m[None, :, None, None]) * inv[None, :, None, None]
+    want = torch.cat([gm.sum((0, 2, 3)), (gm * xh).sum((0, 2, 3))])
+    s = bs.view(SLOTS, 2 * Cc).sum(0).cpu()
+    unsure = (got * (~sure)).abs().sum((0, 2, 3))
+    err = (s - want).abs()
+    bound = 2e-3 * want.abs().max() + torch.cat([unsure, unsure * xh.abs().max()])
+    assert (err <= bound).all(), (err / bound).max()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_rowconv_bn_backward_apply_prologue(shape):
+    """Data gradient of conv1 whose staged operand is the BatchNorm + ReLU backward of (gradient of the activation,
+    BatchNorm input) (pro_mode 2), accumulated onto an existing gradient (res == y), with the BatchNorm input gradient
+    as a side output == hrp_ew_bwd_apply followed by the conv."""
+    nv = nvmod()
+    Cc, N, H = shape
+    W = 2048 // Cc
+    g = torch.Generator().manual_seed(Cc * 31 + N)
+    ga = bf(torch.randn(N, Cc, H, W, generator=g))
+    w = bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc))
+    x1 = bf(torch.randn(N, Cc, H, W, generator=g) * 2.0 + 0.2)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    m, inv, sc, sh, tot, cnt = bn_consts(x1, gamma, beta)
+    act = x1 * sc[None, :, None, None] + sh[None, :, None, None]
+    ga = ga * (act.abs() > 1e-4)                              # no gradient where the mask could fall either way
+    gm = ga * (act > 0)
+    xh = (x1 - m[None, :, None, None]) * inv[None, :, None, None]
+    bt = torch.cat([gm.sum((0, 2, 3)), (gm * xh).sum((0, 2, 3))])
+    k0, k1 = bt[:Cc] / cnt, bt[Cc:] / cnt
+    dx1 = sc[None, :, None, None] * (gm - k0[None, :, None, None] - xh * k1[None, :, None, None])
+    dx1b = bf(dx1)
+    prev = bf(torch.randn(N, Cc, H, W, generator=g))
+    ref = F.conv_transpose2d(dx1b.double(), w.double(), padding=1).float() + prev
+    _, wpt = pack(nv, w)
+    gad, x1d, y = nhwc(ga), nhwc(x1), nhwc(prev)
+    side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
+    st_in, bs_in = slots_of(tot, g), slots_of(bt, g)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    d = desc(nv, gad, wpt, y, N, H, W, Cc, transposed=True)
+    d.res = y.data_ptr()
+    d.pro_mode, d.pro_x2, d.pro_stats, d.pro_bsums = 2, x1d.data_ptr(), st_in.data_ptr(), bs_in.data_ptr()
+    d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps, d.pro_side = gd.data_ptr(), bd.data_ptr(), float(cnt), EPS, side.data_ptr()
+    assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    gside, got = from_nhwc(side, N, H, W, Cc), from_nhwc(y, N, H, W, Cc)
+    assert rel(gside, dx1) < 1.5e-2, rel(gside, dx1)
+    assert rel(got, ref) < 2e-2, rel(got, ref)
+
+
+def test_rowconv_in_a_batched_launch_equals_single_launches():
+    """Row-strip problems (32 and 64 channels) and a general-tile problem (128 channels) in ONE HRP_BATCH_CONV launch:
+    every output bit-identical to the problem's single launch."""
+    nv = nvmod()
+    g = torch.Generator().manual_seed(5)
+    keep, descs, outs = [], [], []
+    for Cc, N, H in [(32, 2, 64), (64, 2, 32), (128, 2, 16), (32, 3, 64)]:
+        W = 2048 // Cc
+        x = nhwc(bf(torch.randn(N, Cc, H, W, generator=g)))
+        wp, _ = pack(nv, bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc)))
+        y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
+        st = torch.zeros(SLOTS * 2 * Cc, device=DEV)
+        d = desc(nv, x, wp, y, N, H, W, Cc)
+        d.stats = st.data_ptr()
+        keep += [x, wp, st]
+        descs.append(d)
+        outs.append(y)
+    singles = []
+    for d, y in zip(descs, outs):
+        nv.call("hrp_conv2d_fwd", C.byref(d), None)
+        torch.cuda.synchronize()
+        singles.append(y.clone())
+        y.zero_()
+    n = len(descs)
+    arr = (nv.ConvDesc * n)(*descs)
+    info = nv.BatchInfo()
+    nb = int(nv.lib().hrp_batch_table_bytes(nv.BATCH_CONV, n))
+    host = (C.c_char * nb)()
+    nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_CONV, arr, n, host, C.byref(info)), "prepare")
+    table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+    nv.check(nv.lib().hrp_batch_launch(table.data_ptr(), C.byref(info), None), "launch")
+    torch.cuda.synchronize()
+    for y, s in zip(outs, singles):
+        assert s.float().abs().max() > 0.1
+        assert torch.equal(y, s)
+
+
+@pytest.mark.parametrize("Cc", [32, 64])
+def test_fused_basic_block_equals_elementwise_path(Cc):
+    """A train-mode bf16 BasicBlock (HRnet.py:28-57) with its interior BatchNorm + ReLU inside the row-strip convolutions
+    (plan.conv_bn_relu_conv) against the same block with the element-wise passes (HRP_NO_ROWCONV_FUSE path): outputs,
+    input gradient, weight and BatchNorm gradients, running statistics."""
+    from hrpe_amd import plan as P
+    from hrpe_amd.lib.models.backbones import HRnet as Hn
+    W = 2048 // Cc
+    N, H = 4, W
+    g = torch.Generator().manual_seed(Cc)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    gy = torch.randn(N, Cc, H, W, generator=g)
+    ref = Hn.BasicBlock(Cc, Cc)
+    with torch.no_grad():
+        for prm in ref.parameters():
+            if prm.dim() == 1:
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5 if prm is ref.bn1.weight or prm is ref.bn2.weight
+                          else torch.randn(prm.shape, generator=g) * 0.2)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    res = {}
+    for fused in (True, False):
+        P.ROWCONV_FUSE = fused
+        try:
+            m = Hn.BasicBlock(Cc, Cc)
+            m.load_state_dict({k: v.clone() for k, v in sd.items()})
+            m = m.to(DEV).set_compute_dtype(torch.bfloat16).train()
+            xd = x.to(DEV).requires_grad_(True)
+            y = m(xd)
+            (y * gy.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            res[fused] = dict(y=y.detach().float().cpu(), dx=xd.grad.float().cpu(),
+                              **{n: p.grad.float().cpu() for n, p in m.named_parameters()},
+                              **{n: b.float().cpu() for n, b in m.named_buffers()})
+        finally:
+            P.ROWCONV_FUSE = True
+    for k in res[True]:
+        a, b = res[True][k].double(), res[False][k].double()
+        err = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        assert err < 1e-2, (k, err)

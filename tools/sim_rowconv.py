@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""CPU model of the address arithmetic of csrc/conv_row.h (development aid, no GPU needed): the DMA placement, the
+swizzled fragment reads (must return the logical (row, x, slot) the MFMA step expects, zero pixels for the padding) and
+the LDS bank conflicts of every ds_read_b128 of the MFMA loop."""
+import sys
+
+GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+GROUPS += [[l + 32 for l in grp] for grp in GROUPS]
+
+
+def run(C):
+    W, P = 2048 // C, 2 * C
+    S, KS, TH = P // 16, C // 16, 8
+    PXP, ROWB, NROWS = 1024 // P, (W + 1) * P, TH + 2
+    g = (lambda x: (x >> 2) & 3) if C == 32 else (lambda x: (x >> 1) & 7)
+    lds = {}          # 16-byte slot index -> content
+    for k in range(NROWS + 1):
+        base = 0 if k == 0 else P + (k - 1) * ROWB + W * P
+        for j in range(S):
+            lds[(base + j * 16) // 16] = "zero"
+    for rs in range(NROWS):
+        for wave in range(4):
+            for lane in range(64):
+                px = lane // S
+                xcol = wave * PXP + px
+                lslot = (lane % S) ^ g(xcol)
+                # source byte offset inside the row: wave*1024 + px*P + lslot*16 -> pixel / slot
+                off = wave * 1024 + px * P + lslot * 16
+                assert off // P == xcol and (off % P) // 16 == lslot
+                dst = P + rs * ROWB + wave * 1024 + lane * 16
+                assert dst % 16 == 0 and dst // 16 not in lds, "overlap"
+                lds[dst // 16] = (rs, xcol, lslot)
+    assert len(lds) == (P + NROWS * ROWB) // 16, (len(lds), (P + NROWS * ROWB) // 16)
+    worst = 1
+    for wave in range(4):
+        sel, rg = wave & 1, wave >> 1
+        col = sel if W == 64 else 0
+        for irel in range(6):
+            for dxi in range(3):
+                for kk in range(KS):
+                    addrs = []
+                    for lane in range(64):
+                        l31, half = lane & 31, lane >> 5
+                        xq = col * 32 + l31 + dxi - 1
+                        a = P + rg * 4 * ROWB + xq * P + (((2 * kk + half) ^ g(xq)) << 4) + irel * ROWB
+                        assert a % 16 == 0 and a >= 0
+                        got = lds[a // 16]
+                        if xq < 0 or xq >= W:
+                            assert got == "zero", (wave, irel, dxi, kk, lane, got)
+                        else:
+                            assert got == (rg * 4 + irel, xq, 2 * kk + half), (wave, irel, dxi, kk, lane, got)
+                        addrs.append(a)
+                    for grp in GROUPS:
+                        banks = {}
+                        for l in grp:
+                            b = (addrs[l] // 16) % 16       # 16-byte slot of the 256-byte bank row
+                            banks.setdefault(b, set()).add(addrs[l])
+                        worst = max(worst, max(len(v) for v in banks.values()))
+    print(f"C={C}: placement and reads consistent; worst ds_read_b128 conflict {worst}-way; tile bytes {P + NROWS * ROWB}")
+
+
+for C in (32, 64):
+    run(C)

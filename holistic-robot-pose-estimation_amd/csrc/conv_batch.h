@@ -16,7 +16,7 @@ struct ConvProblem {
   hrp_conv_desc d;
   ConvTiling t;
   int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64, 4: 0 with persistent workgroups,
-                  // 5 / 6: row-strip kernel (conv_row.h) for 32 / 64 channels
+                  // 5 / 6 / 7 / 8: row-strip kernels (conv_row.h) for 32 / 64 / 128 / 256 channels
   int pgrid;      // cfg 4: workgroups of this problem
   int pad[2];
   RowPlan r;      // cfg 5 / 6
@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256, LIGHT ? 1 : 2) void conv_batch_kernel(const Co
       case 2: conv_tile_body<T, 2, 2, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
       case 5: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_row_body<32>(P.d, P.r, bid, slot); break;
       case 6: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_row_body<64>(P.d, P.r, bid, slot); break;
+      case 7: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_deep_body<128>(P.d, P.r, bid, slot); break;
+      case 8: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_deep_body<256>(P.d, P.r, bid, slot); break;
       default: conv_tile_body<T, 2, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
     }
   }
@@ -62,7 +64,7 @@ static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds)
       row_plan(d, P.r);
       P.t = ConvTiling{};
       P.t.nblocks = P.r.nstrips;
-      P.cfg = rc_ == 32 ? 5 : 6;
+      P.cfg = rc_ == 32 ? 5 : rc_ == 64 ? 6 : rc_ == 128 ? 7 : 8;
       lds = row_lds_bytes(rc_);
       return HRP_OK;
     }

@@ -81,7 +81,7 @@ __device__ __forceinline__ float row_bn_act(float x, float sc, float sh) { retur
 // Host: is this problem one the row-strip kernel takes?  (Everything else runs the general tile program.)
 static inline int row_channels(const hrp_conv_desc& d) {
   if (d.dtype != HRP_BF16 || d.ntaps != 9 || d.in_stride != 1 || d.out_stride != 1) return 0;
-  if (d.Cin != d.Cout || (d.Cin != 32 && d.Cin != 64)) return 0;
+  if (d.Cin != d.Cout || (d.Cin != 32 && d.Cin != 64 && d.Cin != 128 && d.Cin != 256)) return 0;
   const int C = d.Cin;
   if (d.W != 2048 / C || d.Wo != d.W || d.Ho != d.H || d.H % 8 || d.y_H != d.Ho || d.y_W != d.Wo) return 0;
   if (d.x_pitch != C || d.y_pitch != C || d.w_cout_pad != C || (d.res && d.res_pitch != C)) return 0;
@@ -467,7 +467,384 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const hrp_conv_desc d,
   conv_row_body<C>(d, rp, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
 }
 
-static inline int row_lds_bytes(int C) { return C == 32 ? RowCfg<32>::LDS_BYTES : RowCfg<64>::LDS_BYTES; }
+
+// =====================================================================================================================
+// Deep variant: C = 128 @ W = 16 and C = 256 @ W = 8 (the low-resolution branches; K = 9 C = 1 152 / 2 304).  Same skeleton
+// - input rows resident in LDS with ALL their channels, staged by lane-affine DMA pieces, BatchNorm prologues in place,
+// epilogue straight from registers - but the weights no longer fit a wave's registers: they STREAM through them, one
+// 16-channel K chunk (9 taps x MW fragments) per step, double buffered, each fragment one coalesced 1 KiB global load
+// of the packed layout (L2 resident: every workgroup of a layer reads the same slab at about the same time).  No weight
+// ever touches LDS and no wave issues an LDS-DMA piece inside the MFMA loop (the general tile program spends ~100 cycles
+// of a wave's issue slot per piece there, which is why its deep-K loops run the matrix pipe at ~50 %).
+//   C = 128: workgroup = 8 rows x 16 px of one image x 128 channels out; wave = 32 channels out x 128 px (MW 1, NW 4)
+//   C = 256: workgroup = 8 rows x  8 px of one image x 256 channels out; wave = 64 channels out x  64 px (MW 2, NW 2)
+// LDS swizzle: a pixel has 16 / 32 slots; slot' = slot ^ f with f = (y W + x) & 15 of the source pixel's IMAGE position
+// (distinct over the 16 lanes of a ds_read_b128 group, whose pixels are 16 consecutive positions of a 32-pixel tile).
+template <int C>
+struct DeepCfg {
+  static constexpr int W = 2048 / C;        // 16, 8
+  static constexpr int P = 2 * C;           // 256, 512 bytes per pixel
+  static constexpr int S = P / 16;          // 16, 32 slots per pixel
+  static constexpr int KS = C / 16;         // 8, 16 K chunks
+  static constexpr int PXP = 1024 / P;      // 4, 2 pixels per DMA piece
+  static constexpr int ROWB = (W + 1) * P;
+  static constexpr int TH = 8, NROWS = TH + 2;
+  static constexpr int MW = C == 128 ? 1 : 2, NW = 4 / MW;     // wave tile: MW x NW blocks of 32 x 32
+  static constexpr int RPT = 32 / W;        // image rows per 32-pixel tile: 2, 4
+  static constexpr int TILE_BYTES = P + NROWS * ROWB;
+  static constexpr int CTAB_OFF = (TILE_BYTES + 255) & ~255;
+  static constexpr int LDS_BYTES = CTAB_OFF + 8 * C * 4;
+  static_assert(NW * RPT == TH, "the wave's tiles cover the strip");
+  __device__ static __forceinline__ int f(int y, int x) { return (y * W + x) & 15; }
+};
+
+template <int C>
+__device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
+  using R = DeepCfg<C>;
+  constexpr int W = R::W, P = R::P, S = R::S, KS = R::KS, TH = R::TH, ROWB = R::ROWB, NROWS = R::NROWS;
+  constexpr int MW = R::MW, NW = R::NW, RPT = R::RPT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ctab = (float*)(smem + R::CTAB_OFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  HRP_CSTAMP(0);
+  if ((rp.nstrips & 7) == 0) bid = (bid & 7) * (rp.nstrips >> 3) + (bid >> 3);
+  const int n = fdiv(bid, rp.fd_spi);
+  const int y0 = (bid - n * rp.spi) * TH;
+  const int H = d.H;
+  const int pro = d.pro_mode;
+  const unsigned img_off = (unsigned)n * (unsigned)(H * W * P);
+  char* lds_rows = smem + P;
+
+  // ---- staging: piece `wave` of every row (a row is 4 pieces).  lane = (pixel lane / S of the piece, slot lane % S)
+  const int px_in_piece = lane / S, pslot = lane % S;
+  const int xcol = wave * R::PXP + px_in_piece;
+  auto lane_off_of = [&](int y) { return (unsigned)(wave * 1024 + px_in_piece * P + ((pslot ^ R::f(y, xcol)) << 4)); };
+  {
+    const char* xg = (const char*)d.x + img_off;
+#pragma unroll
+    for (int rs = 0; rs < NROWS; ++rs) {
+      const int y = y0 - 1 + rs;
+      char* dst = lds_rows + rs * ROWB + wave * 1024;
+      if (y >= 0 && y < H) dma16(xg + y * (W * P) + lane_off_of(y), dst);
+      else *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (tid < (NROWS + 1) * S) {   // the zero pixels (C = 256: 11 x 32 slots > 256 threads: two rounds)
+    for (int e = tid; e < (NROWS + 1) * S; e += 256) {
+      const int k = e / S, j = e - k * S;
+      *(uint4*)(smem + (k == 0 ? 0 : P + (k - 1) * ROWB + W * P) + j * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  const bool bnb = d.bnb_x != nullptr;
+  if (pro != 0) {
+    for (int c = tid; c < C; c += 256) {
+      float mean, inv, sc, sh;
+      row_bn_consts(d.pro_stats, d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps, c, C, mean, inv, sc, sh);
+      ctab[0 * C + c] = sc; ctab[1 * C + c] = sh;
+      if (pro == 2) {
+        ctab[2 * C + c] = inv; ctab[3 * C + c] = -mean * inv;
+        ctab[4 * C + c] = slot_sum(d.pro_bsums, c, 2 * C) / d.pro_count;
+        ctab[5 * C + c] = slot_sum(d.pro_bsums, C + c, 2 * C) / d.pro_count;
+      }
+    }
+  }
+  if (bnb) {
+    for (int c = tid; c < C; c += 256) {
+      float mean, inv, sc, sh;
+      row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
+      ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+    }
+  }
+  HRP_CSTAMP(1);
+
+  // ---- prologue: the lane's channels depend on the row through the swizzle only for C = 256 (two row parities)
+  if (pro != 0) {
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    char* side = (char*)d.pro_side;
+    constexpr int NPAR = C == 256 ? 2 : 1;
+#pragma unroll
+    for (int par = 0; par < NPAR; ++par) {
+      const int cb = (pslot ^ R::f(par, xcol)) * 8;      // f depends on y only through its parity (W = 8) or not at all
+      float sc[8], sh[8];
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
+        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+      }
+      if (pro == 1) {
+#pragma unroll
+        for (int rs = 0; rs < NROWS; ++rs) {
+          const int y = y0 - 1 + rs;
+          if (y < 0 || y >= H || (NPAR == 2 && ((y & 1) != par))) continue;
+          char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+          float f[8];
+          Elem<bf16_t>::unpack(*(const uint4*)p, f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
+          const uint4 o = Elem<bf16_t>::pack(f);
+          *(uint4*)p = o;
+          if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + y * (W * P) + lane_off_of(y)) = o;
+        }
+      } else {
+        float a[8], b[8], k0[8], k1[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 4) {
+          const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
+          const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
+          a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
+          b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
+          k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
+          k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+        }
+        // the BatchNorm inputs of this parity's rows: same lane-constant addressing, through registers
+        const char* x2g = (const char*)d.pro_x2 + img_off;
+        uint4 x2[NROWS];
+#pragma unroll
+        for (int rs = 0; rs < NROWS; ++rs) {
+          const int y = y0 - 1 + rs;
+          x2[rs] = make_uint4(0, 0, 0, 0);
+          if (y >= 0 && y < H && !(NPAR == 2 && ((y & 1) != par))) x2[rs] = *(const uint4*)(x2g + y * (W * P) + lane_off_of(y));
+        }
+#pragma unroll
+        for (int rs = 0; rs < NROWS; ++rs) {
+          const int y = y0 - 1 + rs;
+          if (y < 0 || y >= H || (NPAR == 2 && ((y & 1) != par))) continue;
+          char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+          float gq[8], xv[8];
+          Elem<bf16_t>::unpack(*(const uint4*)p, gq);
+          Elem<bf16_t>::unpack(x2[rs], xv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float g = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
+            const float xh = fmaf(xv[i], a[i], b[i]);
+            gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
+          }
+          const uint4 o = Elem<bf16_t>::pack(gq);
+          *(uint4*)p = o;
+          if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + y * (W * P) + lane_off_of(y)) = o;
+        }
+      }
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  HRP_CSTAMP(2);
+
+  // ---- MFMA loop.  Tile t of the wave: strip rows t*RPT .. +RPT-1; lane = pixel (row l31 / W, x = l31 % W).
+  f32x16 acc[MW][NW];
+#pragma unroll
+  for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][t][i] = 0.f;
+  {
+    const int r = l31 / W, x = l31 % W;
+    // weight rows of the lane (MFMA row rho = l31 carries channel 16 h + 4 q + i of the block, see conv_row_body)
+    const int co_l = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+    const char* wl = (const char*)d.w + (size_t)((wave * MW) * 32 + co_l) * ROW + half * 16;
+    auto wload = [&](int kk, bf16x8 (&wb)[MW][9]) {
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          wb[mi][t] = *(const bf16x8*)(wl + (size_t)((kk * d.w_ntaps + rp.wslot[t]) * C + mi * 32) * ROW);
+    };
+    // read addresses: corner (dy = -1, dx = -1) of tile t, XOR-ed with the swizzle of the tap's source pixel; the K chunk
+    // adds kk << 5 by XOR as well (the pixel base is P-aligned), dy / dx by immediate offsets
+    constexpr int NCLS = C == 256 ? 6 : 3;       // swizzle classes of a tap: (row parity of the source,) dx
+    int bt[NW][NCLS];
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int yr = t * RPT + r;                                   // strip row of the lane's pixel
+      const int corner = P + yr * ROWB + (x - 1) * P;               // slot yr = strip row yr - 1: the dy = -1 row
+#pragma unroll
+      for (int cls = 0; cls < NCLS; ++cls) {
+        const int dxi = cls % 3, par = cls / 3;                     // par: parity of (source row - lane row) (C = 256 only)
+        const int fy = C == 256 ? ((y0 + yr + par) & 1) : 0;
+        bt[t][cls] = corner ^ (((half ^ R::f(fy, x + dxi - 1)) & (S - 1)) << 4);
+      }
+    }
+    constexpr int CH = 9 * NW, RING = MW == 1 ? 6 : 3, AHEAD = RING - 1;     // steps of one K chunk (a multiple of RING)
+    static_assert(CH % RING == 0 && KS % 2 == 0, "ring positions repeat per chunk; chunks are processed in pairs");
+    bf16x8 bq[RING];
+    auto rd = [&](int kkoff, int q) -> bf16x8 {      // q = tap * NW + t, a constant after unrolling; kkoff = kk << 5
+      const int tap = q / NW, t = q % NW;
+      const int dyi = tap / 3, dxi = tap % 3;
+      const int cls = C == 256 ? ((dyi + 1) & 1) * 3 + dxi : dxi;   // dy = dyi - 1: odd dy flips the row parity
+      return *(const bf16x8*)(smem + (bt[t][cls] ^ kkoff) + dyi * ROWB + dxi * P);
+    };
+    // one K chunk: 9 taps x NW tiles; the B fragments of step q + AHEAD (into the next chunk at the end) are read while
+    // the MFMAs of step q run
+    auto chunk = [&](int kk, const bf16x8 (&wb)[MW][9]) {
+      const int kkoff = kk << 5;
+      const bool more = kk + 1 < KS;
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        if (q + AHEAD < CH) bq[(q + AHEAD) % RING] = rd(kkoff, q + AHEAD);
+        else if (more) bq[(q + AHEAD) % RING] = rd(kkoff + 32, q + AHEAD - CH);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+          acc[mi][q % NW] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[mi][q / NW], bq[q % RING], acc[mi][q % NW], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    bf16x8 wa[MW][9], wb2[MW][9];
+    wload(0, wa);
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) bq[q % RING] = rd(0, q);
+    for (int kk = 0; kk < KS; kk += 2) {
+      wload(kk + 1, wb2);                 // lands while chunk kk runs
+      chunk(kk, wa);
+      if (kk + 2 < KS) wload(kk + 2, wa);
+      chunk(kk + 1, wb2);
+    }
+  }
+  HRP_CSTAMP(4);
+
+  // ---- epilogue: lane = pixel (strip row t*RPT + l31 / W, x = l31 % W); channels (wave*MW + mi)*32 + 16*half .. +15
+  char* yg = (char*)d.y;
+  const unsigned pix_off = img_off + (unsigned)((y0 + l31 / W) * W + (l31 % W)) * P;
+#pragma unroll
+  for (int mi = 0; mi < MW; ++mi) {
+    const int cl = (wave * MW + mi) * 32 + 16 * half;
+    const unsigned out_off = pix_off + cl * 2;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+    if (bnb) {
+      const char* bx = (const char*)d.bnb_x + out_off;
+      uint4 xr[NW][2];
+#pragma unroll
+      for (int t = 0; t < NW; ++t) { xr[t][0] = *(const uint4*)(bx + t * (RPT * W * P)); xr[t][1] = *(const uint4*)(bx + t * (RPT * W * P) + 16); }
+      float sc[16], sh[16];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const float4 a = *(const float4*)(ctab + 4 * C + cl + i), b = *(const float4*)(ctab + 5 * C + cl + i);
+        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+      }
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float v[8], xv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = acc[mi][t][8 * hh + i];
+          const uint4 pk = Elem<bf16_t>::pack(v);
+          *(uint4*)(yg + out_off + t * (RPT * W * P) + 16 * hh) = pk;
+          Elem<bf16_t>::unpack(pk, v);
+          Elem<bf16_t>::unpack(xr[t][hh], xv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
+            s1[8 * hh + i] += g;
+            s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
+          }
+        }
+      }
+    } else {
+      const char* rg_ = (const char*)d.res;
+      uint4 rr[NW][2];
+      if (rg_) {
+#pragma unroll
+        for (int t = 0; t < NW; ++t) { rr[t][0] = *(const uint4*)(rg_ + out_off + t * (RPT * W * P)); rr[t][1] = *(const uint4*)(rg_ + out_off + t * (RPT * W * P) + 16); }
+      }
+      float sc[16], sh[16];
+      const bool aff = d.scale != nullptr;
+      if (aff) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+          const float4 a = *(const float4*)(d.scale + cl + i), b = *(const float4*)(d.shift + cl + i);
+          sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+          sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = acc[mi][t][8 * hh + i];
+          if (aff) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[8 * hh + i] + sh[8 * hh + i];
+          }
+          if (rg_) {
+            float rv[8];
+            Elem<bf16_t>::unpack(rr[t][hh], rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rv[i];
+          }
+          if (d.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          const uint4 pk = Elem<bf16_t>::pack(v);
+          *(uint4*)(yg + out_off + t * (RPT * W * P) + 16 * hh) = pk;
+          if (d.stats) {
+            Elem<bf16_t>::unpack(pk, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[8 * hh + i] += v[i]; s2[8 * hh + i] = fmaf(v[i], v[i], s2[8 * hh + i]); }
+          }
+        }
+      }
+    }
+    if (d.stats) {
+      // reduce-scatter over the 32 lanes of the half wave (conv_row_body); every wave owns its channels: no LDS exchange
+      float v16[16], v8[8], v4[4], v2[2], v1;
+      {
+        const bool up = (l31 & 16) != 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float keep = up ? s2[j] : s1[j], send = up ? s1[j] : s2[j]; v16[j] = keep + __shfl_xor(send, 16, 64); }
+      }
+      {
+        const bool up = (l31 & 8) != 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float keep = up ? v16[8 + j] : v16[j], send = up ? v16[j] : v16[8 + j]; v8[j] = keep + __shfl_xor(send, 8, 64); }
+      }
+      {
+        const bool up = (l31 & 4) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float keep = up ? v8[4 + j] : v8[j], send = up ? v8[j] : v8[4 + j]; v4[j] = keep + __shfl_xor(send, 4, 64); }
+      }
+      {
+        const bool up = (l31 & 2) != 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const float keep = up ? v4[2 + j] : v4[j], send = up ? v4[j] : v4[2 + j]; v2[j] = keep + __shfl_xor(send, 2, 64); }
+      }
+      {
+        const bool up = (l31 & 1) != 0;
+        const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
+        v1 = keep + __shfl_xor(send, 1, 64);
+      }
+      // lane l31 < 16: sum 1 of channel cl + l31; l31 >= 16: sum 2 of channel cl + l31 - 16
+      const int which = l31 >> 4, c = cl + (l31 & 15);
+      const float other = __shfl_xor(v1, 16, 64);     // sum 1 of the same channel, for the lanes holding sum 2
+      float tot = v1;
+      if (bnb && which == 1) tot = fmaf(ctab[6 * C + c], v1, ctab[7 * C + c] * other);
+      atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, tot);
+    }
+  }
+  HRP_CSTAMP(6);
+  HRP_CSTAMP(7);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void conv_deep_kernel(const hrp_conv_desc d, const RowPlan rp) {
+  conv_deep_body<C>(d, rp, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
+}
+
+static inline int row_lds_bytes(int C) {
+  return C == 32 ? RowCfg<32>::LDS_BYTES : C == 64 ? RowCfg<64>::LDS_BYTES : C == 128 ? DeepCfg<128>::LDS_BYTES : DeepCfg<256>::LDS_BYTES;
+}
 
 // -> HRP_OK when launched, -100 when the problem is not a row-strip problem
 static int launch_conv_row(const hrp_conv_desc& d, hipStream_t s) {
@@ -476,7 +853,13 @@ static int launch_conv_row(const hrp_conv_desc& d, hipStream_t s) {
   RowPlan rp;
   row_plan(d, rp);
   if (C == 32) hipLaunchKernelGGL(conv_row_kernel<32>, dim3(rp.nstrips), dim3(256), RowCfg<32>::LDS_BYTES, s, d, rp);
-  else hipLaunchKernelGGL(conv_row_kernel<64>, dim3(rp.nstrips), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
+  else if (C == 64) hipLaunchKernelGGL(conv_row_kernel<64>, dim3(rp.nstrips), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
+  else if (C == 128) hipLaunchKernelGGL(conv_deep_kernel<128>, dim3(rp.nstrips), dim3(256), DeepCfg<128>::LDS_BYTES, s, d, rp);
+  else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_deep_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(conv_deep_kernel<256>, dim3(rp.nstrips), dim3(256), DeepCfg<256>::LDS_BYTES, s, d, rp);
+  }
   return check_launch("conv_row_kernel");
 }
 

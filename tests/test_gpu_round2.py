@@ -76,7 +76,12 @@ def test_batched_conv_equals_single_launches(dtype, N):
         a, b = sa.view(8, -1).sum(0), sb.view(8, -1).sum(0)
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(a.abs().max())), "batch statistics"
     # light-only batch (two 32-channel problems): the LIGHT kernel variant, persistent workgroups when N is large
-    light = [descs[0], _conv_problem(nv, N, 64, 32, 32, 3, dtype, 7)[0]]
+    # (bf16 @64x64 is the row-strip kernel's shape - tests/test_gpu_rowconv.py; 80x80 keeps this on the general tile program)
+    lhw = 64 if dtype == torch.float32 else 80
+    l0, k0 = _conv_problem(nv, N, lhw, 32, 32, 3, dtype, 9)
+    l1, k1 = _conv_problem(nv, N, lhw, 32, 32, 3, dtype, 7)
+    keep += [k0, k1]
+    light = [l0, l1]
     ref = []
     for d in light:
         y = torch.zeros(d.N * d.Ho * d.Wo * d.Cout, device=DEV).to(dtype)

@@ -96,7 +96,7 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-SHAPES = [(32, 3, 64), (64, 2, 32), (32, 1, 16), (64, 5, 8)]     # (C, N, H); W = 2048 / C
+SHAPES = [(32, 3, 64), (64, 2, 32), (32, 1, 16), (64, 5, 8), (128, 3, 16), (256, 3, 8), (128, 1, 8), (256, 2, 16)]     # (C, N, H); W = 2048 / C
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -256,7 +256,7 @@ def test_rowconv_in_a_batched_launch_equals_single_launches():
     nv = nvmod()
     g = torch.Generator().manual_seed(5)
     keep, descs, outs = [], [], []
-    for Cc, N, H in [(32, 2, 64), (64, 2, 32), (128, 2, 16), (32, 3, 64)]:
+    for Cc, N, H in [(32, 2, 64), (64, 2, 32), (128, 2, 16), (32, 3, 64), (256, 2, 8), (128, 2, 20)]:      # (the last one: general tile program)
         W = 2048 // Cc
         x = nhwc(bf(torch.randn(N, Cc, H, W, generator=g)))
         wp, _ = pack(nv, bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc)))
@@ -287,7 +287,7 @@ def test_rowconv_in_a_batched_launch_equals_single_launches():
         assert torch.equal(y, s)
 
 
-@pytest.mark.parametrize("Cc", [32, 64])
+@pytest.mark.parametrize("Cc", [32, 64, 128, 256])
 def test_fused_basic_block_equals_elementwise_path(Cc):
     """A train-mode bf16 BasicBlock (HRnet.py:28-57) with its interior BatchNorm + ReLU inside the row-strip convolutions
     (plan.conv_bn_relu_conv) against the same block with the element-wise passes (HRP_NO_ROWCONV_FUSE path): outputs,

@@ -61,3 +61,66 @@ def run(C):
 
 for C in (32, 64):
     run(C)
+
+
+def run_deep(C, y0=0):
+    W, P = 2048 // C, 2 * C
+    S, KS, TH = P // 16, C // 16, 8
+    PXP, ROWB, NROWS = 1024 // P, (W + 1) * P, TH + 2
+    MW = 1 if C == 128 else 2
+    NW, RPT = 4 // MW, 32 // W
+    f = lambda y, x: (y * W + x) & 15
+    lds = {}
+    for k in range(NROWS + 1):
+        base = 0 if k == 0 else P + (k - 1) * ROWB + W * P
+        for j in range(S):
+            lds[(base + j * 16) // 16] = "zero"
+    for rs in range(NROWS):
+        y = y0 - 1 + rs
+        for wave in range(4):
+            for lane in range(64):
+                px, pslot = lane // S, lane % S
+                xcol = wave * PXP + px
+                lslot = pslot ^ f(y, xcol)
+                off = wave * 1024 + px * P + lslot * 16
+                assert off // P == xcol and (off % P) // 16 == lslot and lslot < S
+                dst = P + rs * ROWB + wave * 1024 + lane * 16
+                assert dst // 16 not in lds
+                lds[dst // 16] = (rs, xcol, lslot)
+    assert len(lds) == (P + NROWS * ROWB) // 16
+    worst = 1
+    ncls = 6 if C == 256 else 3
+    for lane_half in range(1):
+        for kk in range(KS):
+            for tap in range(9):
+                dyi, dxi = tap // 3, tap % 3
+                for t in range(NW):
+                    addrs = []
+                    for lane in range(64):
+                        l31, half = lane & 31, lane >> 5
+                        r, x = l31 // W, l31 % W
+                        yr = t * RPT + r
+                        corner = P + yr * ROWB + (x - 1) * P
+                        cls = ((dyi + 1) & 1) * 3 + dxi if C == 256 else dxi
+                        par = cls // 3
+                        fy = ((y0 + yr + par) & 1) if C == 256 else 0
+                        bt = corner ^ (((half ^ f(fy, x + (cls % 3) - 1)) & (S - 1)) << 4)
+                        a = (bt ^ (kk << 5)) + dyi * ROWB + dxi * P
+                        got = lds[a // 16]
+                        xs, rs = x + dxi - 1, yr + dyi       # source column, LDS row slot
+                        if xs < 0 or xs >= W:
+                            assert got == "zero", (C, kk, tap, t, lane, got)
+                        else:
+                            assert got == (rs, xs, 2 * kk + half), (C, kk, tap, t, lane, got, (rs, xs, 2 * kk + half))
+                        addrs.append(a)
+                    for grp in GROUPS:
+                        banks = {}
+                        for l in grp:
+                            banks.setdefault((addrs[l] // 16) % 16, set()).add(addrs[l])
+                        worst = max(worst, max(len(v) for v in banks.values()))
+    print(f"deep C={C} y0={y0}: placement and reads consistent; worst ds_read_b128 conflict {worst}-way; tile bytes {P + NROWS * ROWB}")
+
+
+for C in (128, 256):
+    run_deep(C, 0)
+    run_deep(C, 8)

@@ -110,6 +110,146 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
   rp.pad[0] = rp.pad[1] = 0;
 }
 
+
+// ---- shared epilogue pieces ------------------------------------------------------------------------------------------
+// The lane holds, for each of NT tiles, 16 consecutive output channels (cl .. cl + 15) of one pixel; off[t] = byte offset of
+// those 32 bytes inside y (the same offset addresses res and bnb_x: same geometry).  okmask bit t clear: tile t lies outside
+// the tensor (its accumulators are zero: nothing is stored, nothing is read).  Options of hrp_conv_desc: folded-BatchNorm
+// affine, residual (res == y: accumulate), ReLU; statistics of the values as stored - sum / sum of squares, or (bnb) the
+// BatchNorm-backward sums of the stored gradient g masked by [bn(bnb_x) > 0]: s1 += g, s2 += g * bnb_x (finished to
+// sum g * xhat = a * s2 + b * s1 by the caller).  ctab rows 4 / 5 hold the mask's scale / shift (bnb).
+template <int NT>
+__device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
+                                             const unsigned okmask, const int cl, const float* ctab, const int C, const bool bnb,
+                                             float (&s1)[16], float (&s2)[16]) {
+  char* yg = (char*)d.y;
+  if (bnb) {
+    const char* bx = (const char*)d.bnb_x;
+    uint4 xr[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      xr[t][0] = xr[t][1] = make_uint4(0, 0, 0, 0);
+      if ((okmask >> t) & 1) { xr[t][0] = *(const uint4*)(bx + off[t]); xr[t][1] = *(const uint4*)(bx + off[t] + 16); }
+    }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      const float4 a = *(const float4*)(ctab + 4 * C + cl + i), b = *(const float4*)(ctab + 5 * C + cl + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float v[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i];
+        const uint4 pk = Elem<bf16_t>::pack(v);
+        if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = pk;
+        Elem<bf16_t>::unpack(pk, v);            // the values as stored
+        Elem<bf16_t>::unpack(xr[t][hh], xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
+          s1[8 * hh + i] += g;
+          s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
+        }
+      }
+    }
+    return;
+  }
+  const char* rg_ = (const char*)d.res;
+  uint4 rr[NT][2];
+  if (rg_) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      rr[t][0] = rr[t][1] = make_uint4(0, 0, 0, 0);
+      if ((okmask >> t) & 1) { rr[t][0] = *(const uint4*)(rg_ + off[t]); rr[t][1] = *(const uint4*)(rg_ + off[t] + 16); }
+    }
+  }
+  float sc[16], sh[16];
+  const bool aff = d.scale != nullptr;
+  if (aff) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      const float4 a = *(const float4*)(d.scale + cl + i), b = *(const float4*)(d.shift + cl + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i];
+      if (aff) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[8 * hh + i] + sh[8 * hh + i];
+      }
+      if (rg_) {
+        float r[8];
+        Elem<bf16_t>::unpack(rr[t][hh], r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += r[i];
+      }
+      if (d.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      const uint4 pk = Elem<bf16_t>::pack(v);
+      if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = pk;
+      if (d.stats && ((okmask >> t) & 1)) {
+        Elem<bf16_t>::unpack(pk, v);          // statistics of the values as stored
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[8 * hh + i] += v[i]; s2[8 * hh + i] = fmaf(v[i], v[i], s2[8 * hh + i]); }
+      }
+    }
+  }
+}
+
+// Reduce-scatter over the 32 lanes of a half wave (they hold sums of the same 16 channels): after the step with lane
+// distance D a lane keeps the half of its values selected by bit D of its lane id; 31 shuffles instead of 32 x 5.
+// -> lane l31 < 16: the total of s1[l31]; l31 >= 16: the total of s2[l31 - 16].
+__device__ __forceinline__ float row_reduce32(const float (&s1)[16], const float (&s2)[16], const int l31) {
+  float v16[16], v8[8], v4[4], v2[2];
+  {
+    const bool up = (l31 & 16) != 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float keep = up ? s2[j] : s1[j], send = up ? s1[j] : s2[j]; v16[j] = keep + __shfl_xor(send, 16, 64); }
+  }
+  {
+    const bool up = (l31 & 8) != 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float keep = up ? v16[8 + j] : v16[j], send = up ? v16[j] : v16[8 + j]; v8[j] = keep + __shfl_xor(send, 8, 64); }
+  }
+  {
+    const bool up = (l31 & 4) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float keep = up ? v8[4 + j] : v8[j], send = up ? v8[j] : v8[4 + j]; v4[j] = keep + __shfl_xor(send, 4, 64); }
+  }
+  {
+    const bool up = (l31 & 2) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const float keep = up ? v4[2 + j] : v4[j], send = up ? v4[j] : v4[2 + j]; v2[j] = keep + __shfl_xor(send, 2, 64); }
+  }
+  const bool up = (l31 & 1) != 0;
+  const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
+  return keep + __shfl_xor(send, 1, 64);
+}
+
+// a wave that owns its 32 channels (deep kernels): straight to the statistic slot
+__device__ __forceinline__ void row_stats_commit(const hrp_conv_desc& d, const float v1, const int l31, const int cl, const float* ctab,
+                                                 const int C, const bool bnb, const int stat_slot) {
+  const int which = l31 >> 4, c = cl + (l31 & 15);
+  const float other = __shfl_xor(v1, 16, 64);     // sum 1 of the same channel, for the lanes holding sum 2
+  float tot = v1;
+  if (bnb && which == 1) tot = fmaf(ctab[6 * C + c], v1, ctab[7 * C + c] * other);     // sum g * xhat = a * sum g x + b * sum g
+  atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, tot);
+}
+
 template <int C>
 __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
   using R = RowCfg<C>;
@@ -309,137 +449,20 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
   HRP_CSTAMP(4);
 
   // ---- epilogue: lane = pixel (row y0 + rg*4 + o, x = col*32 + l31), channels m*32 + 16*half .. +15
-  const unsigned out_off = img_off + (unsigned)((y0 + rg * 4) * W + col * 32 + l31) * P + (m * 32 + 16 * half) * 2;
   const int cl = m * 32 + 16 * half;      // first channel of the lane
-  char* yg = (char*)d.y;
   float s1[16], s2[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-  if (bnb) {
-    // y = gradient of act = relu(bn(bnb_x)), stored unmasked; sums of g = y * [act > 0] and g * bnb_x (finished to
-    // sum g * xhat = a * S2 + b * S1 per workgroup below)
-    const char* bx = (const char*)d.bnb_x + out_off;
-    uint4 xr[4][2];
+  {
+    const unsigned out_off = img_off + (unsigned)((y0 + rg * 4) * W + col * 32 + l31) * P + cl * 2;
+    unsigned off[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { xr[o][0] = *(const uint4*)(bx + o * (W * P)); xr[o][1] = *(const uint4*)(bx + o * (W * P) + 16); }
-    float sc[16], sh[16];
-#pragma unroll
-    for (int i = 0; i < 16; i += 4) {
-      const float4 a = *(const float4*)(ctab + 4 * C + cl + i), b = *(const float4*)(ctab + 5 * C + cl + i);
-      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float v[8], xv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = acc[o][8 * hh + i];
-        const uint4 pk = Elem<bf16_t>::pack(v);
-        *(uint4*)(yg + out_off + o * (W * P) + 16 * hh) = pk;
-        Elem<bf16_t>::unpack(pk, v);            // the values as stored
-        Elem<bf16_t>::unpack(xr[o][hh], xv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
-          s1[8 * hh + i] += g;
-          s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
-        }
-      }
-    }
-  } else {
-    const char* rg_ = (const char*)d.res;
-    uint4 rr[4][2];
-    if (rg_) {
-#pragma unroll
-      for (int o = 0; o < 4; ++o) { rr[o][0] = *(const uint4*)(rg_ + out_off + o * (W * P)); rr[o][1] = *(const uint4*)(rg_ + out_off + o * (W * P) + 16); }
-    }
-    float sc[16], sh[16];
-    const bool aff = d.scale != nullptr;
-    if (aff) {
-#pragma unroll
-      for (int i = 0; i < 16; i += 4) {
-        const float4 a = *(const float4*)(d.scale + cl + i), b = *(const float4*)(d.shift + cl + i);
-        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-      }
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = acc[o][8 * hh + i];
-        if (aff) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[8 * hh + i] + sh[8 * hh + i];
-        }
-        if (rg_) {
-          float r[8];
-          Elem<bf16_t>::unpack(rr[o][hh], r);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] += r[i];
-        }
-        if (d.relu) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
-        const uint4 pk = Elem<bf16_t>::pack(v);
-        *(uint4*)(yg + out_off + o * (W * P) + 16 * hh) = pk;
-        if (d.stats) {
-          Elem<bf16_t>::unpack(pk, v);          // statistics of the values as stored
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { s1[8 * hh + i] += v[i]; s2[8 * hh + i] = fmaf(v[i], v[i], s2[8 * hh + i]); }
-        }
-      }
-    }
+    for (int o = 0; o < 4; ++o) off[o] = out_off + o * (W * P);
+    row_epilogue<4>(d, acc, off, 0xfu, cl, ctab, C, bnb, s1, s2);
   }
   HRP_CSTAMP(5);
   if (d.stats) {
-    // reduce-scatter over the 32 lanes of a half wave (they hold the same 16 channels): after the step with lane
-    // distance D a lane keeps the half of its values selected by its bit D; 31 shuffles instead of 32 x 5, and lane l31
-    // ends with the total of value l31 (s1[0..15], s2[0..15])
-    float v16[16];
-    {
-      const bool up = (l31 & 16) != 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float keep = up ? s2[j] : s1[j], send = up ? s1[j] : s2[j];
-        v16[j] = keep + __shfl_xor(send, 16, 64);
-      }
-    }
-    float v8[8], v4[4], v2[2], v1;
-    {
-      const bool up = (l31 & 8) != 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float keep = up ? v16[8 + j] : v16[j], send = up ? v16[j] : v16[8 + j];
-        v8[j] = keep + __shfl_xor(send, 8, 64);
-      }
-    }
-    {
-      const bool up = (l31 & 4) != 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float keep = up ? v8[4 + j] : v8[j], send = up ? v8[j] : v8[4 + j];
-        v4[j] = keep + __shfl_xor(send, 4, 64);
-      }
-    }
-    {
-      const bool up = (l31 & 2) != 0;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float keep = up ? v4[2 + j] : v4[j], send = up ? v4[j] : v4[2 + j];
-        v2[j] = keep + __shfl_xor(send, 2, 64);
-      }
-    }
-    {
-      const bool up = (l31 & 1) != 0;
-      const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
-      v1 = keep + __shfl_xor(send, 1, 64);
-    }
+    const float v1 = row_reduce32(s1, s2, l31);
     // lane l31 < 16: sum 1 of channel cl + l31; l31 >= 16: sum 2 of channel cl + l31 - 16
     stat_lds[wave * 64 + lane] = v1;
     __syncthreads();
@@ -709,129 +732,18 @@ __device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const Row
   HRP_CSTAMP(4);
 
   // ---- epilogue: lane = pixel (strip row t*RPT + l31 / W, x = l31 % W); channels (wave*MW + mi)*32 + 16*half .. +15
-  char* yg = (char*)d.y;
   const unsigned pix_off = img_off + (unsigned)((y0 + l31 / W) * W + (l31 % W)) * P;
 #pragma unroll
   for (int mi = 0; mi < MW; ++mi) {
     const int cl = (wave * MW + mi) * 32 + 16 * half;
-    const unsigned out_off = pix_off + cl * 2;
+    unsigned off[NW];
+#pragma unroll
+    for (int t = 0; t < NW; ++t) off[t] = pix_off + cl * 2 + t * (RPT * W * P);
     float s1[16], s2[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-    if (bnb) {
-      const char* bx = (const char*)d.bnb_x + out_off;
-      uint4 xr[NW][2];
-#pragma unroll
-      for (int t = 0; t < NW; ++t) { xr[t][0] = *(const uint4*)(bx + t * (RPT * W * P)); xr[t][1] = *(const uint4*)(bx + t * (RPT * W * P) + 16); }
-      float sc[16], sh[16];
-#pragma unroll
-      for (int i = 0; i < 16; i += 4) {
-        const float4 a = *(const float4*)(ctab + 4 * C + cl + i), b = *(const float4*)(ctab + 5 * C + cl + i);
-        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-      }
-#pragma unroll
-      for (int t = 0; t < NW; ++t) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          float v[8], xv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = acc[mi][t][8 * hh + i];
-          const uint4 pk = Elem<bf16_t>::pack(v);
-          *(uint4*)(yg + out_off + t * (RPT * W * P) + 16 * hh) = pk;
-          Elem<bf16_t>::unpack(pk, v);
-          Elem<bf16_t>::unpack(xr[t][hh], xv);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
-            s1[8 * hh + i] += g;
-            s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
-          }
-        }
-      }
-    } else {
-      const char* rg_ = (const char*)d.res;
-      uint4 rr[NW][2];
-      if (rg_) {
-#pragma unroll
-        for (int t = 0; t < NW; ++t) { rr[t][0] = *(const uint4*)(rg_ + out_off + t * (RPT * W * P)); rr[t][1] = *(const uint4*)(rg_ + out_off + t * (RPT * W * P) + 16); }
-      }
-      float sc[16], sh[16];
-      const bool aff = d.scale != nullptr;
-      if (aff) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-          const float4 a = *(const float4*)(d.scale + cl + i), b = *(const float4*)(d.shift + cl + i);
-          sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-          sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < NW; ++t) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          float v[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = acc[mi][t][8 * hh + i];
-          if (aff) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[8 * hh + i] + sh[8 * hh + i];
-          }
-          if (rg_) {
-            float rv[8];
-            Elem<bf16_t>::unpack(rr[t][hh], rv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += rv[i];
-          }
-          if (d.relu) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-          }
-          const uint4 pk = Elem<bf16_t>::pack(v);
-          *(uint4*)(yg + out_off + t * (RPT * W * P) + 16 * hh) = pk;
-          if (d.stats) {
-            Elem<bf16_t>::unpack(pk, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[8 * hh + i] += v[i]; s2[8 * hh + i] = fmaf(v[i], v[i], s2[8 * hh + i]); }
-          }
-        }
-      }
-    }
-    if (d.stats) {
-      // reduce-scatter over the 32 lanes of the half wave (conv_row_body); every wave owns its channels: no LDS exchange
-      float v16[16], v8[8], v4[4], v2[2], v1;
-      {
-        const bool up = (l31 & 16) != 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const float keep = up ? s2[j] : s1[j], send = up ? s1[j] : s2[j]; v16[j] = keep + __shfl_xor(send, 16, 64); }
-      }
-      {
-        const bool up = (l31 & 8) != 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float keep = up ? v16[8 + j] : v16[j], send = up ? v16[j] : v16[8 + j]; v8[j] = keep + __shfl_xor(send, 8, 64); }
-      }
-      {
-        const bool up = (l31 & 4) != 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float keep = up ? v8[4 + j] : v8[j], send = up ? v8[j] : v8[4 + j]; v4[j] = keep + __shfl_xor(send, 4, 64); }
-      }
-      {
-        const bool up = (l31 & 2) != 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const float keep = up ? v4[2 + j] : v4[j], send = up ? v4[j] : v4[2 + j]; v2[j] = keep + __shfl_xor(send, 2, 64); }
-      }
-      {
-        const bool up = (l31 & 1) != 0;
-        const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
-        v1 = keep + __shfl_xor(send, 1, 64);
-      }
-      // lane l31 < 16: sum 1 of channel cl + l31; l31 >= 16: sum 2 of channel cl + l31 - 16
-      const int which = l31 >> 4, c = cl + (l31 & 15);
-      const float other = __shfl_xor(v1, 16, 64);     // sum 1 of the same channel, for the lanes holding sum 2
-      float tot = v1;
-      if (bnb && which == 1) tot = fmaf(ctab[6 * C + c], v1, ctab[7 * C + c] * other);
-      atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, tot);
-    }
+    row_epilogue<NW>(d, acc[mi], off, (1u << NW) - 1, cl, ctab, C, bnb, s1, s2);
+    if (d.stats) row_stats_commit(d, row_reduce32(s1, s2, l31), l31, cl, ctab, C, bnb, stat_slot);
   }
   HRP_CSTAMP(6);
   HRP_CSTAMP(7);

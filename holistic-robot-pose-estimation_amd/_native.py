@@ -179,6 +179,7 @@ PROTOTYPES = {
     "hrp_wgrad_fold_desc_of": [C.POINTER(WgradDesc), C.POINTER(WgradFoldDesc)],
     "hrp_batch_wgrad_fold_descs": [_P, C.POINTER(BatchInfo), C.POINTER(WgradFoldDesc)],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
+    "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hrp_linear_bwd_weight": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],

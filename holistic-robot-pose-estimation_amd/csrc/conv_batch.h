@@ -16,7 +16,7 @@ struct ConvProblem {
   hrp_conv_desc d;
   ConvTiling t;
   int cfg;        // 0: 256 px x 32 cout, 1: 128 px x 32, 2: 256 px x 64, 3: 128 px x 64, 4: 0 with persistent workgroups,
-                  // 5 / 6 / 7 / 8: row-strip kernels (conv_row.h) for 32 / 64 / 128 / 256 channels
+                  // 5 / 6 / 7 / 8: row-strip kernels (conv_row.h) for 32 / 64 / 128 / 256 channels; 9 / 10: whole-image kernels, 128 / 256
   int pgrid;      // cfg 4: workgroups of this problem
   int pad[2];
   RowPlan r;      // cfg 5 / 6
@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256, LIGHT ? 1 : 2) void conv_batch_kernel(const Co
       case 6: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_row_body<64>(P.d, P.r, bid, slot); break;
       case 7: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_deep_body<128>(P.d, P.r, bid, slot); break;
       case 8: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_deep_body<256>(P.d, P.r, bid, slot); break;
+      case 9: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_img_body<128>(P.d, P.r, bid, slot); break;
+      case 10: if constexpr (NT == 9 && Elem<T>::SZ == 2) conv_img_body<256>(P.d, P.r, bid, slot); break;
       default: conv_tile_body<T, 2, 1, 1, 4, NT, false, true>(P.d, P.t, bid, 1, slot); break;
     }
   }
@@ -65,7 +67,8 @@ static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds)
       P.t = ConvTiling{};
       P.t.nblocks = P.r.nstrips;
       P.cfg = rc_ == 32 ? 5 : rc_ == 64 ? 6 : rc_ == 128 ? 7 : 8;
-      lds = row_lds_bytes(rc_);
+      if (P.r.img) P.cfg += 2;
+      lds = row_lds_bytes(rc_, P.r.img);
       return HRP_OK;
     }
   }
@@ -105,7 +108,7 @@ static int conv_batch_prepare_nt(const hrp_conv_desc* descs, int n, ConvProblem*
     // work of one workgroup (MFMA steps): the long-running problems go first so that the launch tail is short
     const int ct = probs[i].cfg >= 2 ? 2 : 1, pt = (probs[i].cfg & 1) ? 1 : 2;
     weight[i] = (long)cdiv(d.Cin * SZ, ROW) * NT * ct * pt;
-    if (probs[i].cfg >= 5) weight[i] = (long)cdiv(d.Cin * SZ, ROW) * NT * 4;     // 4 tiles per wave
+    if (probs[i].cfg >= 5) weight[i] = (long)cdiv(d.Cin * SZ, ROW) * NT * (probs[i].cfg == 9 ? 8 : 4);     // tiles per wave
   }
   int order[HRP_BATCH_MAX];
   for (int i = 0; i < n; ++i) order[i] = i;

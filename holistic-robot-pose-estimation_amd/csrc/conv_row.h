@@ -33,6 +33,7 @@
 //                hrp_ew_bwd_reduce (as conv_tile.h's bnb_*, but without the separate mask tensor)
 #pragma once
 #include "conv_tile.h"
+#include <type_traits>
 
 namespace hrp {
 
@@ -58,9 +59,10 @@ struct RowCfg {
 
 struct RowPlan {
   int wslot[9];        // packed-weight tap slot of the canonical tap (dy + 1) * 3 + (dx + 1)
-  int nstrips, spi;    // workgroups = N * H / TH; strips per image
+  int nstrips, spi;    // workgroups (strip kernels: N * H / TH); strips per image
   FastDiv fd_spi;
-  int pad[2];
+  int img;             // 1: whole-image variant (conv_img_body): C = 128 @ 16 x 16, C = 256 @ 8 x 8
+  int pad;
 };
 
 // mean / invstd / scale / shift of one channel from the statistic slots (the arithmetic of elementwise.hip's
@@ -107,7 +109,13 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
   rp.spi = d.H / 8;
   rp.nstrips = d.N * rp.spi;
   rp.fd_spi = make_fastdiv(rp.spi);
-  rp.pad[0] = rp.pad[1] = 0;
+  rp.img = 0;
+  rp.pad = 0;
+  static const bool no_img = getenv("HRP_NO_IMGCONV") != nullptr;      // A/B switch: deep layers on the strip kernels
+  if (!no_img && (d.Cin == 128 || d.Cin == 256) && d.H == d.W) {
+    rp.img = 1;
+    rp.nstrips = d.Cin == 128 ? d.N : ((d.N + 1) / 2) * 2;
+  }
 }
 
 
@@ -754,7 +762,279 @@ __global__ __launch_bounds__(256, 2) void conv_deep_kernel(const hrp_conv_desc d
   conv_deep_body<C>(d, rp, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
 }
 
-static inline int row_lds_bytes(int C) {
+// =====================================================================================================================
+// Whole-image variant of the deep kernels: C = 128 @ 16 x 16 and C = 256 @ 8 x 8, the production shapes of branches 2 / 3.
+// The strip kernels above stream every weight fragment for 128 pixels (A fragment : MFMA = 1 : 4 resp. 1 : 2); with every
+// CU of an XCD reading the same weight lines at the same time that saturates the XCD's L2 (~1 KiB / clk measured) and the
+// MFMA loop runs at ~45 %.  Here a wave owns 32 output channels x 256 pixels (C = 128: one image, 8 tiles, 1 : 8) or
+// x 128 pixels (C = 256: two images, 4 tiles, 1 : 4 with half as many workgroups streaming).
+//   LDS layout ("tile linear"): tile t = 32 consecutive pixels of the image(s) in memory order (2 rows of 16 / 4 rows of 8)
+//   at t * T, T = 33 pixels: 32 pixels + ONE zero pixel.  A tap's source pixel of lane p is p' = p + dy W + dx of the same
+//   image: inside the tile, or in the previous / next tile - which, the zero pixels sitting between tiles, is the same
+//   affine address -/+ one pixel.  Out-of-image sources (left / right columns, the row above the top tile, below the
+//   bottom tile) read the tile's zero pixel.  So every read is  (B[tap] ^ kk << 5) + t * T  with 15 lane constants B
+//   (9 taps + 3 top-row + 3 bottom-row overrides) and an immediate t * T: no padding rows, 64 KiB of LDS for 256 / 128
+//   pixels of 128 / 256 channels.  The 64 DMA pieces of a workgroup are one contiguous 64 KiB range of the tensor.
+template <int C>
+struct ImgCfg {
+  static constexpr int W = 2048 / C;              // 16, 8 (square images)
+  static constexpr int P = 2 * C, S = P / 16, KS = C / 16;
+  static constexpr int NT = C == 128 ? 8 : 4;     // 32-pixel tiles per workgroup (= per wave)
+  static constexpr int TPI = W * W / 32;          // tiles per image: 8, 2
+  static constexpr int NIMG = NT / TPI;           // images per workgroup: 1, 2
+  static constexpr int T = 33 * P;                // LDS tile pitch
+  static constexpr int PPT = 32 * P / 1024;       // DMA pieces per tile: 8, 16
+  static constexpr int PXP = 1024 / P;            // pixels per piece: 4, 2
+  static constexpr int NCB = C / 128;             // blocks of 128 output channels (4 waves x 32)
+  static constexpr int TILE_BYTES = NT * T;       // 67 584
+  static constexpr int CTAB_OFF = TILE_BYTES;
+  static constexpr int LDS_BYTES = CTAB_OFF + 8 * C * 4;
+  static_assert(TILE_BYTES % 256 == 0 && NT * PPT == 64, "64 pieces of 1 KiB");
+};
+
+template <int C>
+__device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowPlan& rp, const int bid, const int stat_slot) {
+  using R = ImgCfg<C>;
+  constexpr int W = R::W, P = R::P, S = R::S, KS = R::KS, NT = R::NT, TPI = R::TPI, T = R::T, PPT = R::PPT, PXP = R::PXP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ctab = (float*)(smem + R::CTAB_OFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  HRP_CSTAMP(0);
+  const int cbk = bid % R::NCB, grp = bid / R::NCB;
+  const int n0 = grp * R::NIMG;
+  const int nvalid = min(R::NIMG, d.N - n0);                 // images of this group inside the batch
+  const unsigned okmask = (1u << (nvalid * TPI)) - 1;
+  const int pro = d.pro_mode;
+  const unsigned grp_off = (unsigned)n0 * (unsigned)(W * W * P);
+
+  // ---- staging: pieces q = wave + 4 i of the group's 64 (one contiguous 64 KiB range).  lane = (pixel lane / S of the
+  // piece, slot lane % S); the slot holds logical slot (lane % S) ^ (p'' & 15), p'' = the pixel's index inside its tile
+  const int px_in_piece = lane / S, pslot = lane % S;
+  auto lslot_of = [&](int i) {      // i: piece index of the wave (its parity matters for C = 256 only)
+    const int pq = (wave + 4 * i) % PPT;
+    return pslot ^ ((pq * PXP + px_in_piece) & 15);
+  };
+  auto piece_off = [&](int i) { return (unsigned)((wave + 4 * i) * 1024 + px_in_piece * P + (lslot_of(i) << 4)); };
+  {
+    const char* xg = (const char*)d.x + grp_off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = wave + 4 * i, tq = q / PPT;
+      char* dst = smem + tq * T + (q % PPT) * 1024;
+      if (tq < nvalid * TPI) dma16(xg + piece_off(i), dst);
+      else *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (tid < NT * S) {   // the zero pixels behind the tiles (128 slots)
+    const int k = tid / S, j = tid - k * S;
+    *(uint4*)(smem + k * T + 32 * P + j * 16) = make_uint4(0, 0, 0, 0);
+  }
+  const bool bnb = d.bnb_x != nullptr;
+  if (pro != 0) {
+    for (int c = tid; c < C; c += 256) {
+      float mean, inv, sc, sh;
+      row_bn_consts(d.pro_stats, d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps, c, C, mean, inv, sc, sh);
+      ctab[0 * C + c] = sc; ctab[1 * C + c] = sh;
+      if (pro == 2) {
+        ctab[2 * C + c] = inv; ctab[3 * C + c] = -mean * inv;
+        ctab[4 * C + c] = slot_sum(d.pro_bsums, c, 2 * C) / d.pro_count;
+        ctab[5 * C + c] = slot_sum(d.pro_bsums, C + c, 2 * C) / d.pro_count;
+      }
+    }
+  }
+  if (bnb) {
+    for (int c = tid; c < C; c += 256) {
+      float mean, inv, sc, sh;
+      row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
+      ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+    }
+  }
+  HRP_CSTAMP(1);
+
+  // ---- prologue in place (see conv_row_body); the lane's channel set is (pslot ^ swizzle) * 8: one set for C = 128, two
+  // (even / odd pieces) for C = 256; the pieces are handled in two halves to bound the registers of the second operand
+  if (pro != 0) {
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    char* side = (char*)d.pro_side;
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      // C = 128: pieces i = 8 hsel .. 8 hsel + 7; C = 256: pieces of parity hsel (i = hsel, hsel + 2, ...)
+      auto piece_i = [&](int j) { return C == 256 ? 2 * j + hsel : 8 * hsel + j; };
+      const int cb = lslot_of(piece_i(0)) * 8;
+      float sc[8], sh[8];
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
+        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+      }
+      if (pro == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = piece_i(j), q = wave + 4 * i, tq = q / PPT;
+          if (tq >= nvalid * TPI) continue;
+          char* p = smem + tq * T + (q % PPT) * 1024 + lane * 16;
+          float f[8];
+          Elem<bf16_t>::unpack(*(const uint4*)p, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(row_bn_act(f[e], sc[e], sh[e]), 0.f);
+          const uint4 o = Elem<bf16_t>::pack(f);
+          *(uint4*)p = o;
+          if (side) *(uint4*)(side + grp_off + piece_off(i)) = o;
+        }
+      } else {
+        float a[8], b[8], k0[8], k1[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 4) {
+          const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
+          const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
+          a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
+          b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
+          k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
+          k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+        }
+        const char* x2g = (const char*)d.pro_x2 + grp_off;
+        uint4 x2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = piece_i(j), q = wave + 4 * i;
+          x2[j] = make_uint4(0, 0, 0, 0);
+          if (q / PPT < nvalid * TPI) x2[j] = *(const uint4*)(x2g + piece_off(i));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = piece_i(j), q = wave + 4 * i, tq = q / PPT;
+          if (tq >= nvalid * TPI) continue;
+          char* p = smem + tq * T + (q % PPT) * 1024 + lane * 16;
+          float gq[8], xv[8];
+          Elem<bf16_t>::unpack(*(const uint4*)p, gq);
+          Elem<bf16_t>::unpack(x2[j], xv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float g = row_bn_act(xv[e], sc[e], sh[e]) > 0.f ? gq[e] : 0.f;
+            const float xh = fmaf(xv[e], a[e], b[e]);
+            gq[e] = sc[e] * (g - k0[e] - xh * k1[e]);
+          }
+          const uint4 o = Elem<bf16_t>::pack(gq);
+          *(uint4*)p = o;
+          if (side) *(uint4*)(side + grp_off + piece_off(i)) = o;
+        }
+      }
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  HRP_CSTAMP(2);
+
+  // ---- MFMA loop
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  {
+    const int r = l31 / W, x = l31 % W;
+    const int co_l = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+    const char* wl = (const char*)d.w + (size_t)(cbk * 128 + wave * 32 + co_l) * ROW + half * 16;
+    // weights stream through registers in groups of GT taps, NBUF groups in flight (C = 128: the three taps of one
+    // kernel row, 3 buffers - 128 accumulator registers leave no room for two 9-tap buffers; C = 256: all 9 taps, 2 buffers)
+    constexpr int GT = C == 128 ? 3 : 9, NG = 9 / GT, NBUF = C == 128 ? 3 : 2;
+    bf16x8 wbuf[NBUF][GT];
+    auto wload = [&](int g, bf16x8 (&wb)[GT], int gi) {      // group g = kk * NG + gi; gi is a constant after unrolling
+      const int kk = g / NG;
+      if (kk < KS) {
+#pragma unroll
+        for (int t = 0; t < GT; ++t) wb[t] = *(const bf16x8*)(wl + (size_t)((kk * d.w_ntaps + rp.wslot[gi * GT + t]) * C) * ROW);
+      }
+    };
+    // lane constants of the reads (relative to t * T): Bm = every row of the tile has the source row inside the image;
+    // Bt / Bb = the dy = -1 / +1 taps of an image's first / last tile (rows above / below the image read the zero pixel)
+    constexpr int RPT = 32 / W;
+    auto bconst = [&](int dyi, int dxi, bool row_ok) {
+      const int xs = x + dxi - 1;
+      const int ps = l31 + (dyi - 1) * W + dxi - 1;             // source pixel relative to the tile
+      const int rel = ps * P + (ps < 0 ? -P : ps >= 32 ? P : 0);
+      const int v = rel ^ (((half ^ (ps & 15)) & (S - 1)) << 4);
+      return (row_ok && xs >= 0 && xs < W) ? v : 32 * P;
+    };
+    int Bm[9], Bt[3], Bb[3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) Bm[tap] = bconst(tap / 3, tap % 3, true);
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) { Bt[dxi] = bconst(0, dxi, r > 0); Bb[dxi] = bconst(2, dxi, r < RPT - 1); }
+    constexpr int CH = 9 * NT, RING = 6, AHEAD = RING - 1;
+    static_assert(CH % RING == 0 && KS % 2 == 0, "ring positions repeat per chunk; chunks are processed in pairs");
+    bf16x8 bq[RING];
+    auto rd = [&](int kkoff, int q) -> bf16x8 {      // q = tap * NT + t
+      const int tap = q / NT, t = q % NT;
+      const int dyi = tap / 3, dxi = tap % 3;
+      const int b = (dyi == 0 && t % TPI == 0) ? Bt[dxi] : (dyi == 2 && t % TPI == TPI - 1) ? Bb[dxi] : Bm[tap];
+      return *(const bf16x8*)(smem + (b ^ kkoff) + t * T);
+    };
+    // one K chunk (u = its parity: the loop below runs chunks in pairs so that buffer indices are constants)
+    auto chunk = [&](int kk, auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int kkoff = kk << 5;
+      const bool more = kk + 1 < KS;
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        constexpr int GS = GT * NT;                       // steps per weight group
+        const int gi = q / GS;
+        if (q % GS == 0) {                                // group (kk, gi) starts: fetch the group NBUF - 1 ahead
+          const int g = kk * NG + gi;
+          if constexpr (C == 128) wload(g + 2, wbuf[(gi + 2) % 3], (gi + 2) % 3);
+          else wload(g + 1, wbuf[(u + 1) & 1], 0);
+        }
+        if (q + AHEAD < CH) bq[(q + AHEAD) % RING] = rd(kkoff, q + AHEAD);
+        else if (more) bq[(q + AHEAD) % RING] = rd(kkoff + 32, q + AHEAD - CH);
+        const int bi = C == 128 ? gi : u;
+        acc[q % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wbuf[bi][(q / NT) % GT], bq[q % RING], acc[q % NT], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < NBUF - 1; ++g) wload(g, wbuf[g], g % NG);
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) bq[q % RING] = rd(0, q);
+    for (int kk = 0; kk < KS; kk += 2) {
+      chunk(kk, std::integral_constant<int, 0>{});
+      chunk(kk + 1, std::integral_constant<int, 1>{});
+    }
+  }
+  HRP_CSTAMP(4);
+
+  // ---- epilogue: tile t, lane p = pixel n0 * W * W + 32 t + p of the tensor (contiguous); channels cbk*128 + wave*32 + 16*half ..
+  {
+    const int cl = cbk * 128 + wave * 32 + 16 * half;
+    const unsigned pix0 = grp_off + (unsigned)l31 * P + cl * 2;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+    constexpr int EG = NT == 8 ? 2 : 4;       // tiles per epilogue group: bounds the registers of the residual / bnb_x rows
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += EG) {
+      unsigned off[EG];
+#pragma unroll
+      for (int t = 0; t < EG; ++t) off[t] = pix0 + (unsigned)(t0 + t) * (32 * P);
+      row_epilogue<EG>(d, *(const f32x16(*)[EG])&acc[t0], off, (okmask >> t0) & ((1u << EG) - 1), cl, ctab, C, bnb, s1, s2);
+    }
+    if (d.stats) row_stats_commit(d, row_reduce32(s1, s2, l31), l31, cl, ctab, C, bnb, stat_slot);
+  }
+  HRP_CSTAMP(6);
+  HRP_CSTAMP(7);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void conv_img_kernel(const hrp_conv_desc d, const RowPlan rp) {
+  conv_img_body<C>(d, rp, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
+}
+
+static inline int row_lds_bytes(int C, int img) {
+  if (img) return C == 128 ? ImgCfg<128>::LDS_BYTES : ImgCfg<256>::LDS_BYTES;
   return C == 32 ? RowCfg<32>::LDS_BYTES : C == 64 ? RowCfg<64>::LDS_BYTES : C == 128 ? DeepCfg<128>::LDS_BYTES : DeepCfg<256>::LDS_BYTES;
 }
 
@@ -766,6 +1046,16 @@ static int launch_conv_row(const hrp_conv_desc& d, hipStream_t s) {
   row_plan(d, rp);
   if (C == 32) hipLaunchKernelGGL(conv_row_kernel<32>, dim3(rp.nstrips), dim3(256), RowCfg<32>::LDS_BYTES, s, d, rp);
   else if (C == 64) hipLaunchKernelGGL(conv_row_kernel<64>, dim3(rp.nstrips), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
+  else if (rp.img) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv_img_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_img_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (C == 128) hipLaunchKernelGGL(conv_img_kernel<128>, dim3(rp.nstrips), dim3(256), ImgCfg<128>::LDS_BYTES, s, d, rp);
+    else hipLaunchKernelGGL(conv_img_kernel<256>, dim3(rp.nstrips), dim3(256), ImgCfg<256>::LDS_BYTES, s, d, rp);
+  }
   else if (C == 128) hipLaunchKernelGGL(conv_deep_kernel<128>, dim3(rp.nstrips), dim3(256), DeepCfg<128>::LDS_BYTES, s, d, rp);
   else {
     static bool attr = false;

@@ -800,3 +800,29 @@ extern "C" int hrp_fk_project_bwd(const hrp_fk_chain* chain_dev, const float* q,
   hipLaunchKernelGGL(fk_project_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, K, root, d_xyz, d_uv, d_q, d_rot6d, d_trans);
   return check_launch("fk_project_bwd");
 }
+
+// ---- L1 loss of the DepthNet trainer (reference scripts/train_depthnet.py:231-250: L1Loss(model(images, k) / 1000, gt_depth)):
+// loss = mean |pred * scale - gt|, d_pred = sign(pred * scale - gt) * scale / n.  One workgroup (n = batch x 1 values).
+namespace hrp {
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, float scale, int n,
+                                                       float* __restrict__ loss, float* __restrict__ d_pred) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float e = pred[i] * scale - gt[i];
+    s += fabsf(e);
+    if (d_pred) d_pred[i] = (e > 0.f ? 1.f : e < 0.f ? -1.f : 0.f) * scale / (float)n;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (part[0] + part[1] + part[2] + part[3]) / (float)n;
+}
+}  // namespace hrp
+
+extern "C" int hrp_l1_loss(const float* pred, const float* gt, float scale, int n, float* loss, float* d_pred, void* stream) {
+  using namespace hrp;
+  HRP_REQUIRE(pred && gt && loss && n > 0, "l1_loss: bad arguments");
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, gt, scale, n, loss, d_pred);
+  return check_launch("l1_loss_kernel");
+}

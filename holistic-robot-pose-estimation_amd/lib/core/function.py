@@ -113,6 +113,32 @@ class _FusedPoseLoss(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(gs)
 
 
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, scale):
+        from hrpe_amd import _native as nv
+        p, g = pred.contiguous().float(), gt.contiguous().float()
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        grad = torch.empty_like(p) if pred.requires_grad else None
+        nv.call("hrp_l1_loss", p.data_ptr(), g.data_ptr(), float(scale), p.numel(), out.data_ptr(),
+                grad.data_ptr() if grad is not None else None, torch.cuda.current_stream(pred.device).cuda_stream)
+        ctx.grad = grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        return (ctx.grad * g_loss).view_as(ctx.grad) if ctx.grad is not None else None, None, None
+
+
+def depth_l1_loss(pred_depth_mm, gt_depth_m):
+    """nn.L1Loss()(model(images, k_values) / 1000, gt_root_depth) of the DepthNet trainer (reference
+    scripts/train_depthnet.py:231-250) as one launch with its analytic gradient (device tensors; host tensors: torch)."""
+    if not pred_depth_mm.is_cuda:
+        return torch.nn.functional.l1_loss(pred_depth_mm / 1000.0, gt_depth_m)
+    assert pred_depth_mm.shape == gt_depth_m.shape
+    return _L1Loss.apply(pred_depth_mm, gt_depth_m, 1e-3)
+
+
 def full_loss(pred, gt, K, root=3, image_size=256.0, weights=FULL_YAML_WEIGHTS, kps_need_depth=None):
     """pred: the model's 8-tuple.  gt: dict(pose, root_rot, root_trans, root_uv, kp3d, kp2d, mask).
     Returns (loss, dict of the ten terms named as in function.py:313-319).  Device tensors: one fused launch

@@ -457,6 +457,9 @@ typedef struct hrp_pose_loss_desc {
   float image_size;
 } hrp_pose_loss_desc;
 int hrp_pose_loss(const hrp_pose_loss_desc* d, void* stream);
+/* The DepthNet trainer's loss (scripts/train_depthnet.py:231-250, nn.L1Loss on model(images, k) / 1000 against the root depth):
+ * *loss = mean |pred * scale - gt| over n dense fp32 values; d_pred (optional) = sign(pred * scale - gt) * scale / n. */
+int hrp_l1_loss(const float* pred, const float* gt, float scale, int n, float* loss, float* d_pred, void* stream);
 
 /* nn.Dropout of the regression heads (lib/models/full_net.py:98-99, 132-133; p = args.p_dropout, lib/config.py default
  * 0.5), inverted scaling: mask[r,c] = (u < keep) / keep with u from Philox4x32-10 keyed by state_dev[0] (seed) at counter

@@ -513,12 +513,12 @@ def test_batch_prepare_is_host_only():
     host = (C.c_char * nb)()
     assert lib.hrp_batch_prepare(nv.BATCH_CONV, arr, 3, host, C.byref(info)) == 0, lib.hrp_last_error()
     assert info.n == 3 and info.variant == 9 and info.blk0[0] == 0 and info.blk0[3] == info.grid
-    # 2 images: 32 ch @64x64 -> row-strip kernel, 2 x 8 strips of 8 rows; 256 ch @8x8 -> 1 tile x 4 cout blocks;
-    # 64 ch @32x32 -> row-strip kernel, 2 x 4 strips
-    assert sorted(info.blk0[i + 1] - info.blk0[i] for i in range(3)) == [4, 8, 16]
-    assert lib.hrp_conv_rowstrip_channels(C.byref(descs[0])) == 32 and lib.hrp_conv_rowstrip_channels(C.byref(descs[2])) == 64
-    assert lib.hrp_conv_rowstrip_channels(C.byref(descs[1])) == 0
-    assert info.blk0[1] - info.blk0[0] == 4          # the deepest K loop goes first
+    # 2 images: 32 ch @64x64 -> row-strip kernel, 2 x 8 strips of 8 rows; 256 ch @8x8 -> whole-image kernel, one pair of
+    # images x 2 blocks of 128 output channels; 64 ch @32x32 -> row-strip kernel, 2 x 4 strips
+    assert sorted(info.blk0[i + 1] - info.blk0[i] for i in range(3)) == [2, 8, 16]
+    assert [lib.hrp_conv_rowstrip_channels(C.byref(d)) for d in descs] == [32, 256, 64]
+    assert lib.hrp_conv_rowstrip_channels(C.byref(_fake_conv(0x500000, cin=256, cout=128, hw=8))) == 0
+    assert info.blk0[1] - info.blk0[0] == 2          # the deepest K loop goes first
     assert 0 < info.lds_bytes <= 160 * 1024
     # mixed tap counts are refused, and so is a half-filled last channel chunk
     bad = (nv.ConvDesc * 2)(descs[0], _fake_conv(0x400000, ntaps=1))

@@ -124,3 +124,75 @@ def run_deep(C, y0=0):
 for C in (128, 256):
     run_deep(C, 0)
     run_deep(C, 8)
+
+
+def run_img(C):
+    W, P = 2048 // C, 2 * C
+    S, KS = P // 16, C // 16
+    NT = 8 if C == 128 else 4
+    TPI = W * W // 32
+    T, PPT, PXP = 33 * P, 32 * P // 1024, 1024 // P
+    lds = {}
+    for t in range(NT):
+        for j in range(S):
+            lds[(t * T + 32 * P + j * 16) // 16] = "zero"
+    for wave in range(4):
+        for i in range(16):
+            q = wave + 4 * i
+            tq, pq = q // PPT, q % PPT
+            for lane in range(64):
+                px, pslot = lane // S, lane % S
+                pp = pq * PXP + px                      # pixel index inside the tile
+                lslot = pslot ^ (pp & 15)
+                off = q * 1024 + px * P + lslot * 16    # source offset inside the 64 KiB group
+                gpix = off // P                         # global pixel of the group
+                assert gpix == tq * 32 + pp and (off % P) // 16 == lslot
+                dst = tq * T + pq * 1024 + lane * 16
+                assert dst // 16 not in lds
+                lds[dst // 16] = (tq, pp, lslot)
+    assert len(lds) == NT * T // 16
+    worst = 1
+    RPT = 32 // W
+    for kk in range(KS):
+        for tap in range(9):
+            dyi, dxi = tap // 3, tap % 3
+            for t in range(NT):
+                addrs = []
+                for lane in range(64):
+                    l31, half = lane & 31, lane >> 5
+                    r, x = l31 // W, l31 % W
+
+                    def bconst(dyi, dxi, row_ok):
+                        xs = x + dxi - 1
+                        ps = l31 + (dyi - 1) * W + dxi - 1
+                        rel = ps * P + (-P if ps < 0 else P if ps >= 32 else 0)
+                        v = rel ^ (((half ^ (ps & 15)) & (S - 1)) << 4)
+                        return v if (row_ok and 0 <= xs < W) else 32 * P
+                    if dyi == 0 and t % TPI == 0:
+                        b = bconst(0, dxi, r > 0)
+                    elif dyi == 2 and t % TPI == TPI - 1:
+                        b = bconst(2, dxi, r < RPT - 1)
+                    else:
+                        b = bconst(dyi, dxi, True)
+                    a = (b ^ (kk << 5)) + t * T
+                    got = lds[a // 16]
+                    # expected: image coordinates
+                    img, ti = t // TPI, t % TPI
+                    y = ti * RPT + r
+                    ys, xs = y + dyi - 1, x + dxi - 1
+                    if ys < 0 or ys >= W or xs < 0 or xs >= W:
+                        assert got == "zero", (C, kk, tap, t, lane, got)
+                    else:
+                        gp = img * W * W + ys * W + xs        # pixel of the group
+                        assert got == (gp // 32, gp % 32, 2 * kk + half), (C, kk, tap, t, lane, got, (gp // 32, gp % 32, 2 * kk + half))
+                    addrs.append(a)
+                for grp in GROUPS:
+                    banks = {}
+                    for l in grp:
+                        banks.setdefault((addrs[l] // 16) % 16, set()).add(addrs[l])
+                    worst = max(worst, max(len(v) for v in banks.values()))
+    print(f"img C={C}: placement and reads consistent; worst ds_read_b128 conflict {worst}-way; tile bytes {NT * T}")
+
+
+for C in (128, 256):
+    run_img(C)

@@ -271,6 +271,11 @@ def keypoint_px_error(dev, dtypes):
     m = m.to(dev).eval()
     x_reg, x_root, kv, K = [t.to(dev) for t in synth_inputs(2)]
     ref_uv = point_projection_from_3d_tensor(K, torch.tensor(g["xyz_fk"]).to(dev))
+    # the reference's arithmetic in float64 on the same inputs (golden_full_eval_fp64.npz, gen_golden.py full_eval_fp64): what the
+    # reference's own fp32 run loses is the yardstick for the fp32 path here
+    p64 = os.path.join(gdir, "golden_full_eval_fp64.npz")
+    g64 = np.load(p64) if os.path.exists(p64) else None
+    uv64 = point_projection_from_3d_tensor(K.double(), torch.tensor(g64["xyz_fk"]).to(dev)) if g64 is not None else None
     out = {}
     for name, dt in dtypes:
         m.set_compute_dtype(dt)
@@ -278,6 +283,13 @@ def keypoint_px_error(dev, dtypes):
             o = m(x_reg, x_root, kv, K)
         uv = point_projection_from_3d_tensor(K, o[7])
         out[name] = round(float((uv - ref_uv).abs().max()), 6)
+        if uv64 is not None:
+            e = (uv.double() - uv64).abs().amax(-1)            # [B, key-points]
+            out[name + "_vs_fp64"] = round(float(e.max()), 6)
+            if name == "bf16":   # key-point 0 of the fixture sits 0.13 m in front of the camera: 1 / z amplifies everything there
+                out["bf16_by_keypoint"] = [round(float(v), 3) for v in e.amax(0)]
+    if g64 is not None:
+        out["reference_fp32_vs_fp64"] = round(float(g64["ref_fp32_px_err"].max()), 6)
     return out
 
 

@@ -15,6 +15,8 @@ Fixtures (reference call site that produced each):
   golden_depthnet.npz    RootNet('hrnet32') eval forward, and train-mode L1 loss + grads
                          (lib/models/depth_net.py:92-137, scripts/train_depthnet.py:231-250).
   golden_full_eval.npz   RootNetwithRegInt.forward eval 8-tuple (lib/models/full_net.py:239-397).
+  golden_full_eval_fp64.npz   the same call with the reference's arithmetic in float64 (`full_eval_fp64`) + the pixel error of
+                         the reference's own fp32 run against it: the noise floor the HIP fp32 path is held to.
   golden_full_eval_baxter.npz   the same for robot_type = "baxter" (15 DoF, 17 key-points), `full_eval_baxter`.
   golden_full_eval_resnet.npz / golden_full_train_resnet.npz   the same with backbone_name = "resnet50" (ResNet-50
                          trunk + deconv head of the shipped full.yaml), generated with `full_eval_resnet full_train_resnet`.
@@ -397,6 +399,42 @@ def gen_full_eval():
     np.savez_compressed(os.path.join(HERE, "golden_full_eval.npz"),
                         **{n: t.numpy() for n, t in zip(NAMES8, o)})
     print("full eval ok", o[0][0, :3])
+
+
+def gen_full_eval_fp64():
+    """The reference's eval forward in float64 on the inputs of golden_full_eval.npz: the yardstick for what the reference's
+    OWN fp32 arithmetic loses (forward casts with `.to(torch.float)` / `.float()`, lib/models/full_net.py:242-243,
+    lib/utils/transforms.py:150-154: both are redirected to float64 for this one call).  Stores the fp64 8-tuple and the
+    key-point pixel error of the reference's fp32 run against it (both projected with K, transforms.py:17-21)."""
+    full, _ = build_full()
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o32 = full(x_reg, x_root, kv, K)
+    saved = (torch.float, torch.Tensor.float, torch.get_default_dtype(), torch.float32)
+    try:
+        torch.float = torch.float32 = torch.float64      # (integral.py:156 spells out dtype=torch.float32)
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+        torch.set_default_dtype(torch.float64)
+        full.double()
+        for name, val in list(vars(full.robot).items()):      # plain tensor attributes of URDFRobot (key-point offsets)
+            if torch.is_tensor(val) and val.is_floating_point():
+                setattr(full.robot, name, val.double())
+        with torch.no_grad():
+            o64 = full(x_reg.double(), x_root.double(), kv.double(), K.double())
+    finally:
+        torch.float, torch.Tensor.float, torch.float32 = saved[0], saved[1], saved[3]
+        torch.set_default_dtype(saved[2])
+    assert all(t.dtype == torch.float64 for t in o64), [t.dtype for t in o64]
+    uv32 = point_projection_from_3d_tensor(K.double(), o32[7].double())
+    uv64 = point_projection_from_3d_tensor(K.double(), o64[7])
+    px = (uv32 - uv64).abs().amax(-1)
+    out = {n: t.numpy() for n, t in zip(NAMES8, o64)}
+    out["ref_fp32_px_err"] = px.numpy()                                   # [B, key-points]
+    out["ref_fp32_rel_err"] = np.array([float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(o32, o64)])
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_fp64.npz"), **out)
+    print("full eval fp64 ok: reference fp32 vs fp64 px err per key-point", px.numpy().round(5).tolist())
+    print("   rel err of the 8-tuple:", dict(zip(NAMES8, out["ref_fp32_rel_err"].round(9).tolist())))
 
 
 def gen_full_eval_direct_rot():

@@ -198,6 +198,29 @@ class PlannedModule(nn.Module):
         plan.split_active = True
         return plan, ranges
 
+    def check_split_backward(self, ranges):
+        """Self-check of the split on this machine, for library users as for bench.py: call it right after a backward
+        in split mode (only the first part has run).  Runs the rest of the backward and verifies bit for bit that it left the
+        arena ranges handed out by enable_split_backward untouched (they may already be with RCCL) and that the arena is
+        finite.  On a violation the split is switched off and a RuntimeError says so (the caller falls back to the unsplit
+        backward)."""
+        runners = [r for r in self._plans.values() if r.plan.grad_arena is not None and r.plan.split_active]
+        if len(runners) != 1:
+            raise RuntimeError("check_split_backward: no plan with an active split")
+        plan = runners[0].plan
+        arena = plan.grad_arena
+        torch.cuda.synchronize(arena.device)
+        before = torch.cat([arena[o:o + n] for o, n in ranges]).clone() if ranges else arena[:0].clone()
+        plan.run_backward("rest")
+        torch.cuda.synchronize(arena.device)
+        after = torch.cat([arena[o:o + n] for o, n in ranges]) if ranges else arena[:0]
+        ok = torch.equal(before, after) and bool(torch.isfinite(arena).all())
+        if not ok:
+            self.disable_split_backward()
+            raise RuntimeError("split backward self-check failed: the second part of the backward touched gradient ranges "
+                               "that were final after the first")
+        return True
+
     def disable_split_backward(self):
         for r in self._plans.values():
             r.plan.split_active = False

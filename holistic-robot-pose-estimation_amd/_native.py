@@ -168,7 +168,7 @@ PROTOTYPES = {
     "hrp_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_scale_rows": [_P, _I, _I, _I, _P, _F, _P],
     "hrp_mul_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
-    "hrp_opt_grad_sumsq": [_P, _P, _I, _P, _P],
+    "hrp_opt_grad_sumsq": [_P, _P, _I, _P, _P, _P],
     "hrp_opt_adam_step": [_P, _P, _I, _P, _F, _P, _F, _F, _F, _F, _P],
     "hrp_batch_prepare": [_I, _P, _I, _P, C.POINTER(BatchInfo)],
     "hrp_batch_launch": [_P, C.POINTER(BatchInfo), _P],

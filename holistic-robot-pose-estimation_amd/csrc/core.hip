@@ -530,7 +530,7 @@ extern "C" int hrp_bn_param_grad(const hrp_bn_entry* table_dev, int count, void*
 // ---- clip_grad_norm_ + Adam over all parameters, table driven -----------------------------------------
 __global__ __launch_bounds__(256) void opt_grad_sumsq_kernel(const hrp_opt_tensor* __restrict__ tensors,
                                                              const hrp_opt_chunk* __restrict__ chunks,
-                                                             float* __restrict__ slots) {
+                                                             float* __restrict__ slots, float* __restrict__ chunk_sums) {
   const hrp_opt_chunk ck = chunks[blockIdx.x];
   const hrp_opt_tensor t = tensors[ck.tensor];
   const int64_t base = (int64_t)ck.offset * HRP_OPT_CHUNK;
@@ -550,7 +550,27 @@ __global__ __launch_bounds__(256) void opt_grad_sumsq_kernel(const hrp_opt_tenso
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&slots[blockIdx.x & (HRP_STAT_SLOTS - 1)], part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    if (chunk_sums) chunk_sums[blockIdx.x] = tot;      // deterministic path: folded in a fixed order by opt_fold_sumsq_kernel
+    else atomicAdd(&slots[blockIdx.x & (HRP_STAT_SLOTS - 1)], tot);
+  }
+}
+
+// slots[0] = sum of chunk_sums[0 .. n) in a FIXED order (thread t takes t, t + 256, ..; then a fixed tree), slots[1..] = 0:
+// the same bits on every data-parallel rank, whatever order the chunk kernels finished in (fp32 atomics into the slots
+// made the clip coefficient - and with it every parameter - differ by an ulp between replicas holding identical gradients)
+__global__ __launch_bounds__(256) void opt_fold_sumsq_kernel(const float* __restrict__ chunk_sums, int n, float* __restrict__ slots) {
+  __shared__ float part[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += chunk_sums[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < HRP_STAT_SLOTS) slots[threadIdx.x] = threadIdx.x == 0 ? part[0] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void opt_adam_kernel(const hrp_opt_tensor* __restrict__ tensors,
@@ -595,9 +615,12 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const hrp_opt_tensor* __r
 }
 
 extern "C" int hrp_opt_grad_sumsq(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,
-                                  float* sumsq_slots, void* stream) {
+                                  float* sumsq_slots, float* chunk_sums, void* stream) {
   HRP_REQUIRE(tensors_dev && chunks_dev && sumsq_slots && nchunks > 0, "opt_grad_sumsq: bad args");
-  hipLaunchKernelGGL(opt_grad_sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors_dev, chunks_dev, sumsq_slots);
+  hipLaunchKernelGGL(opt_grad_sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors_dev, chunks_dev, sumsq_slots,
+                     chunk_sums);
+  if (chunk_sums)
+    hipLaunchKernelGGL(opt_fold_sumsq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, chunk_sums, nchunks, sumsq_slots);
   return check_launch("opt_grad_sumsq");
 }
 extern "C" int hrp_opt_adam_step(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,

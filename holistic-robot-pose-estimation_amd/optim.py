@@ -51,6 +51,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
         self._publish_state()
         self._slots = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._chunk_sums = None
         self._grad_ptrs = None
         self._tensors = self._chunks = None
         self._nchunks = 0
@@ -111,6 +112,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._tensors = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
         self._chunks = torch.frombuffer(bytearray(bytes(ck)), dtype=torch.uint8).to(self.device)
         self._nchunks = len(chunks)
+        self._chunk_sums = torch.zeros(self._nchunks, dtype=torch.float32, device=self.device)
         self._grad_ptrs = ptrs
 
     def prepare(self):
@@ -128,9 +130,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         s = torch.cuda.current_stream(self.device).cuda_stream
         self.step_count += 1
         if self.max_norm > 0:
-            self._slots.zero_()
+            # per-chunk sums folded in a fixed order (no atomics): every data-parallel rank derives the same clip
+            # coefficient, bit for bit, from the same averaged gradients - replicas stay identical
             nv.call("hrp_opt_grad_sumsq", self._tensors.data_ptr(), self._chunks.data_ptr(), self._nchunks,
-                    self._slots.data_ptr(), s)
+                    self._slots.data_ptr(), self._chunk_sums.data_ptr(), s)
         nv.call("hrp_opt_adam_step", self._tensors.data_ptr(), self._chunks.data_ptr(), self._nchunks,
                 self._slots.data_ptr(), self.max_norm, self.step_count.data_ptr(),
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), s)

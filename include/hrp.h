@@ -323,9 +323,13 @@ typedef struct hrp_opt_chunk {
   int32_t tensor;      /* index into the tensor table               */
   int32_t offset;      /* first element, in units of HRP_OPT_CHUNK  */
 } hrp_opt_chunk;
-/* sumsq_slots[HRP_STAT_SLOTS] += sum of grad^2 (the caller zeroes the slots) */
+/* Sum of grad^2 over all chunks.  chunk_sums == NULL: sumsq_slots[HRP_STAT_SLOTS] += (fp32 atomics; the caller zeroes the
+ * slots; the total depends on the order the chunks finish in, to an ulp).  chunk_sums = nchunks floats of scratch: every
+ * chunk writes its own sum and a second launch folds them in a FIXED order into sumsq_slots[0] (the other slots are set to
+ * 0): the same bits on every data-parallel rank that holds the same gradients - what keeps replicas identical through
+ * hrp_opt_adam_step's clip coefficient (torch.nn.utils.clip_grad_norm_ under DataParallel runs once, on one device). */
 int hrp_opt_grad_sumsq(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* chunks_dev, int nchunks,
-                       float* sumsq_slots, void* stream);
+                       float* sumsq_slots, float* chunk_sums, void* stream);
 /* total_norm = sqrt(sum of the slots); clip = min(1, max_norm / (total_norm + 1e-6)) (max_norm <= 0: no clipping);
  * g = grad * clip (written back); *step_dev is the number of the step being taken (the caller increments it
  * before the launch); Adam without weight decay / amsgrad:

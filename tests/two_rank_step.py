@@ -62,6 +62,12 @@ def main():
     assert torch.equal(arena, mean), f"rank {rank}: all-reduced arena != mean of the ranks' gradients ({(arena - mean).abs().max().item()})"
     assert (both[0] - both[1]).abs().max().item() > 0, "the two ranks computed the same gradient: per-rank data missing"
     reduced_plain = arena.clone()
+    # run-to-run spread of the SAME bf16 step (statistic atomics -> rounding / ReLU ties through ~330 layers, B = 4): the
+    # yardstick for "equal" below
+    fwd_bwd()
+    torch.cuda.synchronize(dev)
+    noise = ((arena - own).norm() / own.norm()).item()
+    tol = max(3.0 * noise, 1e-3)
 
     # ---- the same step with the backward split around the all-reduce of the final ranges (bench.py at N > 1) -----------
     sp = model.enable_split_backward()
@@ -72,7 +78,7 @@ def main():
     # the split backward == the plain backward up to the run-to-run noise of the statistic atomics (bf16 trunk)
     torch.cuda.synchronize(dev)
     rel = ((arena - own).norm() / own.norm()).item()
-    assert rel < 3e-2, f"rank {rank}: split backward differs from the plain backward by {rel}"
+    assert rel < tol, f"rank {rank}: split backward differs from the plain backward by {rel} (run-to-run spread {noise})"
     red = GradAllReducer(bucket_mb=64)
     fwd_bwd()                                       # first part again
     w = red.start(arena, final)                     # final ranges travel ...
@@ -81,7 +87,10 @@ def main():
     red.finish(w, [arena])
     torch.cuda.synchronize(dev)
     rel = ((arena - reduced_plain).norm() / reduced_plain.norm()).item()
-    assert rel < 3e-2, f"rank {rank}: overlapped all-reduce differs from the plain one by {rel}"
+    assert rel < tol, f"rank {rank}: overlapped all-reduce differs from the plain one by {rel} (run-to-run spread {noise})"
+    other_a = [torch.empty_like(arena) for _ in range(2)]
+    dist.all_gather(other_a, arena)
+    assert torch.equal(other_a[0], other_a[1]), "the ranks hold different averaged gradients after the overlapped all-reduce"
     model.disable_split_backward()
 
     # ---- optimizer step on the averaged gradients: replicas stay identical ---------------------------------------------
@@ -96,7 +105,8 @@ def main():
     rms = [torch.empty_like(rm) for _ in range(2)]
     dist.all_gather(rms, rm)
     assert not torch.equal(rms[0], rms[1]), "BatchNorm running statistics are per replica (no SyncBN, as under DataParallel)"
-    print(f"rank {rank}: ok ({arena.numel()} gradient elements, split final fraction {sum(n for _, n in final) / arena.numel():.2f})")
+    print(f"rank {rank}: ok ({arena.numel()} gradient elements, split final fraction {sum(n for _, n in final) / arena.numel():.2f}, "
+          f"run-to-run spread of the step {noise:.3f})")
     dist.destroy_process_group()
 
 

@@ -65,7 +65,7 @@ static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds)
     if (rc_) {   // the lean kernel of the high-resolution BasicBlock layers
       row_plan(d, P.r);
       P.t = ConvTiling{};
-      P.t.nblocks = P.r.nstrips;
+      P.t.nblocks = row_grid(P.r, rc_);
       P.cfg = rc_ == 32 ? 5 : rc_ == 64 ? 6 : rc_ == 128 ? 7 : 8;
       if (P.r.img) P.cfg += 2;
       lds = row_lds_bytes(rc_, P.r.img);

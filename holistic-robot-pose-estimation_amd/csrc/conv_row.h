@@ -52,7 +52,9 @@ struct RowCfg {
   static constexpr int TILE_BYTES = P + NROWS * ROWB;               // leading zero pixel + rows
   static constexpr int CTAB_OFF = (TILE_BYTES + 255) & ~255;        // per-channel constants [8][C] floats
   static constexpr int STAT_OFF = CTAB_OFF + 8 * C * 4;             // [4 waves][64] floats
-  static constexpr int LDS_BYTES = STAT_OFF + 4 * 64 * 4;
+  static constexpr bool PERSIST = C == 32;                          // persistent workgroups, weights parked in LDS (18 KiB)
+  static constexpr int WLDS_OFF = STAT_OFF + 4 * 64 * 4;            // [9 taps][KS] A fragments of 1 KiB, lane linear
+  static constexpr int LDS_BYTES = WLDS_OFF + (PERSIST ? 9 * KS * 1024 : 0);
   static_assert(MT * NCOL == 2, "two waves side by side (columns or channel tiles), two on top of each other");
   __device__ static __forceinline__ int g(int x) { return C == 32 ? (x >> 2) & 3 : (x >> 1) & 7; }
 };
@@ -62,7 +64,7 @@ struct RowPlan {
   int nstrips, spi;    // workgroups (strip kernels: N * H / TH); strips per image
   FastDiv fd_spi;
   int img;             // 1: whole-image variant (conv_img_body): C = 128 @ 16 x 16, C = 256 @ 8 x 8
-  int pad;
+  int spw;             // conv_row_body: strips per (persistent) workgroup
 };
 
 // mean / invstd / scale / shift of one channel from the statistic slots (the arithmetic of elementwise.hip's
@@ -110,7 +112,11 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
   rp.nstrips = d.N * rp.spi;
   rp.fd_spi = make_fastdiv(rp.spi);
   rp.img = 0;
-  rp.pad = 0;
+  // persistent workgroups of the 32 / 64-channel kernel: 2 strips each once the problem has more strips than the chip
+  // has workgroup slots for it (B = 64: 512 / 256 strips -> 256 / 128 workgroups)
+  static const int spw_env = getenv("HRP_ROWCONV_SPW") ? atoi(getenv("HRP_ROWCONV_SPW")) : 0;
+  rp.spw = spw_env > 0 ? spw_env : (rp.nstrips >= 256 ? 2 : 1);
+  if (rp.spi % rp.spw || d.Cin != 32) rp.spw = 1;       // (the 64-channel kernel keeps its weights in registers: one strip)
   static const bool no_img = getenv("HRP_NO_IMGCONV") != nullptr;      // A/B switch: deep layers on the strip kernels
   if (!no_img && (d.Cin == 128 || d.Cin == 256) && d.H == d.W) {
     rp.img = 1;
@@ -274,26 +280,36 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
   const int m = R::MT == 2 ? sel : 0;         // which 32-channel output tile
   HRP_CSTAMP(0);
 
-  if ((rp.nstrips & 7) == 0) bid = (bid & 7) * (rp.nstrips >> 3) + (bid >> 3);   // strips of one image on one XCD
-  const int n = fdiv(bid, rp.fd_spi);
-  const int y0 = (bid - n * rp.spi) * TH;
+  // The workgroup is PERSISTENT over rp.spw consecutive strips (of one image when spw divides the strips per image): the
+  // weights, the BatchNorm constants and the zero pixels are set up once, the statistics leave once, and the DMA of strip
+  // s + 1 is issued before the epilogue (stores) of strip s.
+  const int ngroups = (rp.nstrips + rp.spw - 1) / rp.spw;
+  if ((ngroups & 7) == 0) bid = (bid & 7) * (ngroups >> 3) + (bid >> 3);   // neighbouring groups (one image) on one XCD
+  const int s_begin = bid * rp.spw, s_end = min(s_begin + rp.spw, rp.nstrips);
   const int H = d.H;
   const int pro = d.pro_mode;
 
   // ---- weights: A fragments of this wave's 32 output channels.  MFMA row rho = 8 q + 4 h + i carries output channel
   // 16 h + 4 q + i, so that accumulator register 4 q + i of a lane (half h) is channel 16 h + 4 q + i: consecutive.
+  // C = 64: 144 registers, loaded once per workgroup (one strip).  C = 32: all four waves use the same 18 fragments: they
+  // are DMA'd ONCE into LDS (4.5 pieces per wave instead of 18 global loads per wave, whose issue alone was ~1 us of every
+  // workgroup) and re-read into registers for every strip's MFMA loop, so that they do not occupy registers during the
+  // prologue / epilogue phases of a persistent workgroup.
   bf16x8 wf[9][KS];
-  auto load_weights = [&]() {
-    const int rho = l31;
-    const int co = m * 32 + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
-    const char* wl = (const char*)d.w + co * ROW + half * 16;
+  const int co_lane = m * 32 + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  const char* wl = (const char*)d.w + co_lane * ROW + half * 16;
+  char* wlds = smem + R::WLDS_OFF;
+  if constexpr (R::PERSIST) {
+#pragma unroll
+    for (int f = 0; f < 9 * KS; ++f)
+      if ((f & 3) == wave) dma16(wl + (size_t)(((f % KS) * d.w_ntaps + rp.wslot[f / KS]) * C) * ROW, wlds + f * 1024);
+  } else {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk)
         wf[t][kk] = *(const bf16x8*)(wl + (size_t)((kk * d.w_ntaps + rp.wslot[t]) * C) * ROW);
-  };
-  if (pro == 0) load_weights();
+  }
 
   // ---- staging: piece `wave` of every row; the lane's 16 bytes = (pixel lane / S of the piece, slot lane % S), holding
   // the LOGICAL slot (lane % S) ^ g(x)
@@ -301,10 +317,12 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
   const int xcol = wave * R::PXP + px_in_piece;
   const int lslot = (lane % S) ^ R::g(xcol);
   const unsigned lane_off = (unsigned)(wave * 1024 + px_in_piece * P + lslot * 16);
-  const unsigned img_off = (unsigned)n * (unsigned)(H * W * P);
   char* lds_rows = smem + P;
-  {
-    const char* xg = (const char*)d.x + img_off + lane_off;
+  auto strip_of = [&](int s, int& n, int& y0) { n = fdiv(s, rp.fd_spi); y0 = (s - n * rp.spi) * TH; };
+  auto stage = [&](int s) {
+    int n, y0;
+    strip_of(s, n, y0);
+    const char* xg = (const char*)d.x + (unsigned)n * (unsigned)(H * W * P) + lane_off;
 #pragma unroll
     for (int rs = 0; rs < NROWS; ++rs) {
       const int y = y0 - 1 + rs;
@@ -312,18 +330,8 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
       if (y >= 0 && y < H) dma16(xg + y * (W * P), dst);
       else *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
     }
-  }
-  // second operand of the backward prologue: same bytes of the BatchNorm input, through registers
-  uint4 x2[NROWS];
-  if (pro == 2) {
-    const char* x2g = (const char*)d.pro_x2 + img_off + lane_off;
-#pragma unroll
-    for (int rs = 0; rs < NROWS; ++rs) {
-      const int y = y0 - 1 + rs;
-      x2[rs] = make_uint4(0, 0, 0, 0);
-      if (y >= 0 && y < H) x2[rs] = *(const uint4*)(x2g + y * (W * P));
-    }
-  }
+  };
+  stage(s_begin);
   // the zero pixels: one in front of row slot 0, one behind every row slot
   if (tid < (NROWS + 1) * S) {
     const int k = tid / S, j = tid - k * S;
@@ -352,127 +360,155 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
     ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
   }
   HRP_CSTAMP(1);
+  if (pro != 0) __syncthreads();                                          // the constant table
 
-  // ---- prologue: transform the bytes this lane staged, in place
-  if (pro != 0) {
-    __syncthreads();                                          // the constant table
-    const int cb = lslot * 8;                                 // the lane's 8 channels
-    float sc[8], sh[8];
+  // read address of (dx, kk) for row slot rg*4: pixel x = col*32 + l31 + dx (x = -1 / W are the shared zero pixels)
+  int baddr[3][KS];
 #pragma unroll
-    for (int i = 0; i < 8; i += 4) {
-      const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
-      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this lane's DMA pieces (and x2) have landed
-    char* side = (char*)d.pro_side;
-    if (pro == 1) {
+  for (int dxi = 0; dxi < 3; ++dxi) {
+    const int xq = col * 32 + l31 + dxi - 1;
 #pragma unroll
-      for (int rs = 0; rs < NROWS; ++rs) {
-        const int y = y0 - 1 + rs;
-        if (y < 0 || y >= H) continue;
-        char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
-        float f[8];
-        Elem<bf16_t>::unpack(*(const uint4*)p, f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
-        const uint4 o = Elem<bf16_t>::pack(f);
-        *(uint4*)p = o;
-        if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
-      }
-    } else {
-      float a[8], b[8], k0[8], k1[8];
+    for (int kk = 0; kk < KS; ++kk)
+      baddr[dxi][kk] = P + rg * 4 * ROWB + xq * P + (((2 * kk + half) ^ R::g(xq)) << 4);
+  }
+  const int cl = m * 32 + 16 * half;      // first output channel of the lane
+  float vtot = 0.f;                       // statistics of the strips so far, already reduced over the half wave
+
+  const int s_stop = R::PERSIST ? s_end : s_begin + 1;        // (C = 64: exactly one strip, known to the compiler)
+  for (int s = s_begin; s < s_stop; ++s) {
+    int n, y0;
+    strip_of(s, n, y0);
+    const unsigned img_off = (unsigned)n * (unsigned)(H * W * P);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this lane's DMA pieces of strip s have landed
+    // ---- prologue: transform the bytes this lane staged, in place
+    if (pro != 0) {
+      const int cb = lslot * 8;                                 // the lane's 8 channels
+      float sc[8], sh[8];
 #pragma unroll
       for (int i = 0; i < 8; i += 4) {
-        const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
-        const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
-        a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
-        b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
-        k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
-        k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+        const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
+        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
       }
+      char* side = (char*)d.pro_side;
+      if (pro == 1) {
 #pragma unroll
-      for (int rs = 0; rs < NROWS; ++rs) {
-        const int y = y0 - 1 + rs;
-        if (y < 0 || y >= H) continue;
-        char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
-        float gq[8], xv[8];
-        Elem<bf16_t>::unpack(*(const uint4*)p, gq);
-        Elem<bf16_t>::unpack(x2[rs], xv);
+        for (int rs = 0; rs < NROWS; ++rs) {
+          const int y = y0 - 1 + rs;
+          if (y < 0 || y >= H) continue;
+          char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+          float f[8];
+          Elem<bf16_t>::unpack(*(const uint4*)p, f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float g = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
-          const float xh = fmaf(xv[i], a[i], b[i]);
-          gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
+          for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
+          const uint4 o = Elem<bf16_t>::pack(f);
+          *(uint4*)p = o;
+          if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
         }
-        const uint4 o = Elem<bf16_t>::pack(gq);
-        *(uint4*)p = o;
-        if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
+      } else {
+        float a[8], b[8], k0[8], k1[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 4) {
+          const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
+          const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
+          a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
+          b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
+          k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
+          k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+        }
+        // second operand: the same bytes of the BatchNorm input, through registers, five rows at a time
+        const char* x2g = (const char*)d.pro_x2 + img_off + lane_off;
+#pragma unroll
+        for (int r0 = 0; r0 < NROWS; r0 += 5) {
+          uint4 x2[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int y = y0 - 1 + r0 + j;
+            x2[j] = make_uint4(0, 0, 0, 0);
+            if (y >= 0 && y < H) x2[j] = *(const uint4*)(x2g + y * (W * P));
+          }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int rs = r0 + j, y = y0 - 1 + rs;
+            if (y < 0 || y >= H) continue;
+            char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+            float gq[8], xv[8];
+            Elem<bf16_t>::unpack(*(const uint4*)p, gq);
+            Elem<bf16_t>::unpack(x2[j], xv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float g = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
+              const float xh = fmaf(xv[i], a[i], b[i]);
+              gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
+            }
+            const uint4 o = Elem<bf16_t>::pack(gq);
+            *(uint4*)p = o;
+            if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
+          }
+        }
       }
     }
-    load_weights();
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  HRP_CSTAMP(2);
-
-  // ---- MFMA loop: input rows rg*4 - 1 .. rg*4 + 4 of the strip (LDS row slots rg*4 .. rg*4 + 5)
-  f32x16 acc[4];
+    __syncthreads();
+    if (s == s_begin) HRP_CSTAMP(2);
+    if constexpr (R::PERSIST) {
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[o][i] = 0.f;
-  {
-    // read address of (dx, kk) for row slot rg*4: pixel x = col*32 + l31 + dx (x = -1 / W are the shared zero pixels)
-    int baddr[3][KS];
-#pragma unroll
-    for (int dxi = 0; dxi < 3; ++dxi) {
-      const int xq = col * 32 + l31 + dxi - 1;
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
-        baddr[dxi][kk] = P + rg * 4 * ROWB + xq * P + (((2 * kk + half) ^ R::g(xq)) << 4);
+      for (int f = 0; f < 9 * KS; ++f) wf[f / KS][f % KS] = *(const bf16x8*)(wlds + f * 1024 + lane * 16);
     }
-    constexpr int NSTEP = 6 * 3 * KS, RING = 4, AHEAD = 3;
-    bf16x8 bq[RING];
-    auto rd = [&](int s) -> bf16x8 {   // s is a constant after unrolling
-      const int irel = s / (3 * KS), dxi = (s / KS) % 3, kk = s % KS;
-      return *(const bf16x8*)(smem + baddr[dxi][kk] + irel * ROWB);
-    };
+
+    // ---- MFMA loop: input rows rg*4 - 1 .. rg*4 + 4 of the strip (LDS row slots rg*4 .. rg*4 + 5)
+    f32x16 acc[4];
 #pragma unroll
-    for (int s = 0; s < AHEAD; ++s) bq[s % RING] = rd(s);
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      if (s + AHEAD < NSTEP) bq[(s + AHEAD) % RING] = rd(s + AHEAD);
-      const int irel = s / (3 * KS), dxi = (s / KS) % 3, kk = s % KS;
+      for (int i = 0; i < 16; ++i) acc[o][i] = 0.f;
+    {
+      constexpr int NSTEP = 6 * 3 * KS, RING = 4, AHEAD = 3;
+      bf16x8 bq[RING];
+      auto rd = [&](int q) -> bf16x8 {   // q is a constant after unrolling
+        const int irel = q / (3 * KS), dxi = (q / KS) % 3, kk = q % KS;
+        return *(const bf16x8*)(smem + baddr[dxi][kk] + irel * ROWB);
+      };
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const int dyi = irel - o;                 // input row (rg*4 - 1 + irel) = output row (rg*4 + o) + dy, dy = dyi - 1
-        if (dyi >= 0 && dyi <= 2)
-          acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[dyi * 3 + dxi][kk], bq[s % RING], acc[o], 0, 0, 0);
+      for (int q = 0; q < AHEAD; ++q) bq[q % RING] = rd(q);
+#pragma unroll
+      for (int q = 0; q < NSTEP; ++q) {
+        if (q + AHEAD < NSTEP) bq[(q + AHEAD) % RING] = rd(q + AHEAD);
+        const int irel = q / (3 * KS), dxi = (q / KS) % 3, kk = q % KS;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int dyi = irel - o;                 // input row (rg*4 - 1 + irel) = output row (rg*4 + o) + dy, dy = dyi - 1
+          if (dyi >= 0 && dyi <= 2)
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[dyi * 3 + dxi][kk], bq[q % RING], acc[o], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the read-ahead where it is
       }
-      __builtin_amdgcn_sched_barrier(0);          // keep the read-ahead where it is
     }
-  }
-  HRP_CSTAMP(4);
+    if (s == s_begin) HRP_CSTAMP(4);
+    // every wave is done with the rows: the next strip's DMA runs under this strip's epilogue
+    if constexpr (R::PERSIST) {
+      if (s + 1 < s_end) {
+        __syncthreads();
+        stage(s + 1);
+      }
+    }
 
-  // ---- epilogue: lane = pixel (row y0 + rg*4 + o, x = col*32 + l31), channels m*32 + 16*half .. +15
-  const int cl = m * 32 + 16 * half;      // first channel of the lane
-  float s1[16], s2[16];
+    // ---- epilogue: lane = pixel (row y0 + rg*4 + o, x = col*32 + l31), channels m*32 + 16*half .. +15
+    float s1[16], s2[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-  {
-    const unsigned out_off = img_off + (unsigned)((y0 + rg * 4) * W + col * 32 + l31) * P + cl * 2;
-    unsigned off[4];
+    for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+    {
+      const unsigned out_off = img_off + (unsigned)((y0 + rg * 4) * W + col * 32 + l31) * P + cl * 2;
+      unsigned off[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) off[o] = out_off + o * (W * P);
-    row_epilogue<4>(d, acc, off, 0xfu, cl, ctab, C, bnb, s1, s2);
+      for (int o = 0; o < 4; ++o) off[o] = out_off + o * (W * P);
+      row_epilogue<4>(d, acc, off, 0xfu, cl, ctab, C, bnb, s1, s2);
+    }
+    if (d.stats) vtot += row_reduce32(s1, s2, l31);
+    if (s == s_begin) HRP_CSTAMP(5);
   }
-  HRP_CSTAMP(5);
   if (d.stats) {
-    const float v1 = row_reduce32(s1, s2, l31);
     // lane l31 < 16: sum 1 of channel cl + l31; l31 >= 16: sum 2 of channel cl + l31 - 16
-    stat_lds[wave * 64 + lane] = v1;
+    stat_lds[wave * 64 + lane] = vtot;
     __syncthreads();
     if (tid < 2 * C) {
       const int which = tid / C, c = tid - which * C;
@@ -1033,6 +1069,11 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const hrp_conv_desc d,
   conv_img_body<C>(d, rp, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
 }
 
+// workgroups of a planned problem
+static inline int row_grid(const RowPlan& rp, int C) {
+  return (C <= 64 && !rp.img) ? (rp.nstrips + rp.spw - 1) / rp.spw : rp.nstrips;
+}
+
 static inline int row_lds_bytes(int C, int img) {
   if (img) return C == 128 ? ImgCfg<128>::LDS_BYTES : ImgCfg<256>::LDS_BYTES;
   return C == 32 ? RowCfg<32>::LDS_BYTES : C == 64 ? RowCfg<64>::LDS_BYTES : C == 128 ? DeepCfg<128>::LDS_BYTES : DeepCfg<256>::LDS_BYTES;
@@ -1044,8 +1085,8 @@ static int launch_conv_row(const hrp_conv_desc& d, hipStream_t s) {
   if (!C) return -100;
   RowPlan rp;
   row_plan(d, rp);
-  if (C == 32) hipLaunchKernelGGL(conv_row_kernel<32>, dim3(rp.nstrips), dim3(256), RowCfg<32>::LDS_BYTES, s, d, rp);
-  else if (C == 64) hipLaunchKernelGGL(conv_row_kernel<64>, dim3(rp.nstrips), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
+  if (C == 32) hipLaunchKernelGGL(conv_row_kernel<32>, dim3(row_grid(rp, 32)), dim3(256), RowCfg<32>::LDS_BYTES, s, d, rp);
+  else if (C == 64) hipLaunchKernelGGL(conv_row_kernel<64>, dim3(row_grid(rp, 64)), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
   else if (rp.img) {
     static bool attr = false;
     if (!attr) {

@@ -96,7 +96,8 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-SHAPES = [(32, 3, 64), (64, 2, 32), (32, 1, 16), (64, 5, 8), (128, 3, 16), (256, 3, 8), (128, 1, 8), (256, 2, 16)]     # (C, N, H); W = 2048 / C
+SHAPES = [(32, 3, 64), (64, 2, 32), (32, 1, 16), (64, 5, 8), (128, 3, 16), (256, 3, 8), (128, 1, 8), (256, 2, 16),
+          (32, 32, 64)]     # (C, N, H); W = 2048 / C.  The last one: 256 strips -> persistent workgroups, two strips each
 
 
 @pytest.mark.parametrize("shape", SHAPES)

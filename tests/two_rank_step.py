@@ -95,12 +95,17 @@ def main():
 
     # ---- optimizer step on the averaged gradients: replicas stay identical ---------------------------------------------
     arena.copy_(reduced_plain)
+
+    def same_on_both(t, what):
+        both_t = [torch.empty_like(t) for _ in range(2)]
+        dist.all_gather(both_t, t.contiguous())
+        assert torch.equal(both_t[0], both_t[1]), f"rank {rank}: {what} differ between the ranks ({(both_t[0] - both_t[1]).abs().max().item()})"
+    same_on_both(torch.cat([p.detach().reshape(-1) for p in params]), "parameters before the step")
+    same_on_both(arena, "averaged gradients")
     opt.step()
     torch.cuda.synchronize(dev)
-    flat = torch.cat([p.detach().reshape(-1) for p in params])
-    other = [torch.empty_like(flat) for _ in range(2)]
-    dist.all_gather(other, flat)
-    assert torch.equal(other[0], other[1]), f"rank {rank}: parameters differ after the step ({(other[0] - other[1]).abs().max().item()})"
+    same_on_both(opt._slots, "gradient-norm slots")
+    same_on_both(torch.cat([p.detach().reshape(-1) for p in params]), "parameters after the step")
     rm = torch.cat([b.reshape(-1).float() for n, b in model.named_buffers() if n.endswith("running_mean")])
     rms = [torch.empty_like(rm) for _ in range(2)]
     dist.all_gather(rms, rm)

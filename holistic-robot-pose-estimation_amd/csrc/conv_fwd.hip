@@ -19,7 +19,7 @@ int conv_check(const hrp_conv_desc* d) {
   HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
   HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
   HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
-  if (d->bnb_x && d->bnb_mask) {   // BatchNorm-backward reduce in the epilogue: only the plain vector store path computes it
+  if (d->bnb_x && d->bnb_mask && !hrp_conv_rowstrip_channels(d)) {   // BatchNorm-backward reduce in the epilogue of the general tile program: only the plain vector store path computes it
     const int sz = d->dtype == HRP_F32 ? 4 : 2;
     HRP_REQUIRE(d->stats && d->bnb_mask && d->bnb_consts, "conv: bnb_x needs stats, bnb_mask and bnb_consts");
     HRP_REQUIRE(!d->res && !d->relu && !d->bias && !d->scale, "conv: bnb_x excludes res / relu / bias / scale");
@@ -29,7 +29,7 @@ int conv_check(const hrp_conv_desc* d) {
                 ((size_t)d->bnb_x_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_consts % 16 == 0, "conv: bnb_x alignment");
   }
   // input transforms / the mask-less epilogue reduce exist in the row-strip kernel only (conv_row.h)
-  if (d->pro_mode != 0 || d->pro_side || (d->bnb_x && !d->bnb_mask))
+  if (d->pro_mode != 0 || d->pro_side || d->pro_side2 || d->pro_mask || (d->bnb_x && (!d->bnb_mask || d->res)))
     HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / mask-less bnb_x need a row-strip problem (hrp_conv_rowstrip_channels)");
   return HRP_OK;
 }

@@ -50,8 +50,8 @@ struct RowCfg {
   static constexpr int ROWB = (W + 1) * P;  // LDS row pitch: the row + one zero pixel
   static constexpr int NROWS = TH + 2;
   static constexpr int TILE_BYTES = P + NROWS * ROWB;               // leading zero pixel + rows
-  static constexpr int CTAB_OFF = (TILE_BYTES + 255) & ~255;        // per-channel constants [8][C] floats
-  static constexpr int STAT_OFF = CTAB_OFF + 8 * C * 4;             // [4 waves][64] floats
+  static constexpr int CTAB_OFF = (TILE_BYTES + 255) & ~255;        // per-channel constants [10][C] floats
+  static constexpr int STAT_OFF = CTAB_OFF + 10 * C * 4;             // [4 waves][64] floats
   static constexpr bool PERSIST = C == 32;                          // persistent workgroups, weights parked in LDS (18 KiB)
   static constexpr int WLDS_OFF = STAT_OFF + 4 * 64 * 4;            // [9 taps][KS] A fragments of 1 KiB, lane linear
   static constexpr int LDS_BYTES = WLDS_OFF + (PERSIST ? 9 * KS * 1024 : 0);
@@ -91,12 +91,14 @@ static inline int row_channels(const hrp_conv_desc& d) {
   if (d.x_pitch != C || d.y_pitch != C || d.w_cout_pad != C || (d.res && d.res_pitch != C)) return 0;
   if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.w | (uintptr_t)d.res) % 16) return 0;
   if (d.bias) return 0;
-  if (d.bnb_x && (d.bnb_mask || d.bnb_x_pitch != C || !d.bnb_stats || !d.bnb_gamma || !d.bnb_beta || !d.stats ||
-                  d.res || d.relu || d.scale || (uintptr_t)d.bnb_x % 16)) return 0;
+  if (d.bnb_x && (d.bnb_x_pitch != C || !d.bnb_stats || !d.bnb_gamma || !d.bnb_beta || !d.stats ||
+                  d.relu || d.scale || (uintptr_t)d.bnb_x % 16)) return 0;
+  if (d.bnb_x && d.bnb_mask && (d.bnb_mask_pitch != C / 8 || (uintptr_t)d.bnb_mask % 2)) return 0;
   if (d.pro_mode < 0 || d.pro_mode > 2) return 0;
   if (d.pro_mode && (!d.pro_stats || !d.pro_gamma || !d.pro_beta)) return 0;
-  if (d.pro_mode == 2 && (!d.pro_x2 || !d.pro_bsums || (uintptr_t)d.pro_x2 % 16 || d.bnb_x)) return 0;
-  if (d.pro_side && (uintptr_t)d.pro_side % 16) return 0;
+  if (d.pro_mode == 2 && (!d.pro_x2 || !d.pro_bsums || (uintptr_t)d.pro_x2 % 16)) return 0;
+  if (d.pro_mode != 2 && (d.pro_mask || d.pro_side2)) return 0;
+  if ((d.pro_side && (uintptr_t)d.pro_side % 16) || (d.pro_side2 && (uintptr_t)d.pro_side2 % 16)) return 0;
   if ((long long)d.N * d.H * d.W * C * 2 >= (1ll << 31)) return 0;     // 32-bit byte offsets inside the tensors
   unsigned seen = 0;
   for (int i = 0; i < 9; ++i) {
@@ -125,30 +127,118 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
 }
 
 
+// ---- shared prologue pieces: the per-channel constants of a lane's 8 channels (one 16-byte slot) and the two transforms ----
+struct RowPro {
+  float sc[8], sh[8], a[8], b[8], k0[8], k1[8];
+  __device__ __forceinline__ void load(const float* ctab, const int C, const int cb) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 4) {
+      const float4 va = *(const float4*)(ctab + cb + i), vb = *(const float4*)(ctab + C + cb + i);
+      sc[i] = va.x; sc[i + 1] = va.y; sc[i + 2] = va.z; sc[i + 3] = va.w;
+      sh[i] = vb.x; sh[i + 1] = vb.y; sh[i + 2] = vb.z; sh[i + 3] = vb.w;
+    }
+  }
+  // ... and of pro_mode 2 (called inside that branch only: as a conditional part of load() the 32 values cost the 32-channel
+  // kernel 25 spilled registers)
+  __device__ __forceinline__ void load2(const float* ctab, const int C, const int cb) {
+    {
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
+        const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
+        a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
+        b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
+        k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
+        k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+      }
+    }
+  }
+  // pro_mode 1: relu(bn(x))
+  __device__ __forceinline__ uint4 act(const uint4 raw) const {
+    float f[8];
+    Elem<bf16_t>::unpack(raw, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
+    return Elem<bf16_t>::pack(f);
+  }
+  // pro_mode 2: BatchNorm + ReLU backward of (gradient of the activation, BatchNorm input).  The ReLU mask: recomputed from
+  // the BatchNorm input (bits < 0) or the bit mask hrp_ew_fwd wrote (bit i = channel i of the vector was > 0).
+  // gm: the masked gradient g itself (what an identity / residual input of the same activation receives).
+  // EXT false: the lean instantiation (mask always recomputed, gm unused).
+  template <bool EXT>
+  __device__ __forceinline__ uint4 bwd(const uint4 graw, const uint4 xraw, const int bits, uint4& gm) const {
+    float gq[8], xv[8], gk[8];
+    Elem<bf16_t>::unpack(graw, gq);
+    Elem<bf16_t>::unpack(xraw, xv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool on = (!EXT || bits < 0) ? row_bn_act(xv[i], sc[i], sh[i]) > 0.f : ((bits >> i) & 1) != 0;
+      const float g = on ? gq[i] : 0.f;
+      gk[i] = g;
+      const float xh = fmaf(xv[i], a[i], b[i]);
+      gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
+    }
+    if constexpr (EXT) gm = Elem<bf16_t>::pack(gk);
+    return Elem<bf16_t>::pack(gq);
+  }
+};
+
+// second side output of pro_mode 2: the masked gradient, written or accumulated
+__device__ __forceinline__ void row_side2(const hrp_conv_desc& d, const unsigned off, const uint4 gm) {
+  char* q = (char*)d.pro_side2 + off;
+  if (d.pro_side2_acc) {
+    float o[8], g[8];
+    Elem<bf16_t>::unpack(*(const uint4*)q, o);
+    Elem<bf16_t>::unpack(gm, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] += g[i];
+    *(uint4*)q = Elem<bf16_t>::pack(o);
+  } else {
+    *(uint4*)q = gm;
+  }
+}
+
 // ---- shared epilogue pieces ------------------------------------------------------------------------------------------
 // The lane holds, for each of NT tiles, 16 consecutive output channels (cl .. cl + 15) of one pixel; off[t] = byte offset of
 // those 32 bytes inside y (the same offset addresses res and bnb_x: same geometry).  okmask bit t clear: tile t lies outside
 // the tensor (its accumulators are zero: nothing is stored, nothing is read).  Options of hrp_conv_desc: folded-BatchNorm
 // affine, residual (res == y: accumulate), ReLU; statistics of the values as stored - sum / sum of squares, or (bnb) the
 // BatchNorm-backward sums of the stored gradient g masked by [bn(bnb_x) > 0]: s1 += g, s2 += g * bnb_x (finished to
-// sum g * xhat = a * s2 + b * s1 by the caller).  ctab rows 4 / 5 hold the mask's scale / shift (bnb).
-template <int NT>
+// sum g * xhat = a * s2 + b * s1 by the caller).  ctab rows 8 / 9 hold the mask's scale / shift (bnb).
+// The extended options - ReLU masks given as bits (pro_mask, bnb_mask), the second side output, a residual under the epilogue
+// reduce - live in a second instantiation of every body (EXT): the lean one keeps the registers and schedule of the common
+// launches (measured: the options as run-time checks cost the plain block-interior launches 5 - 12 %).
+__device__ __forceinline__ bool row_ext(const hrp_conv_desc& d) {
+  return d.pro_mask != nullptr || d.pro_side2 != nullptr || (d.bnb_x != nullptr && (d.res != nullptr || d.bnb_mask != nullptr));
+}
+
+template <int NT, bool EXT>
 __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
                                              const unsigned okmask, const int cl, const float* ctab, const int C, const bool bnb,
                                              float (&s1)[16], float (&s2)[16]) {
   char* yg = (char*)d.y;
   if (bnb) {
+    // y = gradient of act = relu(bn(bnb_x)) (+ res: the last of several producers accumulates onto the others'), stored
+    // unmasked; the mask: recomputed from bnb_x (interior of a block) or the bit mask hrp_ew_fwd wrote (block outputs)
     const char* bx = (const char*)d.bnb_x;
+    const char* rq = EXT ? (const char*)d.res : nullptr;
     uint4 xr[NT][2];
+    int mb[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       xr[t][0] = xr[t][1] = make_uint4(0, 0, 0, 0);
-      if ((okmask >> t) & 1) { xr[t][0] = *(const uint4*)(bx + off[t]); xr[t][1] = *(const uint4*)(bx + off[t] + 16); }
+      mb[t] = -1;
+      if ((okmask >> t) & 1) {
+        xr[t][0] = *(const uint4*)(bx + off[t]); xr[t][1] = *(const uint4*)(bx + off[t] + 16);
+        if constexpr (EXT) {
+          if (d.bnb_mask) mb[t] = *(const unsigned short*)(d.bnb_mask + (off[t] >> 4));
+        }
+      }
     }
     float sc[16], sh[16];
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
-      const float4 a = *(const float4*)(ctab + 4 * C + cl + i), b = *(const float4*)(ctab + 5 * C + cl + i);
+      const float4 a = *(const float4*)(ctab + 8 * C + cl + i), b = *(const float4*)(ctab + 9 * C + cl + i);
       sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
       sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
     }
@@ -159,13 +249,23 @@ __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x1
         float v[8], xv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i];
+        if constexpr (EXT) {
+          if (rq && ((okmask >> t) & 1)) {
+            float r[8];
+            Elem<bf16_t>::unpack(*(const uint4*)(rq + off[t] + 16 * hh), r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += r[i];
+          }
+        }
         const uint4 pk = Elem<bf16_t>::pack(v);
         if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = pk;
         Elem<bf16_t>::unpack(pk, v);            // the values as stored
         Elem<bf16_t>::unpack(xr[t][hh], xv);
+        const int bits = (!EXT || mb[t] < 0) ? -1 : (mb[t] >> (8 * hh)) & 0xff;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
+          const bool on = (!EXT || bits < 0) ? row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f : ((bits >> i) & 1) != 0;
+          const float g = (EXT ? (on && ((okmask >> t) & 1)) : on) ? v[i] : 0.f;
           s1[8 * hh + i] += g;
           s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
         }
@@ -264,8 +364,8 @@ __device__ __forceinline__ void row_stats_commit(const hrp_conv_desc& d, const f
   atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, tot);
 }
 
-template <int C>
-__device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
+template <int C, bool EXT>
+__device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
   using R = RowCfg<C>;
   constexpr int W = R::W, P = R::P, S = R::S, KS = R::KS, TH = R::TH, ROWB = R::ROWB, NROWS = R::NROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,10 +438,10 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
     *(uint4*)(smem + (k == 0 ? 0 : P + (k - 1) * ROWB + W * P) + j * 16) = make_uint4(0, 0, 0, 0);
   }
 
-  // ---- per-channel constants (LDS table [8][C]):
+  // ---- per-channel constants (LDS table [10][C]):
   //   0 sc, 1 sh        of pro_stats  (prologue 1 / 2: act = fma(x, sc, sh))
   //   2 a = invstd, 3 b = -mean * invstd, 4 k0, 5 k1     (prologue 2)
-  //   4 sc, 5 sh, 6 a, 7 b   of bnb_stats (epilogue reduce) - prologue 2 and the epilogue reduce never meet in one launch
+  //   6 a, 7 b, 8 sc, 9 sh   of bnb_stats (epilogue reduce)
   const bool bnb = d.bnb_x != nullptr;
   if (pro != 0 && tid < C) {
     float mean, inv, sc, sh;
@@ -357,7 +457,8 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
     const int c = tid - 64;
     float mean, inv, sc, sh;
     row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
-    ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+    ctab[8 * C + c] = sc; ctab[9 * C + c] = sh;
+      ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
   }
   HRP_CSTAMP(1);
   if (pro != 0) __syncthreads();                                          // the constant table
@@ -382,14 +483,10 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this lane's DMA pieces of strip s have landed
     // ---- prologue: transform the bytes this lane staged, in place
     if (pro != 0) {
-      const int cb = lslot * 8;                                 // the lane's 8 channels
-      float sc[8], sh[8];
-#pragma unroll
-      for (int i = 0; i < 8; i += 4) {
-        const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
-        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-      }
+      RowPro pc;
+      int cb = lslot * 8;                                       // the lane's 8 channels
+      asm volatile("" : "+v"(cb));                              // (opaque per strip: the constants are re-read from LDS, not kept
+      pc.load(ctab, C, cb);                                     //  in registers across the MFMA loop of a persistent workgroup)
       char* side = (char*)d.pro_side;
       if (pro == 1) {
 #pragma unroll
@@ -397,53 +494,47 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
           const int y = y0 - 1 + rs;
           if (y < 0 || y >= H) continue;
           char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
-          float f[8];
-          Elem<bf16_t>::unpack(*(const uint4*)p, f);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
-          const uint4 o = Elem<bf16_t>::pack(f);
+          const uint4 o = pc.act(*(const uint4*)p);
           *(uint4*)p = o;
           if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
         }
       } else {
-        float a[8], b[8], k0[8], k1[8];
-#pragma unroll
-        for (int i = 0; i < 8; i += 4) {
-          const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
-          const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
-          a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
-          b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
-          k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
-          k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
-        }
-        // second operand: the same bytes of the BatchNorm input, through registers, five rows at a time
+        pc.load2(ctab, C, cb);
+        // second operand: the same bytes of the BatchNorm input (and the mask byte of the vector), through registers,
+        // five rows at a time
         const char* x2g = (const char*)d.pro_x2 + img_off + lane_off;
+        const uint8_t* mg = (EXT && d.pro_mask) ? d.pro_mask + ((img_off + lane_off) >> 4) : nullptr;
 #pragma unroll
         for (int r0 = 0; r0 < NROWS; r0 += 5) {
           uint4 x2[5];
+          int bits[5];
 #pragma unroll
           for (int j = 0; j < 5; ++j) {
             const int y = y0 - 1 + r0 + j;
             x2[j] = make_uint4(0, 0, 0, 0);
-            if (y >= 0 && y < H) x2[j] = *(const uint4*)(x2g + y * (W * P));
+            bits[j] = -1;
+            if (y >= 0 && y < H) {
+              x2[j] = *(const uint4*)(x2g + y * (W * P));
+              if constexpr (EXT) {
+                if (mg) bits[j] = mg[y * (W * P / 16)];
+              }
+            }
           }
 #pragma unroll
           for (int j = 0; j < 5; ++j) {
             const int rs = r0 + j, y = y0 - 1 + rs;
             if (y < 0 || y >= H) continue;
             char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
-            float gq[8], xv[8];
-            Elem<bf16_t>::unpack(*(const uint4*)p, gq);
-            Elem<bf16_t>::unpack(x2[j], xv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float g = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
-              const float xh = fmaf(xv[i], a[i], b[i]);
-              gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
-            }
-            const uint4 o = Elem<bf16_t>::pack(gq);
+            uint4 gm;
+            const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm);
             *(uint4*)p = o;
-            if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
+            if (rs >= 1 && rs <= TH) {
+              const unsigned off = img_off + lane_off + y * (W * P);
+              if (side) *(uint4*)(side + off) = o;
+              if constexpr (EXT) {
+              if (d.pro_side2) row_side2(d, off, gm);
+            }
+            }
           }
         }
       }
@@ -498,10 +589,15 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
     for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
     {
       const unsigned out_off = img_off + (unsigned)((y0 + rg * 4) * W + col * 32 + l31) * P + cl * 2;
-      unsigned off[4];
+      constexpr int EG = EXT ? 2 : 4;          // tiles per epilogue group: bounds the registers of the residual / bnb_x rows
 #pragma unroll
-      for (int o = 0; o < 4; ++o) off[o] = out_off + o * (W * P);
-      row_epilogue<4>(d, acc, off, 0xfu, cl, ctab, C, bnb, s1, s2);
+      for (int o0 = 0; o0 < 4; o0 += EG) {
+        unsigned off[EG];
+#pragma unroll
+        for (int o = 0; o < EG; ++o) off[o] = out_off + (o0 + o) * (W * P);
+        if constexpr (EG == 4) row_epilogue<4, EXT>(d, acc, off, 0xfu, cl, ctab, C, bnb, s1, s2);
+        else row_epilogue<EG, EXT>(d, *(const f32x16(*)[EG])&acc[o0], off, (1u << EG) - 1, cl, ctab, C, bnb, s1, s2);
+      }
     }
     if (d.stats) vtot += row_reduce32(s1, s2, l31);
     if (s == s_begin) HRP_CSTAMP(5);
@@ -527,6 +623,12 @@ __device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowP
   }
   HRP_CSTAMP(6);
   HRP_CSTAMP(7);
+}
+
+template <int C>
+__device__ __forceinline__ void conv_row_body(const hrp_conv_desc& d, const RowPlan& rp, const int bid, const int stat_slot) {
+  if (row_ext(d)) conv_row_body_t<C, true>(d, rp, bid, stat_slot);
+  else conv_row_body_t<C, false>(d, rp, bid, stat_slot);
 }
 
 template <int C>
@@ -560,13 +662,13 @@ struct DeepCfg {
   static constexpr int RPT = 32 / W;        // image rows per 32-pixel tile: 2, 4
   static constexpr int TILE_BYTES = P + NROWS * ROWB;
   static constexpr int CTAB_OFF = (TILE_BYTES + 255) & ~255;
-  static constexpr int LDS_BYTES = CTAB_OFF + 8 * C * 4;
+  static constexpr int LDS_BYTES = CTAB_OFF + 10 * C * 4;
   static_assert(NW * RPT == TH, "the wave's tiles cover the strip");
   __device__ static __forceinline__ int f(int y, int x) { return (y * W + x) & 15; }
 };
 
-template <int C>
-__device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
+template <int C, bool EXT>
+__device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const RowPlan& rp, int bid, const int stat_slot) {
   using R = DeepCfg<C>;
   constexpr int W = R::W, P = R::P, S = R::S, KS = R::KS, TH = R::TH, ROWB = R::ROWB, NROWS = R::NROWS;
   constexpr int MW = R::MW, NW = R::NW, RPT = R::RPT;
@@ -622,7 +724,8 @@ __device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const Row
     for (int c = tid; c < C; c += 256) {
       float mean, inv, sc, sh;
       row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
-      ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+      ctab[8 * C + c] = sc; ctab[9 * C + c] = sh;
+      ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
     }
   }
   HRP_CSTAMP(1);
@@ -635,65 +738,54 @@ __device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const Row
     constexpr int NPAR = C == 256 ? 2 : 1;
 #pragma unroll
     for (int par = 0; par < NPAR; ++par) {
-      const int cb = (pslot ^ R::f(par, xcol)) * 8;      // f depends on y only through its parity (W = 8) or not at all
-      float sc[8], sh[8];
-#pragma unroll
-      for (int i = 0; i < 8; i += 4) {
-        const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
-        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-      }
+      RowPro pc;
+      const int cb = (pslot ^ R::f(par, xcol)) * 8;               // f depends on y only through its parity (W = 8) or not at all
+      pc.load(ctab, C, cb);
       if (pro == 1) {
 #pragma unroll
         for (int rs = 0; rs < NROWS; ++rs) {
           const int y = y0 - 1 + rs;
           if (y < 0 || y >= H || (NPAR == 2 && ((y & 1) != par))) continue;
           char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
-          float f[8];
-          Elem<bf16_t>::unpack(*(const uint4*)p, f);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
-          const uint4 o = Elem<bf16_t>::pack(f);
+          const uint4 o = pc.act(*(const uint4*)p);
           *(uint4*)p = o;
           if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + y * (W * P) + lane_off_of(y)) = o;
         }
       } else {
-        float a[8], b[8], k0[8], k1[8];
-#pragma unroll
-        for (int i = 0; i < 8; i += 4) {
-          const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
-          const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
-          a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
-          b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
-          k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
-          k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
-        }
-        // the BatchNorm inputs of this parity's rows: same lane-constant addressing, through registers
+        pc.load2(ctab, C, cb);
+        // the BatchNorm inputs (and mask bytes) of this parity's rows: same lane-constant addressing, through registers
         const char* x2g = (const char*)d.pro_x2 + img_off;
         uint4 x2[NROWS];
+        int bits[NROWS];
 #pragma unroll
         for (int rs = 0; rs < NROWS; ++rs) {
           const int y = y0 - 1 + rs;
           x2[rs] = make_uint4(0, 0, 0, 0);
-          if (y >= 0 && y < H && !(NPAR == 2 && ((y & 1) != par))) x2[rs] = *(const uint4*)(x2g + y * (W * P) + lane_off_of(y));
+          bits[rs] = -1;
+          if (y >= 0 && y < H && !(NPAR == 2 && ((y & 1) != par))) {
+            const unsigned off = img_off + y * (W * P) + lane_off_of(y);
+            x2[rs] = *(const uint4*)((const char*)d.pro_x2 + off);
+            if constexpr (EXT) {
+              if (d.pro_mask) bits[rs] = d.pro_mask[off >> 4];
+            }
+          }
         }
+        (void)x2g;
 #pragma unroll
         for (int rs = 0; rs < NROWS; ++rs) {
           const int y = y0 - 1 + rs;
           if (y < 0 || y >= H || (NPAR == 2 && ((y & 1) != par))) continue;
           char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
-          float gq[8], xv[8];
-          Elem<bf16_t>::unpack(*(const uint4*)p, gq);
-          Elem<bf16_t>::unpack(x2[rs], xv);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float g = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
-            const float xh = fmaf(xv[i], a[i], b[i]);
-            gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
-          }
-          const uint4 o = Elem<bf16_t>::pack(gq);
+          uint4 gm;
+          const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[rs], bits[rs], gm);
           *(uint4*)p = o;
-          if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + y * (W * P) + lane_off_of(y)) = o;
+          if (rs >= 1 && rs <= TH) {
+            const unsigned off = img_off + y * (W * P) + lane_off_of(y);
+            if (side) *(uint4*)(side + off) = o;
+            if constexpr (EXT) {
+              if (d.pro_side2) row_side2(d, off, gm);
+            }
+          }
         }
       }
     }
@@ -786,11 +878,17 @@ __device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const Row
     float s1[16], s2[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-    row_epilogue<NW>(d, acc[mi], off, (1u << NW) - 1, cl, ctab, C, bnb, s1, s2);
+    row_epilogue<NW, EXT>(d, acc[mi], off, (1u << NW) - 1, cl, ctab, C, bnb, s1, s2);
     if (d.stats) row_stats_commit(d, row_reduce32(s1, s2, l31), l31, cl, ctab, C, bnb, stat_slot);
   }
   HRP_CSTAMP(6);
   HRP_CSTAMP(7);
+}
+
+template <int C>
+__device__ __forceinline__ void conv_deep_body(const hrp_conv_desc& d, const RowPlan& rp, const int bid, const int stat_slot) {
+  if (row_ext(d)) conv_deep_body_t<C, true>(d, rp, bid, stat_slot);
+  else conv_deep_body_t<C, false>(d, rp, bid, stat_slot);
 }
 
 template <int C>
@@ -824,12 +922,12 @@ struct ImgCfg {
   static constexpr int NCB = C / 128;             // blocks of 128 output channels (4 waves x 32)
   static constexpr int TILE_BYTES = NT * T;       // 67 584
   static constexpr int CTAB_OFF = TILE_BYTES;
-  static constexpr int LDS_BYTES = CTAB_OFF + 8 * C * 4;
+  static constexpr int LDS_BYTES = CTAB_OFF + 10 * C * 4;
   static_assert(TILE_BYTES % 256 == 0 && NT * PPT == 64, "64 pieces of 1 KiB");
 };
 
-template <int C>
-__device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowPlan& rp, const int bid, const int stat_slot) {
+template <int C, bool EXT>
+__device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const RowPlan& rp, const int bid, const int stat_slot) {
   using R = ImgCfg<C>;
   constexpr int W = R::W, P = R::P, S = R::S, KS = R::KS, NT = R::NT, TPI = R::TPI, T = R::T, PPT = R::PPT, PXP = R::PXP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -884,7 +982,8 @@ __device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowP
     for (int c = tid; c < C; c += 256) {
       float mean, inv, sc, sh;
       row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
-      ctab[4 * C + c] = sc; ctab[5 * C + c] = sh; ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+      ctab[8 * C + c] = sc; ctab[9 * C + c] = sh;
+      ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
     }
   }
   HRP_CSTAMP(1);
@@ -899,64 +998,49 @@ __device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowP
     for (int hsel = 0; hsel < 2; ++hsel) {
       // C = 128: pieces i = 8 hsel .. 8 hsel + 7; C = 256: pieces of parity hsel (i = hsel, hsel + 2, ...)
       auto piece_i = [&](int j) { return C == 256 ? 2 * j + hsel : 8 * hsel + j; };
+      RowPro pc;
       const int cb = lslot_of(piece_i(0)) * 8;
-      float sc[8], sh[8];
-#pragma unroll
-      for (int i = 0; i < 8; i += 4) {
-        const float4 a = *(const float4*)(ctab + cb + i), b = *(const float4*)(ctab + C + cb + i);
-        sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
-        sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
-      }
+      pc.load(ctab, C, cb);
       if (pro == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int i = piece_i(j), q = wave + 4 * i, tq = q / PPT;
           if (tq >= nvalid * TPI) continue;
           char* p = smem + tq * T + (q % PPT) * 1024 + lane * 16;
-          float f[8];
-          Elem<bf16_t>::unpack(*(const uint4*)p, f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = fmaxf(row_bn_act(f[e], sc[e], sh[e]), 0.f);
-          const uint4 o = Elem<bf16_t>::pack(f);
+          const uint4 o = pc.act(*(const uint4*)p);
           *(uint4*)p = o;
           if (side) *(uint4*)(side + grp_off + piece_off(i)) = o;
         }
       } else {
-        float a[8], b[8], k0[8], k1[8];
-#pragma unroll
-        for (int i = 0; i < 8; i += 4) {
-          const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
-          const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
-          a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
-          b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
-          k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
-          k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
-        }
-        const char* x2g = (const char*)d.pro_x2 + grp_off;
+        pc.load2(ctab, C, cb);
         uint4 x2[8];
+        int bits[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int i = piece_i(j), q = wave + 4 * i;
           x2[j] = make_uint4(0, 0, 0, 0);
-          if (q / PPT < nvalid * TPI) x2[j] = *(const uint4*)(x2g + piece_off(i));
+          bits[j] = -1;
+          if (q / PPT < nvalid * TPI) {
+            const unsigned off = grp_off + piece_off(i);
+            x2[j] = *(const uint4*)((const char*)d.pro_x2 + off);
+            if constexpr (EXT) {
+              if (d.pro_mask) bits[j] = d.pro_mask[off >> 4];
+            }
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int i = piece_i(j), q = wave + 4 * i, tq = q / PPT;
           if (tq >= nvalid * TPI) continue;
           char* p = smem + tq * T + (q % PPT) * 1024 + lane * 16;
-          float gq[8], xv[8];
-          Elem<bf16_t>::unpack(*(const uint4*)p, gq);
-          Elem<bf16_t>::unpack(x2[j], xv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float g = row_bn_act(xv[e], sc[e], sh[e]) > 0.f ? gq[e] : 0.f;
-            const float xh = fmaf(xv[e], a[e], b[e]);
-            gq[e] = sc[e] * (g - k0[e] - xh * k1[e]);
-          }
-          const uint4 o = Elem<bf16_t>::pack(gq);
+          uint4 gm;
+          const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm);
           *(uint4*)p = o;
-          if (side) *(uint4*)(side + grp_off + piece_off(i)) = o;
+          const unsigned off = grp_off + piece_off(i);
+          if (side) *(uint4*)(side + off) = o;
+          if constexpr (EXT) {
+              if (d.pro_side2) row_side2(d, off, gm);
+            }
         }
       }
     }
@@ -1002,7 +1086,10 @@ __device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowP
     for (int tap = 0; tap < 9; ++tap) Bm[tap] = bconst(tap / 3, tap % 3, true);
 #pragma unroll
     for (int dxi = 0; dxi < 3; ++dxi) { Bt[dxi] = bconst(0, dxi, r > 0); Bb[dxi] = bconst(2, dxi, r < RPT - 1); }
-    constexpr int CH = 9 * NT, RING = 6, AHEAD = RING - 1;
+#ifndef HRP_IMG_RING
+#define HRP_IMG_RING 6
+#endif
+    constexpr int CH = 9 * NT, RING = HRP_IMG_RING, AHEAD = RING - 1;
     static_assert(CH % RING == 0 && KS % 2 == 0, "ring positions repeat per chunk; chunks are processed in pairs");
     bf16x8 bq[RING];
     auto rd = [&](int kkoff, int q) -> bf16x8 {      // q = tap * NT + t
@@ -1056,12 +1143,18 @@ __device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowP
       unsigned off[EG];
 #pragma unroll
       for (int t = 0; t < EG; ++t) off[t] = pix0 + (unsigned)(t0 + t) * (32 * P);
-      row_epilogue<EG>(d, *(const f32x16(*)[EG])&acc[t0], off, (okmask >> t0) & ((1u << EG) - 1), cl, ctab, C, bnb, s1, s2);
+      row_epilogue<EG, EXT>(d, *(const f32x16(*)[EG])&acc[t0], off, (okmask >> t0) & ((1u << EG) - 1), cl, ctab, C, bnb, s1, s2);
     }
     if (d.stats) row_stats_commit(d, row_reduce32(s1, s2, l31), l31, cl, ctab, C, bnb, stat_slot);
   }
   HRP_CSTAMP(6);
   HRP_CSTAMP(7);
+}
+
+template <int C>
+__device__ __forceinline__ void conv_img_body(const hrp_conv_desc& d, const RowPlan& rp, const int bid, const int stat_slot) {
+  if (row_ext(d)) conv_img_body_t<C, true>(d, rp, bid, stat_slot);
+  else conv_img_body_t<C, false>(d, rp, bid, stat_slot);
 }
 
 template <int C>

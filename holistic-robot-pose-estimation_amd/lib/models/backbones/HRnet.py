@@ -89,9 +89,9 @@ class BasicBlock(SingleTensorModule):
     def emit(self, pb, x):
         if self.downsample is None and self.stride == 1:
             # train-mode branch blocks of the row-strip shapes: BatchNorm + ReLU of the interior inside the convolutions
-            y2 = pb.conv_bn_relu_conv(x, self.conv1.weight, self.bn1, self.conv2.weight)
-            if y2 is not None:
-                return pb.act([Term(y2, self.bn2), Term(x)], relu=True)
+            out = pb.conv_bn_relu_conv(x, self.conv1.weight, self.bn1, self.conv2.weight, self.bn2)
+            if out is not None:
+                return out
         h = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
         skip = Term(x) if self.downsample is None else conv_bn(pb, x, self.downsample[0], self.downsample[1])
         return pb.act([conv_bn(pb, h, self.conv2, self.bn2), skip], relu=True)

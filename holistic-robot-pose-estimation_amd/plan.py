@@ -79,6 +79,7 @@ class TensorH:
         self.grad_buf()
         root = self.base if self.base is not None else self
         root.grad_written = True     # (a column slice's gradient lives in its root's buffer: the root's producer must run)
+        self.plan.grad_owner[self.gptr()] = root      # who writes this gradient, for Plan._fuse_bn_reduce
         here = self.plan.lane_path
         if any(lanes_concurrent(here, q) for q in root._grad_paths):
             raise RuntimeError("plan: a gradient is accumulated from two concurrent lanes")
@@ -146,12 +147,16 @@ WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "8"))
 # train-mode BasicBlock interiors conv -> BN -> ReLU -> conv on the row-strip kernel (csrc/conv_row.h): the BatchNorm + ReLU
 # runs in the second convolution's staging path, its backward in the staging path of the first convolution's data gradient
 ROWCONV_FUSE = not os.environ.get("HRP_NO_ROWCONV_FUSE")
+# ... and the block-end activation's backward (apply pass into conv2's data gradient, reduce pass into the next block's)
+BLOCK_END_FUSE = not os.environ.get("HRP_NO_BLOCK_END_FUSE")
+BLOCK_END_REDUCE_FUSE = not os.environ.get("HRP_NO_BLOCK_END_REDUCE_FUSE")
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
 # development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
 BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
 
 # bumped whenever parameters / BatchNorm buffers are modified behind torch's back (see Plan.params_dirty)
 PARAM_EPOCH = 0
+_PLAN_SERIAL = 0      # plans of this process that drew a dropout key (Plan.rng_state)
 
 
 def bump_param_epoch():
@@ -225,7 +230,7 @@ class Launch:
         d = self.desc
         if self.fam == "conv":
             main = d.y + ((d.out_off_y * d.y_W + d.out_off_x) * d.y_pitch if d.out_stride > 1 else 0)
-            return (main, d.pro_side) if d.pro_side else (main,)
+            return tuple(a for a in (main, d.pro_side, d.pro_side2) if a)
         if self.fam in ("wgrad", "wgrad_fold"):
             return (d.dw + 4 * d.dw_tap_off,)
         if self.fam == "ew_fwd":
@@ -397,6 +402,8 @@ class Plan:
         self._block_lanes = {}     # parallel block id -> stream of each lane (None: virtual block)
         self._rng, self.n_dropout = None, 0
         self.linear_grad_written = set()
+        self.grad_owner = {}       # gradient buffer address -> TensorH root (every producer registers through take_grad_slot)
+        self.row_last_writer = {}  # gradient buffer address -> (row-strip conv descriptor that completes it, lane path)
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -444,7 +451,13 @@ class Plan:
     def rng_state(self):
         """Device-side (seed, step) of the plan's dropout masks; the seed comes from torch's generator at build time."""
         if self._rng is None:
-            seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            # torch's seed, decorrelated per data-parallel rank (ranks launched with one manual_seed must not draw the same
+            # masks for different data) and per training plan of the process (a second plan - another batch shape, a plan
+            # re-created after a cache eviction - must not replay the first one's mask sequence)
+            global _PLAN_SERIAL
+            _PLAN_SERIAL += 1
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+            seed = (int(torch.initial_seed()) ^ (rank << 48) ^ (_PLAN_SERIAL << 32)) & 0x7FFFFFFFFFFFFFFF
             self._rng = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
             self.keep.append(self._rng)
         return self._rng
@@ -691,6 +704,12 @@ class Plan:
             fw = fwd_by_mask.get(b.mask)
             if len(cands) != 1 or fw is None or fw.desc.nin != 1:
                 continue
+            # every producer of a gradient registers through take_grad_slot - also the ones that are plain closures in the
+            # launch list (copy_cols, pooling, linear layers, soft-argmax ..), which the scan above cannot see: exactly ONE
+            # producer (the candidate conv) or the epilogue would reduce a partial gradient
+            owner = self.grad_owner.get(b.dout)
+            if owner is None or len(owner._grad_paths) != 1:
+                continue
             j, ce = cands[0]
             d = ce.op.desc
             esz = 4 if d.dtype == nv.HRP_F32 else 2
@@ -771,10 +790,20 @@ class Plan:
         def flush(lane, path, everything=True):
             descs = pending.pop(lane, [])
             while descs and (everything or len(descs) >= nv.BATCH_MAX):
-                b = BatchLaunch(self, [Launch("wgrad_fold", f) for f in descs[:nv.BATCH_MAX]])
+                # one launch folds problems with pairwise DISTINCT outputs only (the fold is a plain read-modify-write of dW:
+                # a weight applied twice - or a tap group launched twice - must fold in consecutive launches, not race in one)
+                grp, rest, seen = [], [], set()
+                for f in descs:
+                    key = f.dw + 4 * f.dw_tap_off
+                    if len(grp) < nv.BATCH_MAX and key not in seen:
+                        grp.append(f)
+                        seen.add(key)
+                    else:
+                        rest.append(f)
+                b = BatchLaunch(self, [Launch("wgrad_fold", f) for f in grp])
                 b.prepare()
                 out.append(Entry(lane, path, b))
-                descs = descs[nv.BATCH_MAX:]
+                descs = rest
             if descs:
                 pending[lane] = descs
 
@@ -785,8 +814,8 @@ class Plan:
             out.append(e)
             if e.lane is not None and isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1:
                 pending.setdefault(e.lane, []).extend(f for f in e.op.fold_descs() if f.G > 0)
-                if len(pending[e.lane]) >= max(WGRAD_FOLD_EVERY, nv.BATCH_MAX):
-                    flush(e.lane, e.path, everything=False)
+                if len(pending[e.lane]) >= min(max(WGRAD_FOLD_EVERY, 1), nv.BATCH_MAX):
+                    flush(e.lane, e.path, everything=WGRAD_FOLD_EVERY < nv.BATCH_MAX)
         for lane in sorted(pending):
             flush(lane, ())
         return out
@@ -1420,14 +1449,20 @@ class PlanBuilder:
         p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
         p.bwd.append(Launch("wgrad", g))
 
-    def conv_bn_relu_conv(self, x, conv1_w, bn1, conv2_w):
+    def conv_bn_relu_conv(self, x, conv1_w, bn1, conv2_w, bn2=None):
         """y2 = conv2(relu(bn1(conv1(x)))), the interior of a BasicBlock (reference HRnet.py:41-50), in a TRAINING plan on the
         row-strip kernel: conv1 as usual (statistics in its epilogue), conv2 with the BatchNorm + ReLU applied while its
         input rows are staged (the activation leaves as a side output, the operand of conv2's weight gradient) - no
         hrp_ew_fwd pass.  Backward: conv2's data gradient accumulates the BatchNorm-backward sums in its epilogue, conv1's
         data gradient applies the BatchNorm + ReLU backward while IT stages (side output: the gradient of conv1's output,
         the operand of conv1's weight gradient) - no hrp_ew_bwd_reduce / hrp_ew_bwd_apply passes.
-        -> y2 (raw, with statistics), or None when the shapes / mode are not the row-strip kernel's (caller: general path)."""
+        bn2 given: the whole BasicBlock, out = relu(bn2(y2) + x) (HRnet.py:52-56).  The block-end activation keeps its forward
+        pass (hrp_ew_fwd, with the ReLU bit mask); its BACKWARD apply pass moves into conv2's data gradient (pro_mode 2 with the
+        bit mask: side output = y2.grad for conv2's weight gradient, second side output = the masked gradient for the
+        residual), and its reduce pass into the epilogue of the NEXT block's conv1 data gradient when that launch is the
+        last producer of out.grad (the blocks of a branch stack) - no hrp_ew_bwd_apply and mostly no hrp_ew_bwd_reduce.
+        -> y2 (raw, with statistics) or, with bn2, out; None when the shapes / mode are not the row-strip kernel's (caller:
+        general path)."""
         p = self.plan
         if not (ROWCONV_FUSE and p.training and x.dtype == torch.bfloat16):
             return None
@@ -1469,11 +1504,23 @@ class PlanBuilder:
         p.fwd.append(Launch("conv", d2))
         y1.producer, y2.producer = None, ("conv", d2)
         p.counters["rowconv_fused_blocks"] = p.counters.get("rowconv_fused_blocks", 0) + 1
+        out, fd = None, None
+        if bn2 is not None:
+            out = self.act([Term(y2, bn2), Term(x)], relu=True)
+            fd = out.ew_desc
+            act_bw = list.pop(self.bwd_stack) if p.need_grad else None      # the activation's own backward
+            if not (p.need_grad and fd.mask and BLOCK_END_FUSE):
+                fd = None                         # ... stays (hrp_ew_bwd_reduce + hrp_ew_bwd_apply), re-pushed behind bw below
         if p.need_grad:
             def bw():
-                if not y2.grad_written:
+                if fd is not None:
+                    if not out.grad_written:
+                        return
+                    y2.take_grad_slot()
+                elif not y2.grad_written:
                     return
-                if conv2_w.requires_grad:
+                wg2_first = fd is None and not os.environ.get("HRP_WG2_LATE")
+                if wg2_first and conv2_w.requires_grad:
                     self._wgrad_launch(h, w2, y2)
                 # data gradient of conv2 -> gradient of the activation h (raw), BatchNorm-backward sums in the epilogue
                 h.take_grad_slot()
@@ -1481,6 +1528,36 @@ class PlanBuilder:
                 p.bn_bwd.append((bn1, boff))
                 g2 = self._conv_desc(y2, w2, h, 1, 3, dtype)
                 g2.x, g2.y = y2.gptr(), h.gptr()
+                red = None
+                if fd is not None:
+                    # the block-end BatchNorm + ReLU backward (bn2, mask bits): staged operand of this launch
+                    boff2 = p.alloc_bsums(Cc)
+                    p.bn_bwd.append((bn2, boff2))
+                    acc2 = x.take_grad_slot()
+                    g2.x = out.gptr()
+                    g2.pro_mode, g2.pro_x2, g2.pro_gamma, g2.pro_beta = 2, y2.ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
+                    g2.pro_count, g2.pro_eps, g2.pro_mask = cnt, bn2.eps, fd.mask
+                    g2.pro_side, g2.pro_side2, g2.pro_side2_acc = y2.gptr(), x.gptr(), acc2
+                    # its reduce: in the epilogue of the launch that completes out.grad when that is a row-strip data gradient
+                    # of this lane accumulating onto ONE earlier producer (the next block of the stack), else a pass of its own
+                    nxt = p.row_last_writer.get(out.gptr())
+                    if (BLOCK_END_REDUCE_FUSE and nxt is not None and not nxt[0].bnb_x and nxt[2] == len(out._grad_paths)
+                            and all(q == p.lane_path for q in out._grad_paths)):
+                        gn = nxt[0]
+                        gn.bnb_x, gn.bnb_x_pitch, gn.bnb_mask, gn.bnb_mask_pitch = y2.ptr(), y2.pitch, fd.mask, fd.mask_pitch
+                        gn.bnb_gamma, gn.bnb_beta, gn.bnb_count, gn.bnb_eps = bn2.weight.data_ptr(), bn2.bias.data_ptr(), cnt, bn2.eps
+                        red = gn
+                        p.counters["block_end_reduce_fused"] = p.counters.get("block_end_reduce_fused", 0) + 1
+                    else:
+                        b = nv.EwBwdDesc()
+                        b.dout, b.out, b.dout_pitch, b.out_pitch = out.gptr(), out.ptr(), out.pitch, out.pitch
+                        for f, _ in nv.EwInput._fields_:
+                            setattr(b.inp, f, getattr(fd.inp[0], f))
+                        b.dtype, b.N, b.H, b.W, b.C, b.relu = fd.dtype, fd.N, fd.H, fd.W, fd.C, fd.relu
+                        b.mask, b.mask_pitch = fd.mask, fd.mask_pitch
+                        red = b
+                        p.bwd.append(Launch("ew_red", b))
+                    p.counters["block_end_apply_fused"] = p.counters.get("block_end_apply_fused", 0) + 1
                 for i, (a, b) in enumerate(_TAPS3):
                     g2.dy[i], g2.dx[i], g2.wtap[i] = -a, -b, i
                 g2.bnb_x, g2.bnb_x_pitch = y1.ptr(), y1.pitch
@@ -1502,13 +1579,26 @@ class PlanBuilder:
                     g2.stats = p.bsums.data_ptr() + 4 * boff
                     g2.bnb_stats = g1.pro_stats = p.stats.data_ptr() + 4 * y1.stats
                     g1.pro_bsums = g2.stats
+                    if fd is not None:
+                        sums2 = p.bsums.data_ptr() + 4 * boff2
+                        g2.pro_stats, g2.pro_bsums = p.stats.data_ptr() + 4 * y2.stats, sums2
+                        if isinstance(red, nv.ConvDesc):
+                            red.stats, red.bnb_stats = sums2, g2.pro_stats
+                        else:
+                            red.sums, red.inp.stats = sums2, fd.inp[0].stats
                 p.late(late_b)
                 p.bwd.append(Launch("conv", g2))
+                if conv2_w.requires_grad and not wg2_first:
+                    self._wgrad_launch(h, w2, y2)
                 p.bwd.append(Launch("conv", g1))
+                if acc:   # the last producer of x.grad: the block in front of this one may put its BatchNorm reduce here
+                    p.row_last_writer[x.gptr()] = (g1, p.lane_path, len((x.base if x.base is not None else x)._grad_paths))
                 if conv1_w.requires_grad:
                     self._wgrad_launch(x, w1, y1)
             self.bwd_stack.append(bw)
-        return y2
+            if bn2 is not None and fd is None:
+                list.append(self.bwd_stack, act_bw)
+        return out if bn2 is not None else y2
 
     def linear(self, x, weight, bias=None, residual=None):
         """y = x W^T + b (+ residual) on fp32 [N, C] tensors: nn.Linear of the regression heads as a skinny GEMM that reads
@@ -1701,6 +1791,7 @@ class PlanBuilder:
             p.keep.append(mask)
             d.mask, d.mask_pitch = mask.data_ptr(), Cc // vec
         p.fwd.append(Launch("ew_fwd", d))
+        out.ew_desc = d
         if p.need_grad:
             self.bwd_stack.append(lambda: self._act_bwd(terms, out, relu, d))
         return out

@@ -105,9 +105,11 @@ typedef struct hrp_conv_desc {
   /* ---- fields below: row-strip kernels only (hrp_conv_rowstrip_channels(d) != 0: the 3x3 stride-1 C -> C layers of the
    * HRNet branches, bf16, dense NHWC rows of 4 KiB: C = 32 @ W = 64, C = 64 @ W = 32).  Any other problem that sets them
    * is HRP_ERR_ARG: callers ask hrp_conv_rowstrip_channels first.
-   * bnb_x with bnb_mask == NULL: the ReLU mask of the epilogue reduce is recomputed from bnb_x itself,
-   * mask = (bn(bnb_x) > 0), BatchNorm constants derived in the kernel from bnb_stats (the forward sum / sum-of-squares
-   * slots of bnb_x), bnb_gamma, bnb_beta, bnb_count, bnb_eps - the arithmetic the forward prologue (pro_mode 1) applied. */
+   * bnb_x with bnb_stats set: the BatchNorm constants of the epilogue reduce are derived in the kernel from bnb_stats (the forward
+   * sum / sum-of-squares slots of bnb_x), bnb_gamma, bnb_beta, bnb_count, bnb_eps; with bnb_mask == NULL the ReLU mask is
+   * recomputed from bnb_x itself, mask = (bn(bnb_x) > 0) - the arithmetic the forward prologue (pro_mode 1) applied -, else
+   * the bit mask is read ([pixels][C / 8] bytes).  `res` (== y: accumulate onto the other producers of the gradient) is
+   * allowed here: the sums are taken over the final stored value. */
   const float* bnb_stats;
   const float* bnb_gamma;
   const float* bnb_beta;
@@ -129,6 +131,13 @@ typedef struct hrp_conv_desc {
   const float* pro_beta;
   float pro_count, pro_eps;
   void* pro_side;
+  /* pro_mode 2 only: pro_mask (optional) = the ReLU bit mask hrp_ew_fwd wrote for the activation ([pixels][C / 8] bytes, bit i =
+   * channel i of the 16-byte vector was > 0) instead of recomputing the mask from pro_x2 - the activation then may have had
+   * further summands (the residual of a block output, HRnet.py:52-56); pro_side2 (optional, geometry of x) = the masked gradient
+   * g itself, i.e. the gradient of an identity (residual) summand of that activation, written (pro_side2_acc 0) or accumulated. */
+  const uint8_t* pro_mask;
+  void* pro_side2;
+  int32_t pro_side2_acc, pro_reserved2;
 } hrp_conv_desc;
 
 /* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],

@@ -493,6 +493,11 @@ def test_plan_folds_bn_backward_reduce_into_the_data_gradient():
     for op in (P.Launch("ew_app", other), P.Launch("conv", c1), P.Launch("ew_red", r1), P.Launch("ew_app", r1),
                P.Launch("conv", c2), P.Launch("ew_red", r2), P.Launch("ew_app", r2)):
         list.append(pl.bwd, P.Entry(0, (), op))
+    # every gradient producer registers through TensorH.take_grad_slot: activation 1 has one producer (the conv), activation 2
+    # two (the conv and the residual rider of an ew_app launch)
+    import types
+    pl.grad_owner[0x1300000] = types.SimpleNamespace(_grad_paths=[()])
+    pl.grad_owner[0x2300000] = types.SimpleNamespace(_grad_paths=[(), ()])
     pl._fuse_bn_reduce()
     fams = [e.op.fam for e in pl.bwd]
     assert fams == ["ew_app", "conv", "ew_app", "conv", "ew_red", "ew_app"] and pl.counters["bn_reduce_fused"] == 1

@@ -20,6 +20,7 @@ from hrpe_amd import _native as nv  # noqa: E402
 
 DEV = bk.DEV
 CLASSES = [(32, 64), (64, 32), (128, 16), (256, 8)]
+KIND = "plain"
 
 
 def mk_conv(N, hw, c, dtype, stats=True, k=3):
@@ -43,7 +44,38 @@ def mk_conv(N, hw, c, dtype, stats=True, k=3):
     d.w_cout_pad = bk.rup(c, 32)
     if stats:
         d.stats = st.data_ptr()
-    return d, (x, wp, y, st)
+    bufs = [x, wp, y, st]
+    kind = KIND
+    if kind != "plain" and k == 3:
+        # the launch kinds of a fused BasicBlock (plan.conv_bn_relu_conv): "pro1" conv2 forward, "g2" conv2 data gradient
+        # (epilogue reduce), "g1" conv1 data gradient (apply prologue + residual), "g2e" / "g1e" with the block-end backward
+        n = N * hw * hw * c
+        t = lambda: torch.randn(n, device=DEV).to(dtype)     # noqa: E731
+        sts = torch.rand(16 * c, device=DEV) * 100 + 50
+        sts[8 * c:] += 1e5
+        gam, bet = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+        bs = torch.zeros(16 * c, device=DEV)
+        x2, side, side2, x3 = t(), t(), t(), t()
+        mask = torch.randint(0, 255, (n // 8,), dtype=torch.uint8, device=DEV)
+        bufs += [sts, gam, bet, bs, x2, side, side2, x3, mask]
+        cnt = float(N * hw * hw)
+        if kind == "pro1":
+            d.pro_mode, d.pro_stats, d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps = 1, sts.data_ptr(), gam.data_ptr(), bet.data_ptr(), cnt, 1e-5
+            d.pro_side = side.data_ptr()
+        if kind in ("g2", "g2e"):
+            d.stats, d.bnb_x, d.bnb_x_pitch = bs.data_ptr(), x2.data_ptr(), c
+            d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps = sts.data_ptr(), gam.data_ptr(), bet.data_ptr(), cnt, 1e-5
+        if kind in ("g1", "g1e", "g2e"):
+            d.pro_mode, d.pro_stats, d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps = 2, sts.data_ptr(), gam.data_ptr(), bet.data_ptr(), cnt, 1e-5
+            d.pro_x2, d.pro_bsums, d.pro_side = x3.data_ptr(), bs.data_ptr(), side.data_ptr()
+        if kind in ("g1", "g1e"):
+            d.res, d.stats = y.data_ptr(), 0
+        if kind == "g1e":
+            d.stats, d.bnb_x, d.bnb_x_pitch, d.bnb_mask, d.bnb_mask_pitch = bs.data_ptr(), x2.data_ptr(), c, mask.data_ptr(), c // 8
+            d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps = sts.data_ptr(), gam.data_ptr(), bet.data_ptr(), cnt, 1e-5
+        if kind == "g2e":
+            d.pro_mask, d.pro_side2 = mask.data_ptr(), side2.data_ptr()
+    return d, tuple(bufs)
 
 
 class Batch:
@@ -146,7 +178,9 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--nets", type=int, default=2)
     ap.add_argument("--branches", type=int, default=4)
+    ap.add_argument("--kind", default="plain", choices=["plain", "pro1", "g2", "g1", "g2e", "g1e"])
     a = ap.parse_args()
+    KIND = a.kind
     dt = torch.bfloat16
     if a.what in ("conv", "all"):
         conv_batch(a.batch, a.nets, a.branches, dt)

@@ -152,6 +152,7 @@ PROTOTYPES = {
     "hrp_maxpool3x3s2_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hrp_conv2d_fwd": [C.POINTER(ConvDesc), _P],
     "hrp_conv_rowstrip_channels": [C.POINTER(ConvDesc)],
+    "hrp_conv_pointwise": [C.POINTER(ConvDesc)],
     "hrp_conv2d_bwd_weight": [C.POINTER(WgradDesc), _P],
     "hrp_colsum": [_P, _I, _L, _I, _I, _P, _I, _P],
     "hrp_ew_fwd": [C.POINTER(EwDesc), _P],

@@ -147,6 +147,9 @@ static int conv_batch_prepare_t(const hrp_conv_desc* descs, int n, void* table, 
     const int rc = conv_check(&descs[i]);
     if (rc != HRP_OK) return rc;
     HRP_REQUIRE(descs[i].ntaps == descs[0].ntaps && descs[i].dtype == descs[0].dtype, "conv batch: mixed tap counts / element types");
+    // a pointwise problem runs the tile program inside a batch: only the forms that program knows
+    HRP_REQUIRE(descs[i].ntaps != 1 || !descs[i].bnb_x || (descs[i].bnb_mask && descs[i].bnb_consts && !descs[i].res),
+                "conv batch: a 1x1 problem with a mask-less / residual epilogue reduce must be launched on its own (hrp_conv_pointwise)");
     // skinny fp32 linear layers take the split-K path of the single launcher (memset + atomics): not batched
     HRP_REQUIRE(!(descs[i].dtype == HRP_F32 && descs[i].H == 1 && descs[i].W == 1 && descs[i].Cin >= 512),
                 "conv batch: linear layers are launched one by one");

@@ -2,6 +2,7 @@
 // (The fp32 kernels live in conv_fwd_f32.hip, the batched kernels in conv_batch_{bf16,f32}.hip: four translation
 // units, for build time only.)
 #include "conv_row.h"
+#include "conv_pw.h"
 
 namespace hrp {
 
@@ -19,7 +20,9 @@ int conv_check(const hrp_conv_desc* d) {
   HRP_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "conv: empty problem");
   HRP_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides");
   HRP_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "conv: scale and shift go together");
-  if (d->bnb_x && d->bnb_mask && !hrp_conv_rowstrip_channels(d)) {   // BatchNorm-backward reduce in the epilogue of the general tile program: only the plain vector store path computes it
+  PwPlan pwp;
+  const bool lean_kernel = hrp_conv_rowstrip_channels(d) != 0 || pw_plan(*d, pwp) != 0;      // (their own eligibility checks cover bnb_*)
+  if (d->bnb_x && d->bnb_mask && !lean_kernel) {   // BatchNorm-backward reduce in the epilogue of the general tile program: only the plain vector store path computes it
     const int sz = d->dtype == HRP_F32 ? 4 : 2;
     HRP_REQUIRE(d->stats && d->bnb_mask && d->bnb_consts, "conv: bnb_x needs stats, bnb_mask and bnb_consts");
     HRP_REQUIRE(!d->res && !d->relu && !d->bias && !d->scale, "conv: bnb_x excludes res / relu / bias / scale");
@@ -29,8 +32,10 @@ int conv_check(const hrp_conv_desc* d) {
                 ((size_t)d->bnb_x_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_consts % 16 == 0, "conv: bnb_x alignment");
   }
   // input transforms / the mask-less epilogue reduce exist in the row-strip kernel only (conv_row.h)
-  if (d->pro_mode != 0 || d->pro_side || d->pro_side2 || d->pro_mask || (d->bnb_x && (!d->bnb_mask || d->res)))
-    HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / mask-less bnb_x need a row-strip problem (hrp_conv_rowstrip_channels)");
+  if (d->pro_mode != 0 || d->pro_side || d->pro_side2 || d->pro_mask)
+    HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / pro_mask need a row-strip problem (hrp_conv_rowstrip_channels)");
+  if (d->bnb_x && (!d->bnb_mask || d->res))
+    HRP_REQUIRE(lean_kernel, "conv: a mask-less bnb_x / bnb_x with res needs a row-strip or pointwise problem (hrp_conv_rowstrip_channels, hrp_conv_pointwise)");
   return HRP_OK;
 }
 
@@ -41,12 +46,19 @@ extern "C" int hrp_conv_rowstrip_channels(const hrp_conv_desc* d) {
   return (d && !off) ? hrp::row_channels(*d) : 0;
 }
 
+extern "C" int hrp_conv_pointwise(const hrp_conv_desc* d) {
+  hrp::PwPlan pw;
+  return d ? hrp::pw_plan(*d, pw) : 0;
+}
+
 extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   using namespace hrp;
   const int rc = conv_check(d);
   if (rc != HRP_OK) return rc;
   if (d->dtype == HRP_F32) return launch_conv_f32(*d, (hipStream_t)stream);
   if (hrp_conv_rowstrip_channels(d)) return launch_conv_row(*d, (hipStream_t)stream);
+  PwPlan pw;
+  if (pw_plan(*d, pw)) return launch_conv_pw(*d, pw, (hipStream_t)stream);
   return launch_conv<bf16_t>(*d, (hipStream_t)stream);
 }
 

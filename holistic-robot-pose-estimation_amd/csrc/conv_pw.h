@@ -1,0 +1,280 @@
+// Pointwise (1x1, stride 1) convolution for the wide high-resolution layers of HRNet (gfx950, bf16): the Bottleneck 1x1
+// layers of layer1 and of the classification-style head (reference HRnet.py:60-98: conv1 256 -> 64, conv3 64 -> 256 at
+// 64 x 64), their data gradients, and the other dense 1x1 layers with >= PW_MIN_PIXELS output pixels.
+//
+// Why a third kernel: a 1x1 convolution with 32 .. 256 input channels has 2 .. 16 MFMA k-steps per output tile - the general
+// tile program (conv_tile.h) never leaves its pipeline prologue, stages everything through LDS and round-trips the output
+// through LDS again: 64 -> 256 @ 64 x 64 x 64 images ran at 1.7 TB/s of algorithmic traffic.  A 1x1 convolution needs no
+// halo, so nothing has to be staged at all:
+//   B operand : lane (pixel l & 31, half l >> 5) of MFMA 32x32x16 needs input channels 16 kk + 8 half .. + 7 of its pixel:
+//               16 contiguous bytes of the NHWC tensor, read STRAIGHT from global memory into the operand registers (the KS
+//               loads of a tile touch every 128-byte line of its 32 pixels exactly once between them)
+//   A operand : the wave's 32 MW output channels x all input channels live in registers (KS x MW fragments), read once per
+//               workgroup from the packed layout of hrp_pack_weights; MFMA row -> channel permuted as in conv_row.h so that
+//               a lane's 16 accumulators are 16 consecutive channels of its pixel (two 16-byte stores, no LDS)
+//   workgroup : 4 waves = WC (channel blocks of 32 MW) x WP (pixel tiles); it walks a contiguous run of 32-pixel tiles, the
+//               next tile's operand loads in flight under the current tile's MFMAs and stores (PF)
+//   statistics: from a second, transposed product per tile (lane = one channel x 16 pixels: sums without cross-lane traffic),
+//               accumulated over the tiles of the workgroup; one atomic per channel per wave at the end
+// Epilogue options: the ones of conv_row.h's row_epilogue (affine, residual, ReLU, statistics; the BatchNorm-backward reduce
+// with the ReLU mask as bits or recomputed, constants from bnb_consts or from bnb_stats).  No bias, no prologue.
+#pragma once
+#include "conv_row.h"
+
+namespace hrp {
+
+constexpr long PW_MIN_PIXELS = 131072;     // below: the tile program (those layers sit in lock-step batches of small problems)
+
+struct PwPlan {
+  int ks, mw;          // k-steps (Cin / 16), channel blocks per wave: the kernel instantiation
+  int wc, wp;          // waves across channel blocks / across pixel tiles (wc * wp == 4)
+  int groups;          // channel groups of 32 * mw * wc output channels (every group reads x once)
+  int ntiles, tpw;     // 32-pixel tiles, tiles per wave (contiguous run of tpw * wp tiles per workgroup)
+  int wgs;             // workgroups per channel group
+};
+
+// Host: is this problem one the pointwise kernel takes?  -> 1 and the plan, else 0.
+static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
+  const bool off = getenv("HRP_NO_PWCONV") != nullptr;          // (read per call: tests lower the threshold for small problems)
+  const char* mp = getenv("HRP_PW_MIN_PIXELS");
+  const long min_px = mp ? atol(mp) : PW_MIN_PIXELS;
+  if (off || d.dtype != HRP_BF16 || d.ntaps != 1 || d.in_stride != 1 || d.out_stride != 1) return 0;
+  if (d.dy[0] != 0 || d.dx[0] != 0 || d.H != d.Ho || d.W != d.Wo || d.y_H != d.Ho || d.y_W != d.Wo || d.out_off_y || d.out_off_x) return 0;
+  if (d.Cin != 32 && d.Cin != 64 && d.Cin != 128 && d.Cin != 256) return 0;
+  if (d.Cout % 32 || d.Cout > 1024 || d.w_cout_pad < d.Cout || d.x_pitch != d.Cin || d.y_pitch != d.Cout) return 0;
+  const long M = (long)d.N * d.Ho * d.Wo;
+  if (M < min_px || M * (d.Cin > d.Cout ? d.Cin : d.Cout) * 2 >= (1ll << 31)) return 0;
+  if (d.bias || d.pro_mode || d.pro_side || d.pro_mask || d.pro_side2 || (!d.scale) != (!d.shift)) return 0;
+  if (d.res && d.res_pitch != d.Cout) return 0;
+  if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.w | (uintptr_t)d.res | (uintptr_t)d.bnb_x) % 16) return 0;
+  if (d.bnb_x) {
+    if (d.bnb_x_pitch != d.Cout || !d.stats || d.relu || d.scale) return 0;
+    if (d.bnb_mask && (d.bnb_mask_pitch != d.Cout / 8 || (uintptr_t)d.bnb_mask % 2)) return 0;
+    if (!d.bnb_consts && !(d.bnb_stats && d.bnb_gamma && d.bnb_beta)) return 0;
+    if (!d.bnb_mask && !d.bnb_stats) return 0;       // a recomputed mask needs scale / shift: the bnb_stats form only
+  }
+  if (d.bnb_x && d.Cin == 256) return 0;           // 16 k-steps leave no registers for the prefetch next to the butterfly: the tile program is 10 % faster
+  p.ks = d.Cin / 16;
+  p.mw = (p.ks <= 8 && d.Cout % 64 == 0) ? 2 : 1;
+  const int nb = d.Cout / (32 * p.mw);
+  p.wc = nb % 4 == 0 ? 4 : nb % 2 == 0 ? 2 : 1;
+  p.wp = 4 / p.wc;
+  p.groups = nb / p.wc;
+  p.ntiles = (int)((M + 31) / 32);
+  p.tpw = p.wgs = 0;       // filled by the launcher from the instantiation's occupancy (pw_fill_grid)
+  return 1;
+}
+
+// LDS: [4 waves][2 blocks][64 lanes] statistic partials (waves that share channels are added up before the atomics), then rows
+// 6 .. 9 of conv_row.h's constant table (epilogue reduce only)
+constexpr int PW_STAT_BYTES = 4 * 2 * 64 * 4;
+static inline int pw_lds_bytes(const hrp_conv_desc& d) { return PW_STAT_BYTES + (d.bnb_x ? 10 * d.Cout * 4 : 0); }
+
+template <int KS, int MW, bool EXT>
+__device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwPlan& p, const int bid, const int stat_slot) {
+  constexpr bool PF = KS <= 8;                       // next tile's operand in flight under this tile's MFMAs (registers allow)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stat_lds = (float*)smem;
+  float* ctab = (float*)(smem + PW_STAT_BYTES);      // rows 6 .. 9 of conv_row.h's constant table (epilogue reduce)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int Cin = KS * 16, Cout = d.Cout;
+  const int grp = bid % p.groups, wg = bid / p.groups;
+  const int wci = wave % p.wc, wpi = wave / p.wc;
+  const int cbase = (grp * p.wc + wci) * (32 * MW);      // first output channel of the wave
+  const bool bnb = d.bnb_x != nullptr;
+
+  if (bnb) {
+    for (int c = tid; c < Cout; c += 256) {
+      if (d.bnb_stats) {
+        float mean, inv, sc, sh;
+        row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, Cout, mean, inv, sc, sh);
+        ctab[8 * Cout + c] = sc; ctab[9 * Cout + c] = sh;
+        ctab[6 * Cout + c] = inv; ctab[7 * Cout + c] = -mean * inv;
+      } else {
+        const float mean = d.bnb_consts[c], inv = d.bnb_consts[Cout + c];
+        ctab[8 * Cout + c] = 0.f; ctab[9 * Cout + c] = 0.f;
+        ctab[6 * Cout + c] = inv; ctab[7 * Cout + c] = -mean * inv;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- weights: MFMA row rho = l31 carries output channel 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3) of the block
+  bf16x8 wf[MW][KS];
+  {
+    const int co_lane = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+    const char* wl = (const char*)d.w + (size_t)(d.wtap[0] * d.w_cout_pad + cbase + co_lane) * ROW + half * 16;
+    const size_t kstride = (size_t)d.w_ntaps * d.w_cout_pad * ROW;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) wf[mi][kk] = *(const bf16x8*)(wl + kk * kstride + mi * 32 * ROW);
+  }
+
+  // ---- the wave's tiles: t0, t0 + wp, ...   (the workgroup's run is contiguous in memory)
+  const long M = (long)d.N * d.Ho * d.Wo;
+  const int tile0 = wg * (p.tpw * p.wp) + wpi, tstep = p.wp;
+  const char* xg = (const char*)d.x + half * 16;
+  auto load_tile = [&](int t, bf16x8 (&xb)[KS]) {
+    const long pix = (long)t * 32 + l31;
+    if (t < p.ntiles && pix < M) {
+      const char* q = xg + (size_t)pix * (Cin * 2);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) xb[kk] = *(const bf16x8*)(q + kk * 32);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xb[kk][i] = (__bf16)0.f;
+    }
+  };
+
+  // Statistics.  Plain sum / sum of squares (train-mode forward layers): a SECOND product per tile with the operands swapped -
+  // the x fragment is as well the A operand of pixel rows, the weight fragment the B operand of channel columns - gives the
+  // transposed tile, lane = one channel (co_lane of l31) x 16 pixels: its sums are 32 VALU operations on the lane's own
+  // registers, accumulated over all tiles of the workgroup (the values rounded to bf16 as the stored ones are).  KS more MFMAs
+  // per tile on an idle matrix pipe instead of a 31-shuffle butterfly per tile (measured 64 -> 256: 50 -> 38 us).
+  // The BatchNorm-backward sums need the BatchNorm input and the mask at the same positions: those launches fold every tile's
+  // sums with the reduce-scatter butterfly of conv_row.h (lane l31 < 16 keeps sum 1 of channel cl + l31, else sum 2).
+  const bool tstats = d.stats && !bnb && !d.scale && !d.res && !d.relu;
+  float vt[MW], vq[MW];
+#pragma unroll
+  for (int mi = 0; mi < MW; ++mi) vt[mi] = vq[mi] = 0.f;
+
+  auto compute = [&](int t, const bf16x8 (&xb)[KS]) {
+    const long pix = (long)t * 32 + l31;
+    const unsigned ok = (t < p.ntiles && pix < M) ? 1u : 0u;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      f32x16 acc[1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mi][kk], xb[kk], acc[0], 0, 0, 0);
+      if (tstats) {
+        f32x16 tr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tr[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[kk], wf[mi][kk], tr, 0, 0, 0);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = tr[8 * hh + i];
+          Elem<bf16_t>::unpack(Elem<bf16_t>::pack(v), v);          // the values as stored (pixels outside the tensor: zero)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { vt[mi] += v[i]; vq[mi] = fmaf(v[i], v[i], vq[mi]); }
+        }
+      }
+      float s1[16], s2[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+      const int cl = cbase + mi * 32 + 16 * half;
+      const unsigned off[1] = {(unsigned)(pix * Cout + cl) * 2u};
+      if (tstats) {
+        row_epilogue<1, EXT, false>(d, acc, off, ok, cl, ctab, Cout, false, s1, s2);
+      } else {
+        row_epilogue<1, EXT>(d, acc, off, ok, cl, ctab, Cout, bnb, s1, s2);
+        if (d.stats) vt[mi] += row_reduce32(s1, s2, l31);
+      }
+    }
+  };
+
+  if constexpr (PF) {
+    bf16x8 xa[KS], xb[KS];
+    load_tile(tile0, xa);
+    for (int it = 0; it < p.tpw; it += 2) {
+      load_tile(tile0 + (it + 1) * tstep, xb);
+      compute(tile0 + it * tstep, xa);
+      if (it + 2 < p.tpw) load_tile(tile0 + (it + 2) * tstep, xa);
+      if (it + 1 < p.tpw) compute(tile0 + (it + 1) * tstep, xb);
+    }
+  } else {
+    for (int it = 0; it < p.tpw; ++it) {
+      bf16x8 xa[KS];
+      load_tile(tile0 + it * tstep, xa);
+      compute(tile0 + it * tstep, xa);
+    }
+  }
+
+  if (d.stats) {
+    // per lane ONE value per channel block.  tstats: half 0 = sum, half 1 = sum of squares of channel co_lane(l31);
+    // butterfly: l31 < 16 sum 1, l31 >= 16 sum 2 of channel cl + (l31 & 15).  Waves over different pixel tiles hold the same
+    // channels in the same lanes: added up through LDS, then one atomic per channel and workgroup.
+    float v[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      v[mi] = vt[mi];
+      if (tstats) {
+        const float a = vt[mi] + __shfl_xor(vt[mi], 32, 64), b = vq[mi] + __shfl_xor(vq[mi], 32, 64);      // 16 + 16 pixel rows
+        v[mi] = half ? b : a;
+      }
+    }
+    if (p.wp > 1) {
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi) stat_lds[(wave * 2 + mi) * 64 + lane] = v[mi];
+      __syncthreads();
+      if (wpi != 0) return;
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi)
+        for (int q = 1; q < p.wp; ++q) v[mi] += stat_lds[((wci + q * p.wc) * 2 + mi) * 64 + lane];
+    }
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      if (tstats) {
+        const int co_lane = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+        atomicAdd(d.stats + stat_slot * 2 * Cout + half * Cout + cbase + mi * 32 + co_lane, v[mi]);
+      } else {
+        row_stats_commit(d, v[mi], l31, cbase + mi * 32 + 16 * half, ctab, Cout, bnb, stat_slot);
+      }
+    }
+  }
+}
+
+template <int KS, int MW>
+__device__ __forceinline__ void conv_pw_body(const hrp_conv_desc& d, const PwPlan& p, const int bid, const int stat_slot) {
+  if (row_ext(d)) conv_pw_body_t<KS, MW, true>(d, p, bid, stat_slot);
+  else conv_pw_body_t<KS, MW, false>(d, p, bid, stat_slot);
+}
+
+template <int KS, int MW>
+__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const hrp_conv_desc d, const PwPlan p) {
+  conv_pw_body<KS, MW>(d, p, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
+}
+
+// ONE round of workgroups: as many as are resident at once (all of them run side by side and finish together - a second,
+// partly filled round would idle most of the chip), each walking ntiles / (that many) tiles
+static inline void pw_fill_grid(PwPlan& p, int occupancy) {
+  const int cus = 256;
+  long per_group = (long)cus * occupancy / p.groups;
+  if (per_group < 1) per_group = 1;
+  long tpw = (p.ntiles + per_group * p.wp - 1) / (per_group * p.wp);
+  if (tpw < 2) tpw = 2;
+  p.tpw = (int)tpw;
+  p.wgs = (p.ntiles + p.tpw * p.wp - 1) / (p.tpw * p.wp);
+}
+
+template <int KS, int MW>
+static inline int pw_occupancy() {
+  static int occ = 0;
+  if (!occ) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_kernel<KS, MW>, 256, 16) != hipSuccess || nb < 1) nb = 2;
+    occ = nb;
+  }
+  return occ;
+}
+
+static inline int launch_conv_pw(const hrp_conv_desc& d, const PwPlan& p0, hipStream_t s) {
+  PwPlan p = p0;
+  const dim3 blk(256);
+  const int lds = pw_lds_bytes(d);
+#define HRP_PW_CASE(K, M_) if (p.ks == K && p.mw == M_) { pw_fill_grid(p, pw_occupancy<K, M_>()); hipLaunchKernelGGL((conv_pw_kernel<K, M_>), dim3(p.wgs * p.groups), blk, lds, s, d, p); return check_launch("conv_pw_kernel"); }
+  HRP_PW_CASE(2, 1) HRP_PW_CASE(2, 2) HRP_PW_CASE(4, 1) HRP_PW_CASE(4, 2) HRP_PW_CASE(8, 1) HRP_PW_CASE(8, 2) HRP_PW_CASE(16, 1)
+#undef HRP_PW_CASE
+  set_error("conv: no pointwise instantiation for Cin=%d (ks %d, mw %d)", d.Cin, p.ks, p.mw);
+  return HRP_ERR_ARG;
+}
+
+}  // namespace hrp

@@ -212,7 +212,7 @@ __device__ __forceinline__ bool row_ext(const hrp_conv_desc& d) {
   return d.pro_mask != nullptr || d.pro_side2 != nullptr || (d.bnb_x != nullptr && (d.res != nullptr || d.bnb_mask != nullptr));
 }
 
-template <int NT, bool EXT>
+template <int NT, bool EXT, bool STATS = true>
 __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
                                              const unsigned okmask, const int cl, const float* ctab, const int C, const bool bnb,
                                              float (&s1)[16], float (&s2)[16]) {
@@ -315,7 +315,7 @@ __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x1
       }
       const uint4 pk = Elem<bf16_t>::pack(v);
       if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = pk;
-      if (d.stats && ((okmask >> t) & 1)) {
+      if (STATS && d.stats && ((okmask >> t) & 1)) {
         Elem<bf16_t>::unpack(pk, v);          // statistics of the values as stored
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1[8 * hh + i] += v[i]; s2[8 * hh + i] = fmaf(v[i], v[i], s2[8 * hh + i]); }

@@ -218,6 +218,8 @@ class Launch:
         if self.fam == "conv":
             if d.ntaps not in (1, 2, 4, 9) or (d.Cin * esz) % 32 or (d.dtype == nv.HRP_F32 and d.H == 1 and d.W == 1 and d.Cin >= 512):
                 return None
+            if d.ntaps == 1 and nv.lib().hrp_conv_pointwise(C.byref(d)):
+                return None      # the pointwise kernel (csrc/conv_pw.h) exists as a single launch only
             return ("conv", d.dtype, d.ntaps)
         if self.fam == "wgrad":
             return ("wgrad", d.dtype, d.ntaps, d.reserved)

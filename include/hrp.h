@@ -311,6 +311,10 @@ int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream);
 /* 32 / 64 when hrp_conv2d_fwd (and a HRP_BATCH_CONV launch) will run problem d on the row-strip kernel - the only one that
  * honours pro_mode / pro_side / a mask-less bnb_x - else 0.  Host only. */
 int hrp_conv_rowstrip_channels(const hrp_conv_desc* d);
+/* 1 when hrp_conv2d_fwd will run problem d on the pointwise kernel (csrc/conv_pw.h: dense bf16 1x1 stride-1 layers with 32 ..
+ * 256 input channels and >= 131 072 output pixels - the Bottleneck 1x1 layers at 64 x 64, HRnet.py:60-98), else 0.  Such a
+ * problem placed in a HRP_BATCH_CONV launch runs the general tile program: callers launch it on its own.  Host only. */
+int hrp_conv_pointwise(const hrp_conv_desc* d);
 int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream);
 /* scratch bytes hrp_conv2d_bwd_weight wants for this problem (0 is never returned for a valid problem) */
 int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d);

@@ -231,6 +231,12 @@ def conv_bytes(name, args):
                 b += d.N * d.Ho * d.Wo * d.Cout * esz
             if d.bnb_x:      # BatchNorm-backward reduce in the epilogue: reads the BatchNorm input once (+ 1/16 mask)
                 b += d.N * d.Ho * d.Wo * d.Cout * esz
+            # fused BatchNorm prologues of the row-strip kernels: the second operand (BatchNorm input) read once, every side
+            # output written once (an accumulated one also read)
+            tin = d.N * d.H * d.W * d.Cin * esz
+            if d.pro_mode == 2:
+                b += tin
+            b += tin * (bool(d.pro_side) + bool(d.pro_side2) * (2 if d.pro_side2_acc else 1))
             tot += b
         else:
             tot += (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout) * esz + d.Cout * d.dw_cin * d.ntaps * 4
@@ -647,7 +653,7 @@ def main():
     traffic, traffic_source = None, None
     tpath = next((pp for pp in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic.json") for r in (3, 2)) if os.path.exists(pp)),
                  os.path.join(ROOT, "profiles", "r02_traffic.json"))
-    fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel", "conv_row_kernel", "conv_deep_kernel", "conv_img_kernel"),
+    fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel", "conv_row_kernel", "conv_deep_kernel", "conv_img_kernel", "conv_pw_kernel"),
                    "hrp_conv2d_bwd_weight": ("conv_wgrad_kernel", "wgrad_batch_kernel", "wgrad_reduce_kernel", "wgrad_reduce_batch_kernel"),
                    "hrp_ew_fwd": ("ew_fwd_kernel", "ew_fwd_batch_kernel"),
                    "hrp_ew_bwd_reduce": ("ew_bwd_reduce_kernel",), "hrp_ew_bwd_apply": ("ew_bwd_apply_kernel",)}.get(dom[0])

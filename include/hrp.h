@@ -103,8 +103,10 @@ typedef struct hrp_conv_desc {
   const float* bnb_consts;  /* [2 * Cout]: mean, invstd of the BatchNorm input (hrp_ew_desc.consts_out)        */
   int32_t bnb_x_pitch, bnb_mask_pitch;
   /* ---- fields below: row-strip kernels only (hrp_conv_rowstrip_channels(d) != 0: the 3x3 stride-1 C -> C layers of the
-   * HRNet branches, bf16, dense NHWC rows of 4 KiB: C = 32 @ W = 64, C = 64 @ W = 32).  Any other problem that sets them
-   * is HRP_ERR_ARG: callers ask hrp_conv_rowstrip_channels first.
+   * HRNet branches, bf16, dense NHWC rows of 4 KiB: C = 32 @ W = 64, C = 64 @ W = 32, C = 128 @ W = 16, C = 256 @ W = 8,
+   * H a multiple of 8).  Any other problem that sets them is HRP_ERR_ARG: callers ask hrp_conv_rowstrip_channels first.
+   * (The bnb_stats form of the epilogue reduce, with or without bnb_mask / res, is also taken by the pointwise kernel:
+   * hrp_conv_pointwise.)
    * bnb_x with bnb_stats set: the BatchNorm constants of the epilogue reduce are derived in the kernel from bnb_stats (the forward
    * sum / sum-of-squares slots of bnb_x), bnb_gamma, bnb_beta, bnb_count, bnb_eps; with bnb_mask == NULL the ReLU mask is
    * recomputed from bnb_x itself, mask = (bn(bnb_x) > 0) - the arithmetic the forward prologue (pro_mode 1) applied -, else
@@ -308,8 +310,8 @@ int hrp_maxpool3x3s2_bwd(const void* dy, int dy_pitch, const uint8_t* argmax, vo
                          int C, int pitch, int accumulate, void* stream);
 
 int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream);
-/* 32 / 64 when hrp_conv2d_fwd (and a HRP_BATCH_CONV launch) will run problem d on the row-strip kernel - the only one that
- * honours pro_mode / pro_side / a mask-less bnb_x - else 0.  Host only. */
+/* 32 / 64 / 128 / 256 (the channel count) when hrp_conv2d_fwd (and a HRP_BATCH_CONV launch) will run problem d on a row-strip
+ * kernel - the only ones that honour pro_mode / pro_side / pro_mask / pro_side2 - else 0.  Host only. */
 int hrp_conv_rowstrip_channels(const hrp_conv_desc* d);
 /* 1 when hrp_conv2d_fwd will run problem d on the pointwise kernel (csrc/conv_pw.h: dense bf16 1x1 stride-1 layers with 32 ..
  * 256 input channels and >= 131 072 output pixels - the Bottleneck 1x1 layers at 64 x 64, HRnet.py:60-98), else 0.  Such a

@@ -40,7 +40,8 @@ class ConvDesc(C.Structure):
                 ("pro_x2", C.c_void_p), ("pro_stats", C.c_void_p), ("pro_bsums", C.c_void_p),
                 ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p),
                 ("pro_count", C.c_float), ("pro_eps", C.c_float), ("pro_side", C.c_void_p),
-                ("pro_mask", C.c_void_p), ("pro_side2", C.c_void_p), ("pro_side2_acc", C.c_int32), ("pro_reserved2", C.c_int32)]
+                ("pro_mask", C.c_void_p), ("pro_side2", C.c_void_p), ("pro_side2_acc", C.c_int32), ("pro_reserved2", C.c_int32),
+                ("res_mask", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

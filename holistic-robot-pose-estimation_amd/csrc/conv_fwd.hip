@@ -32,8 +32,8 @@ int conv_check(const hrp_conv_desc* d) {
                 ((size_t)d->bnb_x_pitch * sz) % 16 == 0 && (uintptr_t)d->bnb_consts % 16 == 0, "conv: bnb_x alignment");
   }
   // input transforms / the mask-less epilogue reduce exist in the row-strip kernel only (conv_row.h)
-  if (d->pro_mode != 0 || d->pro_side || d->pro_side2 || d->pro_mask)
-    HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / pro_mask need a row-strip problem (hrp_conv_rowstrip_channels)");
+  if (d->pro_mode != 0 || d->pro_side || d->pro_side2 || d->pro_mask || d->res_mask)
+    HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / pro_mask / res_mask need a row-strip problem (hrp_conv_rowstrip_channels)");
   if (d->bnb_x && (!d->bnb_mask || d->res))
     HRP_REQUIRE(lean_kernel, "conv: a mask-less bnb_x / bnb_x with res needs a row-strip or pointwise problem (hrp_conv_rowstrip_channels, hrp_conv_pointwise)");
   return HRP_OK;

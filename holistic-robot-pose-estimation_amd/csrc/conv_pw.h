@@ -44,7 +44,7 @@ static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
   if (d.Cout % 32 || d.Cout > 1024 || d.w_cout_pad < d.Cout || d.x_pitch != d.Cin || d.y_pitch != d.Cout) return 0;
   const long M = (long)d.N * d.Ho * d.Wo;
   if (M < min_px || M * (d.Cin > d.Cout ? d.Cin : d.Cout) * 2 >= (1ll << 31)) return 0;
-  if (d.bias || d.pro_mode || d.pro_side || d.pro_mask || d.pro_side2 || (!d.scale) != (!d.shift)) return 0;
+  if (d.bias || d.pro_mode || d.pro_side || d.pro_mask || d.pro_side2 || d.res_mask || (!d.scale) != (!d.shift)) return 0;
   if (d.res && d.res_pitch != d.Cout) return 0;
   if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.w | (uintptr_t)d.res | (uintptr_t)d.bnb_x) % 16) return 0;
   if (d.bnb_x) {

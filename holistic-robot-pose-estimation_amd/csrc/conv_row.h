@@ -99,6 +99,7 @@ static inline int row_channels(const hrp_conv_desc& d) {
   if (d.pro_mode == 2 && (!d.pro_x2 || !d.pro_bsums || (uintptr_t)d.pro_x2 % 16)) return 0;
   if (d.pro_mode != 2 && (d.pro_mask || d.pro_side2)) return 0;
   if ((d.pro_side && (uintptr_t)d.pro_side % 16) || (d.pro_side2 && (uintptr_t)d.pro_side2 % 16)) return 0;
+  if (d.res_mask && (!d.res || (uintptr_t)d.res_mask % 2 || d.relu || d.scale)) return 0;
   if ((long long)d.N * d.H * d.W * C * 2 >= (1ll << 31)) return 0;     // 32-bit byte offsets inside the tensors
   unsigned seen = 0;
   for (int i = 0; i < 9; ++i) {
@@ -209,7 +210,8 @@ __device__ __forceinline__ void row_side2(const hrp_conv_desc& d, const unsigned
 // reduce - live in a second instantiation of every body (EXT): the lean one keeps the registers and schedule of the common
 // launches (measured: the options as run-time checks cost the plain block-interior launches 5 - 12 %).
 __device__ __forceinline__ bool row_ext(const hrp_conv_desc& d) {
-  return d.pro_mask != nullptr || d.pro_side2 != nullptr || (d.bnb_x != nullptr && (d.res != nullptr || d.bnb_mask != nullptr));
+  return d.pro_mask != nullptr || d.pro_side2 != nullptr || d.res_mask != nullptr ||
+         (d.bnb_x != nullptr && (d.res != nullptr || d.bnb_mask != nullptr));
 }
 
 template <int NT, bool EXT, bool STATS = true>
@@ -253,8 +255,9 @@ __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x1
           if (rq && ((okmask >> t) & 1)) {
             float r[8];
             Elem<bf16_t>::unpack(*(const uint4*)(rq + off[t] + 16 * hh), r);
+            const int rb = d.res_mask ? d.res_mask[(off[t] >> 4) + hh] : 0xff;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += r[i];
+            for (int i = 0; i < 8; ++i) v[i] += ((rb >> i) & 1) ? r[i] : 0.f;
           }
         }
         const uint4 pk = Elem<bf16_t>::pack(v);
@@ -306,6 +309,13 @@ __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x1
       if (rg_) {
         float r[8];
         Elem<bf16_t>::unpack(rr[t][hh], r);
+        if constexpr (EXT) {
+          if (d.res_mask && ((okmask >> t) & 1)) {
+            const int rb = d.res_mask[(off[t] >> 4) + hh];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = ((rb >> i) & 1) ? r[i] : 0.f;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += r[i];
       }
@@ -458,7 +468,7 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
     float mean, inv, sc, sh;
     row_bn_consts(d.bnb_stats, d.bnb_gamma, d.bnb_beta, d.bnb_count, d.bnb_eps, c, C, mean, inv, sc, sh);
     ctab[8 * C + c] = sc; ctab[9 * C + c] = sh;
-      ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
+    ctab[6 * C + c] = inv; ctab[7 * C + c] = -mean * inv;
   }
   HRP_CSTAMP(1);
   if (pro != 0) __syncthreads();                                          // the constant table
@@ -532,8 +542,8 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
               const unsigned off = img_off + lane_off + y * (W * P);
               if (side) *(uint4*)(side + off) = o;
               if constexpr (EXT) {
-              if (d.pro_side2) row_side2(d, off, gm);
-            }
+                if (d.pro_side2) row_side2(d, off, gm);
+              }
             }
           }
         }
@@ -754,7 +764,6 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
       } else {
         pc.load2(ctab, C, cb);
         // the BatchNorm inputs (and mask bytes) of this parity's rows: same lane-constant addressing, through registers
-        const char* x2g = (const char*)d.pro_x2 + img_off;
         uint4 x2[NROWS];
         int bits[NROWS];
 #pragma unroll
@@ -770,7 +779,6 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
             }
           }
         }
-        (void)x2g;
 #pragma unroll
         for (int rs = 0; rs < NROWS; ++rs) {
           const int y = y0 - 1 + rs;
@@ -1039,8 +1047,8 @@ __device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const Ro
           const unsigned off = grp_off + piece_off(i);
           if (side) *(uint4*)(side + off) = o;
           if constexpr (EXT) {
-              if (d.pro_side2) row_side2(d, off, gm);
-            }
+            if (d.pro_side2) row_side2(d, off, gm);
+          }
         }
       }
     }

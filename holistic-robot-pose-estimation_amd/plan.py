@@ -150,6 +150,8 @@ ROWCONV_FUSE = not os.environ.get("HRP_NO_ROWCONV_FUSE")
 # ... and the block-end activation's backward (apply pass into conv2's data gradient, reduce pass into the next block's)
 BLOCK_END_FUSE = not os.environ.get("HRP_NO_BLOCK_END_FUSE")
 BLOCK_END_REDUCE_FUSE = not os.environ.get("HRP_NO_BLOCK_END_REDUCE_FUSE")
+# ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
+MASKED_RES = not os.environ.get("HRP_NO_MASKED_RES")
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
 # development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
 BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
@@ -1535,11 +1537,16 @@ class PlanBuilder:
                     # the block-end BatchNorm + ReLU backward (bn2, mask bits): staged operand of this launch
                     boff2 = p.alloc_bsums(Cc)
                     p.bn_bwd.append((bn2, boff2))
-                    acc2 = x.take_grad_slot()
                     g2.x = out.gptr()
                     g2.pro_mode, g2.pro_x2, g2.pro_gamma, g2.pro_beta = 2, y2.ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
                     g2.pro_count, g2.pro_eps, g2.pro_mask = cnt, bn2.eps, fd.mask
-                    g2.pro_side, g2.pro_side2, g2.pro_side2_acc = y2.gptr(), x.gptr(), acc2
+                    g2.pro_side = y2.gptr()
+                    # the identity shortcut's gradient (out.grad under the block-end mask): nobody has written x.grad yet ->
+                    # conv1's data gradient below adds it as a MASKED residual and writes x.grad once; else this launch
+                    # accumulates it as a second side output
+                    masked_res = MASKED_RES and not x.grad_written
+                    if not masked_res:
+                        g2.pro_side2, g2.pro_side2_acc = x.gptr(), x.take_grad_slot()
                     # its reduce: in the epilogue of the launch that completes out.grad when that is a row-strip data gradient
                     # of this lane accumulating onto ONE earlier producer (the next block of the stack), else a pass of its own
                     nxt = p.row_last_writer.get(out.gptr())
@@ -1571,7 +1578,11 @@ class PlanBuilder:
                 g1.x, g1.y = h.gptr(), x.gptr()
                 for i, (a, b) in enumerate(_TAPS3):
                     g1.dy[i], g1.dx[i], g1.wtap[i] = -a, -b, i
-                if acc:
+                if fd is not None and masked_res:
+                    assert not acc
+                    g1.res, g1.res_pitch, g1.res_mask = out.gptr(), out.pitch, fd.mask
+                    p.counters["block_end_masked_residual"] = p.counters.get("block_end_masked_residual", 0) + 1
+                elif acc:
                     g1.res, g1.res_pitch = x.gptr(), x.pitch
                 g1.pro_mode, g1.pro_x2, g1.pro_gamma, g1.pro_beta, g1.pro_count, g1.pro_eps = 2, y1.ptr(), gam, bet, cnt, bn1.eps
                 g1.pro_side = y1.gptr()
@@ -1593,7 +1604,9 @@ class PlanBuilder:
                 if conv2_w.requires_grad and not wg2_first:
                     self._wgrad_launch(h, w2, y2)
                 p.bwd.append(Launch("conv", g1))
-                if acc:   # the last producer of x.grad: the block in front of this one may put its BatchNorm reduce here
+                # (so far) the last producer of x.grad: the block in front of this one may put its BatchNorm reduce here if
+                # that is still so when its own backward is emitted
+                if acc or (fd is not None and masked_res):
                     p.row_last_writer[x.gptr()] = (g1, p.lane_path, len((x.base if x.base is not None else x)._grad_paths))
                 if conv1_w.requires_grad:
                     self._wgrad_launch(x, w1, y1)

@@ -140,6 +140,11 @@ typedef struct hrp_conv_desc {
   const uint8_t* pro_mask;
   void* pro_side2;
   int32_t pro_side2_acc, pro_reserved2;
+  /* res_mask (optional, row-strip kernels, with res): ReLU bit mask ([pixels][Cout / 8] bytes) applied to the residual before it
+   * is added: y = conv(x') + [bit] * res.  The data gradient of a block's first conv then produces the WHOLE gradient of the
+   * block input in one write - conv1's data gradient plus the gradient of the identity shortcut, which is the block output's
+   * gradient masked by the block-end ReLU (HRnet.py:52-56) - instead of accumulating onto a tensor another launch wrote. */
+  const uint8_t* res_mask;
 } hrp_conv_desc;
 
 /* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],

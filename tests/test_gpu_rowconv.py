@@ -210,8 +210,9 @@ def test_rowconv_bn_backward_reduce_epilogue(shape):
     assert (err <= bound).all(), (err / bound).max()
 
 
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_rowconv_bn_backward_apply_prologue(shape):
+def test_rowconv_bn_backward_apply_prologue(shape, masked):
     """Data gradient of conv1 whose staged operand is the BatchNorm + ReLU backward of (gradient of the activation,
     BatchNorm input) (pro_mode 2), accumulated onto an existing gradient (res == y), with the BatchNorm input gradient
     as a side output == hrp_ew_bwd_apply followed by the conv."""
@@ -233,7 +234,8 @@ def test_rowconv_bn_backward_apply_prologue(shape):
     dx1 = sc[None, :, None, None] * (gm - k0[None, :, None, None] - xh * k1[None, :, None, None])
     dx1b = bf(dx1)
     prev = bf(torch.randn(N, Cc, H, W, generator=g))
-    ref = F.conv_transpose2d(dx1b.double(), w.double(), padding=1).float() + prev
+    onr = torch.rand(N, Cc, H, W, generator=g) > 0.5             # masked: residual = another tensor under a bit mask (res_mask)
+    ref = F.conv_transpose2d(dx1b.double(), w.double(), padding=1).float() + (prev * onr if masked else prev)
     _, wpt = pack(nv, w)
     gad, x1d, y = nhwc(ga), nhwc(x1), nhwc(prev)
     side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
@@ -241,6 +243,10 @@ def test_rowconv_bn_backward_apply_prologue(shape):
     gd, bd = gamma.to(DEV), beta.to(DEV)
     d = desc(nv, gad, wpt, y, N, H, W, Cc, transposed=True)
     d.res = y.data_ptr()
+    if masked:
+        resd, mkr = nhwc(prev), mask_bits(onr)
+        y.fill_(3.0)
+        d.res, d.res_mask = resd.data_ptr(), mkr.data_ptr()
     d.pro_mode, d.pro_x2, d.pro_stats, d.pro_bsums = 2, x1d.data_ptr(), st_in.data_ptr(), bs_in.data_ptr()
     d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps, d.pro_side = gd.data_ptr(), bd.data_ptr(), float(cnt), EPS, side.data_ptr()
     assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
@@ -322,8 +328,9 @@ def test_rowconv_block_end_apply_prologue(shape, acc2):
     assert (err <= bound).all(), (err / bound).max()
 
 
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_rowconv_block_end_reduce_epilogue(shape):
+def test_rowconv_block_end_reduce_epilogue(shape, masked):
     """conv1's data gradient of the NEXT block completing the gradient of a block output: interior BatchNorm + ReLU backward
     in the prologue (mask recomputed), accumulation onto the residual's gradient (res == y), and in the epilogue the
     block-end BatchNorm's sums of the COMPLETED gradient masked by hrp_ew_fwd's bit mask (bnb_mask) == hrp_ew_bwd_apply,
@@ -345,7 +352,9 @@ def test_rowconv_block_end_reduce_epilogue(shape):
     k0, k1 = bt[:Cc] / cnt, bt[Cc:] / cnt
     dx1b = bf(sc[None, :, None, None] * (gm - k0[None, :, None, None] - xh * k1[None, :, None, None]))
     prev = bf(torch.randn(N, Cc, H, W, generator=g))
-    ref = F.conv_transpose2d(dx1b.double(), w.double(), padding=1).float() + prev
+    # masked: the residual is ANOTHER tensor (the block output's gradient) under a ReLU bit mask (res_mask), y is written once
+    onr = torch.rand(N, Cc, H, W, generator=g) > 0.5
+    ref = F.conv_transpose2d(dx1b.double(), w.double(), padding=1).float() + (prev * onr if masked else prev)
     # the previous block's end: BatchNorm over yp, ReLU decisions as bits
     yp = bf(torch.randn(N, Cc, H, W, generator=g) * 1.7 - 0.2)
     onp = torch.rand(N, Cc, H, W, generator=g) > 0.4
@@ -359,6 +368,10 @@ def test_rowconv_block_end_reduce_epilogue(shape):
     gd, bd, gdp, bdp = gamma.to(DEV), beta.to(DEV), gammap.to(DEV), betap.to(DEV)
     d = desc(nv, gad, wpt, y, N, H, W, Cc, transposed=True)
     d.res = y.data_ptr()
+    if masked:
+        resd, mkr = nhwc(prev), mask_bits(onr)
+        y.fill_(3.0)
+        d.res, d.res_mask = resd.data_ptr(), mkr.data_ptr()
     d.pro_mode, d.pro_x2, d.pro_stats, d.pro_bsums = 2, x1d.data_ptr(), st_in.data_ptr(), bs_in.data_ptr()
     d.pro_gamma, d.pro_beta, d.pro_count, d.pro_eps, d.pro_side = gd.data_ptr(), bd.data_ptr(), float(cnt), EPS, side.data_ptr()
     d.stats, d.bnb_x, d.bnb_x_pitch, d.bnb_mask, d.bnb_mask_pitch = bsp.data_ptr(), ypd.data_ptr(), Cc, mk.data_ptr(), Cc // 8
@@ -531,6 +544,7 @@ def test_block_stack_with_fused_block_end_backward_equals_elementwise_backward(C
         finally:
             P.BLOCK_END_FUSE = True
     assert counters[True].get("block_end_apply_fused") == NB and counters[True].get("block_end_reduce_fused") == NB - 1, counters[True]
+    assert counters[True].get("block_end_masked_residual") == NB, counters[True]
     assert not counters[False].get("block_end_apply_fused")
 
     def err(a, b):

@@ -155,7 +155,8 @@ PROTOTYPES = {
     "hrp_conv_rowstrip_channels": [C.POINTER(ConvDesc)],
     "hrp_conv_pointwise": [C.POINTER(ConvDesc)],
     "hrp_conv2d_bwd_weight": [C.POINTER(WgradDesc), _P],
-    "hrp_colsum": [_P, _I, _L, _I, _I, _P, _I, _P],
+    "hrp_colsum": [_P, _I, _L, _I, _I, _P, _I, _P, _L, _P],
+    "hrp_colsum_workspace_bytes": [_L, _I],
     "hrp_ew_fwd": [C.POINTER(EwDesc), _P],
     "hrp_ew_bwd_reduce": [C.POINTER(EwBwdDesc), _P],
     "hrp_ew_bwd_apply": [C.POINTER(EwBwdDesc), _P],
@@ -183,8 +184,9 @@ PROTOTYPES = {
     "hrp_batch_wgrad_fold_descs": [_P, C.POINTER(BatchInfo), C.POINTER(WgradFoldDesc)],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
-    "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
-    "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
+    "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
+    "hrp_linear_workspace_bytes": [_I, _I, _I],
     "hrp_linear_bwd_weight": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "hrp_rng_advance": [_P, _P],
     "hrp_dropout_f32": [_P, _I, _P, _I, _P, _I, _I, _F, _P, C.c_uint32, _P],
@@ -237,6 +239,8 @@ def lib():
         L.hrp_source_hash.restype = C.c_char_p
         L.hrp_source_hash.argtypes = []
         L.hrp_wgrad_workspace_bytes.restype = C.c_int64
+        L.hrp_linear_workspace_bytes.restype = C.c_int64
+        L.hrp_colsum_workspace_bytes.restype = C.c_int64
         L.hrp_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         L.hrp_batch_table_bytes.restype = C.c_int64
         L.hrp_batch_table_bytes.argtypes = [C.c_int, C.c_int]

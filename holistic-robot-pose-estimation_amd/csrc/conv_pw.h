@@ -224,7 +224,7 @@ __device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwP
     for (int mi = 0; mi < MW; ++mi) {
       if (tstats) {
         const int co_lane = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
-        atomicAdd(d.stats + stat_slot * 2 * Cout + half * Cout + cbase + mi * 32 + co_lane, v[mi]);
+        atomicAdd(d.stats + stat_slot * 2 * Cout + half * Cout + cbase + mi * 32 + co_lane, (double)v[mi]);
       } else {
         row_stats_commit(d, v[mi], l31, cbase + mi * 32 + 16 * half, ctab, Cout, bnb, stat_slot);
       }

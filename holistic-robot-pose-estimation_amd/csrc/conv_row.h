@@ -69,7 +69,7 @@ struct RowPlan {
 
 // mean / invstd / scale / shift of one channel from the statistic slots (the arithmetic of elementwise.hip's
 // channel_consts: m = sum / n, var = max(sumsq / n - m^2, 0), invstd = rsqrt(var + eps), sc = gamma * invstd, sh = beta - m * sc)
-__device__ __forceinline__ void row_bn_consts(const float* stats, const float* gamma, const float* beta, float count, float eps,
+__device__ __forceinline__ void row_bn_consts(const double* stats, const float* gamma, const float* beta, float count, float eps,
                                               int c, int C, float& mean, float& inv, float& sc, float& sh) {
   const float m = slot_sum(stats, c, 2 * C) / count;
   const float var = fmaxf(slot_sum(stats, C + c, 2 * C) / count - m * m, 0.f);
@@ -371,7 +371,7 @@ __device__ __forceinline__ void row_stats_commit(const hrp_conv_desc& d, const f
   const float other = __shfl_xor(v1, 16, 64);     // sum 1 of the same channel, for the lanes holding sum 2
   float tot = v1;
   if (bnb && which == 1) tot = fmaf(ctab[6 * C + c], v1, ctab[7 * C + c] * other);     // sum g * xhat = a * sum g x + b * sum g
-  atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, tot);
+  atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, (double)tot);
 }
 
 template <int C, bool EXT>
@@ -628,7 +628,7 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
       };
       float t = tot(which);
       if (bnb && which == 1) t = fmaf(ctab[6 * C + c], t, ctab[7 * C + c] * tot(0));     // sum g * xhat = a * sum g x + b * sum g
-      atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, t);
+      atomicAdd(d.stats + stat_slot * 2 * C + which * C + c, (double)t);
     }
   }
   HRP_CSTAMP(6);

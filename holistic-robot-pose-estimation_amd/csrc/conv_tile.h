@@ -574,8 +574,8 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
         if (co0 + ch < d.Cout) {
           float v = lds_stats[(0 * 2 + which) * BN + ch] + lds_stats[(1 * 2 + which) * BN + ch] +
                     lds_stats[(2 * 2 + which) * BN + ch] + lds_stats[(3 * 2 + which) * BN + ch];
-          float* slot = d.stats + stat_slot * 2 * d.Cout;
-          atomicAdd(&slot[which * d.Cout + co0 + ch], v);
+          double* slot = d.stats + stat_slot * 2 * d.Cout;
+          atomicAdd(&slot[which * d.Cout + co0 + ch], (double)v);
         }
       }
     }

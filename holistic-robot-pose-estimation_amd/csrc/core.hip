@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
 // ---- column sums -----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, long rows, int C, int pitch,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, float* __restrict__ ws) {
   // thread (tx = channel within a 64-wide slab, ty = row phase); grid.x strides rows, grid.y = channel slab
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -251,7 +251,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     for (long r = (long)blockIdx.x * 4 + ty; r < rows; r += (long)gridDim.x * 4) s += Elem<T>::ld(x, (size_t)r * pitch + c);
   part[ty][tx] = s;
   __syncthreads();
-  if (ty == 0 && c < C) atomicAdd(&out[c], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+  if (ty == 0 && c < C) {
+    const float v = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
+    if (ws) ws[(size_t)blockIdx.x * C + c] = v;          // deterministic: colsum_fold_kernel adds the row groups in order
+    else atomicAdd(&out[c], v);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ ws, int groups, int C, float* __restrict__ out,
+                                                          int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float v = 0.f;
+  for (int g0 = 0; g0 < groups; g0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = g0 + u < groups ? ws[(size_t)(g0 + u) * C + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  out[c] = accumulate ? out[c] + v : v;
 }
 
 // ---- batch-norm tables -----------------------------------------------------------------------------
@@ -521,15 +540,25 @@ extern "C" int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int 
   return check_launch("pack_weights");
 }
 
-extern "C" int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream) {
-  HRP_REQUIRE(x && out && rows > 0 && C > 0, "colsum: bad args");
-  if (!accumulate) zero_async(out, sizeof(float) * C, (hipStream_t)stream);
+static inline int colsum_groups(int64_t rows) {
   int gx = (int)((rows + 63) / 64);
   if (gx > 512) gx = 512;
-  if (gx < 1) gx = 1;
+  return gx < 1 ? 1 : gx;
+}
+
+extern "C" int64_t hrp_colsum_workspace_bytes(int64_t rows, int C) { return rows > 0 && C > 0 ? (int64_t)colsum_groups(rows) * C * 4 : 0; }
+
+extern "C" int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+  HRP_REQUIRE(x && out && rows > 0 && C > 0, "colsum: bad args");
+  const int gx = colsum_groups(rows);
+  float* ws = (float*)workspace;
+  HRP_REQUIRE(!ws || workspace_bytes >= (int64_t)gx * C * 4, "colsum: workspace too small");
+  if (!ws && !accumulate) zero_async(out, sizeof(float) * C, (hipStream_t)stream);
   dim3 grid(gx, cdiv(C, 64));
-  if (dtype == HRP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, pitch, out);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, pitch, out);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, pitch, out, ws);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, pitch, out, ws);
+  if (ws) hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, gx, C, out, accumulate);
   return check_launch("colsum");
 }
 

@@ -380,9 +380,9 @@ __device__ __forceinline__ void ew_bwd_reduce_body(const hrp_ew_bwd_desc& d, con
       a0 += red0[(k * tpr + lc) * V + i];
       a1 += red1[(k * tpr + lc) * V + i];
     }
-    float* slot = d.sums + stat_slot * 2 * d.C;
-    atomicAdd(&slot[ch], a0);
-    atomicAdd(&slot[d.C + ch], a1);
+    double* slot = d.sums + stat_slot * 2 * d.C;
+    atomicAdd(&slot[ch], (double)a0);
+    atomicAdd(&slot[d.C + ch], (double)a1);
   }
 }
 

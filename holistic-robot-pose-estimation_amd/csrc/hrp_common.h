@@ -75,8 +75,8 @@ struct Elem<bf16_t> {
 };
 
 // sum of the HRP_STAT_SLOTS replicas of statistic element i (buffer laid out [slot][n])
-__device__ __forceinline__ float slot_sum(const float* p, int i, int n) {
-  float s = 0.f;
+__device__ __forceinline__ float slot_sum(const double* p, int i, int n) {
+  double s = 0.0;
 #pragma unroll
   for (int k = 0; k < HRP_STAT_SLOTS; ++k) s += p[k * n + i];
   return s;

@@ -27,7 +27,8 @@ constexpr int LPA = LBK + 1;        // padded row of the row-operand tile (lanes
 template <bool TRANS>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ a, int a_pitch, const float* __restrict__ w, int w_ld,
                                                      const float* __restrict__ bias, const float* __restrict__ res, int res_pitch,
-                                                     float* __restrict__ out, int out_pitch, int M, int R, int Cn, int use_atomics) {
+                                                     float* __restrict__ out, int out_pitch, int M, int R, int Cn, int use_atomics,
+                                                     float* __restrict__ ws_part) {
   __shared__ float As[4 * 64 * 33 > 64 * LPA ? 4 * 64 * 33 : 64 * LPA];   // row-operand tile, later the 4 partial output tiles
   __shared__ float Bs[TRANS ? LBK * 33 : 32 * LPA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,6 +74,19 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ a
     part[(wave * 64 + 32 + row) * 33 + l31] = acc1[i];
   }
   __syncthreads();
+  if (ws_part) {
+    // Deterministic reduction over the splits: every workgroup parks its partial tile in the workspace, linear_fold_kernel adds
+    // them up in split order.  (fp32 atomics into the output - the path without a workspace - depend on arrival order; a
+    // last-ticket reduction inside this kernel needs device-scope fences, which write back / invalidate the L2 of an XCD:
+    // measured 63 us against 18.)
+    const int Mp = gridDim.z * 64, Cp = gridDim.x * 32;
+    for (int i = tid; i < 64 * 32; i += 256) {
+      const int m = i >> 5, c = i & 31;
+      ws_part[((size_t)blockIdx.y * Mp + m0 + m) * Cp + c0 + c] =
+          part[m * 33 + c] + part[(64 + m) * 33 + c] + part[(128 + m) * 33 + c] + part[(192 + m) * 33 + c];
+    }
+    return;
+  }
   for (int i = tid; i < 64 * 32; i += 256) {
     const int m = i >> 5, c = i & 31;
     if (m0 + m >= M || c0 + c >= Cn) continue;
@@ -136,17 +150,58 @@ __global__ void zero_rows_kernel(float* __restrict__ p, int pitch, int rows, int
   p[(size_t)r * pitch + (i - r * cols)] = 0.f;
 }
 
+// workspace of the deterministic reduction: [ct * mb] tickets (zero before the FIRST launch, self-resetting), 256-byte aligned,
+// then [rs][mb * 64][ct * 32] partial sums
+// out[m][c] (+)= sum over the splits y (in order) of part[y][m][c] + bias[c] + res[m][c]
+__global__ __launch_bounds__(256) void linear_fold_kernel(const float* __restrict__ part, int rs, int Mp, int Cp, const float* __restrict__ bias,
+                                                          const float* __restrict__ res, int res_pitch, float* __restrict__ out, int out_pitch,
+                                                          int M, int Cn, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * Cn) return;
+  const int m = i / Cn, c = i - m * Cn;
+  const float* pp = part + (size_t)m * Cp + c;
+  const size_t ystride = (size_t)Mp * Cp;
+  float v = 0.f;
+  for (int y0 = 0; y0 < rs; y0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = y0 + u < rs ? pp[(size_t)(y0 + u) * ystride] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  if (bias) v += bias[c];
+  if (res) v += res[(size_t)m * res_pitch + c];
+  float* o = out + (size_t)m * out_pitch + c;
+  *o = accumulate ? *o + v : v;
+}
+
+// workspace of the deterministic reduction: [rs][mb * 64][ct * 32] partial sums (no initialisation needed)
+static inline size_t linear_ws_bytes(int M, int R, int Cn) {
+  return (size_t)cdiv(R, LBK) * cdiv(M, 64) * 64 * cdiv(Cn, 32) * 32 * 4;
+}
+
 static int linear_launch(bool trans, const float* a, int a_pitch, const float* w, int w_ld, const float* bias, const float* res,
-                         int res_pitch, float* out, int out_pitch, int M, int R, int Cn, int accumulate, hipStream_t s) {
+                         int res_pitch, float* out, int out_pitch, int M, int R, int Cn, int accumulate, void* ws, int64_t ws_bytes,
+                         hipStream_t s) {
   const int ct = cdiv(Cn, 32), rs = cdiv(R, LBK), mb = cdiv(M, 64);
+  const dim3 grid(ct, rs, mb);
+  if (ws && rs > 1) {
+    HRP_REQUIRE((uintptr_t)ws % 16 == 0 && (size_t)ws_bytes >= linear_ws_bytes(M, R, Cn), "linear: workspace too small (%lld < %zu bytes)",
+                (long long)ws_bytes, linear_ws_bytes(M, R, Cn));
+    float* part = (float*)ws;
+    if (trans) hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, s, a, a_pitch, w, w_ld, nullptr, nullptr, 0, out, out_pitch, M, R, Cn, 0, part);
+    else hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), 0, s, a, a_pitch, w, w_ld, nullptr, nullptr, 0, out, out_pitch, M, R, Cn, 0, part);
+    hipLaunchKernelGGL(linear_fold_kernel, dim3(cdiv(M * Cn, 256)), dim3(256), 0, s, part, rs, mb * 64, ct * 32, bias, res, res_pitch, out, out_pitch,
+                       M, Cn, accumulate);
+    return check_launch("linear");
+  }
   const int atomics = (rs > 1 || accumulate) ? 1 : 0;
   if (atomics && !accumulate) {     // partial sums of the reduction splits meet in a zeroed output
     if (out_pitch == Cn) zero_async(out, sizeof(float) * (size_t)M * Cn, s);
     else hipLaunchKernelGGL(zero_rows_kernel, dim3(cdiv(M * Cn, 256)), dim3(256), 0, s, out, out_pitch, M, Cn);
   }
-  const dim3 grid(ct, rs, mb);
-  if (trans) hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, s, a, a_pitch, w, w_ld, bias, res, res_pitch, out, out_pitch, M, R, Cn, atomics);
-  else hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), 0, s, a, a_pitch, w, w_ld, bias, res, res_pitch, out, out_pitch, M, R, Cn, atomics);
+  if (trans) hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, s, a, a_pitch, w, w_ld, bias, res, res_pitch, out, out_pitch, M, R, Cn, atomics, nullptr);
+  else hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), 0, s, a, a_pitch, w, w_ld, bias, res, res_pitch, out, out_pitch, M, R, Cn, atomics, nullptr);
   return check_launch("linear");
 }
 
@@ -154,17 +209,24 @@ static int linear_launch(bool trans, const float* a, int a_pitch, const float* w
 
 using namespace hrp;
 
+extern "C" int64_t hrp_linear_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const size_t f = linear_ws_bytes(M, K, N), b = linear_ws_bytes(M, N, K);      // forward reduces over K, the data gradient over N
+  return (int64_t)(f > b ? f : b);
+}
+
 extern "C" int hrp_linear_fwd(const float* x, int x_pitch, const float* w, const float* bias, const float* res, int res_pitch,
-                              float* y, int y_pitch, int M, int K, int N, void* stream) {
+                              float* y, int y_pitch, int M, int K, int N, void* workspace, int64_t workspace_bytes, void* stream) {
   HRP_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0 && x_pitch >= K && y_pitch >= N, "linear_fwd: bad arguments");
   HRP_REQUIRE(!res || (res_pitch >= N && res != y), "linear_fwd: residual");
-  return linear_launch(false, x, x_pitch, w, K, bias, res, res_pitch, y, y_pitch, M, K, N, 0, (hipStream_t)stream);
+  return linear_launch(false, x, x_pitch, w, K, bias, res, res_pitch, y, y_pitch, M, K, N, 0, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int hrp_linear_bwd_data(const float* dy, int dy_pitch, const float* w, float* dx, int dx_pitch, int M, int K, int N,
-                                   int accumulate, void* stream) {
+                                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   HRP_REQUIRE(dy && w && dx && M > 0 && K > 0 && N > 0 && dy_pitch >= N && dx_pitch >= K, "linear_bwd_data: bad arguments");
-  return linear_launch(true, dy, dy_pitch, w, K, nullptr, nullptr, 0, dx, dx_pitch, M, N, K, accumulate, (hipStream_t)stream);
+  return linear_launch(true, dy, dy_pitch, w, K, nullptr, nullptr, 0, dx, dx_pitch, M, N, K, accumulate, workspace, workspace_bytes,
+                       (hipStream_t)stream);
 }
 
 extern "C" int hrp_linear_bwd_weight(const float* x, int x_pitch, const float* dy, int dy_pitch, float* dw, float* dbias, int M, int K,

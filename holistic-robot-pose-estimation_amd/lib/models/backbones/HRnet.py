@@ -38,6 +38,11 @@ class Conv2d(SingleTensorModule):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def emit(self, pb, x, want_stats=False):
+        if (self.kernel_size == 1 and self.stride == 1 and not want_stats and x.H == 1 and x.W == 1 and x.dtype == torch.float32
+                and not os.environ.get("HRP_LINEAR_AS_CONV")):
+            # a 1x1 conv on pooled fp32 features is nn.Linear (depth_layer, depth_net.py:121-123 / full_net.py:271-274): the skinny
+            # GEMM kernels with their ordered reduction instead of the conv path's split-K atomics
+            return pb.linear(x, self.weight, self.bias)
         return pb.conv(x, self.weight, self.bias, stride=self.stride, want_stats=want_stats)
 
     def extra_repr(self):

@@ -479,8 +479,8 @@ class Plan:
     # ---- finalisation -----------------------------------------------------------------------------
     def finalize(self):
         dev = self.device
-        self.stats = torch.zeros(max(self.stats_floats, 2), dtype=torch.float32, device=dev)
-        self.bsums = torch.zeros(max(self.bsums_floats, 2), dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(max(self.stats_floats, 2), dtype=torch.float64, device=dev)       # fp64 slots (include/hrp.h)
+        self.bsums = torch.zeros(max(self.bsums_floats, 2), dtype=torch.float64, device=dev)
         # packed weights: separate arenas per element type.  Training plans with parallel blocks pack in two parts:
         # the weights of the first block (stem, layer1) on the main stream, the rest (99 % of the bytes) on a side
         # stream that the forward list joins right after that block - the 0.7 ms gather runs under the stem instead of
@@ -858,7 +858,7 @@ class Plan:
         if self.bn_train:
             ents = []
             for bn, off, count in self.bn_train:
-                ents.append(dict(stats=self.stats.data_ptr() + 4 * off, a=bn.running_mean.data_ptr(),
+                ents.append(dict(stats=self.stats.data_ptr() + 8 * off, a=bn.running_mean.data_ptr(),
                                  b=bn.running_var.data_ptr(), counter=bn.num_batches_tracked.data_ptr(),
                                  C=bn.num_features, count=float(count), momentum=bn.momentum, eps=bn.eps))
             self._run_tab = self._table(ents)
@@ -872,7 +872,7 @@ class Plan:
         if self.bn_bwd:
             ents = []
             for bn, off in self.bn_bwd:
-                ents.append(dict(stats=self.bsums.data_ptr() + 4 * off, a=self.grad_of_param(bn.weight).data_ptr(),
+                ents.append(dict(stats=self.bsums.data_ptr() + 8 * off, a=self.grad_of_param(bn.weight).data_ptr(),
                                  b=self.grad_of_param(bn.bias).data_ptr(), C=bn.num_features, accumulate=0))
             self._pgrad_tab = self._table(ents)
 
@@ -1207,7 +1207,7 @@ class PlanBuilder:
         def late():
             d.w = w.arena.data_ptr() + w.fwd_off * esz
             if y.stats is not None:
-                d.stats = p.stats.data_ptr() + 4 * y.stats
+                d.stats = p.stats.data_ptr() + 8 * y.stats
         p.late(late)
         p.fwd.append(Launch("conv", d))
         y.producer = ("conv", d)
@@ -1302,7 +1302,7 @@ class PlanBuilder:
             def late(d=d):
                 d.w = w.arena.data_ptr() + w.bwd_off * esz
                 if y.stats is not None:
-                    d.stats = p.stats.data_ptr() + 4 * y.stats
+                    d.stats = p.stats.data_ptr() + 8 * y.stats
             p.late(late)
             p.fwd.append(Launch("conv", d))
         if p.need_grad:
@@ -1423,7 +1423,7 @@ class PlanBuilder:
         def late():
             d.w = w.arena.data_ptr() + w.fwd_off * esz
             if y.stats is not None:
-                d.stats = p.stats.data_ptr() + 4 * y.stats
+                d.stats = p.stats.data_ptr() + 8 * y.stats
         p.late(late)
         p.fwd.append(Launch("conv", d))
         y.producer = ("conv", d)
@@ -1501,7 +1501,7 @@ class PlanBuilder:
 
         def late():
             d1.w, d2.w = w1.arena.data_ptr() + w1.fwd_off * esz, w2.arena.data_ptr() + w2.fwd_off * esz
-            d1.stats, d2.stats = p.stats.data_ptr() + 4 * y1.stats, p.stats.data_ptr() + 4 * y2.stats
+            d1.stats, d2.stats = p.stats.data_ptr() + 8 * y1.stats, p.stats.data_ptr() + 8 * y2.stats
             d2.pro_stats = d1.stats
         p.late(late)
         p.fwd.append(Launch("conv", d1))
@@ -1589,12 +1589,12 @@ class PlanBuilder:
 
                 def late_b():
                     g2.w, g1.w = w2.arena.data_ptr() + w2.bwd_off * esz, w1.arena.data_ptr() + w1.bwd_off * esz
-                    g2.stats = p.bsums.data_ptr() + 4 * boff
-                    g2.bnb_stats = g1.pro_stats = p.stats.data_ptr() + 4 * y1.stats
+                    g2.stats = p.bsums.data_ptr() + 8 * boff
+                    g2.bnb_stats = g1.pro_stats = p.stats.data_ptr() + 8 * y1.stats
                     g1.pro_bsums = g2.stats
                     if fd is not None:
-                        sums2 = p.bsums.data_ptr() + 4 * boff2
-                        g2.pro_stats, g2.pro_bsums = p.stats.data_ptr() + 4 * y2.stats, sums2
+                        sums2 = p.bsums.data_ptr() + 8 * boff2
+                        g2.pro_stats, g2.pro_bsums = p.stats.data_ptr() + 8 * y2.stats, sums2
                         if isinstance(red, nv.ConvDesc):
                             red.stats, red.bnb_stats = sums2, g2.pro_stats
                         else:
@@ -1620,16 +1620,21 @@ class PlanBuilder:
         the PyTorch-shaped weight directly (hrp_linear_*; no packed copy, no split-K memset + conv launch)."""
         p = self.plan
         x.check_readable()
-        assert x.dtype == torch.float32 and x.H == 1 and x.W == 1 and weight.dim() == 2 and weight.shape[1] == x.C
+        assert x.dtype == torch.float32 and x.H == 1 and x.W == 1 and weight.shape[1] == x.C
+        assert weight.dim() == 2 or (weight.dim() == 4 and weight.shape[2] == weight.shape[3] == 1)     # (a 1x1 conv on pooled features)
         M, Kf, Nf = x.N, weight.shape[1], weight.shape[0]
         y = p.new(M, 1, 1, Nf, torch.float32)
         y.requires_grad = p.need_grad
         if residual is not None:
             residual.check_readable()
         bp = bias.data_ptr() if bias is not None else None
+        # workspace of the deterministic split reduction; forward and data gradient of one layer never overlap
+        wsb = int(nv.lib().hrp_linear_workspace_bytes(M, Kf, Nf))
+        ws = torch.zeros(wsb // 4 + 4, dtype=torch.float32, device=p.device)
+        p.keep.append(ws)
         p.fwd.append(lambda s: nv.call("hrp_linear_fwd", x.ptr(), x.pitch, weight.data_ptr(), bp,
                                        residual.ptr() if residual is not None else None, residual.pitch if residual is not None else 0,
-                                       y.ptr(), y.pitch, M, Kf, Nf, s))
+                                       y.ptr(), y.pitch, M, Kf, Nf, ws.data_ptr(), wsb, s))
         if p.need_grad:
             def bw():
                 if not y.grad_written:
@@ -1648,7 +1653,7 @@ class PlanBuilder:
                 if x.requires_grad:
                     acc = x.take_grad_slot()
                     p.bwd.append(lambda s: nv.call("hrp_linear_bwd_data", y.gptr(), y.pitch, weight.data_ptr(), x.gptr(), x.pitch,
-                                                   M, Kf, Nf, acc, s))
+                                                   M, Kf, Nf, acc, ws.data_ptr(), wsb, s))
             self.bwd_stack.append(bw)
         return y
 
@@ -1669,8 +1674,11 @@ class PlanBuilder:
         # bias gradient
         if bias is not None and bias.requires_grad:
             gb = p.grad_of_param(bias)
+            cwb = int(nv.lib().hrp_colsum_workspace_bytes(y.N * y.H * y.W, y.C))      # deterministic: partial sums folded in order
+            cws = torch.empty(cwb // 4 + 4, dtype=torch.float32, device=p.device)
+            p.keep.append(cws)
             p.bwd.append(lambda s: nv.call("hrp_colsum", y.gptr(), _dt(dtype), y.N * y.H * y.W, y.C, y.pitch,
-                                           gb.data_ptr(), 1 if p.grad_arena is not None else 0, s))
+                                           gb.data_ptr(), 1 if p.grad_arena is not None else 0, cws.data_ptr(), cwb, s))
         # weight gradient
         if w.param.requires_grad:
             g = nv.WgradDesc()
@@ -1793,7 +1801,7 @@ class PlanBuilder:
                 e.count, e.eps = float(tm.t.N * tm.t.H * tm.t.W), tm.bn.eps
                 p.bn_train.append((tm.bn, tm.t.stats, tm.t.N * tm.t.H * tm.t.W))
                 off = tm.t.stats
-                p.late(lambda e=e, off=off: setattr(e, "stats", p.stats.data_ptr() + 4 * off))
+                p.late(lambda e=e, off=off: setattr(e, "stats", p.stats.data_ptr() + 8 * off))
             else:
                 sc, sh = self._fold(tm.bn)
                 e.mode = nv.EW_AFFINE
@@ -1845,7 +1853,7 @@ class PlanBuilder:
             if tm.bn is not None:
                 off = p.alloc_bsums(fd.C)
                 p.bn_bwd.append((tm.bn, off))
-                p.late(lambda b=b, off=off: setattr(b, "sums", p.bsums.data_ptr() + 4 * off))
+                p.late(lambda b=b, off=off: setattr(b, "sums", p.bsums.data_ptr() + 8 * off))
                 p.bwd.append(Launch("ew_red", b))
             p.bwd.append(Launch("ew_app", b))
 

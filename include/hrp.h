@@ -62,10 +62,14 @@ typedef enum {
 
 #define HRP_MAX_TAPS 16
 
-/* Per-channel statistics (BN forward sum/sumsq, BN backward sums) are accumulated with fp32 atomics.
- * Same-address atomics serialise (~20 ns each on MI355X), so every statistics buffer has HRP_STAT_SLOTS
- * replicas laid out [slot][2*C]; a workgroup adds into slot (blockIdx & (SLOTS-1)) and readers sum the
- * slots.  The caller zeroes all slots before the producing launch. */
+/* Per-channel statistics (BN forward sum/sumsq, BN backward sums): every workgroup reduces its share in fp32 in a fixed order
+ * and adds ONE partial per channel with an fp64 atomic.  The order of those atomics varies from run to run; in fp64 the
+ * rounding of the total does not depend on it in practice (fp32 partials, < 2^11 of them per slot), so the fp32 constants
+ * every consumer derives - and with them every ReLU decision of a training step - repeat bit for bit.  (Round 2 used fp32
+ * atomics: the last bit of a sum moved between runs, a bf16 rounding then flipped and a ReLU mask with it: ~1 % run-to-run
+ * spread of bf16 gradients.)  Same-address atomics serialise (~20 ns each on MI355X), so every statistics buffer has
+ * HRP_STAT_SLOTS replicas laid out [slot][2*C] doubles; a workgroup adds into slot (blockIdx & (SLOTS-1)) and readers sum
+ * the slots.  The caller zeroes all slots before the producing launch. */
 #define HRP_STAT_SLOTS 8
 
 /* One convolution "problem": out[n, oy, ox, co] = sum_t sum_ci in[n, oy*IS+dy[t], ox*IS+dx[t], ci] * W[t][co][ci].
@@ -79,7 +83,7 @@ typedef struct hrp_conv_desc {
   const float* bias;   /* optional [Cout]                                                         */
   const float* scale;  /* optional per-channel affine applied after bias: v*scale+shift           */
   const float* shift;
-  float* stats;        /* optional [HRP_STAT_SLOTS][2*Cout]: += sum(y), sum(y*y) over output pixels */
+  double* stats;       /* optional [HRP_STAT_SLOTS][2*Cout]: += sum(y), sum(y*y) over output pixels */
   int32_t dtype;       /* hrp_dtype of x, w, y, res                                               */
   int32_t N, H, W, Cin, x_pitch;
   int32_t Ho, Wo, Cout; /* logical output grid walked by the kernel                               */
@@ -112,7 +116,7 @@ typedef struct hrp_conv_desc {
    * recomputed from bnb_x itself, mask = (bn(bnb_x) > 0) - the arithmetic the forward prologue (pro_mode 1) applied -, else
    * the bit mask is read ([pixels][C / 8] bytes).  `res` (== y: accumulate onto the other producers of the gradient) is
    * allowed here: the sums are taken over the final stored value. */
-  const float* bnb_stats;
+  const double* bnb_stats;
   const float* bnb_gamma;
   const float* bnb_beta;
   float bnb_count, bnb_eps;
@@ -127,8 +131,8 @@ typedef struct hrp_conv_desc {
    *               of the neighbouring layer reads (forward: the activation; backward: the BatchNorm input gradient). */
   int32_t pro_mode, pro_reserved;
   const void* pro_x2;
-  const float* pro_stats;
-  const float* pro_bsums;
+  const double* pro_stats;
+  const double* pro_bsums;
   const float* pro_gamma;
   const float* pro_beta;
   float pro_count, pro_eps;
@@ -208,7 +212,7 @@ typedef struct hrp_ew_input {
   int32_t mode;        /* hrp_ew_mode */
   const float* a;      /* AFFINE: scale[C]; BN_TRAIN: gamma[C] */
   const float* b;      /* AFFINE: shift[C]; BN_TRAIN: beta[C]  */
-  const float* stats;  /* BN_TRAIN: [HRP_STAT_SLOTS][2C] sum, sumsq of this input over its own pixels */
+  const double* stats; /* BN_TRAIN: [HRP_STAT_SLOTS][2C] sum, sumsq of this input over its own pixels */
   float count;         /* BN_TRAIN: number of pixels the statistics were taken over */
   float eps;
 } hrp_ew_input;
@@ -239,7 +243,7 @@ typedef struct hrp_ew_bwd_desc {
   hrp_ew_input in;     /* the forward input this call differentiates (ptr = forward input values) */
   void* din;           /* [N, H/up, W/up, din_pitch]; apply only */
   int32_t din_pitch;
-  float* sums;         /* [HRP_STAT_SLOTS][2C] */
+  double* sums;        /* [HRP_STAT_SLOTS][2C] */
   int32_t dtype;
   int32_t N, H, W, C;  /* geometry of out */
   int32_t relu;
@@ -253,7 +257,7 @@ typedef struct hrp_ew_bwd_desc {
 
 /* Table entry for the one-launch batch-norm bookkeeping kernels. */
 typedef struct hrp_bn_entry {
-  const float* stats;  /* [HRP_STAT_SLOTS][2C] forward sums (running_update) or backward sums (param_grad) */
+  const double* stats; /* [HRP_STAT_SLOTS][2C] forward sums (running_update) or backward sums (param_grad) */
   float* a;            /* running_update: running_mean | fold: gamma | param_grad: dgamma */
   float* b;            /* running_update: running_var  | fold: beta  | param_grad: dbeta  */
   const float* c;      /* fold: running_mean */
@@ -326,7 +330,11 @@ int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream);
 /* scratch bytes hrp_conv2d_bwd_weight wants for this problem (0 is never returned for a valid problem) */
 int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d);
 /* out[c] (+)= sum over rows of x[rows, pitch] (bias gradients) */
-int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* stream);
+/* workspace (hrp_colsum_workspace_bytes(rows, C) bytes, no initialisation; NULL: fp32 atomics, order-dependent last bits): the
+ * row groups' partial sums are parked there and added in a fixed order by a second small launch */
+int64_t hrp_colsum_workspace_bytes(int64_t rows, int C);
+int hrp_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int accumulate, void* workspace,
+               int64_t workspace_bytes, void* stream);
 
 /* ---- optimizer step of the training loop (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step, the pair
  * scripts/train_full.py:42 / lib/core/function.py use), table driven: one launch per pass for all parameters.
@@ -457,11 +465,16 @@ int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float*
  * w is the PyTorch-shaped parameter [N][K] itself (no packing), bias [N] / res [M, res_pitch] optional.
  *   fwd:        y[M,N]  = x[M,K] w^T + bias + res
  *   bwd_data:   dx[M,K] (+)= dy[M,N] w
- *   bwd_weight: dw[N,K] (+)= dy^T x ;  dbias[N] (+)= column sums of dy (dbias may be NULL) */
+ *   bwd_weight: dw[N,K] (+)= dy^T x ;  dbias[N] (+)= column sums of dy (dbias may be NULL)
+ * fwd / bwd_data split their reduction over workgroups.  workspace (hrp_linear_workspace_bytes(M, K, N) bytes, 16-byte aligned,
+ * no initialisation, used by one launch at a time): the partial sums are parked there and a second small launch adds them in
+ * a fixed order - the result is bit-reproducible.  workspace NULL: fp32 atomics into the (zeroed) output: the last bits
+ * depend on the arrival order and vary from run to run. */
+int64_t hrp_linear_workspace_bytes(int M, int K, int N);
 int hrp_linear_fwd(const float* x, int x_pitch, const float* w, const float* bias, const float* res, int res_pitch,
-                   float* y, int y_pitch, int M, int K, int N, void* stream);
+                   float* y, int y_pitch, int M, int K, int N, void* workspace, int64_t workspace_bytes, void* stream);
 int hrp_linear_bwd_data(const float* dy, int dy_pitch, const float* w, float* dx, int dx_pitch, int M, int K, int N,
-                        int accumulate, void* stream);
+                        int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 int hrp_linear_bwd_weight(const float* x, int x_pitch, const float* dy, int dy_pitch, float* dw, float* dbias, int M, int K,
                           int N, int accumulate, void* stream);
 

@@ -79,14 +79,14 @@ def test_pwconv_plain_statistics_and_eval_epilogue(shape):
     wp, _ = pack1(nv, w)
     xd = nhwc(x)
     y = torch.zeros(N * H * W * cout, dtype=torch.bfloat16, device=DEV)
-    st = torch.zeros(SLOTS * 2 * cout, device=DEV)
+    st = torch.zeros(SLOTS * 2 * cout, dtype=torch.float64, device=DEV)
     d = desc1(nv, xd, wp, y, N, H, W, cin, cout)
     d.stats = st.data_ptr()
     run(nv, d)
     ref = torch.nn.functional.conv2d(x.double(), w.double()).float()
     got = from_nhwc(y, N, H, W, cout)
     assert rel(got, ref) < 2e-2, rel(got, ref)
-    s = st.view(SLOTS, 2 * cout).sum(0).cpu()
+    s = st.view(SLOTS, 2 * cout).sum(0).float().cpu()
     want = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
     assert rel(s, want) < 2e-3, rel(s, want)
     # the tile program on the same problem
@@ -108,7 +108,7 @@ def test_pwconv_plain_statistics_and_eval_epilogue(shape):
     ref2 = torch.relu(ref * sc[None, :, None, None] + sh[None, :, None, None] + r)
     got = from_nhwc(y, N, H, W, cout)
     assert rel(got, ref2) < 2e-2, rel(got, ref2)
-    s = st.view(SLOTS, 2 * cout).sum(0).cpu()
+    s = st.view(SLOTS, 2 * cout).sum(0).float().cpu()
     want = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
     assert rel(s, want) < 2e-3, rel(s, want)
 
@@ -153,7 +153,7 @@ def test_pwconv_bn_backward_reduce_epilogue(shape, form):
     _, wpt = pack1(nv, w)
     dyd, x1d = nhwc(dy), nhwc(x1)
     y = torch.zeros(N * H * W * cout, dtype=torch.bfloat16, device=DEV)
-    bs = torch.zeros(SLOTS * 2 * cout, device=DEV)
+    bs = torch.zeros(SLOTS * 2 * cout, dtype=torch.float64, device=DEV)
     keep = []
     d = desc1(nv, dyd, wpt, y, N, H, W, cin, cout)
     d.stats, d.bnb_x, d.bnb_x_pitch = bs.data_ptr(), x1d.data_ptr(), cout
@@ -183,7 +183,7 @@ def test_pwconv_bn_backward_reduce_epilogue(shape, form):
     gm = got * on * sure
     xh = (x1 - m[None, :, None, None]) * inv[None, :, None, None]
     want = torch.cat([gm.sum((0, 2, 3)), (gm * xh).sum((0, 2, 3))])
-    s = bs.view(SLOTS, 2 * cout).sum(0).cpu()
+    s = bs.view(SLOTS, 2 * cout).sum(0).float().cpu()
     unsure = (got * (~sure)).abs().sum((0, 2, 3))
     err = (s - want).abs()
     bound = 2e-3 * want.abs().max() + torch.cat([unsure, unsure * xh.abs().max()])

@@ -55,7 +55,7 @@ def test_batched_conv_equals_single_launches(dtype, N):
         ys, sts = [], []
         for d in descs:
             y = torch.full((d.N * d.Ho * d.Wo * d.Cout,), 7.0, device=DEV).to(dtype)
-            st = torch.zeros(16 * d.Cout, device=DEV)
+            st = torch.zeros(16 * d.Cout, dtype=torch.float64, device=DEV)
             d.y, d.stats = y.data_ptr(), st.data_ptr()
             ys.append(y)
             sts.append(st)
@@ -125,7 +125,7 @@ def test_conv_epilogue_bn_backward_reduce(dtype, batched):
         consts = torch.cat([torch.randn(cout, generator=g) * 0.3, torch.rand(cout, generator=g) + 0.5]).to(DEV)
         y0 = torch.zeros(npx * cout, device=DEV).to(dtype)
         y1 = torch.zeros(npx * cout, device=DEV).to(dtype)
-        sums = torch.zeros(8 * 2 * cout, device=DEV)
+        sums = torch.zeros(8 * 2 * cout, dtype=torch.float64, device=DEV)
         probs.append((d, keep, bx, mask, consts, y0, y1, sums, cout))
     plain, fused = [], []
     for d, keep, bx, mask, consts, y0, y1, sums, cout in probs:
@@ -538,25 +538,35 @@ def test_fused_pose_loss_matches_tensor_expressions(damped):
         assert torch.allclose(a.grad, b.grad, rtol=2e-5, atol=2e-7 * float(b.grad.abs().max())), i
 
 
+@pytest.mark.parametrize("det", [False, True])
 @pytest.mark.parametrize("M,K,N", [(64, 2056, 1024), (64, 1024, 8), (5, 2054, 1024), (130, 1024, 6), (64, 1024, 1024)])
-def test_linear_kernels_match_torch(M, K, N):
+def test_linear_kernels_match_torch(M, K, N, det):
     """hrp_linear_fwd / _bwd_data / _bwd_weight (nn.Linear of the regression heads, full_net.py:95-100) against torch in
-    fp64; padded pitches, residual, accumulate into existing gradients."""
+    fp64; padded pitches, residual, accumulate into existing gradients.  det: with the workspace of the deterministic split
+    reduction (what the plans pass) - the same launch twice gives the same bits; without: fp32 atomics."""
     from hrpe_amd import _native as nv
+    wsb = int(nv.lib().hrp_linear_workspace_bytes(M, K, N)) if det else 0
+    ws = torch.zeros(wsb // 4 + 4, device=DEV) if det else None
+    wsp = ws.data_ptr() if det else None
     g = torch.Generator(device="cpu").manual_seed(M + K + N)
     x = torch.randn(M, K + 3, generator=g).to(DEV)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
     b = torch.randn(N, generator=g).to(DEV)
     res = torch.randn(M, N + 5, generator=g).to(DEV)
     y = torch.full((M, N + 2), 9.0, device=DEV)
-    nv.call("hrp_linear_fwd", x.data_ptr(), K + 3, w.data_ptr(), b.data_ptr(), res.data_ptr(), N + 5, y.data_ptr(), N + 2, M, K, N, None)
+    nv.call("hrp_linear_fwd", x.data_ptr(), K + 3, w.data_ptr(), b.data_ptr(), res.data_ptr(), N + 5, y.data_ptr(), N + 2, M, K, N, wsp, wsb, None)
+    if det:
+        y2 = torch.full((M, N + 2), 9.0, device=DEV)
+        for _ in range(3):
+            nv.call("hrp_linear_fwd", x.data_ptr(), K + 3, w.data_ptr(), b.data_ptr(), res.data_ptr(), N + 5, y2.data_ptr(), N + 2, M, K, N, wsp, wsb, None)
+            assert torch.equal(y, y2)
     want = (x[:, :K].double() @ w.double().t() + b.double() + res[:, :N].double())
     assert torch.allclose(y[:, :N].double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
     assert float((y[:, N:] - 9.0).abs().max()) == 0.0, "columns beyond N are not touched"
     dy = torch.randn(M, N + 2, generator=g).to(DEV)
     for acc in (0, 1):
         dx = torch.full((M, K + 3), 0.5, device=DEV)
-        nv.call("hrp_linear_bwd_data", dy.data_ptr(), N + 2, w.data_ptr(), dx.data_ptr(), K + 3, M, K, N, acc, None)
+        nv.call("hrp_linear_bwd_data", dy.data_ptr(), N + 2, w.data_ptr(), dx.data_ptr(), K + 3, M, K, N, acc, wsp, wsb, None)
         want = dy[:, :N].double() @ w.double() + (0.5 if acc else 0.0)
         assert torch.allclose(dx[:, :K].double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max())), acc
         assert float((dx[:, K:] - 0.5).abs().max()) == 0.0

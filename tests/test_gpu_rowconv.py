@@ -77,7 +77,7 @@ def slots_of(total, g):
     """Split per-channel totals [2C] over the 8 statistic slots at random (the kernel must add the slots)."""
     r = torch.rand(SLOTS, total.numel(), generator=g)
     r = r / r.sum(0, keepdim=True)
-    return (r * total[None]).float().contiguous().to(DEV)
+    return (r * total[None]).double().contiguous().to(DEV)       # statistic slots are fp64 (include/hrp.h)
 
 
 def bn_consts(x, gamma, beta):
@@ -111,7 +111,7 @@ def test_rowconv_plain_and_eval_epilogue(shape):
     wp, _ = pack(nv, w)
     xd = nhwc(x)
     y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
-    st = torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    st = torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
     d = desc(nv, xd, wp, y, N, H, W, Cc)
     d.stats = st.data_ptr()
     assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
@@ -120,7 +120,7 @@ def test_rowconv_plain_and_eval_epilogue(shape):
     ref = F.conv2d(x.double(), w.double(), padding=1).float()
     got = from_nhwc(y, N, H, W, Cc)
     assert rel(got, ref) < 2e-2, rel(got, ref)
-    s = st.view(SLOTS, 2 * Cc).sum(0).cpu()
+    s = st.view(SLOTS, 2 * Cc).sum(0).float().cpu()
     own = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
     assert rel(s, own) < 2e-3, rel(s, own)
     # eval-mode epilogue: folded BatchNorm affine + residual + ReLU (HRnet.py:52-56 in an inference plan)
@@ -153,7 +153,7 @@ def test_rowconv_bn_relu_prologue(shape):
     xd = nhwc(x)
     y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
     side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
-    st_in, st = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    st_in, st = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
     d = desc(nv, xd, wp, y, N, H, W, Cc)
     d.stats = st.data_ptr()
@@ -166,7 +166,7 @@ def test_rowconv_bn_relu_prologue(shape):
     assert rel(gside, a) < 1e-2, rel(gside, a)           # (one bf16 ulp where the fp32 affine rounds the other way)
     assert ((gside > 0) != (a > 0)).float().mean().item() < 1e-4
     assert rel(got, ref) < 2e-2, rel(got, ref)
-    s = st.view(SLOTS, 2 * Cc).sum(0).cpu()
+    s = st.view(SLOTS, 2 * Cc).sum(0).float().cpu()
     own = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
     assert rel(s, own) < 2e-3, rel(s, own)
 
@@ -187,7 +187,7 @@ def test_rowconv_bn_backward_reduce_epilogue(shape):
     _, wpt = pack(nv, w)
     dyd, x1d = nhwc(dy), nhwc(x1)
     y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
-    st_in, bs = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    st_in, bs = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
     d = desc(nv, dyd, wpt, y, N, H, W, Cc, transposed=True)
     d.stats, d.bnb_x, d.bnb_x_pitch = bs.data_ptr(), x1d.data_ptr(), Cc
@@ -203,7 +203,7 @@ def test_rowconv_bn_backward_reduce_epilogue(shape):
     gm = got * (act > 0) * sure
     xh = (x1 - m[None, :, None, None]) * inv[None, :, None, None]
     want = torch.cat([gm.sum((0, 2, 3)), (gm * xh).sum((0, 2, 3))])
-    s = bs.view(SLOTS, 2 * Cc).sum(0).cpu()
+    s = bs.view(SLOTS, 2 * Cc).sum(0).float().cpu()
     unsure = (got * (~sure)).abs().sum((0, 2, 3))
     err = (s - want).abs()
     bound = 2e-3 * want.abs().max() + torch.cat([unsure, unsure * xh.abs().max()])
@@ -300,7 +300,7 @@ def test_rowconv_block_end_apply_prologue(shape, acc2):
     side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
     side2 = nhwc(prev2) if acc2 else torch.full((N * H * W * Cc,), 5.0, dtype=torch.bfloat16, device=DEV)
     mk = mask_bits(on)
-    st2, bs2, st1, bs1 = slots_of(tot, g), slots_of(bt, g), slots_of(tot1, g), torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    st2, bs2, st1, bs1 = slots_of(tot, g), slots_of(bt, g), slots_of(tot1, g), torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
     gd, bd, gd1, bd1 = gamma.to(DEV), beta.to(DEV), gamma1.to(DEV), beta1.to(DEV)
     d = desc(nv, god, wpt, y, N, H, W, Cc, transposed=True)
     d.pro_mode, d.pro_x2, d.pro_stats, d.pro_bsums = 2, y2d.data_ptr(), st2.data_ptr(), bs2.data_ptr()
@@ -321,7 +321,7 @@ def test_rowconv_block_end_apply_prologue(shape, acc2):
     g1m = got * (act1 > 0) * sure
     xh1 = (y1 - m1[None, :, None, None]) * inv1[None, :, None, None]
     want = torch.cat([g1m.sum((0, 2, 3)), (g1m * xh1).sum((0, 2, 3))])
-    sres = bs1.view(SLOTS, 2 * Cc).sum(0).cpu()
+    sres = bs1.view(SLOTS, 2 * Cc).sum(0).float().cpu()
     unsure = (got * (~sure)).abs().sum((0, 2, 3))
     err = (sres - want).abs()
     bound = 2e-3 * want.abs().max() + torch.cat([unsure, unsure * xh1.abs().max()])
@@ -364,7 +364,7 @@ def test_rowconv_block_end_reduce_epilogue(shape, masked):
     gad, x1d, y, ypd = nhwc(ga), nhwc(x1), nhwc(prev), nhwc(yp)
     side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
     mk = mask_bits(onp)
-    st_in, bs_in, stp, bsp = slots_of(tot, g), slots_of(bt, g), slots_of(totp, g), torch.zeros(SLOTS * 2 * Cc, device=DEV)
+    st_in, bs_in, stp, bsp = slots_of(tot, g), slots_of(bt, g), slots_of(totp, g), torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
     gd, bd, gdp, bdp = gamma.to(DEV), beta.to(DEV), gammap.to(DEV), betap.to(DEV)
     d = desc(nv, gad, wpt, y, N, H, W, Cc, transposed=True)
     d.res = y.data_ptr()
@@ -384,7 +384,7 @@ def test_rowconv_block_end_reduce_epilogue(shape, masked):
     gpm = got * onp
     xhp = (yp - mp[None, :, None, None]) * invp[None, :, None, None]
     want = torch.cat([gpm.sum((0, 2, 3)), (gpm * xhp).sum((0, 2, 3))])
-    sres = bsp.view(SLOTS, 2 * Cc).sum(0).cpu()
+    sres = bsp.view(SLOTS, 2 * Cc).sum(0).float().cpu()
     err = (sres - want).abs()
     assert (err <= 2e-3 * want.abs().max()).all(), (err / want.abs().max()).max()
 
@@ -400,7 +400,7 @@ def test_rowconv_in_a_batched_launch_equals_single_launches():
         x = nhwc(bf(torch.randn(N, Cc, H, W, generator=g)))
         wp, _ = pack(nv, bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc)))
         y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
-        st = torch.zeros(SLOTS * 2 * Cc, device=DEV)
+        st = torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
         d = desc(nv, x, wp, y, N, H, W, Cc)
         d.stats = st.data_ptr()
         keep += [x, wp, st]

@@ -29,7 +29,7 @@ def mk_conv(N, hw, c, dtype, stats=True, k=3):
     w = torch.randn(c, c, k, k, device=DEV) / (c * k * k) ** 0.5
     wp, _ = bk.pack(w, dtype)
     y = torch.zeros(N * hw * hw * c, dtype=dtype, device=DEV)
-    st = torch.zeros(16 * c, device=DEV)
+    st = torch.zeros(16 * c, dtype=torch.float64, device=DEV)
     d = nv.ConvDesc()
     d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     d.dtype = nv.HRP_BF16
@@ -51,10 +51,10 @@ def mk_conv(N, hw, c, dtype, stats=True, k=3):
         # (epilogue reduce), "g1" conv1 data gradient (apply prologue + residual), "g2e" / "g1e" with the block-end backward
         n = N * hw * hw * c
         t = lambda: torch.randn(n, device=DEV).to(dtype)     # noqa: E731
-        sts = torch.rand(16 * c, device=DEV) * 100 + 50
+        sts = torch.rand(16 * c, dtype=torch.float64, device=DEV) * 100 + 50
         sts[8 * c:] += 1e5
         gam, bet = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
-        bs = torch.zeros(16 * c, device=DEV)
+        bs = torch.zeros(16 * c, dtype=torch.float64, device=DEV)
         x2, side, side2, x3 = t(), t(), t(), t()
         mask = torch.randint(0, 255, (n // 8,), dtype=torch.uint8, device=DEV)
         bufs += [sts, gam, bet, bs, x2, side, side2, x3, mask]

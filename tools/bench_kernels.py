@@ -67,7 +67,7 @@ def conv_case(N, H, W, cin, cout, k, stride, dtype, stats):
     w = torch.randn(cout, cin, k, k, device=DEV) / (cin * k * k) ** 0.5
     wp, wpt = pack(w, dtype)
     y = torch.zeros(N * Ho * Wo * rup(cout, 8), dtype=dtype, device=DEV)
-    st = torch.zeros(16 * cout, device=DEV)
+    st = torch.zeros(16 * cout, dtype=torch.float64, device=DEV)
     d = nv.ConvDesc()
     d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     d.dtype = nv.HRP_BF16 if esz == 2 else nv.HRP_F32
@@ -140,7 +140,7 @@ def ew_case(N, H, W, Cc, dtype):
     a = torch.randn(N * H * W * Cc, device=DEV).to(dtype)
     b = torch.randn(N * H * W * Cc, device=DEV).to(dtype)
     out = torch.zeros_like(a)
-    st = torch.rand(16 * Cc, device=DEV) + 1.0
+    st = torch.rand(16 * Cc, dtype=torch.float64, device=DEV) + 1.0      # statistic slots are fp64
     gam, bet = torch.ones(Cc, device=DEV), torch.zeros(Cc, device=DEV)
     d = nv.EwDesc()
     d.nin, d.out, d.out_pitch, d.dtype = 2, out.data_ptr(), Cc, nv.HRP_BF16 if esz == 2 else nv.HRP_F32
@@ -155,7 +155,7 @@ def ew_case(N, H, W, Cc, dtype):
     print(f"ew_fwd (bn+res+relu) N={N} C={Cc:4d} @{H:3d}x{W:<3d}: {us:8.1f} us  {by / us / 1e3:7.1f} GB/s")
     bd = nv.EwBwdDesc()
     din = torch.zeros_like(a)
-    sums = torch.zeros(16 * Cc, device=DEV)
+    sums = torch.zeros(16 * Cc, dtype=torch.float64, device=DEV)
     bd.dout, bd.out, bd.dout_pitch, bd.out_pitch = b.data_ptr(), out.data_ptr(), Cc, Cc
     for f, _ in nv.EwInput._fields_:
         setattr(bd.inp, f, getattr(d.inp[0], f))

@@ -21,7 +21,7 @@ def mk(N, hw, cin, cout, kind):
     w = torch.randn(cout, cin, 1, 1, device=DEV) / cin ** 0.5
     wp, _ = bk.pack(w, torch.bfloat16)
     y = torch.zeros(M * cout, dtype=torch.bfloat16, device=DEV)
-    st = torch.zeros(16 * cout, device=DEV)
+    st = torch.zeros(16 * cout, dtype=torch.float64, device=DEV)
     d = nv.ConvDesc()
     d.x, d.w, d.y, d.dtype = x.data_ptr(), wp.data_ptr(), y.data_ptr(), nv.HRP_BF16
     d.N, d.H, d.W, d.Cin, d.x_pitch = N, hw, hw, cin, cin

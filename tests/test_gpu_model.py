@@ -38,16 +38,14 @@ def summary_check(t, g, key, rtol, atol_frac=1e-4, what=""):
         # mathematically zero gradient (bias of a conv that feeds a train-mode BatchNorm): only rounding noise
         assert np.abs(got).max() < 1e-6, f"{what}{key}: expected ~0, got {np.abs(got).max():.3e}"
         return
-    # L2 error of the 256 samples against rtol, elements against 3 * rtol (atomics make the summation order - and with it
-    # the noise the tiny-batch BN backward amplifies - vary run to run).  At most 2 % of the samples may lie beyond that:
-    # once in ~16 runs a ReLU / max-pool tie of the B = 2 step falls the other way than in the reference and moves a
-    # few elements of one layer's gradient by 10 % of its scale (measured on layer3.2.conv2 of the ResNet-50 trunk:
-    # typical l2 6e-3 / worst 7e-3, the tie run l2 2.4e-2 / worst 1.0e-1).
+    # L2 error of the 256 samples against rtol, every element against 3 * rtol.  (Round 2 allowed 2 % of the samples beyond that
+    # and 10 * rtol for the worst one: the statistic sums were fp32 atomics, their order moved the last bit from run to run
+    # and with it ReLU / max-pool ties of the B = 2 step.  The step is bit-reproducible now - fp64 statistic slots, ordered
+    # split reductions - so the measured value is ONE number per gate and the allowance is gone.)
     err = np.linalg.norm(got - val) / (np.linalg.norm(val) + 1e-30)
     dev = np.abs(got - val) / scale
-    worst, beyond = dev.max(), float((dev >= 3 * rtol).mean())
-    assert err < rtol and beyond <= 0.02 and worst < 10 * rtol, \
-        f"{what}{key}: l2 err {err:.3e} worst {worst:.3e} beyond {beyond:.3f} (scale {scale:.3e})"
+    worst = dev.max()
+    assert err < rtol and worst < 3 * rtol, f"{what}{key}: l2 err {err:.3e} worst {worst:.3e} (scale {scale:.3e})"
     assert abs(f.abs().mean().item() - s[1]) <= rtol * abs(s[1]) + 1e-30, f"{what}{key}: abs-mean"
 
 

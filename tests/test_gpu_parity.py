@@ -19,16 +19,20 @@ from synth import synth_inputs
 from test_gpu_model import DEV, NAMES8, build_full, load, summary_check
 
 pytestmark = pytest.mark.gpu
-GRAD_TOL_B8 = 2.5e-2
-# Measured on MI355X (round 2) with the bf16 trunk against the reference's fp32 fixtures / the fp32 HIP path; the bounds are
-# ~3x the measurement.  Eval mode (running statistics) is tight.  Train mode normalises with the statistics of 8 (or 64)
+GRAD_TOL_B8 = 1.5e-2         # fp32 gradients at B = 8: measured 7.5e-3 at most (round 2 gated 2.5e-2 on a noisy quantity)
+# Measured on MI355X with the bf16 trunk against the reference's fp32 fixtures / the fp32 HIP path.  The step is
+# bit-reproducible since round 3 (every gate sees ONE value, not a distribution), so the bounds are 2x the measurement
+# (round 2: ~3x of the worst of several runs: uvd 0.6, root_uv 0.12, cosine 0.6).  Eval mode (running statistics) is tight.  Train mode normalises with the statistics of 8 (or 64)
 # images of a randomly weighted 330-layer network: the soft-argmax over 262 144 nearly flat heat-map bins turns bf16
 # rounding of the logits into visible uvd shifts, and gradients stored in bf16 lose the cancelling terms of the
 # BatchNorm backward (g - mean(g) - xhat * mean(g * xhat)) - the heads' gradients stay within 10 %, the trunk's keep
 # their direction (cosine), which is what the bounds below hold them to.
-BF16_EVAL_TOL = {"pose": 1e-3, "rot": 2e-3, "trans": 5e-4, "root_uv": 1.5e-3, "depth": 5e-4, "uvd": 1.5e-2, "xyz_int": 8e-3, "xyz_fk": 2e-3}
-BF16_TRAIN_TOL = {"pose": 8e-3, "rot": 1.5e-2, "trans": 4e-2, "root_uv": 0.12, "depth": 1.5e-2, "uvd": 0.6, "xyz_int": 8e-2, "xyz_fk": 4e-2}
-BF16_B64_TOL = {"pose": 1.2e-2, "rot": 2e-2, "trans": 9e-2, "root_uv": 0.25, "depth": 3.5e-2, "uvd": 0.7, "xyz_int": 0.25, "xyz_fk": 9e-2}
+# measured eval:  pose 2.6e-4 rot 6.6e-4 trans 2.7e-4 root_uv 9.4e-4 depth 2.2e-4 uvd 4.9e-3 xyz_int 2.5e-3 xyz_fk 5.5e-4
+BF16_EVAL_TOL = {"pose": 5e-4, "rot": 1.3e-3, "trans": 5e-4, "root_uv": 1.5e-3, "depth": 4e-4, "uvd": 1e-2, "xyz_int": 5e-3, "xyz_fk": 1.1e-3}
+# measured B = 8: pose 1.9e-3 rot 4.0e-3 trans 1.0e-2 root_uv 3.3e-2 depth 2.0e-3 uvd 0.151 xyz_int 2.4e-2 xyz_fk 1.0e-2
+BF16_TRAIN_TOL = {"pose": 4e-3, "rot": 8e-3, "trans": 2e-2, "root_uv": 6.5e-2, "depth": 4e-3, "uvd": 0.3, "xyz_int": 5e-2, "xyz_fk": 2e-2}
+# measured B = 64: pose 3.0e-3 rot 5.6e-3 trans 4.5e-2 root_uv 9.5e-2 depth 8.7e-3 uvd 0.25 xyz_int 6.2e-2 xyz_fk 4.5e-2
+BF16_B64_TOL = {"pose": 6e-3, "rot": 1.1e-2, "trans": 9e-2, "root_uv": 0.19, "depth": 1.8e-2, "uvd": 0.5, "xyz_int": 0.125, "xyz_fk": 9e-2}
 HEADS = ("fc_pose", "fc_rot", "decpose", "decrot", "depth_layer")
 
 
@@ -39,7 +43,7 @@ def _check_bf16_grads(l2, cos, what):
         elif "final_layer" in n:
             assert cos[n] > 0.95, f"{what} {n}: cosine {cos[n]}"
         else:
-            assert cos[n] > 0.6, f"{what} {n}: cosine {cos[n]}"
+            assert cos[n] > 0.65, f"{what} {n}: cosine {cos[n]}"      # (measured minimum 0.70: a BatchNorm weight of the depth trunk at B = 64)
 
 
 def _train_step_inputs(g, m, B):

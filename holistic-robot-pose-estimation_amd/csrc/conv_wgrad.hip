@@ -50,8 +50,31 @@ struct WgradTiling {
   int x_pieces, dy_pieces, buf_bytes;   // 1 KiB DMA pieces of the X halo tile / dY tile; one stage buffer
   int lds_tab_off, lds_red_off;
   int use_ws, lds_bytes;
+  // batched launch: workgroup -> (pixel share, channel-block pair) so that the workgroups which read the same 32-channel
+  // slices of x / dY sit on ONE XCD (its L2 serves the re-reads).  xmode 1: >= 8 pairs - XCD k owns an xa x xb block of
+  // (cout, cin) blocks for every pixel share; xmode 2: 1 / 2 / 4 pairs - XCD k owns whole pixel shares; 0: pair-major.
+  int xmode, xa, xb, xnb;
   FastDiv fd_ihw, fd_iwt, fd_thw, fd_tw, fd_tx, fd_ty, fd_cib, fd_g;
 };
+
+// Workgroup ids go round-robin over the 8 XCDs; a weight-gradient workgroup reads the cin slice `cib` of x and the cout
+// slice `cob` of dY for its pixel share, so with pair-major numbering every slice is fetched from HBM by n_cob (n_cib)
+// different L2s: 28.4 GB per step against 18.5 GB of operands (profiles/r03_traffic.json).
+__device__ __forceinline__ void wgrad_block_of(const WgradTiling& t, const int local, int& gxi, int& blk) {
+  if (t.xmode == 1) {
+    const int j = local >> 3, xk = local & 7, ppx = t.xa * t.xb;
+    gxi = j / ppx;
+    const int r = j - gxi * ppx, ka = xk / t.xnb, kb = xk - ka * t.xnb;
+    blk = (ka * t.xa + r / t.xb) * t.n_cib + kb * t.xb + r % t.xb;
+  } else if (t.xmode == 2) {
+    const int j = local >> 3, xk = local & 7, pairs = t.n_cob * t.n_cib, q = j / pairs;
+    gxi = q * 8 + xk;
+    blk = j - q * pairs;
+  } else {
+    blk = fdiv(local, t.fd_g);        // consecutive workgroups = the pixel shares of one (cout, cin) pair
+    gxi = local - blk * t.G;
+  }
+}
 
 template <typename T>
 struct WG;
@@ -531,6 +554,30 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
   int G = (wg_budget > 0 ? wg_budget : wg_total) / pairs;
   if (G < 1) G = 1;
   if (G > t.ntiles) G = t.ntiles;
+  t.xmode = 0; t.xa = t.xb = t.xnb = 1;
+  static const bool no_xcd = getenv("HRP_NO_WGRAD_XCD") != nullptr;
+  // tuning knob: bit 0 mode 1, bit 1 mode 2.  Measured (PMC FETCH_SIZE of the weight-gradient launches of one step, B = 64):
+  // pair-major 27.1 GB, mode 2 only 22.1 GB, mode 1 only 28.5 GB, both 23.5 GB; kernel time one by one 8.31 / 8.75 / 8.38 /
+  // 8.78 ms; step time the same within 0.1 ms -> mode 2 (the 2 x 2 blocks of the 64-channel layers share an L2)
+  static const int xmask = getenv("HRP_WGRAD_XCD_MODES") ? atoi(getenv("HRP_WGRAD_XCD_MODES")) : 2;
+  if (wg_budget > 0 && !no_xcd) {          // batched launches (1-D grid): XCD-aware numbering
+    if (pairs >= 8 && pairs % 8 == 0 && (xmask & 1)) {
+      // xa | n_cob, xb | n_cib, (n_cob / xa) * (n_cib / xb) == 8, xa + xb minimal (slices fetched per XCD)
+      int best = 1 << 30;
+      for (int a = 1; a <= t.n_cob; ++a) {
+        if (t.n_cob % a) continue;
+        const int na = t.n_cob / a;
+        if (8 % na) continue;
+        const int nb_ = 8 / na;
+        if (t.n_cib % nb_) continue;
+        const int b = t.n_cib / nb_;
+        if (a + b < best) { best = a + b; t.xa = a; t.xb = b; t.xnb = nb_; t.xmode = 1; }
+      }
+    } else if ((pairs == 1 || pairs == 2 || pairs == 4) && G >= 8 && (xmask & 2)) {
+      G -= G % 8;
+      t.xmode = 2;
+    }
+  }
   t.G = G;
   t.fd_g = make_fastdiv(G);
   t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
@@ -619,8 +666,8 @@ __global__ __launch_bounds__(256) WGRAD_OCC void wgrad_batch_kernel(const WgradP
   const int g = batch_find(h, blockIdx.x, base);
   const WgradProblem& P = tab[g];
   const int local = (int)blockIdx.x - base;
-  const int blk = fdiv(local, P.t.fd_g);        // consecutive workgroups = the pixel shares of one (cout, cin) pair
-  const int gxi = local - blk * P.t.G;
+  int gxi, blk;
+  wgrad_block_of(P.t, local, gxi, blk);
   if constexpr (Elem<T>::SZ == 4) {
     conv_wgrad_body<T, NT, 0, 1>(P.d, P.t, gxi, blk);
   } else if constexpr (NT == 1) {

@@ -152,10 +152,12 @@ def wgrad_batch(N, nets, branches, dtype):
     arr = (nv.WgradDesc * len(descs))(*descs)
     info = nv.BatchInfo()
     nv.check(nv.lib().hrp_batch_prepare(nv.BATCH_WGRAD, arr, len(descs), None, C.byref(info)), "query")
+    wss = []
     for i, g in enumerate(descs):
-        ws = torch.zeros(info.ws_bytes[i] // 4 + 4, device=DEV)
+        ws = torch.zeros(info.ws_bytes[i] // 4 + 4 + ((1 << 18) if bk.TIMELINE else 0), device=DEV)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         keep.append(ws)
+        wss.append(ws)
     singles = []
     for g in descs[:branches]:
         g1 = nv.WgradDesc.from_buffer_copy(bytes(g))
@@ -166,6 +168,19 @@ def wgrad_batch(N, nets, branches, dtype):
     b = Batch("wgrad", descs)
     us = bk.timeit(b)
     fl = sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * 9 for d in descs)
+    if bk.TIMELINE:
+        for ws in wss:
+            ws.view(torch.int64)[-(1 << 17):].zero_()
+        b()
+        torch.cuda.synchronize()
+        names = ["entry", "setup", "issued", "t0 ready", "t0 done", "t1 ready", "t1 done", "t2 ready", "t2 done",
+                 "t3 ready", "t3 done", "loop end", "round1", "stored"]
+        tls = [ws.view(torch.int64)[-(1 << 17):].cpu().view(-1, 16).double() for ws in wss]
+        t0 = min(float(t[t[:, 0] > 0][:, 0].min()) for t in tls)
+        for i, t in enumerate(tls[:branches]):
+            t = t[t[:, 0] > 0]
+            print(f"   problem {i} ({t.shape[0]} workgroups; us after the first entry, mean/max): " +
+                  "  ".join(f"{n} {((t[:, k] - t0).mean() / 100):.2f}/{((t[:, k] - t0).max() / 100):.2f}" for k, n in enumerate(names) if t[:, k].max() > 0))
     print(f"wgrad batch{len(descs)} (nets {nets} x branches {branches}, B={N}): {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  "
           f"grid {b.info.grid}+{b.info.grid2} lds {b.info.lds_bytes}  | one by one: " + " ".join(f"{t:.1f}" for t in singles)
           + f" (sum x nets {sum(singles) * nets:.1f})")

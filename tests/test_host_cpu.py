@@ -550,6 +550,51 @@ def test_batch_prepare_is_host_only():
     assert info.grid <= 2 * 512 and info.grid2 > 0
 
 
+def test_kernel_choice_and_workspace_queries_are_host_only():
+    """Which kernel a convolution problem gets, and the workspace sizes of the ordered reductions, are host decisions that a
+    caller can query without a GPU: hrp_conv_rowstrip_channels (3x3 C -> C layers with 4 KiB rows and their fused-BatchNorm
+    fields), hrp_conv_pointwise (dense 1x1 layers above a pixel threshold), hrp_linear_workspace_bytes,
+    hrp_colsum_workspace_bytes."""
+    lib = nv.lib()
+    # row-strip: the four branch shapes; fused fields are accepted there and nowhere else
+    for c, hw in ((32, 64), (64, 32), (128, 16), (256, 8)):
+        d = _fake_conv(0x400000, cin=c, cout=c, hw=hw)
+        assert lib.hrp_conv_rowstrip_channels(C.byref(d)) == c
+        d.res, d.res_mask = 0x600000, 0x700000                       # masked residual
+        assert lib.hrp_conv_rowstrip_channels(C.byref(d)) == c
+        d.relu = 1                                                     # ... not together with a ReLU epilogue
+        assert lib.hrp_conv_rowstrip_channels(C.byref(d)) == 0
+    d = _fake_conv(0x400000, cin=32, cout=32, hw=32)                  # 32 channels at 32 x 32: rows of 2 KiB -> tile program
+    assert lib.hrp_conv_rowstrip_channels(C.byref(d)) == 0
+    d = _fake_conv(0x400000, cin=64, cout=64, hw=32)
+    d.pro_mode, d.pro_x2 = 2, 0x800000                                # the backward prologue needs its statistics
+    assert lib.hrp_conv_rowstrip_channels(C.byref(d)) == 0
+    d.pro_stats, d.pro_bsums, d.pro_gamma, d.pro_beta = 0x900000, 0x910000, 0x920000, 0x930000
+    assert lib.hrp_conv_rowstrip_channels(C.byref(d)) == 64
+    # pointwise: 64 -> 256 at 64 x 64 x 32 images = 131 072 pixels is in, half of that is not (default threshold)
+    os.environ.pop("HRP_PW_MIN_PIXELS", None)
+    d = _fake_conv(0x400000, ntaps=1, cin=64, cout=256, hw=64)
+    d.N = 32
+    assert lib.hrp_conv_pointwise(C.byref(d)) == 1
+    d.N = 16
+    assert lib.hrp_conv_pointwise(C.byref(d)) == 0
+    d.N = 32
+    d.bias = 0x600000
+    assert lib.hrp_conv_pointwise(C.byref(d)) == 0
+    d.bias = None
+    d.Cin = d.x_pitch = 256                                            # 16 k-steps with an epilogue reduce: tile program
+    d.Cout = d.y_pitch = d.res_pitch = d.w_cout_pad = 64
+    assert lib.hrp_conv_pointwise(C.byref(d)) == 1
+    d.bnb_x, d.bnb_x_pitch, d.bnb_mask, d.bnb_mask_pitch, d.bnb_consts, d.stats = 0x600000, 64, 0x700000, 8, 0x800000, 0x900000
+    assert lib.hrp_conv_pointwise(C.byref(d)) == 0
+    # ordered reductions: partial tiles of the reduction splits, padded to whole 64 x 32 tiles; forward and data gradient share
+    assert lib.hrp_linear_workspace_bytes(64, 2056, 1024) == max(17 * 64 * 1024 * 4, 8 * 64 * 2080 * 4)
+    assert lib.hrp_linear_workspace_bytes(5, 100, 6) == 64 * 128 * 4        # one split each way: max(1 x 64 x 32, 1 x 64 x 128) floats
+    assert lib.hrp_linear_workspace_bytes(0, 8, 8) == 0
+    assert lib.hrp_colsum_workspace_bytes(262144, 448) == 512 * 448 * 4       # at most 512 row groups
+    assert lib.hrp_colsum_workspace_bytes(100, 32) == 2 * 32 * 4
+
+
 def test_resnet_full_net_state_dict_keys():
     """backbone_name='resnet50' (the shipped full.yaml): key names / shapes of the reference's RootNetwithRegInt
     (reg_backbone.* 318 entries, deconv_layers.* 18, final_layer.*)."""

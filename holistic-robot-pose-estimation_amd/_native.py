@@ -65,7 +65,7 @@ class WgradFoldDesc(C.Structure):
 
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p),
-                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ntaps", C.c_int32)]
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ntaps", C.c_int32), ("pad_t", C.c_int32)]
 
 
 class EwInput(C.Structure):

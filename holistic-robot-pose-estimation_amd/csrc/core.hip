@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
         const unsigned co = ch * CK + k;
         v[k] = (co < Cout && ci < Cin) ? e.src[((size_t)co * Cin + ci) * nt + tap] : 0.f;
       }
-      store_row(e.dst_t, (size_t)(ch * nt + tap) * cin_pad + ci, v);
+      store_row(e.dst_t, (size_t)(ch * (nt + e.pad_t) + tap) * cin_pad + ci, v);
     }
   }
 }

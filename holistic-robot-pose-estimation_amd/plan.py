@@ -108,6 +108,7 @@ class ParamW:
     def __init__(self, param, cout, cin, ntaps):
         self.param, self.cout, self.cin, self.ntaps = param, cout, cin, ntaps
         self.fwd_off = self.bwd_off = None
+        self.pad_t = 0      # extra (zero) tap slots per chunk of the transposed packing (hrp_pack_entry.pad_t)
         self.grad_written = False
         self.first_use = None    # index into Plan.fwd at (or before) the first launch that reads the packed copy
         self.src = None          # fp32 tensor packed instead of `param` (derived layouts, e.g. the 4x4 form of the stem)
@@ -146,6 +147,8 @@ WGRAD_FOLD_EVERY = int(os.environ.get("HRP_WGRAD_FOLD_EVERY", "32"))
 WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "8"))
 # train-mode BasicBlock interiors conv -> BN -> ReLU -> conv on the row-strip kernel (csrc/conv_row.h): the BatchNorm + ReLU
 # runs in the second convolution's staging path, its backward in the staging path of the first convolution's data gradient
+# stride-2 data gradients: parity classes padded to 4 taps (PlanBuilder._conv_bwd)
+PARITY_PAD = not os.environ.get("HRP_NO_PARITY_PAD")
 ROWCONV_FUSE = not os.environ.get("HRP_NO_ROWCONV_FUSE")
 # ... and the block-end activation's backward (apply pass into conv2's data gradient, reduce pass into the next block's)
 BLOCK_END_FUSE = not os.environ.get("HRP_NO_BLOCK_END_FUSE")
@@ -500,7 +503,7 @@ class Plan:
                 total += _rup(nf, 64)
                 w.max_elems = nf
                 if w.need_t:
-                    nb = math.ceil(w.cout / ck) * w.ntaps * _rup(w.cin_used, 32) * ck
+                    nb = math.ceil(w.cout / ck) * (w.ntaps + w.pad_t) * _rup(w.cin_used, 32) * ck
                     w.bwd_off = total
                     total += _rup(nb, 64)
                     w.max_elems = max(nf, nb)
@@ -518,7 +521,7 @@ class Plan:
                     tab[i].src = (w.src if w.src is not None else w.param).data_ptr()
                     tab[i].dst = arena.data_ptr() + w.fwd_off * esz
                     tab[i].dst_t = (arena.data_ptr() + w.bwd_off * esz) if w.need_t else None
-                    tab[i].Cout, tab[i].Cin, tab[i].ntaps = w.cout, w.cin, w.ntaps
+                    tab[i].Cout, tab[i].Cin, tab[i].ntaps, tab[i].pad_t = w.cout, w.cin, w.ntaps, w.pad_t
                 tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
                 self.keep.append(tdev)
                 dest.append((tdev, len(group), _dt(dtype), max(w.max_elems for w in group)))
@@ -1705,6 +1708,13 @@ class PlanBuilder:
                 gb_bytes = x.N * x.H * x.W * x.pitch * esz
                 p.bwd.append(lambda s: nv.call("hrp_fill_zero", x.gptr(), gb_bytes, s))
                 acc = 1
+            # stride-2 3x3 layers below ~4 GFLOP of data gradient (the fuse / transition layers of the branches: launch-latency
+            # bound): the 1- / 2- / 2- / 4-tap parity classes all become 4-tap problems - missing taps point at a zero tap
+            # slot of the transposed packing - and share ONE batched launch instead of three (246 -> ~100 launches per step)
+            pad4 = (PARITY_PAD and stride == 2 and ksize == 3 and dtype == torch.bfloat16 and
+                    2.0 * 9 * y.N * y.H * y.W * y.C * x.C < 4e9)
+            if pad4:
+                w.pad_t = 1
             par = None
             if len(classes) > 1:   # the parity classes write disjoint pixels: virtual lanes, one batched launch per tap count
                 vp = self.parallel(len(classes), virtual=True)
@@ -1729,10 +1739,12 @@ class PlanBuilder:
                     tl = self._class_taps(ksize, ksize // 2, py, px)
                     if not tl:       # 1x1 stride 2: the odd pixels get no gradient from this conv
                         continue
+                if pad4:
+                    tl = tl + [(tl[0][0], tl[0][1], len(taps))] * (4 - len(tl))      # (zero slot; any offset inside the halo)
                 d.ntaps = len(tl)
                 for i, (a, b, t) in enumerate(tl):
                     d.dy[i], d.dx[i], d.wtap[i] = a, b, t
-                d.w_ntaps = len(taps)
+                d.w_ntaps = len(taps) + (1 if pad4 else 0)
                 d.w_cout_pad = _rup(x.C, 32)
                 p.late(lambda d=d: setattr(d, "w", w.arena.data_ptr() + w.bwd_off * esz))
                 if acc:

@@ -198,6 +198,10 @@ typedef struct hrp_pack_entry {
   void* dst;           /* forward packing or NULL */
   void* dst_t;         /* transposed (data-gradient) packing or NULL */
   int32_t Cout, Cin, ntaps;
+  int32_t pad_t;       /* extra tap slots per chunk of the transposed packing (never written: they stay what the caller put    */
+                       /* there - zeros).  A data gradient refers to such a slot (hrp_conv_desc.wtap) for a tap it does not have: */
+                       /* the four output-parity classes of a stride-2 3x3 layer (1 / 2 / 2 / 4 taps) then all run as 4-tap       */
+                       /* problems of ONE batched launch */
 } hrp_pack_entry;
 
 #define HRP_EW_MAX_IN 4

@@ -63,6 +63,20 @@ class WgradFoldDesc(C.Structure):
                 ("dw_tap_off", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
+ROWBW_MAX = 2
+
+
+class RowBwDesc(C.Structure):
+    _fields_ = [("conv", ConvDesc), ("wg_x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("wg_act", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class RowBwInfo(C.Structure):
+    _fields_ = [("n", C.c_int32), ("grid", C.c_int32), ("lds_bytes", C.c_int32), ("total_strips", C.c_int32),
+                ("strip0", C.c_int32 * (ROWBW_MAX + 1)), ("first_wg", C.c_int32 * ROWBW_MAX), ("G", C.c_int32 * ROWBW_MAX),
+                ("ws_bytes", C.c_int64 * ROWBW_MAX)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ntaps", C.c_int32), ("pad_t", C.c_int32)]
@@ -182,6 +196,10 @@ PROTOTYPES = {
     "hrp_rot6d_compose_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "hrp_wgrad_fold_desc_of": [C.POINTER(WgradDesc), C.POINTER(WgradFoldDesc)],
     "hrp_batch_wgrad_fold_descs": [_P, C.POINTER(BatchInfo), C.POINTER(WgradFoldDesc)],
+    "hrp_rowbw_channels": [C.POINTER(RowBwDesc)],
+    "hrp_rowbw_prepare": [_P, _I, _I, _P, C.POINTER(RowBwInfo)],
+    "hrp_rowbw_launch": [_P, C.POINTER(RowBwInfo), _P],
+    "hrp_rowbw_fold_descs": [_P, C.POINTER(RowBwInfo), C.POINTER(WgradFoldDesc)],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
@@ -244,6 +262,8 @@ def lib():
         L.hrp_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         L.hrp_batch_table_bytes.restype = C.c_int64
         L.hrp_batch_table_bytes.argtypes = [C.c_int, C.c_int]
+        L.hrp_rowbw_table_bytes.restype = C.c_int64
+        L.hrp_rowbw_table_bytes.argtypes = []
         _lib = L
     return _lib
 
@@ -290,5 +310,5 @@ def call_batch(batch, stream):
     fn()
 
 
-FAMILY_FN = {"conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
+FAMILY_FN = {"rowbw": "hrp_rowbw", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
              "ew_app": "hrp_ew_bwd_apply"}

@@ -129,8 +129,15 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
 
 
 // ---- shared prologue pieces: the per-channel constants of a lane's 8 channels (one 16-byte slot) and the two transforms ----
+// v & (bit i of bits ? ~0 : 0) on the bit pattern of a float: one signed bit-field extract + one AND (a compare + select pair
+// costs three instructions and a VCC round trip)
+__device__ __forceinline__ float row_keep_if_bit(const float v, const int bits, const int i) {
+  const int m = (int)((unsigned)bits << (31 - i)) >> 31;
+  return __int_as_float(__float_as_int(v) & m);
+}
+
 struct RowPro {
-  float sc[8], sh[8], a[8], b[8], k0[8], k1[8];
+  float sc[8], sh[8], c1[8], c0[8];
   __device__ __forceinline__ void load(const float* ctab, const int C, const int cb) {
 #pragma unroll
     for (int i = 0; i < 8; i += 4) {
@@ -139,18 +146,21 @@ struct RowPro {
       sh[i] = vb.x; sh[i + 1] = vb.y; sh[i + 2] = vb.z; sh[i + 3] = vb.w;
     }
   }
-  // ... and of pro_mode 2 (called inside that branch only: as a conditional part of load() the 32 values cost the 32-channel
-  // kernel 25 spilled registers)
+  // ... and of pro_mode 2 (called inside that branch only: as a conditional part of load() the extra values cost the 32-channel
+  // kernel 25 spilled registers).  Table rows 2 .. 5: a = invstd, b = -mean * invstd, k0 = sum g / n, k1 = sum g xhat / n.  The
+  // BatchNorm backward  sc * (g - k0 - xhat * k1),  xhat = a x + b,  is evaluated as  sc * g + (c1 * x + c0)  with
+  // c1 = -sc k1 a,  c0 = -sc (k0 + k1 b): two FMAs per element.
   __device__ __forceinline__ void load2(const float* ctab, const int C, const int cb) {
-    {
 #pragma unroll
-      for (int i = 0; i < 8; i += 4) {
-        const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
-        const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
-        a[i] = va.x; a[i + 1] = va.y; a[i + 2] = va.z; a[i + 3] = va.w;
-        b[i] = vb.x; b[i + 1] = vb.y; b[i + 2] = vb.z; b[i + 3] = vb.w;
-        k0[i] = v0.x; k0[i + 1] = v0.y; k0[i + 2] = v0.z; k0[i + 3] = v0.w;
-        k1[i] = v1.x; k1[i + 1] = v1.y; k1[i + 2] = v1.z; k1[i + 3] = v1.w;
+    for (int i = 0; i < 8; i += 4) {
+      const float4 va = *(const float4*)(ctab + 2 * C + cb + i), vb = *(const float4*)(ctab + 3 * C + cb + i);
+      const float4 v0 = *(const float4*)(ctab + 4 * C + cb + i), v1 = *(const float4*)(ctab + 5 * C + cb + i);
+      const float a[4] = {va.x, va.y, va.z, va.w}, b[4] = {vb.x, vb.y, vb.z, vb.w};
+      const float k0[4] = {v0.x, v0.y, v0.z, v0.w}, k1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c1[i + e] = -sc[i + e] * k1[e] * a[e];
+        c0[i + e] = -sc[i + e] * fmaf(k1[e], b[e], k0[e]);
       }
     }
   }
@@ -163,24 +173,33 @@ struct RowPro {
     return Elem<bf16_t>::pack(f);
   }
   // pro_mode 2: BatchNorm + ReLU backward of (gradient of the activation, BatchNorm input).  The ReLU mask: recomputed from
-  // the BatchNorm input (bits < 0) or the bit mask hrp_ew_fwd wrote (bit i = channel i of the vector was > 0).
-  // gm: the masked gradient g itself (what an identity / residual input of the same activation receives).
-  // EXT false: the lean instantiation (mask always recomputed, gm unused).
-  template <bool EXT>
-  __device__ __forceinline__ uint4 bwd(const uint4 graw, const uint4 xraw, const int bits, uint4& gm) const {
-    float gq[8], xv[8], gk[8];
+  // the BatchNorm input or (BITS) the bit mask hrp_ew_fwd wrote (bit i = channel i of the vector was > 0).
+  // gm (GM): the masked gradient g itself (what an identity / residual input of the same activation receives).
+  template <bool BITS, bool GM>
+  __device__ __forceinline__ uint4 bwd_t(const uint4 graw, const uint4 xraw, const int bits, uint4& gm) const {
+    float gq[8], xv[8];
     Elem<bf16_t>::unpack(graw, gq);
     Elem<bf16_t>::unpack(xraw, xv);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool on = (!EXT || bits < 0) ? row_bn_act(xv[i], sc[i], sh[i]) > 0.f : ((bits >> i) & 1) != 0;
-      const float g = on ? gq[i] : 0.f;
-      gk[i] = g;
-      const float xh = fmaf(xv[i], a[i], b[i]);
-      gq[i] = sc[i] * (g - k0[i] - xh * k1[i]);
+      if constexpr (BITS) gq[i] = row_keep_if_bit(gq[i], bits, i);
+      else gq[i] = row_bn_act(xv[i], sc[i], sh[i]) > 0.f ? gq[i] : 0.f;
     }
-    if constexpr (EXT) gm = Elem<bf16_t>::pack(gk);
+    if constexpr (GM) gm = Elem<bf16_t>::pack(gq);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gq[i] = fmaf(sc[i], gq[i], fmaf(c1[i], xv[i], c0[i]));
     return Elem<bf16_t>::pack(gq);
+  }
+  // ub / wgm: WORKGROUP-UNIFORM choices (descriptor pointers): the mask comes as bits; the masked gradient is wanted.  They
+  // select a code version per call with a scalar branch (as a per-element `bits < 0 ? .. : ..` the choice compiled to an
+  // exec-mask branch pair per element: 1 200 scalar instructions per strip).
+  template <bool EXT>
+  __device__ __forceinline__ uint4 bwd(const uint4 graw, const uint4 xraw, const int bits, uint4& gm, const bool ub, const bool wgm) const {
+    if constexpr (!EXT) return bwd_t<false, false>(graw, xraw, bits, gm);
+    else {
+      if (ub) return wgm ? bwd_t<true, true>(graw, xraw, bits, gm) : bwd_t<true, false>(graw, xraw, bits, gm);
+      return wgm ? bwd_t<false, true>(graw, xraw, bits, gm) : bwd_t<false, false>(graw, xraw, bits, gm);
+    }
   }
 };
 
@@ -214,65 +233,125 @@ __device__ __forceinline__ bool row_ext(const hrp_conv_desc& d) {
          (d.bnb_x != nullptr && (d.res != nullptr || d.bnb_mask != nullptr));
 }
 
-template <int NT, bool EXT, bool STATS = true>
-__device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
-                                             const unsigned okmask, const int cl, const float* ctab, const int C, const bool bnb,
-                                             float (&s1)[16], float (&s2)[16]) {
-  char* yg = (char*)d.y;
-  if (bnb) {
-    // y = gradient of act = relu(bn(bnb_x)) (+ res: the last of several producers accumulates onto the others'), stored
-    // unmasked; the mask: recomputed from bnb_x (interior of a block) or the bit mask hrp_ew_fwd wrote (block outputs)
-    const char* bx = (const char*)d.bnb_x;
-    const char* rq = EXT ? (const char*)d.res : nullptr;
-    uint4 xr[NT][2];
-    int mb[NT];
+// The epilogue reduce (bnb): y = gradient of act = relu(bn(bnb_x)) (+ res: the last of several producers accumulates onto the
+// others'), stored unmasked; sums of the stored value under the mask - recomputed from bnb_x (interior of a block) or (BITS) the bit
+// mask hrp_ew_fwd wrote (block outputs).  RES: a residual (optionally under its own bit mask, res_mask) is added first.  A tile
+// outside the tensor (okmask bit clear) has zero accumulators and loads nothing: its masked values are zero without a test.
+// Operands of the epilogue forms that read tensors (the reduce's BatchNorm input and bit mask, a residual and its bit mask):
+// loaded by row_epi_load - possibly long before row_epi_bnb_math / row_epi_res_math consume them (conv_rowbw.hip issues the
+// loads in front of its MFMA loop).
+template <int NT>
+struct RowEpiOps {
+  uint4 xr[NT][2], rr[NT][2];
+  int mb[NT], rb[NT];
+};
+
+template <int NT, bool BNB, bool BITS, bool RES>
+__device__ __forceinline__ void row_epi_load(const hrp_conv_desc& d, const unsigned (&off)[NT], const unsigned okmask, RowEpiOps<NT>& e) {
+  const char* bx = (const char*)d.bnb_x;
+  const char* rq = (const char*)d.res;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      xr[t][0] = xr[t][1] = make_uint4(0, 0, 0, 0);
-      mb[t] = -1;
-      if ((okmask >> t) & 1) {
-        xr[t][0] = *(const uint4*)(bx + off[t]); xr[t][1] = *(const uint4*)(bx + off[t] + 16);
-        if constexpr (EXT) {
-          if (d.bnb_mask) mb[t] = *(const unsigned short*)(d.bnb_mask + (off[t] >> 4));
-        }
+  for (int t = 0; t < NT; ++t) {
+    e.xr[t][0] = e.xr[t][1] = e.rr[t][0] = e.rr[t][1] = make_uint4(0, 0, 0, 0);
+    e.mb[t] = 0;
+    e.rb[t] = 0xffff;
+    if ((okmask >> t) & 1) {
+      if constexpr (BNB) { e.xr[t][0] = *(const uint4*)(bx + off[t]); e.xr[t][1] = *(const uint4*)(bx + off[t] + 16); }
+      if constexpr (BNB && BITS) e.mb[t] = *(const unsigned short*)(d.bnb_mask + (off[t] >> 4));
+      if constexpr (RES) {
+        e.rr[t][0] = *(const uint4*)(rq + off[t]); e.rr[t][1] = *(const uint4*)(rq + off[t] + 16);
+        if (d.res_mask) e.rb[t] = *(const unsigned short*)(d.res_mask + (off[t] >> 4));
       }
     }
-    float sc[16], sh[16];
+  }
+}
+
+// The epilogue reduce (bnb): y = gradient of act = relu(bn(bnb_x)) (+ res: the last of several producers accumulates onto the
+// others'), stored unmasked; sums of the stored value under the mask - recomputed from bnb_x (interior of a block) or (BITS) the bit
+// mask hrp_ew_fwd wrote (block outputs).  RES: a residual (optionally under its own bit mask, res_mask) is added first.  A tile
+// outside the tensor (okmask bit clear) has zero accumulators and loads nothing: its masked values are zero without a test.
+template <int NT, bool BITS, bool RES>
+__device__ __forceinline__ void row_epi_bnb_math(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
+                                                 const unsigned okmask, const int cl, const float* ctab, const int C,
+                                                 const RowEpiOps<NT>& e, float (&s1)[16], float (&s2)[16]) {
+  char* yg = (char*)d.y;
+  float sc[16], sh[16];
+  if constexpr (!BITS) {
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
       const float4 a = *(const float4*)(ctab + 8 * C + cl + i), b = *(const float4*)(ctab + 9 * C + cl + i);
       sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
       sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
     }
+  }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float v[8], xv[8];
+    for (int hh = 0; hh < 2; ++hh) {
+      float v[8], xv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i];
-        if constexpr (EXT) {
-          if (rq && ((okmask >> t) & 1)) {
-            float r[8];
-            Elem<bf16_t>::unpack(*(const uint4*)(rq + off[t] + 16 * hh), r);
-            const int rb = d.res_mask ? d.res_mask[(off[t] >> 4) + hh] : 0xff;
+      for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i];
+      if constexpr (RES) {
+        float r[8];
+        Elem<bf16_t>::unpack(e.rr[t][hh], r);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += ((rb >> i) & 1) ? r[i] : 0.f;
-          }
-        }
-        const uint4 pk = Elem<bf16_t>::pack(v);
-        if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = pk;
-        Elem<bf16_t>::unpack(pk, v);            // the values as stored
-        Elem<bf16_t>::unpack(xr[t][hh], xv);
-        const int bits = (!EXT || mb[t] < 0) ? -1 : (mb[t] >> (8 * hh)) & 0xff;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool on = (!EXT || bits < 0) ? row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f : ((bits >> i) & 1) != 0;
-          const float g = (EXT ? (on && ((okmask >> t) & 1)) : on) ? v[i] : 0.f;
-          s1[8 * hh + i] += g;
-          s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
-        }
+        for (int i = 0; i < 8; ++i) v[i] += row_keep_if_bit(r[i], e.rb[t], 8 * hh + i);
       }
+      const uint4 pk = Elem<bf16_t>::pack(v);
+      if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = pk;
+      Elem<bf16_t>::unpack(pk, v);            // the values as stored
+      Elem<bf16_t>::unpack(e.xr[t][hh], xv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float g;
+        if constexpr (BITS) g = row_keep_if_bit(v[i], e.mb[t], 8 * hh + i);
+        else g = row_bn_act(xv[i], sc[8 * hh + i], sh[8 * hh + i]) > 0.f ? v[i] : 0.f;
+        s1[8 * hh + i] += g;
+        s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
+      }
+    }
+  }
+}
+
+// y = conv + residual (under res_mask when given), no statistics: the data gradient of a block's first conv without a reduce
+template <int NT>
+__device__ __forceinline__ void row_epi_res_math(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
+                                                 const unsigned okmask, const RowEpiOps<NT>& e) {
+  char* yg = (char*)d.y;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float v[8], r[8];
+      Elem<bf16_t>::unpack(e.rr[t][hh], r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i] + row_keep_if_bit(r[i], e.rb[t], 8 * hh + i);
+      if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = Elem<bf16_t>::pack(v);
+    }
+  }
+}
+
+template <int NT, bool BITS, bool RES>
+__device__ __forceinline__ void row_epi_bnb(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
+                                            const unsigned okmask, const int cl, const float* ctab, const int C,
+                                            float (&s1)[16], float (&s2)[16]) {
+  RowEpiOps<NT> e;
+  row_epi_load<NT, true, BITS, RES>(d, off, okmask, e);
+  row_epi_bnb_math<NT, BITS, RES>(d, acc, off, okmask, cl, ctab, C, e, s1, s2);
+}
+
+template <int NT, bool EXT, bool STATS = true>
+__device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
+                                             const unsigned okmask, const int cl, const float* ctab, const int C, const bool bnb,
+                                             float (&s1)[16], float (&s2)[16]) {
+  char* yg = (char*)d.y;
+  if (bnb) {
+    // (workgroup-uniform choices - descriptor pointers - select the code version with scalar branches)
+    if constexpr (!EXT) row_epi_bnb<NT, false, false>(d, acc, off, okmask, cl, ctab, C, s1, s2);
+    else {
+      const bool ubits = d.bnb_mask != nullptr, ures = d.res != nullptr;
+      if (ubits) { if (ures) row_epi_bnb<NT, true, true>(d, acc, off, okmask, cl, ctab, C, s1, s2); else row_epi_bnb<NT, true, false>(d, acc, off, okmask, cl, ctab, C, s1, s2); }
+      else { if (ures) row_epi_bnb<NT, false, true>(d, acc, off, okmask, cl, ctab, C, s1, s2); else row_epi_bnb<NT, false, false>(d, acc, off, okmask, cl, ctab, C, s1, s2); }
     }
     return;
   }
@@ -313,7 +392,7 @@ __device__ __forceinline__ void row_epilogue(const hrp_conv_desc& d, const f32x1
           if (d.res_mask && ((okmask >> t) & 1)) {
             const int rb = d.res_mask[(off[t] >> 4) + hh];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = ((rb >> i) & 1) ? r[i] : 0.f;
+            for (int i = 0; i < 8; ++i) r[i] = row_keep_if_bit(r[i], rb, i);
           }
         }
 #pragma unroll
@@ -398,6 +477,7 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
   const int s_begin = bid * rp.spw, s_end = min(s_begin + rp.spw, rp.nstrips);
   const int H = d.H;
   const int pro = d.pro_mode;
+  const bool ub = EXT && d.pro_mask != nullptr, wgm = EXT && d.pro_side2 != nullptr;     // (uniform: RowPro::bwd)
 
   // ---- weights: A fragments of this wave's 32 output channels.  MFMA row rho = 8 q + 4 h + i carries output channel
   // 16 h + 4 q + i, so that accumulator register 4 q + i of a lane (half h) is channel 16 h + 4 q + i: consecutive.
@@ -536,7 +616,7 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
             if (y < 0 || y >= H) continue;
             char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
             uint4 gm;
-            const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm);
+            const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm, ub, wgm);
             *(uint4*)p = o;
             if (rs >= 1 && rs <= TH) {
               const unsigned off = img_off + lane_off + y * (W * P);
@@ -694,6 +774,7 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
   const int y0 = (bid - n * rp.spi) * TH;
   const int H = d.H;
   const int pro = d.pro_mode;
+  const bool ub = EXT && d.pro_mask != nullptr, wgm = EXT && d.pro_side2 != nullptr;     // (uniform: RowPro::bwd)
   const unsigned img_off = (unsigned)n * (unsigned)(H * W * P);
   char* lds_rows = smem + P;
 
@@ -785,7 +866,7 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
           if (y < 0 || y >= H || (NPAR == 2 && ((y & 1) != par))) continue;
           char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
           uint4 gm;
-          const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[rs], bits[rs], gm);
+          const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[rs], bits[rs], gm, ub, wgm);
           *(uint4*)p = o;
           if (rs >= 1 && rs <= TH) {
             const unsigned off = img_off + y * (W * P) + lane_off_of(y);
@@ -949,6 +1030,7 @@ __device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const Ro
   const int nvalid = min(R::NIMG, d.N - n0);                 // images of this group inside the batch
   const unsigned okmask = (1u << (nvalid * TPI)) - 1;
   const int pro = d.pro_mode;
+  const bool ub = EXT && d.pro_mask != nullptr, wgm = EXT && d.pro_side2 != nullptr;     // (uniform: RowPro::bwd)
   const unsigned grp_off = (unsigned)n0 * (unsigned)(W * W * P);
 
   // ---- staging: pieces q = wave + 4 i of the group's 64 (one contiguous 64 KiB range).  lane = (pixel lane / S of the
@@ -1042,7 +1124,7 @@ __device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const Ro
           if (tq >= nvalid * TPI) continue;
           char* p = smem + tq * T + (q % PPT) * 1024 + lane * 16;
           uint4 gm;
-          const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm);
+          const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm, ub, wgm);
           *(uint4*)p = o;
           const unsigned off = grp_off + piece_off(i);
           if (side) *(uint4*)(side + off) = o;

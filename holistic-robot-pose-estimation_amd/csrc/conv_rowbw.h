@@ -610,13 +610,27 @@ __device__ __forceinline__ void rowbw_body(const hrp_rowbw_desc& q, const RowPla
   }
 }
 
+// Work split of a launch.  A strip of a 64-channel problem costs more than one of a 32-channel problem (twice the MFMAs for the
+// same bytes: measured 12.2 against 8.9 us), so workgroups get equal shares of COST, not of strips: problem i occupies the cost
+// interval [cost0[i], cost0[i] + nstrips[i] * cost[i]), workgroup w the interval [w T / nwg, (w + 1) T / nwg), and strip k of a
+// problem belongs to the workgroup whose interval holds the strip's first cost unit.
 struct RowBwArgs {
   hrp_rowbw_desc q[HRP_ROWBW_MAX];
   RowPlan rp[HRP_ROWBW_MAX];
-  int strip0[HRP_ROWBW_MAX + 1];
+  int cost0[HRP_ROWBW_MAX + 1];
+  int cost[HRP_ROWBW_MAX], nstrips[HRP_ROWBW_MAX];
   int first_wg[HRP_ROWBW_MAX];
-  int n, total, nwg, pad;
+  int n, total, nwg, pad;        // total: cost units of the launch
 };
+
+// strips [k_lo, k_hi) of a problem (cost interval starting at c0, cost c per strip, n strips) that workgroup interval [lo, hi) owns
+__host__ __device__ inline void rowbw_range(int lo, int hi, int c0, int c, int n, int& k_lo, int& k_hi) {
+  const int a = lo - c0, b = hi - c0;
+  k_lo = a <= 0 ? 0 : (a + c - 1) / c;
+  k_hi = b <= 0 ? 0 : (b + c - 1) / c;
+  if (k_lo > n) k_lo = n;
+  if (k_hi > n) k_hi = n;
+}
 
 // Problems are addressed with COMPILE-TIME indices into the by-value kernel argument: descriptor fields then are scalar loads
 // from the kernarg segment that the compiler re-issues instead of keeping them live (with a run-time problem index, or a table in
@@ -626,15 +640,15 @@ template <int C0, int C1, int FORM>
 __global__ __launch_bounds__(512) void rowbw_kernel(const RowBwArgs A) {
   const int w = blockIdx.x;
   const int lo = (int)((long long)w * A.total / A.nwg), hi = (int)((long long)(w + 1) * A.total / A.nwg);
-  const int b0 = hi < A.strip0[1] ? hi : A.strip0[1];
-  rowbw_body<C0, FORM>(A.q[0], A.rp[0], lo, b0, w - A.first_wg[0], w & (HRP_STAT_SLOTS - 1));
+  int k0, k1;
+  rowbw_range(lo, hi, A.cost0[0], A.cost[0], A.nstrips[0], k0, k1);
+  rowbw_body<C0, FORM>(A.q[0], A.rp[0], k0, k1, w - A.first_wg[0], w & (HRP_STAT_SLOTS - 1));
   if constexpr (C1 != 0) {
-    const int a1 = lo > A.strip0[1] ? lo : A.strip0[1];
+    rowbw_range(lo, hi, A.cost0[1], A.cost[1], A.nstrips[1], k0, k1);
     __syncthreads();      // (a workgroup that crosses the boundary: the second segment re-initialises the tiles)
-    rowbw_body<C1, FORM>(A.q[1], A.rp[1], a1 - A.strip0[1], hi - A.strip0[1], w - A.first_wg[1], w & (HRP_STAT_SLOTS - 1));
+    rowbw_body<C1, FORM>(A.q[1], A.rp[1], k0, k1, w - A.first_wg[1], w & (HRP_STAT_SLOTS - 1));
   }
 }
-
 
 // one translation unit per form (conv_rowbw_f*.hip): the three channel combinations of a launch
 template <int FORM>

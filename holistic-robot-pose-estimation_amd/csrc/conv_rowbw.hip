@@ -51,20 +51,28 @@ extern "C" int hrp_rowbw_prepare(const hrp_rowbw_desc* descs, int n, int max_wgs
   HRP_REQUIRE(descs && info, "rowbw: null pointer");
   HRP_REQUIRE(n >= 1 && n <= HRP_ROWBW_MAX, "rowbw: n=%d is outside 1..%d", n, HRP_ROWBW_MAX);
   memset(info, 0, sizeof(*info));
-  int total = 0, lds = 0;
+  int total = 0, lds = 0, nstr = 0;
   HRP_REQUIRE(n == 1 || (rowbw_channels(descs[0]) == 32 && rowbw_channels(descs[1]) == 64 && rowbw_form(descs[0]) == rowbw_form(descs[1])),
               "rowbw: two problems of one launch are a 32-channel and a 64-channel one of the same form, in this order");
+  // cost of a strip in the split of the launch (conv_rowbw.h, RowBwArgs): measured 8.9 us (C = 32) against 12.2 us (C = 64)
+  static const int cost64 = getenv("HRP_ROWBW_COST64") ? atoi(getenv("HRP_ROWBW_COST64")) : 14;
+  int cost0[HRP_ROWBW_MAX + 1], cost[HRP_ROWBW_MAX], ns[HRP_ROWBW_MAX];
   for (int i = 0; i < n; ++i) {
     const int C = rowbw_channels(descs[i]);
     HRP_REQUIRE(C != 0, "rowbw: problem %d is not a 32- / 64-channel row-strip data gradient with wg_x / dw set", i);
     const int rc = conv_check(&descs[i].conv);
     if (rc != HRP_OK) return rc;
-    info->strip0[i] = total;
-    total += descs[i].conv.N * (descs[i].conv.H / 8);
+    info->strip0[i] = nstr;
+    ns[i] = descs[i].conv.N * (descs[i].conv.H / 8);
+    cost[i] = C == 32 ? 10 : (cost64 > 0 ? cost64 : 14);
+    cost0[i] = total;
+    total += ns[i] * cost[i];
+    nstr += ns[i];
     const int l = C == 32 ? BwCfg<32>::LDS_BYTES : BwCfg<64>::LDS_BYTES;
     lds = l > lds ? l : lds;
   }
-  info->strip0[n] = total;
+  cost0[n] = total;
+  info->strip0[n] = nstr;
   if (max_wgs <= 0) {
     static const int env = getenv("HRP_ROWBW_WGS") ? atoi(getenv("HRP_ROWBW_WGS")) : 0;
     max_wgs = env;
@@ -77,15 +85,22 @@ extern "C" int hrp_rowbw_prepare(const hrp_rowbw_desc* descs, int n, int max_wgs
       (void)hipGetLastError();
     }
   }
-  const int nwg = total < max_wgs ? total : max_wgs;
-  info->n = n; info->grid = nwg; info->lds_bytes = lds; info->total_strips = total;
+  // (every workgroup interval is at least one strip of the costliest problem long: no workgroup between a problem's first and
+  // last one is left without a strip - its slab would stay unwritten)
+  int maxc = 0;
+  for (int i = 0; i < n; ++i) maxc = cost[i] > maxc ? cost[i] : maxc;
+  int nwg = nstr < max_wgs ? nstr : max_wgs;
+  if (nwg > total / maxc) nwg = total / maxc;
+  info->n = n; info->grid = nwg; info->lds_bytes = lds; info->total_strips = nstr;
   for (int i = 0; i < n; ++i) {
-    // workgroup w holds strips [w * total / nwg, (w + 1) * total / nwg)
     int first = -1, last = -1;
     for (int w = 0; w < nwg; ++w) {
       const int lo = (int)((long long)w * total / nwg), hi = (int)((long long)(w + 1) * total / nwg);
-      if (lo < info->strip0[i + 1] && hi > info->strip0[i]) { if (first < 0) first = w; last = w; }
+      int k0, k1;
+      rowbw_range(lo, hi, cost0[i], cost[i], ns[i], k0, k1);
+      if (k0 < k1) { if (first < 0) first = w; last = w; }
     }
+    HRP_REQUIRE(first >= 0, "rowbw: problem %d got no workgroup", i);
     info->first_wg[i] = first;
     info->G[i] = last - first + 1;
     const int C = rowbw_channels(descs[i]);
@@ -100,9 +115,9 @@ extern "C" int hrp_rowbw_prepare(const hrp_rowbw_desc* descs, int n, int max_wgs
       A.q[i] = descs[i];
       row_plan(descs[i].conv, A.rp[i]);
       A.first_wg[i] = info->first_wg[i];
-      A.strip0[i] = info->strip0[i];
+      A.cost0[i] = cost0[i]; A.cost[i] = cost[i]; A.nstrips[i] = ns[i];
     }
-    A.strip0[n] = total;
+    A.cost0[n] = total;
     A.n = n; A.total = total; A.nwg = nwg;
   }
   return HRP_OK;
@@ -126,7 +141,7 @@ extern "C" int hrp_rowbw_fold_descs(const hrp_rowbw_desc* descs, const hrp_rowbw
 extern "C" int hrp_rowbw_launch(const void* table, const hrp_rowbw_info* info, void* stream) {
   HRP_REQUIRE(table && info && info->n >= 1 && info->n <= HRP_ROWBW_MAX && info->grid > 0, "rowbw launch: bad arguments");
   const RowBwArgs& A = *(const RowBwArgs*)table;
-  HRP_REQUIRE(A.n == info->n && A.nwg == info->grid && A.total == info->total_strips, "rowbw launch: table and info do not belong together");
+  HRP_REQUIRE(A.n == info->n && A.nwg == info->grid, "rowbw launch: table and info do not belong together");
   hipStream_t s = (hipStream_t)stream;
   switch (rowbw_form(A.q[0])) {
     case 1: return rowbw_launch_form<1>(A, info->grid, info->lds_bytes, s);

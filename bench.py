@@ -201,6 +201,8 @@ def launch_descs(name, args):
     if name == "hrp_batch_launch":
         b = args[0]
         return nv.FAMILY_FN[b.fam], [it.desc for it in b.items]
+    if name == "hrp_rowbw_launch":      # fused data gradient + weight gradient of a row-strip conv (hrp_rowbw_desc)
+        return name, [it.desc for it in args[0].items]
     try:
         return name, [args[0]._obj]
     except (AttributeError, IndexError):
@@ -214,12 +216,16 @@ def conv_flops(name, args):
         return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps for d in descs)
     if fam == "hrp_conv2d_bwd_weight":
         return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps for d in descs)
+    if fam == "hrp_rowbw_launch":       # both gradients of the layer
+        return sum(2 * 2.0 * q.conv.N * q.conv.Ho * q.conv.Wo * q.conv.Cout * q.conv.Cin * q.conv.ntaps for q in descs)
     return 0.0
 
 
 def conv_bytes(name, args):
     """Algorithmic HBM bytes of one launch: every operand read once, the result written once."""
     fam, descs = launch_descs(name, args)
+    if fam == "hrp_rowbw_launch":       # dY and X read once, dX written once, W read, dW written (SURVEY 8d: each operand once)
+        return float(sum(3 * q.conv.N * q.conv.H * q.conv.W * q.conv.Cin * 2 + q.conv.ntaps * q.conv.Cin * q.conv.Cout * (2 + 4) for q in descs))
     if fam not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
         return 0.0
     tot = 0.0

@@ -310,5 +310,17 @@ def call_batch(batch, stream):
     fn()
 
 
-FAMILY_FN = {"rowbw": "hrp_rowbw", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
+def call_rowbw(batch, stream):
+    """One fused row-strip backward launch (plan.RowBwBatch: .table host launch table, .info RowBwInfo, .items)."""
+    name = "hrp_rowbw_launch"
+    if _skip and name in _skip:
+        return
+    fn = lambda: check(lib().hrp_rowbw_launch(batch.table, C.byref(batch.info), stream), name)   # noqa: E731
+    if _profile_hook is not None:
+        _profile_hook(name, (batch,), fn)
+        return
+    fn()
+
+
+FAMILY_FN = {"rowbw": "hrp_rowbw_launch", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
              "ew_app": "hrp_ew_bwd_apply"}

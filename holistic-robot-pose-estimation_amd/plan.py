@@ -153,6 +153,10 @@ ROWCONV_FUSE = not os.environ.get("HRP_NO_ROWCONV_FUSE")
 # ... and the block-end activation's backward (apply pass into conv2's data gradient, reduce pass into the next block's)
 BLOCK_END_FUSE = not os.environ.get("HRP_NO_BLOCK_END_FUSE")
 BLOCK_END_REDUCE_FUSE = not os.environ.get("HRP_NO_BLOCK_END_REDUCE_FUSE")
+# ... and, for the 32- / 64-channel branches, the data gradient AND the weight gradient of each conv of a block in ONE launch from one
+# staging of the output gradient (csrc/conv_rowbw.h, hrp_rowbw_*): the BatchNorm-input gradients (y1.grad, y2.grad) and the forward
+# activation h are never written to HBM.  HRP_ROWBW_FUSE=0 / 1 overrides the default (DESIGN 5 has the A/B measurement).
+ROWBW_FUSE = os.environ.get("HRP_ROWBW_FUSE", "0") not in ("0", "")
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
 MASKED_RES = not os.environ.get("HRP_NO_MASKED_RES")
 BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
@@ -306,6 +310,77 @@ class BatchLaunch:
                 it(s)
         else:
             nv.call_batch(self, s)
+
+
+class RowBwLaunch:
+    """One fused backward problem (data gradient + weight gradient of a row-strip conv, hrp_rowbw_desc).  Runs inside a
+    RowBwBatch (one or two problems of one launch); Plan.finalize wraps the ones the lock-step merge left alone."""
+    fam = "rowbw"
+
+    def __init__(self, desc):
+        self.desc = desc
+
+    def launches(self):
+        return [self]
+
+    def merge_key(self):
+        return ("rowbw",)
+
+    def written(self):
+        return (self.desc.conv.y, self.desc.dw)
+
+
+class RowBwBatch:
+    """hrp_rowbw_launch of one problem, or of the 32-channel + the 64-channel problem of one lock-step position."""
+    fam = "rowbw"
+
+    def __init__(self, plan, items):
+        self.plan, self.items = plan, sorted(items, key=lambda it: it.desc.conv.Cin)
+        self.info, self.table, self.folds = None, None, None
+
+    def launches(self):
+        return self.items
+
+    def merge_key(self):
+        return None
+
+    def _arr(self):
+        n = len(self.items)
+        return (nv.RowBwDesc * n)(*[it.desc for it in self.items]), n
+
+    def ws_query(self):
+        arr, n = self._arr()
+        info = nv.RowBwInfo()
+        nv.check(nv.lib().hrp_rowbw_prepare(arr, n, 0, None, C.byref(info)), "hrp_rowbw_prepare")
+        return [int(info.ws_bytes[i]) for i in range(n)]
+
+    def prepare(self):
+        arr, n = self._arr()                 # copies: every pointer (workspace included) is final by now
+        self.info = nv.RowBwInfo()
+        self.table = (C.c_char * int(nv.lib().hrp_rowbw_table_bytes()))()
+        nv.check(nv.lib().hrp_rowbw_prepare(arr, n, 0, self.table, C.byref(self.info)), "hrp_rowbw_prepare")
+        folds = (nv.WgradFoldDesc * n)()
+        nv.check(nv.lib().hrp_rowbw_fold_descs(arr, C.byref(self.info), folds), "hrp_rowbw_fold_descs")
+        self.folds = list(folds)
+
+    def fold_descs(self):
+        return self.folds
+
+    def __call__(self, s):
+        nv.call_rowbw(self, s)
+
+
+def _pair_rowbw(plan, ops):
+    """Fused backward problems of one lock-step position -> launches of one 32-channel + one 64-channel problem (the two
+    high-resolution branches of one trunk), leftovers alone."""
+    items = [l for op in ops for l in op.launches()]
+    c32 = [it for it in items if it.desc.conv.Cin == 32]
+    c64 = [it for it in items if it.desc.conv.Cin != 32]
+    out = []
+    while c32 and c64:
+        out.append(RowBwBatch(plan, [c32.pop(0), c64.pop(0)]))
+    out += [RowBwBatch(plan, [it]) for it in c32 + c64]
+    return out
 
 
 def _merge_ops(plan, ops):
@@ -542,20 +617,28 @@ class Plan:
         if self.merged:
             # lock-step merge of the virtual lanes into batched launches; streams only where a block asked for them
             self.fwd_run, self.bwd_run = self._flatten(self.fwd), self._flatten(self.bwd)
+            self.bwd_run = [Entry(e.lane, e.path, RowBwBatch(self, [e.op])) if isinstance(e.op, RowBwLaunch) else e for e in self.bwd_run]
             if WGRAD_SINK > 1 and WGRAD_DEFER and BATCHING:
                 self.bwd_run = self._sink_wgrads(self.bwd_run)
             ops = [e.op for e in self.fwd_run + self.bwd_run if e.lane is not None]
             batches = [op for op in ops if isinstance(op, BatchLaunch)]
-            wg_ops = [e for e in self.bwd_run if isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad"]
+            wg_ops = [e for e in self.bwd_run if isinstance(e.op, (Launch, BatchLaunch, RowBwBatch)) and e.op.fam in ("wgrad", "rowbw")]
+            assert WGRAD_DEFER or not any(e.op.fam == "rowbw" for e in wg_ops), "fused row-strip backward launches need deferred folds"
             defer = WGRAD_DEFER and bool(wg_ops)
             # (descriptor.reserved == 1: a gradient some later launch of the list reads - folded on the spot)
-            now = {id(e.op) for e in wg_ops if any(it.desc.reserved for it in e.op.launches())}
+            now = {id(e.op) for e in wg_ops if e.op.fam == "wgrad" and any(it.desc.reserved for it in e.op.launches())}
             if defer:
                 # deferred folds: every launch keeps its slabs until its lane folds them, so every problem gets its own
                 # scratch region (one bump allocation over the whole backward: ~4 GB for the benchmark network at B=64)
                 total, ws_off = 0, {}
                 for e in wg_ops:
                     op = e.op
+                    if op.fam == "rowbw":
+                        ws_off[id(op)] = []
+                        for b in op.ws_query():
+                            ws_off[id(op)].append((total, b))
+                            total += _rup(b, 256)
+                        continue
                     for it in op.launches():
                         it.desc.phase = 0 if id(op) in now else 1
                     if isinstance(op, BatchLaunch):
@@ -577,6 +660,10 @@ class Plan:
                         it.desc.workspace, it.desc.workspace_bytes = (base + off, b) if b else (None, 0)
                 for op in batches:
                     op.prepare()
+                for e in wg_ops:
+                    if e.op.fam == "rowbw":
+                        e.op.prepare()
+                self.counters["rowbw_launches"] = sum(e.op.fam == "rowbw" for e in wg_ops)
                 self.bwd_run = self._insert_folds(self.bwd_run)
             else:
                 # weight-gradient scratch: one buffer per stream, every launch of that stream uses it in turn
@@ -646,7 +733,7 @@ class Plan:
             seq.items.append(e.op)
 
         def key_of(op):
-            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch)) else None
+            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, RowBwLaunch)) else None
 
         def lockstep(kids):
             out = []
@@ -659,8 +746,11 @@ class Plan:
                             out.append(x[k])
                         else:
                             groups.setdefault(key, []).append(x[k])
-                for ops in groups.values():
-                    out += ops if len(ops) == 1 else _merge_ops(self, ops)
+                for key, ops in groups.items():
+                    if key[0] == "rowbw":
+                        out += _pair_rowbw(self, ops)
+                    else:
+                        out += ops if len(ops) == 1 else _merge_ops(self, ops)
             return out
 
         def walk(seq, lane):
@@ -819,7 +909,8 @@ class Plan:
                 for c in e.op.children:
                     flush(c, e.path)
             out.append(e)
-            if e.lane is not None and isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1:
+            if e.lane is not None and ((isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1)
+                                       or isinstance(e.op, RowBwBatch)):
                 pending.setdefault(e.lane, []).extend(f for f in e.op.fold_descs() if f.G > 0)
                 if len(pending[e.lane]) >= min(max(WGRAD_FOLD_EVERY, 1), nv.BATCH_MAX):
                     flush(e.lane, e.path, everything=WGRAD_FOLD_EVERY < nv.BATCH_MAX)
@@ -1032,7 +1123,7 @@ class Plan:
                 if depth == 0:
                     tops.append(i)
                 del hits[:]
-                if isinstance(op, (Launch, BatchLaunch)):
+                if isinstance(op, (Launch, BatchLaunch, RowBwBatch)):
                     for it in op.launches():     # the descriptors say what a launch touches
                         walk(it.desc)
                 else:
@@ -1380,8 +1471,8 @@ class PlanBuilder:
         return holder
 
     # ---- convolution ----------------------------------------------------------------------------------
-    def _conv_desc(self, x, w, y, stride, ksize, dtype):
-        d = nv.ConvDesc()
+    def _conv_desc(self, x, w, y, stride, ksize, dtype, into=None):
+        d = into if into is not None else nv.ConvDesc()
         d.x, d.y = x.ptr(), y.ptr()
         d.dtype = _dt(dtype)
         d.N, d.H, d.W, d.Cin, d.x_pitch = x.N, x.H, x.W, _rup(x.C, 8 if dtype == torch.bfloat16 else 4), x.pitch
@@ -1523,9 +1614,18 @@ class PlanBuilder:
                 if fd is not None:
                     if not out.grad_written:
                         return
-                    y2.take_grad_slot()
                 elif not y2.grad_written:
                     return
+                # the identity shortcut's gradient (out.grad under the block-end mask): nobody has written x.grad yet -> conv1's data
+                # gradient below adds it as a MASKED residual and writes x.grad once; else conv2's data gradient accumulates it as
+                # a second side output
+                masked_res = fd is not None and MASKED_RES and not x.grad_written
+                # both convs' data gradient + weight gradient as fused launches (csrc/conv_rowbw.h): 32 / 64 channels, block-end
+                # backward fused, masked residual, both weights trained, deferred folds (merged / hybrid plans)
+                fuse_bw = (ROWBW_FUSE and Cc in (32, 64) and fd is not None and masked_res and conv1_w.requires_grad
+                           and conv2_w.requires_grad and PLAN_MODE in ("merged", "hybrid") and WGRAD_DEFER and BATCHING)
+                if fd is not None and not fuse_bw:
+                    y2.take_grad_slot()
                 wg2_first = fd is None and not os.environ.get("HRP_WG2_LATE")
                 if wg2_first and conv2_w.requires_grad:
                     self._wgrad_launch(h, w2, y2)
@@ -1533,8 +1633,10 @@ class PlanBuilder:
                 h.take_grad_slot()
                 boff = p.alloc_bsums(Cc)
                 p.bn_bwd.append((bn1, boff))
-                g2 = self._conv_desc(y2, w2, h, 1, 3, dtype)
-                g2.x, g2.y = y2.gptr(), h.gptr()
+                q2 = nv.RowBwDesc() if fuse_bw else None
+                g2 = q2.conv if fuse_bw else nv.ConvDesc()
+                self._conv_desc(y2, w2, h, 1, 3, dtype, into=g2)
+                g2.x, g2.y = y2.gptr() if (fd is None) else 0, h.gptr()
                 red = None
                 if fd is not None:
                     # the block-end BatchNorm + ReLU backward (bn2, mask bits): staged operand of this launch
@@ -1543,11 +1645,8 @@ class PlanBuilder:
                     g2.x = out.gptr()
                     g2.pro_mode, g2.pro_x2, g2.pro_gamma, g2.pro_beta = 2, y2.ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
                     g2.pro_count, g2.pro_eps, g2.pro_mask = cnt, bn2.eps, fd.mask
-                    g2.pro_side = y2.gptr()
-                    # the identity shortcut's gradient (out.grad under the block-end mask): nobody has written x.grad yet ->
-                    # conv1's data gradient below adds it as a MASKED residual and writes x.grad once; else this launch
-                    # accumulates it as a second side output
-                    masked_res = MASKED_RES and not x.grad_written
+                    if not fuse_bw:
+                        g2.pro_side = y2.gptr()
                     if not masked_res:
                         g2.pro_side2, g2.pro_side2_acc = x.gptr(), x.take_grad_slot()
                     # its reduce: in the epilogue of the launch that completes out.grad when that is a row-strip data gradient
@@ -1575,9 +1674,12 @@ class PlanBuilder:
                 g2.bnb_x, g2.bnb_x_pitch = y1.ptr(), y1.pitch
                 g2.bnb_gamma, g2.bnb_beta, g2.bnb_count, g2.bnb_eps = gam, bet, cnt, bn1.eps
                 # data gradient of conv1 -> x.grad; its staged operand is the BatchNorm + ReLU backward of (h.grad, y1)
-                y1.take_grad_slot()
+                if not fuse_bw:
+                    y1.take_grad_slot()
                 acc = x.take_grad_slot()
-                g1 = self._conv_desc(h, w1, x, 1, 3, dtype)
+                q1 = nv.RowBwDesc() if fuse_bw else None
+                g1 = q1.conv if fuse_bw else nv.ConvDesc()
+                self._conv_desc(h, w1, x, 1, 3, dtype, into=g1)
                 g1.x, g1.y = h.gptr(), x.gptr()
                 for i, (a, b) in enumerate(_TAPS3):
                     g1.dy[i], g1.dx[i], g1.wtap[i] = -a, -b, i
@@ -1588,7 +1690,19 @@ class PlanBuilder:
                 elif acc:
                     g1.res, g1.res_pitch = x.gptr(), x.pitch
                 g1.pro_mode, g1.pro_x2, g1.pro_gamma, g1.pro_beta, g1.pro_count, g1.pro_eps = 2, y1.ptr(), gam, bet, cnt, bn1.eps
-                g1.pro_side = y1.gptr()
+                if not fuse_bw:
+                    g1.pro_side = y1.gptr()
+                else:
+                    # the weight gradients ride along: X operand of conv2 = relu(bn1(y1)) recomputed from y1 (the forward launch
+                    # no longer writes the activation h), of conv1 = the block input
+                    d2.pro_side = None
+                    acc_w = 1 if p.grad_arena is not None else 0
+                    q2.wg_x, q2.wg_act, q2.dw = y1.ptr(), 1, p.grad_of_param(w2.param).data_ptr()
+                    q1.wg_x, q1.wg_act, q1.dw = x.ptr(), 0, p.grad_of_param(w1.param).data_ptr()
+                    q2.accumulate = 1 if (w2.grad_written or acc_w) else 0
+                    q1.accumulate = 1 if (w1.grad_written or acc_w) else 0
+                    w1.grad_written = w2.grad_written = True
+                    p.counters["rowbw_fused_blocks"] = p.counters.get("rowbw_fused_blocks", 0) + 1
 
                 def late_b():
                     g2.w, g1.w = w2.arena.data_ptr() + w2.bwd_off * esz, w1.arena.data_ptr() + w1.bwd_off * esz
@@ -1603,15 +1717,15 @@ class PlanBuilder:
                         else:
                             red.sums, red.inp.stats = sums2, fd.inp[0].stats
                 p.late(late_b)
-                p.bwd.append(Launch("conv", g2))
-                if conv2_w.requires_grad and not wg2_first:
+                p.bwd.append(RowBwLaunch(q2) if fuse_bw else Launch("conv", g2))
+                if conv2_w.requires_grad and not wg2_first and not fuse_bw:
                     self._wgrad_launch(h, w2, y2)
-                p.bwd.append(Launch("conv", g1))
+                p.bwd.append(RowBwLaunch(q1) if fuse_bw else Launch("conv", g1))
                 # (so far) the last producer of x.grad: the block in front of this one may put its BatchNorm reduce here if
                 # that is still so when its own backward is emitted
                 if acc or (fd is not None and masked_res):
                     p.row_last_writer[x.gptr()] = (g1, p.lane_path, len((x.base if x.base is not None else x)._grad_paths))
-                if conv1_w.requires_grad:
+                if conv1_w.requires_grad and not fuse_bw:
                     self._wgrad_launch(x, w1, y1)
             self.bwd_stack.append(bw)
             if bn2 is not None and fd is None:

@@ -221,11 +221,20 @@ def conv_flops(name, args):
     return 0.0
 
 
-def conv_bytes(name, args):
-    """Algorithmic HBM bytes of one launch: every operand read once, the result written once."""
+def conv_bytes(name, args, extended=False):
+    """Algorithmic HBM bytes of one launch by SURVEY 8(d): the layer's input read once, its output written once, its weights
+    once.  extended=True adds what THIS design moves on top inside the same launch - residuals, the operands of the fused
+    BatchNorm prologues / epilogues, side outputs - reported as `bytes_incl_fused_operands`, never used for `frac`."""
     fam, descs = launch_descs(name, args)
-    if fam == "hrp_rowbw_launch":       # dY and X read once, dX written once, W read, dW written (SURVEY 8d: each operand once)
-        return float(sum(3 * q.conv.N * q.conv.H * q.conv.W * q.conv.Cin * 2 + q.conv.ntaps * q.conv.Cin * q.conv.Cout * (2 + 4) for q in descs))
+    if fam == "hrp_rowbw_launch":       # dY and X read once, dX written once, W read, dW written
+        tot = 0.0
+        for q in descs:
+            d = q.conv
+            t = d.N * d.H * d.W * d.Cin * 2
+            tot += 3 * t + d.ntaps * d.Cin * d.Cout * (2 + 4)
+            if extended:      # second prologue operand (+ 25 % halo on both staged operands), residual, epilogue-reduce operand
+                tot += 0.25 * t + (1.25 * t if d.pro_mode == 2 else 0) + (t if d.res else 0) + (t if (d.bnb_x and not q.wg_act) else 0)
+        return float(tot)
     if fam not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
         return 0.0
     tot = 0.0
@@ -233,16 +242,17 @@ def conv_bytes(name, args):
         esz = 2 if d.dtype == nv.HRP_BF16 else 4
         if fam == "hrp_conv2d_fwd":
             b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
-            if d.res:
-                b += d.N * d.Ho * d.Wo * d.Cout * esz
-            if d.bnb_x:      # BatchNorm-backward reduce in the epilogue: reads the BatchNorm input once (+ 1/16 mask)
-                b += d.N * d.Ho * d.Wo * d.Cout * esz
-            # fused BatchNorm prologues of the row-strip kernels: the second operand (BatchNorm input) read once, every side
-            # output written once (an accumulated one also read)
-            tin = d.N * d.H * d.W * d.Cin * esz
-            if d.pro_mode == 2:
-                b += tin
-            b += tin * (bool(d.pro_side) + bool(d.pro_side2) * (2 if d.pro_side2_acc else 1))
+            if extended:
+                if d.res:
+                    b += d.N * d.Ho * d.Wo * d.Cout * esz
+                if d.bnb_x:      # BatchNorm-backward reduce in the epilogue: reads the BatchNorm input once (+ 1/16 mask)
+                    b += d.N * d.Ho * d.Wo * d.Cout * esz
+                # fused BatchNorm prologues of the row-strip kernels: the second operand (BatchNorm input) read once, every side
+                # output written once (an accumulated one also read)
+                tin = d.N * d.H * d.W * d.Cin * esz
+                if d.pro_mode == 2:
+                    b += tin
+                b += tin * (bool(d.pro_side) + bool(d.pro_side2) * (2 if d.pro_side2_acc else 1))
             tot += b
         else:
             tot += (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout) * esz + d.Cout * d.dw_cin * d.ntaps * 4
@@ -610,7 +620,7 @@ def main():
         e1.record()
         fl = conv_flops(name, args)
         fam = launch_descs(name, args)[0]      # batched launches count towards their family
-        records.append((fam, fl, e0, e1, conv_bytes(name, args)))
+        records.append((fam, fl, e0, e1, conv_bytes(name, args), conv_bytes(name, args, extended=True)))
         if os.environ.get("HRP_BENCH_SHAPES"):
             records_shape.append((fam, fl, e0, e1, shape_key(name, args)))
 
@@ -638,12 +648,13 @@ def main():
             tf = f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s" if v[2] else ""
             print(f"{name:24s} {key:44s} n={v[0]:4d} {v[1]:8.3f} ms  avg {v[1] / v[0] * 1e3:7.1f} us {tf}", file=sys.stderr)
     fam = {}
-    for name, fl, e0, e1, by in records:
-        f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
+    for name, fl, e0, e1, by, byx in records:
+        f = fam.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
         f[0] += 1
         f[1] += e0.elapsed_time(e1)
         f[2] += fl
         f[3] += by
+        f[4] += byx
     kernels = {n: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
                for n, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}
     dom = max(fam.items(), key=lambda kv: kv[1][1])
@@ -657,27 +668,35 @@ def main():
     # passes over tools/one_step.py, the same network and batch) summarised in profiles/r02_traffic.json; a family = its
     # single-problem and its batched kernels together
     traffic, traffic_source = None, None
-    tpath = next((pp for pp in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic.json") for r in (3, 2)) if os.path.exists(pp)),
-                 os.path.join(ROOT, "profiles", "r02_traffic.json"))
+    tpath = next((pp for pp in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic.json") for r in (4, 3, 2)) if os.path.exists(pp)), None)
     fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel", "conv_row_kernel", "conv_deep_kernel", "conv_img_kernel", "conv_pw_kernel"),
+                   "hrp_rowbw_launch": ("rowbw_kernel",),
                    "hrp_conv2d_bwd_weight": ("conv_wgrad_kernel", "wgrad_batch_kernel", "wgrad_reduce_kernel", "wgrad_reduce_batch_kernel"),
                    "hrp_ew_fwd": ("ew_fwd_kernel", "ew_fwd_batch_kernel"),
                    "hrp_ew_bwd_reduce": ("ew_bwd_reduce_kernel",), "hrp_ew_bwd_apply": ("ew_bwd_apply_kernel",)}.get(dom[0])
-    if os.path.exists(tpath) and fam_kernels and B == 64 and a.dtype == "bf16" and not hrnet and not fwd_only:
+    if tpath and fam_kernels and B == 64 and a.dtype == "bf16" and not hrnet and not fwd_only:
         with open(tpath) as fh:
-            fams = json.load(fh)["families"]
-        by = sum(fams.get(k, {}).get("hbm_bytes_per_step", 0.0) for k in fam_kernels)
-        if by > 0:
-            traffic = by / dom[1][0]      # per launch of the family as bench.py counts launches
-            traffic_source = ("profiles/" + os.path.basename(tpath) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                              "tools/one_step.py (same network and batch), not collected in this run")
+            tj = json.load(fh)
+        have = nv.lib().hrp_source_hash().decode()
+        if tj.get("source_hash") != have:
+            # the counter passes were collected on other sources than the library measured here: no figure rather than a stale one
+            traffic_source = (f"dropped: profiles/{os.path.basename(tpath)} was collected on library sources {tj.get('source_hash')}, "
+                              f"this run measures {have} (re-run tools/collect_profiles.sh)")
+        else:
+            by = sum(tj["families"].get(k, {}).get("hbm_bytes_per_step", 0.0) for k in fam_kernels)
+            if by > 0:
+                traffic = by / dom[1][0]      # per launch of the family as bench.py counts launches
+                traffic_source = ("profiles/" + os.path.basename(tpath) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                  "tools/one_step.py (same network, batch and library sources), not collected in this run")
     roofline = {"kernel": dom[0], "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb if hbm_bound else ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((ach_gb / PEAK_HBM_GBS) if hbm_bound else (ach_tf / peak), 4),
                 "traffic": traffic, "traffic_source": traffic_source, "launches": dom[1][0],
                 "avg_launch_us": round(dom[1][1] / dom[1][0] * 1e3, 2),
-                "algorithmic_bytes_per_launch": round(dom[1][3] / dom[1][0]), "flop_per_byte": round(intensity, 1),
+                "algorithmic_bytes_per_launch": round(dom[1][3] / dom[1][0]),
+                "bytes_incl_fused_operands_per_launch": round(dom[1][4] / dom[1][0]),
+                "achieved_incl_fused_operands": round(dom[1][4] / (dom[1][1] * 1e-3) / 1e9, 2), "flop_per_byte": round(intensity, 1),
                 "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4)}
     gf_img = FWD_GFLOP_PER_IMAGE["depthnet" if hrnet else "full"] * (1 if fwd_only else 3)
     step_tflops = gf_img * 1e9 * B * world / (ms_per_step * 1e-3) / 1e12 / world     # per GPU
@@ -690,7 +709,7 @@ def main():
     clip = 1 if hrnet else 5
     out = {
         "metric": "images/sec/GPU fwd+bwd HRNet-W32 256x256 bs=64; 1/2/4/8-GPU scaling",
-        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": round(value, 2), "value_per_gpu": round(value / world, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": what,
@@ -724,18 +743,20 @@ def main():
     # clip + Adam) and BASELINE.json configs[1] (the full network's eval forward, BatchNorm folded), 10 steps each, in fresh
     # processes (one training plan per process: a second plan next to the first runs ~16 % slower), while this
     # process idles on the GPU.  Each carries its own roofline entry; `value` above stays the headline.
-    if world == 1 and not a.no_extra and not hrnet and not fwd_only and not h2d and B == 64 and a.dtype == "bf16":
+    profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and not a.no_extra and not profiled and not hrnet and not fwd_only and not h2d and B == 64 and a.dtype == "bf16":
         import subprocess
         for key, extra in (("hrnet_step", ["--workload", "hrnet"]), ("forward_only", ["--forward-only"])):
+            r = None
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--no-cpu-baseline", "--steps", "10",
-                                    "--warmup", "3"] + extra, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
+                                    "--warmup", "3"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=150)
                 c = json.loads(r.stdout.strip().splitlines()[-1])
                 out[key] = {k: c[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_model_tflops",
                                               "step_frac_of_mfma_peak", "roofline") if k in c}
                 out[key]["workload"] = c["config"]["workload"]
             except Exception as e:
-                out[key] = {"value": None, "error": repr(e)[:200]}
+                out[key] = {"value": None, "error": repr(e)[:200], "stderr_tail": (r.stderr[-400:] if r is not None and r.stderr else None)}
     if not a.no_cpu_baseline:
         # separate process (own thread pool, hard time limit): the baseline must never take the GPU number
         # down with it

@@ -150,8 +150,8 @@ __global__ void zero_rows_kernel(float* __restrict__ p, int pitch, int rows, int
   p[(size_t)r * pitch + (i - r * cols)] = 0.f;
 }
 
-// workspace of the deterministic reduction: [ct * mb] tickets (zero before the FIRST launch, self-resetting), 256-byte aligned,
-// then [rs][mb * 64][ct * 32] partial sums
+// workspace of the deterministic reduction: [rs][mb * 64][ct * 32] partial sums (every element is written by the main launch
+// before this one reads it: no initialisation needed)
 // out[m][c] (+)= sum over the splits y (in order) of part[y][m][c] + bias[c] + res[m][c]
 __global__ __launch_bounds__(256) void linear_fold_kernel(const float* __restrict__ part, int rs, int Mp, int Cp, const float* __restrict__ bias,
                                                           const float* __restrict__ res, int res_pitch, float* __restrict__ out, int out_pitch,

@@ -109,6 +109,7 @@ class ParamW:
         self.param, self.cout, self.cin, self.ntaps = param, cout, cin, ntaps
         self.fwd_off = self.bwd_off = None
         self.pad_t = 0      # extra (zero) tap slots per chunk of the transposed packing (hrp_pack_entry.pad_t)
+        self.t_ntaps = set()   # w_ntaps of every data-gradient descriptor that reads the transposed packing (Plan.finalize checks)
         self.grad_written = False
         self.first_use = None    # index into Plan.fwd at (or before) the first launch that reads the packed copy
         self.src = None          # fp32 tensor packed instead of `param` (derived layouts, e.g. the 4x4 form of the stem)
@@ -485,7 +486,7 @@ class Plan:
         self._rng, self.n_dropout = None, 0
         self.linear_grad_written = set()
         self.grad_owner = {}       # gradient buffer address -> TensorH root (every producer registers through take_grad_slot)
-        self.row_last_writer = {}  # gradient buffer address -> (row-strip conv descriptor that completes it, lane path)
+        self.row_last_writer = {}  # gradient buffer address -> (row-strip conv descriptor that completes it, lane path, producers of the gradient so far)
 
     # ---- build-time helpers -------------------------------------------------------------------
     def new(self, N, H, W, Cc, dtype=None, pitch=None):
@@ -564,6 +565,10 @@ class Plan:
         # stream that the forward list joins right after that block - the 0.7 ms gather runs under the stem instead of
         # in front of it.  `cut` = index in fwd of the join.
         self._pack_tables, self._pack_tables_late = [], []
+        for w in self.weight_list:
+            # the tap stride of the transposed packing is ntaps + pad_t for EVERY data gradient of the weight: a use that was
+            # emitted with another w_ntaps (a weight shared by a padded and an unpadded stride-2 layer) would read shifted taps
+            assert all(t == w.ntaps + w.pad_t for t in w.t_ntaps), f"plan: data gradients of one weight disagree on its tap slots ({w.t_ntaps}, pad_t {w.pad_t})"
         cut = self._late_pack_cut()
         for dtype in (torch.float32, torch.bfloat16):
             ws = [w for w in self.weight_list if w.dtype == dtype]
@@ -1747,7 +1752,7 @@ class PlanBuilder:
         bp = bias.data_ptr() if bias is not None else None
         # workspace of the deterministic split reduction; forward and data gradient of one layer never overlap
         wsb = int(nv.lib().hrp_linear_workspace_bytes(M, Kf, Nf))
-        ws = torch.zeros(wsb // 4 + 4, dtype=torch.float32, device=p.device)
+        ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=p.device)      # (needs no initialisation, include/hrp.h)
         p.keep.append(ws)
         p.fwd.append(lambda s: nv.call("hrp_linear_fwd", x.ptr(), x.pitch, weight.data_ptr(), bp,
                                        residual.ptr() if residual is not None else None, residual.pitch if residual is not None else 0,
@@ -1759,14 +1764,24 @@ class PlanBuilder:
                 if residual is not None and residual.requires_grad:
                     acc = residual.take_grad_slot()
                     p.bwd.append(lambda s: nv.call("hrp_copy_cols", y.gptr(), y.pitch, residual.gptr(), residual.pitch, M, Nf, acc, s))
+                want_b = bias is not None and bias.requires_grad
                 if weight.requires_grad:
                     gw = p.grad_of_param(weight)
-                    gb = p.grad_of_param(bias) if bias is not None and bias.requires_grad else None
+                    gb = p.grad_of_param(bias) if want_b else None
                     first = id(weight) not in p.linear_grad_written
                     p.linear_grad_written.add(id(weight))
                     accw = 1 if (p.grad_arena is not None or not first) else 0
                     p.bwd.append(lambda s: nv.call("hrp_linear_bwd_weight", x.ptr(), x.pitch, y.gptr(), y.pitch, gw.data_ptr(),
                                                    gb.data_ptr() if gb is not None else None, M, Kf, Nf, accw, s))
+                elif want_b:     # a frozen weight with a trainable bias: the bias gradient is a column sum of its own
+                    gb = p.grad_of_param(bias)
+                    first = id(bias) not in p.linear_grad_written
+                    p.linear_grad_written.add(id(bias))
+                    cwb = int(nv.lib().hrp_colsum_workspace_bytes(M, Nf))
+                    cws = torch.empty(cwb // 4 + 4, dtype=torch.float32, device=p.device)
+                    p.keep.append(cws)
+                    accb = 1 if (p.grad_arena is not None or not first) else 0
+                    p.bwd.append(lambda s: nv.call("hrp_colsum", y.gptr(), nv.HRP_F32, M, Nf, y.pitch, gb.data_ptr(), accb, cws.data_ptr(), cwb, s))
                 if x.requires_grad:
                     acc = x.take_grad_slot()
                     p.bwd.append(lambda s: nv.call("hrp_linear_bwd_data", y.gptr(), y.pitch, weight.data_ptr(), x.gptr(), x.pitch,
@@ -1859,6 +1874,7 @@ class PlanBuilder:
                 for i, (a, b, t) in enumerate(tl):
                     d.dy[i], d.dx[i], d.wtap[i] = a, b, t
                 d.w_ntaps = len(taps) + (1 if pad4 else 0)
+                w.t_ntaps.add(int(d.w_ntaps))
                 d.w_cout_pad = _rup(x.C, 32)
                 p.late(lambda d=d: setattr(d, "w", w.arena.data_ptr() + w.bwd_off * esz))
                 if acc:

@@ -7,7 +7,10 @@ HBM bytes of a kernel family = (2 * FETCH_SIZE + WRITE_SIZE) KiB: both counters 
 doubled on gfx950 (128-byte requests counted as 64 bytes, MI355X_MICROARCH.md, HBM section).  Families are the kernel
 names up to the template arguments; bench.py divides the conv family's bytes by its launches for `roofline.traffic`."""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def fam(name):
@@ -27,7 +30,13 @@ def main():
     for e in fams.values():
         e["hbm_bytes_per_step"] = (2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0
         e["hbm_bytes_per_launch"] = e["hbm_bytes_per_step"] / max(e["launches"], 1)
+    import hrpe_amd  # noqa: F401
+    from hrpe_amd import _native as nv
     res = {
+        # sha256[:16] of the library sources the counters were collected on: bench.py reports `roofline.traffic` only while the
+        # library it measures carries the same hash
+        "source_hash": nv.source_hash(),
+        "plan": {"HRP_ROWBW_FUSE": os.environ.get("HRP_ROWBW_FUSE", "default")},
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/one_step.py: one eager "
                   "forward+loss+backward of the benchmark network, B=64, bf16, lanes folded onto one stream",
         "correction": "FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE doubled (gfx950 counts 128-byte "

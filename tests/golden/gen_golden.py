@@ -24,6 +24,11 @@ Fixtures (reference call site that produced each):
   golden_full_train.npz  lib/core/function.py farward_loss(train=True): loss terms + grads + BN
                          running stats after one step.
   golden_full_train_b8.npz   the same step at B = 8 (`full_train_b8`): tighter gradient tolerance (less BN noise).
+  golden_depthnet_2iter.npz / golden_full_2iter.npz   TWO iterations of the trainers' loop - forward, loss, backward,
+                         clip_grad_norm_, Adam(lr 1e-4).step - (scripts/train_depthnet.py:105, 231-250, 316-318 with
+                         configs/panda/depthnet.yaml: B = 4, clip 1.0 = BASELINE.json configs[0]; scripts/train_full.py:42, 56-66
+                         with full.yaml: clip 5.0, B = 2), `depthnet_2iter full_2iter`: losses of both iterations, the clipped
+                         gradient norms, sampled parameter UPDATES and BatchNorm running statistics after the second step.
 """
 import os
 import sys
@@ -658,6 +663,78 @@ def gen_full_train(backbone_name=None, B=2):
     name = "golden_full_train_resnet.npz" if backbone_name else ("golden_full_train.npz" if B == 2 else f"golden_full_train_b{B}.npz")
     np.savez_compressed(os.path.join(HERE, name), **out)
     print("full train ok", name, out["loss"], {k: float(v) for k, v in terms.items()})
+
+
+PICK_UPDATES_DEPTHNET = ["backbone.conv1.weight", "backbone.stage3.1.branches.0.2.conv2.weight", "backbone.stage4.0.fuse_layers.1.0.0.0.weight",
+                         "backbone.stage2.0.branches.1.3.bn2.weight", "backbone.final_feat_layer.0.weight", "depth_layer.weight"]
+PICK_UPDATES_FULL = ["reg_backbone.conv1.weight", "reg_backbone.stage3.0.branches.0.1.conv1.weight", "reg_backbone.final_layer.weight",
+                     "rootnet_backbone.stage4.1.fuse_layers.2.0.0.0.weight", "fc_pose_1.weight", "decrot.bias", "depth_layer.weight"]
+
+
+def _two_iterations(model, loss_fn, clip, picks, out):
+    """The trainers' inner loop twice (scripts/train_full.py:56-66 / train_depthnet.py:316-322): zero_grad, loss, backward,
+    clip_grad_norm_, Adam.step.  Records per iteration the loss and the total gradient norm clip_grad_norm_ returns, and after
+    the second step the sampled parameter updates (p - p0) and running statistics."""
+    params = dict(model.named_parameters())
+    p0 = {n: params[n].detach().clone() for n in picks}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0.0)
+    for it in range(2):
+        opt.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        opt.step()
+        out[f"loss{it + 1}"] = np.array(loss.item())
+        out[f"grad_norm{it + 1}"] = np.array(float(norm))
+    for i, n in enumerate(picks):
+        upd = (params[n].detach() - p0[n]).reshape(-1).double()
+        idx = sample_indices(upd.numel(), 256, 300 + i)
+        out[f"upd:{n}:idx"], out[f"upd:{n}:val"] = idx, upd[idx].float().numpy()
+        out[f"upd:{n}:absmean"] = np.array(upd.abs().mean().item())
+
+
+def gen_depthnet_2iter():
+    """BASELINE.json configs[0]: depthnet.yaml, B = 4, two iterations (random 256 x 256 images)."""
+    m = get_rootnet("hrnet32")
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    x, _, kv, _ = synth_inputs(4)
+    gt = torch.tensor([[1.1], [0.7], [1.6], [0.9]])
+    m.train()
+    out = {"gt_depth": gt.numpy()}
+    _two_iterations(m, lambda: torch.nn.L1Loss()(m(x, kv) / 1000.0, gt), 1.0, PICK_UPDATES_DEPTHNET, out)
+    sd = m.state_dict()
+    for n in ["backbone.bn1.running_mean", "backbone.stage4.2.branches.3.3.bn2.running_var", "backbone.bn1.num_batches_tracked"]:
+        out["buf:" + n] = sd[n].reshape(-1)[:64].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_depthnet_2iter.npz"), **out)
+    print("depthnet 2 iterations ok", {k: float(v) for k, v in out.items() if k.startswith(("loss", "grad_norm"))})
+
+
+def gen_full_2iter():
+    """scripts/train_full.py:56-66 with configs/panda/full.yaml (clip 5.0), B = 2, two iterations through the reference's own
+    farward_loss."""
+    function = import_reference_step_function()
+    full, margs = build_full(None)
+    batch, small = make_batch(2, full.robot)
+    args = rh._AttrDict(dict(margs))
+    args.update(urdf_robot_name="panda", use_origin_bbox=False, use_extended_bbox=True,
+                train_ds_names="dream/synthetic/panda_synth_train_dr", use_joint_valid_mask=False,
+                known_joint=False, joint_individual_weights=None, image_size=256.0, fix_mask=False,
+                pose_loss_func="mse", rot_loss_func="mse", trans_loss_func="l2norm",
+                depth_loss_func="l1", uv_loss_func="l2norm", kp2d_loss_func="l2norm",
+                kp3d_loss_func="l2norm", kp2d_int_loss_func="l2norm", kp3d_int_loss_func="l2norm",
+                align_3d_loss_func="l2norm", pose_loss_weight=1.0, rot_loss_weight=1.0,
+                trans_loss_weight=1.0, depth_loss_weight=10.0, uv_loss_weight=1.0,
+                kp2d_loss_weight=10.0, kp3d_loss_weight=10.0, kp2d_int_loss_weight=10.0,
+                kp3d_int_loss_weight=10.0, align_3d_loss_weight=0.0)
+    full.train()
+    out = {"in:" + k: v for k, v in small.items()}
+    _two_iterations(full, lambda: function.farward_loss(args, batch, full, full.robot, "cpu", [0], train=True)[0], 5.0,
+                    PICK_UPDATES_FULL, out)
+    sd = full.state_dict()
+    for n in ["reg_backbone.bn1.running_mean", "rootnet_backbone.stage4.2.branches.3.3.bn2.running_var"]:
+        out["buf:" + n] = sd[n][:64].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_full_2iter.npz"), **out)
+    print("full 2 iterations ok", {k: float(v) for k, v in out.items() if k.startswith(("loss", "grad_norm"))})
 
 
 if __name__ == "__main__":

@@ -1,0 +1,90 @@
+"""Round-4 GPU parity tests.
+
+* TWO iterations of the reference's trainers (scripts/train_depthnet.py:105, 231-250, 316-322 with depthnet.yaml - BASELINE.json
+  configs[0]: B = 4, clip 1.0, Adam 1e-4 - and scripts/train_full.py:42, 56-66 with full.yaml, clip 5.0, B = 2) against the
+  fixtures the reference itself wrote (tests/golden/gen_golden.py depthnet_2iter / full_2iter): forward -> loss -> backward ->
+  clip -> Adam -> forward with repacked weights and updated running statistics, end to end, with hrpe_amd.optim.FusedClipAdam
+  and with torch.optim.Adam + clip_grad_norm_.  fp32 tolerances: loss 1e-3 (relative), gradient norm 2e-2, parameter updates:
+  median error < 5 % of the mean update (Adam's first steps are ~ lr * sign(g): single elements with noise-level gradients may
+  land on the other side, at most 5 % of the samples may miss by more than half a step).
+* The benchmarked bf16 configuration: end-to-end key-point error in pixels, gated per key-point.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from synth import synth_inputs, synth_state_dict
+import test_gpu_model as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def two_iterations(model, loss_fn, clip, g, fused):
+    from hrpe_amd.optim import FusedClipAdam
+    params = [p for p in model.parameters() if p.requires_grad]
+    named = dict(model.named_parameters())
+    picks = [k.split(":")[1] for k in g.files if k.startswith("upd:") and k.endswith(":val")]
+    p0 = {n: named[n].detach().clone() for n in picks}
+    opt = FusedClipAdam(params, lr=1e-4, max_norm=clip) if fused else torch.optim.Adam(params, lr=1e-4)
+    for it in range(2):
+        opt.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        if fused:
+            opt.step()
+            norm = float(opt.total_norm())
+        else:
+            norm = float(torch.nn.utils.clip_grad_norm_(params, clip))
+            opt.step()
+        np.testing.assert_allclose(loss.item(), g[f"loss{it + 1}"], rtol=1e-3, err_msg=f"loss of iteration {it + 1}")
+        np.testing.assert_allclose(norm, g[f"grad_norm{it + 1}"], rtol=2e-2, err_msg=f"gradient norm of iteration {it + 1}")
+    for n in picks:
+        upd = (named[n].detach() - p0[n]).reshape(-1).cpu()[g[f"upd:{n}:idx"]].numpy()
+        err = np.abs(upd - g[f"upd:{n}:val"])
+        am = g[f"upd:{n}:absmean"]
+        assert np.median(err) < 0.05 * am and np.mean(err > 0.5 * am) < 0.05, (n, float(np.median(err)), float(am), float(np.mean(err > 0.5 * am)))
+    sd = model.state_dict()
+    for key in g.files:
+        if key.startswith("buf:") and "num_batches" not in key:
+            # (after two Adam steps of ~ lr * sign(g) per element: a few 1e-5 of absolute drift on statistics of O(0.1))
+            np.testing.assert_allclose(sd[key[4:]].reshape(-1)[:64].cpu().numpy(), g[key], rtol=2e-3, atol=5e-5)
+        if key.startswith("buf:") and "num_batches" in key:
+            assert int(sd[key[4:]]) == int(g[key][0]) == 2
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["FusedClipAdam", "torch.optim.Adam"])
+def test_depthnet_two_iterations_golden(fused):
+    from hrpe_amd.lib.models.depth_net import get_rootnet
+    g = load("golden_depthnet_2iter.npz")
+    m = get_rootnet("hrnet32")
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m = m.to(DEV).train()
+    x, _, kv, _ = synth_inputs(4)
+    x, kv, gt = x.to(DEV), kv.to(DEV), torch.tensor(g["gt_depth"]).to(DEV)
+    two_iterations(m, lambda: torch.nn.functional.l1_loss(m(x, kv) / 1000.0, gt), 1.0, g, fused)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["FusedClipAdam", "torch.optim.Adam"])
+def test_full_two_iterations_golden(fused):
+    from hrpe_amd.lib.core.function import compute_k_values, full_loss
+    from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+    g = load("golden_full_2iter.npz")
+    m = M.build_full().train()
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    x_root = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    K = torch.tensor(g["in:K"]).to(DEV)
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], torch.tensor(g["in:bbox"]).to(DEV))
+    q, R, t = [torch.tensor(g[k]).to(DEV) for k in ("in:q", "in:R", "in:t")]
+    kp3d, kp2d, mask = [torch.tensor(g[k]).to(DEV) for k in ("in:kp3d", "in:kp2d", "in:mask")]
+    gt = dict(pose=q, root_rot=m.robot.get_rotation_at_specific_root(q, rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    two_iterations(m, lambda: full_loss(m(x_reg, x_root, kv, K), gt, K)[0], 5.0, g, fused)

@@ -498,3 +498,63 @@ def test_depthnet_resnet_golden(robot):
         out = heads.full_forward(fsd, robot, x_reg, x_root, kv, K, reg_backbone="resnet50", root_backbone="resnet50")
     for n, t in zip(NAMES8, out):
         np.testing.assert_allclose(t.numpy(), g["full:" + n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
+def _two_iterations(sd, loss_fn, clip, g, rtol_loss):
+    """The trainers' loop twice on the oracle's state dict (scripts/train_full.py:56-66): zero_grad, loss, backward,
+    clip_grad_norm_, Adam(lr 1e-4).step, checked against the reference's own two iterations."""
+    params = [v for k, v in sd.items() if v.requires_grad]
+    p0 = {k: v.detach().clone() for k, v in sd.items() if v.requires_grad}
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=0.0)
+    for it in range(2):
+        opt.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(params, clip)
+        opt.step()
+        np.testing.assert_allclose(loss.item(), g[f"loss{it + 1}"], rtol=rtol_loss, err_msg=f"loss of iteration {it + 1}")
+        np.testing.assert_allclose(float(norm), g[f"grad_norm{it + 1}"], rtol=5e-3, err_msg=f"gradient norm of iteration {it + 1}")
+    for key in g.files:
+        if key.startswith("upd:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            upd = (sd[name].detach() - p0[name]).reshape(-1)[g[f"upd:{name}:idx"]].numpy()
+            ref = g[key]
+            # Adam's first steps are ~ lr * sign(g): an element whose gradient is rounding noise may land on the other side
+            err = np.abs(upd - ref)
+            assert np.median(err) < 0.02 * g[f"upd:{name}:absmean"] and np.mean(err > 0.5 * g[f"upd:{name}:absmean"]) < 0.03, \
+                (name, np.median(err), g[f"upd:{name}:absmean"], np.mean(err > 0.5 * g[f"upd:{name}:absmean"]))
+        if key.startswith("buf:") and "num_batches" not in key:
+            np.testing.assert_allclose(sd[key[4:]].reshape(-1)[:64].detach().numpy(), g[key], rtol=1e-4, atol=1e-6)
+
+
+def test_depthnet_two_iterations_golden():
+    """BASELINE.json configs[0]: depthnet.yaml, B = 4, two iterations of the DepthNet trainer (golden_depthnet_2iter.npz)."""
+    g = load("golden_depthnet_2iter.npz")
+    sd = depthnet_sd()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x, _, kv, _ = synth_inputs(4)
+    gt = torch.tensor(g["gt_depth"])
+    _two_iterations(sd, lambda: torch.nn.functional.l1_loss(heads.rootnet_forward(sd, x, kv, training=True) / 1000.0, gt), 1.0, g, 2e-4)
+
+
+def test_full_two_iterations_golden(robot):
+    """scripts/train_full.py:56-66 with full.yaml (clip 5), B = 2, two iterations (golden_full_2iter.npz)."""
+    g = load("golden_full_2iter.npz")
+    sd = full_sd()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
+            v.requires_grad_(True)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.
+    x_root = torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.
+    K = torch.tensor(g["in:K"])
+    bbox = g["in:bbox"]
+    area = np.maximum(np.abs(bbox[:, 2] - bbox[:, 0]), np.abs(bbox[:, 3] - bbox[:, 1])) ** 2
+    kv = torch.tensor(np.sqrt(g["in:K"][:, 0, 0] ** 2 * 1000.0 * 1000.0 / area).astype(np.float32))
+    q, R, t = torch.tensor(g["in:q"]), torch.tensor(g["in:R"]), torch.tensor(g["in:t"])
+    kp3d, kp2d, mask = torch.tensor(g["in:kp3d"]), torch.tensor(g["in:kp2d"]), torch.tensor(g["in:mask"])
+    gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, fk.rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    _two_iterations(sd, lambda: heads.full_loss(heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=True), gt, K)[0], 5.0, g, 2e-4)

@@ -18,6 +18,7 @@ from hrpe_amd.runtime import PlannedModule, SingleTensorModule
 from .configs import HRNET_CONFIGS, AttrDict
 
 BN_MOMENTUM = 0.1  # reference HRnet.py:18
+HEAD_FP32 = os.environ.get("HRP_HEAD_FP32", "0") not in ("0", "")
 logger = logging.getLogger(__name__)
 
 
@@ -478,6 +479,10 @@ class PoseHighResolutionNet(PlannedModule):
         if self.generate_hm:
             heat = self.final_layer.emit(pb, ys[0])
         if self.generate_feat:
+            if HEAD_FP32 and not self.generate_hm and ys[0].dtype != torch.float32:
+                # the classification head of a feature-only trunk (the DepthNet) in fp32: its pooled feature sets the root depth,
+                # where 1 mm is 3 px for a key-point 0.13 m in front of the camera
+                ys = [pb.cast(y, torch.float32) for y in ys]
             y = self.incre_modules[0][0].emit(pb, ys[0])
             for i, dm in enumerate(self.downsamp_modules):
                 d = pb.act([conv_bn(pb, y, dm[0], dm[1])], relu=True)

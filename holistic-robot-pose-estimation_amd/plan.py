@@ -2017,6 +2017,31 @@ class PlanBuilder:
             self.bwd_stack.append(bw)
         return y
 
+    def cast(self, x, dtype):
+        """NHWC tensor in another element type (bf16 trunk -> fp32 head): two layout launches through an fp32 NCHW scratch
+        (hrp_nhwc_to_nchw + hrp_nchw_to_nhwc: both exist for the public boundary), the gradient the same way back.  The tensor
+        must have no other gradient producer before this one (the gradient is written, not accumulated)."""
+        p = self.plan
+        if x.dtype == dtype:
+            return x
+        x.check_readable()
+        y = p.new(x.N, x.H, x.W, x.C, dtype)
+        y.requires_grad = p.need_grad and x.requires_grad
+        tmp = torch.empty(x.N * x.C * x.H * x.W, dtype=torch.float32, device=p.device)
+        p.keep.append(tmp)
+        p.fwd.append(lambda s: (nv.call("hrp_nhwc_to_nchw", x.ptr(), tmp.data_ptr(), _dt(x.dtype), x.N, x.C, x.H, x.W, x.pitch, s),
+                                nv.call("hrp_nchw_to_nhwc", tmp.data_ptr(), y.ptr(), _dt(dtype), x.N, x.C, x.H, x.W, y.pitch, s)))
+        if y.requires_grad:
+            def bw():
+                if not y.grad_written:
+                    return
+                if x.take_grad_slot():
+                    raise RuntimeError("plan: cast() needs to be the first producer of its input's gradient")
+                p.bwd.append(lambda s: (nv.call("hrp_nhwc_to_nchw", y.gptr(), tmp.data_ptr(), _dt(dtype), x.N, x.C, x.H, x.W, y.pitch, s),
+                                        nv.call("hrp_nchw_to_nhwc", tmp.data_ptr(), x.gptr(), _dt(x.dtype), x.N, x.C, x.H, x.W, x.pitch, s)))
+            self.bwd_stack.append(bw)
+        return y
+
     def new_like(self, t):
         return self.plan.new(t.N, t.H, t.W, t.C, t.dtype, pitch=t.pitch)
 

@@ -88,3 +88,80 @@ def test_full_two_iterations_golden(fused):
     gt = dict(pose=q, root_rot=m.robot.get_rotation_at_specific_root(q, rotmat_to_rot6d(R), t, root=3),
               root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
     two_iterations(m, lambda: full_loss(m(x_reg, x_root, kv, K), gt, K)[0], 5.0, g, fused)
+
+
+def _bf16_px_by_keypoint():
+    """-> per key-point max |uv - uv_fp64| in pixels of the bf16 path on the reference's eval fixture (B = 2), computed exactly as
+    bench.py's `max_px_err.bf16_by_keypoint` (the network's FK key-points against the reference's float64 run, both projected
+    with K, lib/utils/transforms.py:17-21)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r = bench.keypoint_px_error(torch.device(DEV), [("bf16", torch.bfloat16)])
+    return r["bf16_by_keypoint"], r
+
+
+def test_bf16_keypoint_error_is_gated_per_keypoint():
+    """The benchmarked precision, in pixels (the figure existed only as a bench.py report field).  Six of the
+    seven key-points of the fixture are held below 0.5 px.  Key-point 0 sits 0.13 m in front of the camera (f = 800 px: 1 mm of
+    root depth is 3 px): the bf16 DepthNet trunk's ~1 % feature noise is 4.5 px there - gated at 5.5 px, and at 1.3 px with the
+    DepthNet's classification head in fp32 (HRP_HEAD_FP32=1: 0.92 px measured, +6.6 ms per training step, DESIGN 4 - not the
+    default)."""
+    from hrpe_amd.lib.models.backbones import HRnet
+    by_kp, r = _bf16_px_by_keypoint()
+    print("\nbf16 px error by key-point:", by_kp)
+    assert by_kp[0] < 5.5 and max(by_kp[1:]) < 0.5, by_kp
+    saved = HRnet.HEAD_FP32
+    try:
+        HRnet.HEAD_FP32 = True
+        by_kp2, _ = _bf16_px_by_keypoint()
+    finally:
+        HRnet.HEAD_FP32 = saved
+    print("with the DepthNet head in fp32:", by_kp2)
+    assert by_kp2[0] < 1.3 and max(by_kp2[1:]) < 0.5, by_kp2
+
+
+def _train_curve(dtype, steps, B=8):
+    """`steps` training steps of the full network (synthetic batch of bench.py, the loss of lib/core/function.py:191-322, clip 5 + Adam
+    1e-4, no dropout) -> losses.  Same seeded weights and batch for every call."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from hrpe_amd.lib.core.function import compute_k_values, full_loss
+    from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+    from hrpe_amd.optim import FusedClipAdam
+    m = M.build_full().set_compute_dtype(dtype).train()
+    d = {k: torch.tensor(v).to(DEV) for k, v in bench.synthetic_batch(B, 4242).items()}
+    K = d["K"]
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], d["bbox"])
+    rot6 = rotmat_to_rot6d(d["R"])
+    with torch.no_grad():
+        kp3d, kp2d = m.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
+        gt = dict(pose=d["q"], root_rot=m.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
+                  root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7, device=DEV))
+    opt = FusedClipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-4, max_norm=5.0)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss, _ = full_loss(m(d["x_reg"], d["x_root"], kv, K), gt, K)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return np.array(losses)
+
+
+def test_bf16_training_follows_the_fp32_loss_curve():
+    """60 optimizer steps in fp32 and in bf16 from the same weights on the same batch (the cosine-0.65 gate on
+    bf16 trunk gradients was the only evidence that bf16 training is sound).  The bf16 loss must fall like the fp32 loss: both end
+    below 40 % of their first value and the curves stay within 20 % of each other at every 10th step (measured: fp32 66.0 -> 21.6,
+    bf16 66.1 -> 23.9: the bf16 run trails by 11 % at step 60)."""
+    f32 = _train_curve(torch.float32, 60)
+    b16 = _train_curve(torch.bfloat16, 60)
+    idx = list(range(0, 60, 10)) + [59]
+    print("\nstep   fp32      bf16")
+    for i in idx:
+        print(f"{i:4d} {f32[i]:9.4f} {b16[i]:9.4f}")
+    assert f32[-1] < 0.40 * f32[0] and b16[-1] < 0.40 * b16[0], (f32[0], f32[-1], b16[0], b16[-1])
+    for i in idx:
+        lo, hi = (f32[max(i - 2, 0):i + 3].mean(), b16[max(i - 2, 0):i + 3].mean())
+        assert abs(lo - hi) < 0.20 * lo, (i, lo, hi)

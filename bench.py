@@ -467,54 +467,70 @@ def main():
                 return step
 
             def capture_overlapped():
-                """Backward in two graphs around the plan's split: the gradients that are final after the first (the
-                late stages and the heads, most of the bytes) are all-reduced while the second runs."""
-                sp = None if os.environ.get("HRP_NO_AR_OVERLAP") else model.enable_split_backward()
-                if sp is None:
+                """Backward in k + 1 graphs around the plan's cuts (PlannedModule.enable_split_backward(fracs=...)): the gradients
+                that are final after a segment - first the heads, then stage 4, then stage 3 - are all-reduced while the next
+                segment runs; only the stems' and stage 2's gradients (a few per cent of the bytes) travel behind the backward."""
+                if os.environ.get("HRP_NO_AR_OVERLAP"):
+                    info["ar_overlap"] = {"enabled": False, "reason": "HRP_NO_AR_OVERLAP is set"}
                     return None
-                plan, final = sp
+                fracs = tuple(float(v) for v in os.environ.get("HRP_AR_SPLITS", "0.25,0.5,0.8,0.9").split(","))
+                sp = model.enable_split_backward(fracs=fracs)
+                if sp is None:
+                    info["ar_overlap"] = {"enabled": False, "reason": "the plan has no top-level cut positions for these fractions"}
+                    return None
+                plan, groups = sp
                 arena = plan.grad_arena
-                # small final ranges are not worth a collective of their own: they travel with the rest
-                final = [(o, n) for o, n in final if n >= (1 << 18)]
-                rest = GradAllReducer.complement(final, arena.numel())
-                g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1a, **gmode):
-                    fwd_bwd()                       # (split active: the backward stops at the split)
-                with torch.cuda.graph(g1b, **gmode):
-                    plan.run_backward("rest")
-                with torch.cuda.graph(g2, **gmode):
+                # small ranges are not worth a collective of their own: they travel with the rest
+                groups = [[(o, n) for o, n in grp if n >= (1 << 18)] for grp in groups]
+                covered = [r for grp in groups for r in grp]
+                rest = GradAllReducer.complement(covered, arena.numel())
+                nseg = len(plan.bwd_cuts) + 1
+                g_first, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                g_seg = [torch.cuda.CUDAGraph() for _ in range(nseg - 1)]
+                with torch.cuda.graph(g_first, **gmode):
+                    fwd_bwd()                       # (split active: the backward stops at the first cut)
+                for j, gj in enumerate(g_seg):
+                    with torch.cuda.graph(gj, **gmode):
+                        plan.run_backward(("seg", j + 1))
+                with torch.cuda.graph(g_upd, **gmode):
                     update()
-                # self-check on this machine (PlannedModule.check_split_backward: the rest of the backward must leave the ranges
+                # self-check on this machine (PlannedModule.check_split_backward: every later segment must leave the ranges
                 # already handed to RCCL untouched, bit for bit), here on the captured graphs' first part
-                g1a.replay()
-                model.check_split_backward(final)
-                if sum(n for _, n in final) + sum(n for _, n in rest) != arena.numel():
+                g_first.replay()
+                model.check_split_backward(groups)
+                if sum(n for _, n in covered) + sum(n for _, n in rest) != arena.numel():
                     raise RuntimeError("split backward self-check failed: ranges do not cover the arena")
-                info["ar_overlap"] = {"final_fraction": round(sum(n for _, n in final) / arena.numel(), 3),
-                                      "ranges_mb": [round(n * 4 / 2 ** 20, 1) for _, n in final],
-                                      "rest_ranges": len(rest), "split_at": plan.bwd_split, "bwd_ops": len(plan.bwd_ops())}
+                info["ar_overlap"] = {"enabled": True, "cuts": list(plan.bwd_cuts), "bwd_ops": len(plan.bwd_ops()),
+                                      "final_fraction_after_each_cut": [round(sum(n for grp in groups[:j + 1] for _, n in grp) / arena.numel(), 3)
+                                                                         for j in range(len(groups))],
+                                      "tail_fraction": round(sum(n for _, n in rest) / arena.numel(), 3),
+                                      "payload": reducer.payload}
 
                 def step():
-                    g1a.replay()
-                    w = reducer.start(arena, final)
-                    g1b.replay()
+                    g_first.replay()
+                    w = reducer.start(arena, groups[0])
+                    for j, gj in enumerate(g_seg):
+                        gj.replay()
+                        if j + 1 < len(groups):
+                            w += reducer.start(arena, groups[j + 1])
                     w += reducer.start(arena, rest)
                     reducer.finish(w, [arena])
-                    g2.replay()
+                    g_upd.replay()
                 return step
 
             step = None
             try:
                 step = capture_overlapped()
-            except Exception as e:   # anything unexpected: the plain two-graph step
+            except Exception as e:   # anything unexpected: the plain two-graph step - said in the line, not only on stderr
                 print(f"warning: overlapped all-reduce disabled ({e!r})", file=sys.stderr)
+                info["ar_overlap"] = {"enabled": False, "reason": repr(e)[:300]}
                 step = None
             if world > 1:   # every rank must issue the same sequence of collectives: one failure -> all fall back
                 flag = torch.tensor([1.0 if step is not None else 0.0], device=dev)
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-                if flag.item() < 0.5:
+                if flag.item() < 0.5 and step is not None:
                     step = None
-                    info.pop("ar_overlap", None)
+                    info["ar_overlap"] = {"enabled": False, "reason": "another rank could not set up the split backward"}
             if step is None:
                 model.disable_split_backward()
                 step = capture_plain()

@@ -477,6 +477,7 @@ class Plan:
         self._grad_views = {}
         self._grad_layout = []
         self.bwd_split, self.split_active = None, False
+        self.bwd_cuts = None       # k cut positions of the backward list (PlannedModule.enable_split_backward(fracs=...))
         self.pre_pack = []         # ops run before the weight packing of every step (derived weight layouts)
         self.counters = {}         # build statistics (HRP_PLAN_STATS=1 prints them at finalize)
         self.wgrad_ws_bytes = {}   # lane -> scratch bytes shared by that lane's weight-gradient launches
@@ -1061,25 +1062,35 @@ class Plan:
     def run_backward(self, part=None):
         """part None: the whole backward.  "first" / "rest": the two halves around self.bwd_split (a top-level position
         of the launch list chosen by analyze_backward_split) - the data-parallel step all-reduces the gradients that
-        are final after the first half while the second half runs."""
+        are final after the first half while the second half runs.  ("seg", j): segment j of the k + 1 segments around the k
+        cuts self.bwd_cuts ("first" == ("seg", 0) when cuts are set)."""
         s = self._stream()
-        if part in (None, "first"):
+        cuts = self.bwd_cuts if self.bwd_cuts else ([self.bwd_split] if self.bwd_split is not None else [])
+        if part == "first":
+            part = ("seg", 0)
+        if part == "rest":
+            assert len(cuts) == 1, "run_backward('rest') is the two-segment form"
+            part = ("seg", 1)
+        j = None if part is None else part[1]
+        if j in (None, 0):
             if self.grad_arena is not None:
                 self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
             if self.bsums_floats:
                 self.bsums.zero_()
         ops = self.bwd_ops()
-        if part is None:
+        if j is None:
             self._run_list(ops)
-        elif part == "first":
-            self._run_list(list.__getitem__(ops, slice(0, self.bwd_split)))
         else:
-            self._run_list(list.__getitem__(ops, slice(self.bwd_split, None)))
-        if part in (None, "rest") and self._pgrad_tab:
+            lo = 0 if j == 0 else cuts[j - 1]
+            hi = cuts[j] if j < len(cuts) else None
+            self._run_list(list.__getitem__(ops, slice(lo, hi)))
+        if (j is None or j == len(cuts)) and self._pgrad_tab:
             nv.call("hrp_bn_param_grad", self._pgrad_tab[0].data_ptr(), self._pgrad_tab[1], s)
 
-    def analyze_backward_split(self, min_frac=0.55):
+    def analyze_backward_split(self, min_frac=0.55, fracs=None):
         """-> (split index, [(offset, numel)] arena ranges that no launch at or after the split touches) or None.
+        fracs (e.g. (0.25, 0.6, 0.9)): k cuts instead -> [(split index, ranges that became final since the previous cut)], so
+        that the collective left behind the last launch is a small tail (buckets in reverse registration order).
 
         Every backward launch is replayed against a recording stand-in for the C ABI (nothing runs); any pointer
         argument or descriptor field that points into the gradient arena marks that parameter as touched by that
@@ -1148,21 +1159,36 @@ class Plan:
                 if st in bn_ptrs:
                     last[k] = len(self.bwd_ops())
         total = sum(n for _, n in self._grad_layout)
+
+        def ranges_final_before(c, lo=-1):
+            """arena ranges whose last toucher lies in [lo, c)"""
+            ranges = []
+            for (off, n), l in zip(self._grad_layout, last):
+                if not (lo <= l < c):
+                    continue
+                n4 = _rup(n, 4)
+                if ranges and ranges[-1][0] + ranges[-1][1] == off:
+                    ranges[-1][1] += n4
+                else:
+                    ranges.append([off, n4])
+            return [tuple(r) for r in ranges]
+
+        if fracs is not None:
+            # k cut positions: the first top-level position at which at least f of the gradient bytes are final, for every f
+            cuts, prev = [], -1
+            for f in sorted(fracs):
+                c = next((c for c in tops if c > 0 and sum(n for (_, n), l in zip(self._grad_layout, last) if l < c) >= f * total), None)
+                if c is None or (cuts and c <= cuts[-1][0]):
+                    continue
+                cuts.append((c, ranges_final_before(c, prev)))
+                prev = c
+            return cuts or None
         for c in tops:
             if c == 0:
                 continue
             final = sum(n for (_, n), l in zip(self._grad_layout, last) if l < c)
             if final >= min_frac * total:
-                ranges = []
-                for (off, n), l in zip(self._grad_layout, last):
-                    if l >= c:
-                        continue
-                    n4 = _rup(n, 4)
-                    if ranges and ranges[-1][0] + ranges[-1][1] == off:
-                        ranges[-1][1] += n4
-                    else:
-                        ranges.append([off, n4])
-                return c, [tuple(r) for r in ranges]
+                return c, ranges_final_before(c)
         return None
 
     def publish_param_grads(self):

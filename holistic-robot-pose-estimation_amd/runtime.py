@@ -182,19 +182,31 @@ class PlannedModule(nn.Module):
         """Flat fp32 gradient arena of the training plan(s) (views of it are the parameters' .grad)."""
         return [r.plan.grad_arena for r in self._plans.values() if r.plan.grad_arena is not None]
 
-    def enable_split_backward(self, min_frac=0.55):
+    def enable_split_backward(self, min_frac=0.55, fracs=None):
         """Data-parallel overlap: from now on a backward through this module runs only the first part of the training
         plan's backward list; the caller runs ``plan.run_backward("rest")`` itself (e.g. in a second HIP graph) and may
         all-reduce the returned arena ranges in between - no launch of the second part touches them.
-        -> (plan, [(offset, numel), ...]) or None when the plan has no suitable split."""
+        -> (plan, [(offset, numel), ...]) or None when the plan has no suitable split.
+        fracs (e.g. (0.25, 0.6, 0.9)): k cuts: the backward becomes k + 1 segments - the autograd call runs segment 0, the caller
+        ``plan.run_backward(("seg", j))`` for j = 1 .. k - and the return value is (plan, [ranges_0, .., ranges_{k-1}]): ranges_j
+        are final once segment j has run, so each can travel while the next segment computes and only the gradients of the
+        last segment (the stems and first stages: a few per cent of the bytes) are reduced behind the backward."""
         runners = [r for r in self._plans.values() if r.plan.grad_arena is not None]
         if len(runners) != 1:
             return None
         plan = runners[0].plan
+        if fracs is not None:
+            cuts = plan.analyze_backward_split(fracs=fracs)
+            if not cuts:
+                return None
+            plan.bwd_cuts, plan.bwd_split = [c for c, _ in cuts], None
+            plan.split_active = True
+            return plan, [r for _, r in cuts]
         info = plan.analyze_backward_split(min_frac)
         if info is None:
             return None
         plan.bwd_split, ranges = info
+        plan.bwd_cuts = None
         plan.split_active = True
         return plan, ranges
 
@@ -203,22 +215,31 @@ class PlannedModule(nn.Module):
         in split mode (only the first part has run).  Runs the rest of the backward and verifies bit for bit that it left the
         arena ranges handed out by enable_split_backward untouched (they may already be with RCCL) and that the arena is
         finite.  On a violation the split is switched off and a RuntimeError says so (the caller falls back to the unsplit
-        backward)."""
+        backward).  With k cuts `ranges` is the list of k range lists: every later segment must leave every earlier list alone."""
         runners = [r for r in self._plans.values() if r.plan.grad_arena is not None and r.plan.split_active]
         if len(runners) != 1:
             raise RuntimeError("check_split_backward: no plan with an active split")
         plan = runners[0].plan
         arena = plan.grad_arena
-        torch.cuda.synchronize(arena.device)
-        before = torch.cat([arena[o:o + n] for o, n in ranges]).clone() if ranges else arena[:0].clone()
-        plan.run_backward("rest")
-        torch.cuda.synchronize(arena.device)
-        after = torch.cat([arena[o:o + n] for o, n in ranges]) if ranges else arena[:0]
-        ok = torch.equal(before, after) and bool(torch.isfinite(arena).all())
+        multi = plan.bwd_cuts is not None
+        groups = ranges if multi else [ranges]
+        nseg = len(plan.bwd_cuts) + 1 if multi else 2
+        snaps = []
+        ok = True
+        for j in range(1, nseg):
+            torch.cuda.synchronize(arena.device)
+            grp = groups[j - 1]
+            snaps.append((grp, torch.cat([arena[o:o + n] for o, n in grp]).clone() if grp else arena[:0].clone()))
+            plan.run_backward(("seg", j))
+            torch.cuda.synchronize(arena.device)
+            for grp_, before in snaps:
+                after = torch.cat([arena[o:o + n] for o, n in grp_]) if grp_ else arena[:0]
+                ok = ok and torch.equal(before, after)
+        ok = ok and bool(torch.isfinite(arena).all())
         if not ok:
             self.disable_split_backward()
-            raise RuntimeError("split backward self-check failed: the second part of the backward touched gradient ranges "
-                               "that were final after the first")
+            raise RuntimeError("split backward self-check failed: a later part of the backward touched gradient ranges "
+                               "that were final after an earlier one")
         return True
 
     def disable_split_backward(self):

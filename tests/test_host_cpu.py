@@ -222,6 +222,21 @@ def _ddp_worker(rank, world, port, q):
     works += red.start(flat2, rest)
     red.finish(works, [flat2])
     assert torch.equal(flat, flat2)
+    # k groups of ranges started one after the other (the k-cut backward of bench.py), tail last, one finish
+    flat3 = torch.arange(10_000, dtype=torch.float32) * (rank + 1)
+    groups = [[(0, 1000)], [(1000, 2500), (6000, 1000)], [(3500, 2500)]]
+    tail = GradAllReducer.complement([r for g in groups for r in g], flat3.numel())
+    assert tail == [(7000, 3000)]
+    works = []
+    for g in groups:
+        works += red.start(flat3, g)
+    works += red.start(flat3, tail)
+    red.finish(works, [flat3])
+    assert torch.equal(flat, flat3)
+    # bf16 payload: the sum is formed in bf16, the mean in fp32 in the arena
+    flat4 = torch.arange(10_000, dtype=torch.float32) * (rank + 1)
+    GradAllReducer(bucket_mb=0.01, payload="bf16")([flat4])
+    assert (flat4 - flat).abs().max().item() <= 2.0 ** -6 * flat.abs().max().item() and not torch.equal(flat4, flat)      # (three bf16 roundings)
     q.put((rank, lin.weight.detach().numpy().copy(), flat[:5].numpy().copy(), flat[-1].item()))
     dist.destroy_process_group()
 

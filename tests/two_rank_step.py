@@ -91,6 +91,39 @@ def main():
     assert torch.equal(other_a[0], other_a[1]), "the ranks hold different averaged gradients after the overlapped all-reduce"
     model.disable_split_backward()
 
+    # ---- k-way split (bench.py at N > 1): the heads', stage 4's, stage 3's gradients travel while the next segment runs -----
+    sp = model.enable_split_backward(fracs=(0.25, 0.5, 0.8, 0.9))
+    assert sp is not None, "no cuts found"
+    plan, groups = sp
+    assert len(plan.bwd_cuts) >= 2 and len(groups) == len(plan.bwd_cuts), (plan.bwd_cuts, len(groups))      # (after stage 4, after stage 3)
+    covered = [r for grp in groups for r in grp]
+    tail = GradAllReducer.complement(covered, arena.numel())
+    tail_frac = sum(n for _, n in tail) / arena.numel()
+    assert tail_frac <= 0.20, f"the collective left behind the backward carries {tail_frac:.2f} of the bytes"
+    fwd_bwd()                                       # segment 0
+    model.check_split_backward(groups)              # runs segments 1 .. k; raises if one touched an earlier group's ranges
+    torch.cuda.synchronize(dev)
+    assert torch.equal(arena, own), f"rank {rank}: {len(groups) + 1}-segment backward differs from the plain backward"
+    fwd_bwd()
+    w = red.start(arena, groups[0])
+    for j in range(1, len(plan.bwd_cuts) + 1):
+        plan.run_backward(("seg", j))
+        if j < len(groups):
+            w += red.start(arena, groups[j])
+    w += red.start(arena, tail)
+    red.finish(w, [arena])
+    torch.cuda.synchronize(dev)
+    assert torch.equal(arena, reduced_plain), \
+        f"rank {rank}: {len(groups)}-cut overlapped all-reduce differs from the plain one by {((arena - reduced_plain).norm() / reduced_plain.norm()).item()}"
+    # bf16 payload (HRP_GRAD_PAYLOAD=bf16): half the bytes on the links, the mean within bf16 rounding of the fp32 one
+    redh = GradAllReducer(bucket_mb=64, payload="bf16")
+    arena.copy_(own)
+    redh([arena])
+    torch.cuda.synchronize(dev)
+    rel = ((arena - reduced_plain).norm() / reduced_plain.norm()).item()
+    assert 0 < rel < 8e-3, f"rank {rank}: bf16-payload all-reduce is {rel} away from the fp32 one"
+    model.disable_split_backward()
+
     # ---- optimizer step on the averaged gradients: replicas stay identical ---------------------------------------------
     arena.copy_(reduced_plain)
 
@@ -109,6 +142,7 @@ def main():
     dist.all_gather(rms, rm)
     assert not torch.equal(rms[0], rms[1]), "BatchNorm running statistics are per replica (no SyncBN, as under DataParallel)"
     print(f"rank {rank}: ok ({arena.numel()} gradient elements, split final fraction {sum(n for _, n in final) / arena.numel():.2f}, "
+          f"{len(groups)} cuts at {plan.bwd_cuts} leave a tail of {tail_frac:.3f}, bf16 payload within {rel:.1e}, "
           f"the step repeats bit for bit)")
     dist.destroy_process_group()
 

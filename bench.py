@@ -201,7 +201,7 @@ def launch_descs(name, args):
     if name == "hrp_batch_launch":
         b = args[0]
         return nv.FAMILY_FN[b.fam], [it.desc for it in b.items]
-    if name == "hrp_rowbw_launch":      # fused data gradient + weight gradient of a row-strip conv (hrp_rowbw_desc)
+    if name in ("hrp_rowbw_launch", "hrp_block_launch"):      # fused row-strip launches (hrp_rowbw_desc / hrp_block_desc)
         return name, [it.desc for it in args[0].items]
     try:
         return name, [args[0]._obj]
@@ -218,6 +218,8 @@ def conv_flops(name, args):
         return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps for d in descs)
     if fam == "hrp_rowbw_launch":       # both gradients of the layer
         return sum(2 * 2.0 * q.conv.N * q.conv.Ho * q.conv.Wo * q.conv.Cout * q.conv.Cin * q.conv.ntaps for q in descs)
+    if fam == "hrp_block_launch":       # both convolutions of the block
+        return sum(2 * 2.0 * q.conv1.N * q.conv1.Ho * q.conv1.Wo * q.conv1.Cout * q.conv1.Cin * q.conv1.ntaps for q in descs)
     return 0.0
 
 
@@ -235,6 +237,8 @@ def conv_bytes(name, args, extended=False):
             if extended:      # second prologue operand (+ 25 % halo on both staged operands), residual, epilogue-reduce operand
                 tot += 0.25 * t + (1.25 * t if d.pro_mode == 2 else 0) + (t if d.res else 0) + (t if (d.bnb_x and not q.wg_act) else 0)
         return float(tot)
+    if fam == "hrp_block_launch":       # what the fused block must move: x read once, out written once, both weights
+        return float(sum(2 * d.conv1.N * d.conv1.H * d.conv1.W * d.conv1.Cin * 2 + 2 * 9 * d.conv1.Cin * d.conv1.Cout * 2 for d in descs))
     if fam not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
         return 0.0
     tot = 0.0
@@ -686,7 +690,7 @@ def main():
     traffic, traffic_source = None, None
     tpath = next((pp for pp in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic.json") for r in (4, 3, 2)) if os.path.exists(pp)), None)
     fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel", "conv_row_kernel", "conv_deep_kernel", "conv_img_kernel", "conv_pw_kernel"),
-                   "hrp_rowbw_launch": ("rowbw_kernel",),
+                   "hrp_rowbw_launch": ("rowbw_kernel",), "hrp_block_launch": ("block_kernel",),
                    "hrp_conv2d_bwd_weight": ("conv_wgrad_kernel", "wgrad_batch_kernel", "wgrad_reduce_kernel", "wgrad_reduce_batch_kernel"),
                    "hrp_ew_fwd": ("ew_fwd_kernel", "ew_fwd_batch_kernel"),
                    "hrp_ew_bwd_reduce": ("ew_bwd_reduce_kernel",), "hrp_ew_bwd_apply": ("ew_bwd_apply_kernel",)}.get(dom[0])

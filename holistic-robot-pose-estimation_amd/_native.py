@@ -77,6 +77,18 @@ class RowBwInfo(C.Structure):
                 ("ws_bytes", C.c_int64 * ROWBW_MAX)]
 
 
+BLOCK_MAX = 2
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("conv1", ConvDesc), ("conv2", ConvDesc)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [("n", C.c_int32), ("grid", C.c_int32), ("lds_bytes", C.c_int32), ("reserved", C.c_int32),
+                ("first_wg", C.c_int32 * BLOCK_MAX), ("bands", C.c_int32 * BLOCK_MAX)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ntaps", C.c_int32), ("pad_t", C.c_int32)]
@@ -200,6 +212,9 @@ PROTOTYPES = {
     "hrp_rowbw_prepare": [_P, _I, _I, _P, C.POINTER(RowBwInfo)],
     "hrp_rowbw_launch": [_P, C.POINTER(RowBwInfo), _P],
     "hrp_rowbw_fold_descs": [_P, C.POINTER(RowBwInfo), C.POINTER(WgradFoldDesc)],
+    "hrp_block_channels": [C.POINTER(BlockDesc)],
+    "hrp_block_prepare": [_P, _I, _P, C.POINTER(BlockInfo)],
+    "hrp_block_launch": [_P, C.POINTER(BlockInfo), _P],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
@@ -264,6 +279,8 @@ def lib():
         L.hrp_batch_table_bytes.argtypes = [C.c_int, C.c_int]
         L.hrp_rowbw_table_bytes.restype = C.c_int64
         L.hrp_rowbw_table_bytes.argtypes = []
+        L.hrp_block_table_bytes.restype = C.c_int64
+        L.hrp_block_table_bytes.argtypes = []
         _lib = L
     return _lib
 
@@ -322,5 +339,17 @@ def call_rowbw(batch, stream):
     fn()
 
 
-FAMILY_FN = {"rowbw": "hrp_rowbw_launch", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
+def call_block(batch, stream):
+    """One fused inference BasicBlock launch (plan.BlockBatch: .table host launch table, .info BlockInfo, .items)."""
+    name = "hrp_block_launch"
+    if _skip and name in _skip:
+        return
+    fn = lambda: check(lib().hrp_block_launch(batch.table, C.byref(batch.info), stream), name)   # noqa: E731
+    if _profile_hook is not None:
+        _profile_hook(name, (batch,), fn)
+        return
+    fn()
+
+
+FAMILY_FN = {"block": "hrp_block_launch", "rowbw": "hrp_rowbw_launch", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
              "ew_app": "hrp_ew_bwd_apply"}

@@ -94,6 +94,10 @@ class BasicBlock(SingleTensorModule):
 
     def emit(self, pb, x):
         if self.downsample is None and self.stride == 1:
+            # inference plans, 32 / 64-channel branch blocks: the whole block as one launch, the intermediate in LDS
+            out = pb.basic_block_eval(x, self.conv1.weight, self.bn1, self.conv2.weight, self.bn2)
+            if out is not None:
+                return out
             # train-mode branch blocks of the row-strip shapes: BatchNorm + ReLU of the interior inside the convolutions
             out = pb.conv_bn_relu_conv(x, self.conv1.weight, self.bn1, self.conv2.weight, self.bn2)
             if out is not None:
@@ -269,6 +273,9 @@ def _transition(pb, tr, src):
 # kernel time, roofline fraction 0.177 against 0.197): not the default.  "flat": round 1's structure - every branch of
 # every trunk is a lane of one flat block.
 TRUNK_LANES = os.environ.get("HRP_TRUNK_LANES", "nets")
+# lanes of bf16 INFERENCE plans when HRP_TRUNK_LANES is "nets": "flat22" = two streams per trunk (branches {0, 1} | {2, 3}), "" = as
+# the training plans
+EVAL_LANES = os.environ.get("HRP_EVAL_LANES", "flat22")
 
 
 def _trunk_segments(net):
@@ -304,7 +311,12 @@ def emit_trunks(pb, nets, xs, rider=None):
     shipped full.yaml next to the HRNet root trunk); every parallel block gets one more lane that advances it by
     one unit, so the chain overlaps the HRNet branches without nesting blocks."""
     n = len(nets)
-    if TRUNK_LANES == "nets" and rider is None:
+    mode = TRUNK_LANES
+    if mode == "nets" and EVAL_LANES and pb.fuse_inference and pb.plan.dtype == torch.bfloat16:
+        # inference plans with the fused BasicBlock launch (csrc/conv_block.h): the two high-resolution branches of a net (one
+        # chip-exclusive launch per block) and its low-resolution branches (batched whole-image launches) on two streams
+        mode = EVAL_LANES
+    if mode == "nets" and rider is None:
         ys = list(xs)
         segs = [_trunk_segments(net) for net in nets]
         for k in range(4):
@@ -338,7 +350,21 @@ def emit_trunks(pb, nets, xs, rider=None):
     for k in range(3):
         for mi in range(len(stages[0][k])):
             mods = [st[k][mi] for st in stages]
-            if TRUNK_LANES == "flat3":
+            if mode == "flat22":
+                # two lanes per net: branches {0, 1} and branches {2, 3}, each a lock-step merge of its branches
+                with pb.parallel(2 * n + extra()) as par:
+                    ride(par, 2 * n)
+                    for i, m in enumerate(mods):
+                        ys[i] = list(ys[i])
+                        for half, bs in enumerate(([b for b in range(m.num_branches) if b < 2], [b for b in range(m.num_branches) if b >= 2])):
+                            if not bs:
+                                continue
+                            with par.lane(2 * i + half):
+                                with pb.parallel(len(bs), virtual=True) as vp:
+                                    for q, b in enumerate(bs):
+                                        with vp.lane(q):
+                                            ys[i][b] = _emit_seq(pb, m.branches[b], ys[i][b])
+            elif mode == "flat3":
                 # two lanes per RESOLUTION CLASS: the high-resolution branch of every net (HBM-heavy, small-K launches:
                 # the batch runs the light conv kernel with persistent workgroups) and all other branches of every net
                 # (MFMA-heavy batched launches) - complementary kernels on two streams
@@ -357,7 +383,7 @@ def emit_trunks(pb, nets, xs, rider=None):
                             for q, (i, b) in enumerate(items):
                                 with vp.lane(q):
                                     ys[i][b] = _emit_seq(pb, mods[i].branches[b], ys[i][b])
-            elif TRUNK_LANES == "flat2":
+            elif mode == "flat2":
                 # two lanes per net: the high-resolution branch (HBM-heavy launches) and the other branches as virtual
                 # lanes of one chain (MFMA-heavy batched launches)
                 with pb.parallel(2 * n + extra()) as par:

@@ -157,6 +157,7 @@ BLOCK_END_REDUCE_FUSE = not os.environ.get("HRP_NO_BLOCK_END_REDUCE_FUSE")
 # ... and, for the 32- / 64-channel branches, the data gradient AND the weight gradient of each conv of a block in ONE launch from one
 # staging of the output gradient (csrc/conv_rowbw.h, hrp_rowbw_*): the BatchNorm-input gradients (y1.grad, y2.grad) and the forward
 # activation h are never written to HBM.  HRP_ROWBW_FUSE=0 / 1 overrides the default (DESIGN 5 has the A/B measurement).
+BLOCK_FUSE = os.environ.get("HRP_BLOCK_FUSE", "1") not in ("0", "")      # fused inference BasicBlock (csrc/conv_block.h)
 ROWBW_FUSE = os.environ.get("HRP_ROWBW_FUSE", "0") not in ("0", "")
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
 MASKED_RES = not os.environ.get("HRP_NO_MASKED_RES")
@@ -369,6 +370,70 @@ class RowBwBatch:
 
     def __call__(self, s):
         nv.call_rowbw(self, s)
+
+
+class BlockLaunch:
+    """One fused inference BasicBlock (csrc/conv_block.h, descriptor nv.BlockDesc).  The lock-step merge pairs the 32- and the
+    64-channel block of one position into one hrp_block_launch; alone it is a launch of one problem."""
+    fam = "block"
+
+    def __init__(self, desc):
+        self.desc = desc
+        self._single = None
+
+    def launches(self):
+        return [self]
+
+    def merge_key(self):
+        return ("block",)
+
+    def written(self):
+        return (self.desc.conv2.y,)
+
+    def __call__(self, s):
+        if self._single is None:
+            self._single = BlockBatch(None, [self])
+        self._single(s)
+
+
+class BlockBatch:
+    """hrp_block_launch of one problem, or of the 32-channel + the 64-channel block of one lock-step position."""
+    fam = "block"
+
+    def __init__(self, plan, items):
+        self.plan, self.items = plan, sorted(items, key=lambda it: it.desc.conv1.Cin)
+        self.info, self.table = None, None
+
+    def launches(self):
+        return self.items
+
+    def merge_key(self):
+        return None
+
+    def prepare(self):
+        n = len(self.items)
+        arr = (nv.BlockDesc * n)(*[it.desc for it in self.items])      # copies: every pointer is final by now
+        self.info = nv.BlockInfo()
+        self.table = (C.c_char * int(nv.lib().hrp_block_table_bytes()))()
+        nv.check(nv.lib().hrp_block_prepare(arr, n, self.table, C.byref(self.info)), "hrp_block_prepare")
+
+    def __call__(self, s):
+        if self.table is None:
+            self.prepare()
+        nv.call_block(self, s)
+
+
+def _pair_block(plan, ops):
+    """Fused inference blocks of one lock-step position -> launches of one 32-channel + one 64-channel problem (the two
+    high-resolution branches of one trunk), leftovers alone."""
+    items = [l for op in ops for l in op.launches()]
+    c32 = [it for it in items if it.desc.conv1.Cin == 32]
+    c64 = [it for it in items if it.desc.conv1.Cin != 32]
+    out = []
+    while c32 and c64:
+        out.append(BlockBatch(plan, [c32.pop(0), c64.pop(0)]))
+    out += [BlockBatch(plan, [it]) for it in c32 + c64]
+    return out
 
 
 def _pair_rowbw(plan, ops):
@@ -739,7 +804,7 @@ class Plan:
             seq.items.append(e.op)
 
         def key_of(op):
-            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, RowBwLaunch)) else None
+            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, RowBwLaunch, BlockLaunch)) else None
 
         def lockstep(kids):
             out = []
@@ -755,6 +820,8 @@ class Plan:
                 for key, ops in groups.items():
                     if key[0] == "rowbw":
                         out += _pair_rowbw(self, ops)
+                    elif key[0] == "block":
+                        out += _pair_block(self, ops)
                     else:
                         out += ops if len(ops) == 1 else _merge_ops(self, ops)
             return out
@@ -1139,7 +1206,7 @@ class Plan:
                 if depth == 0:
                     tops.append(i)
                 del hits[:]
-                if isinstance(op, (Launch, BatchLaunch, RowBwBatch)):
+                if isinstance(op, (Launch, BatchLaunch, RowBwBatch, BlockLaunch, BlockBatch)):
                     for it in op.launches():     # the descriptors say what a launch touches
                         walk(it.desc)
                 else:
@@ -1577,6 +1644,43 @@ class PlanBuilder:
         p.wgrad_ws_bytes[lane] = max(p.wgrad_ws_bytes.get(lane, 0), int(nv.lib().hrp_wgrad_workspace_bytes(C.byref(g))))
         p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
         p.bwd.append(Launch("wgrad", g))
+
+    def basic_block_eval(self, x, conv1_w, bn1, conv2_w, bn2):
+        """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), a whole BasicBlock without downsample (reference HRnet.py:41-57) of an
+        INFERENCE plan as ONE launch (csrc/conv_block.h): BatchNorm folded to scale / shift, the intermediate stays in LDS.
+        -> out, or None when the shapes are not the fused kernel's (32 / 64 channels at 64 / 32 pixels per row, bf16; caller:
+        the general path - two convolutions with folded epilogues)."""
+        p = self.plan
+        if not (BLOCK_FUSE and self.fuse_inference and not p.training and not p.need_grad and x.dtype == torch.bfloat16):
+            return None
+        Cc = x.C
+        if Cc not in (32, 64) or tuple(conv1_w.shape) != (Cc, Cc, 3, 3) or tuple(conv2_w.shape) != (Cc, Cc, 3, 3) or x.pitch != Cc or x.offset:
+            return None
+        x.check_readable()
+        dtype = x.dtype
+        w1, w2 = p.weight(conv1_w, Cc, Cc, 9), p.weight(conv2_w, Cc, Cc, 9)
+        out = p.new(x.N, x.H, x.W, Cc, dtype)
+        b = nv.BlockDesc()
+        d1 = self._conv_desc(x, w1, out, 1, 3, dtype, into=b.conv1)
+        d2 = self._conv_desc(x, w2, out, 1, 3, dtype, into=b.conv2)
+        (sc1, sh1), (sc2, sh2) = self._fold(bn1), self._fold(bn2)
+        d1.scale, d1.shift, d1.relu, d1.y = sc1.data_ptr(), sh1.data_ptr(), 1, None
+        d2.scale, d2.shift, d2.relu, d2.x = sc2.data_ptr(), sh2.data_ptr(), 1, None
+        d2.res, d2.res_pitch = x.ptr(), x.pitch
+        d1.w = d2.w = x.ptr()                      # (placeholders for the host-side shape query; final in late())
+        if nv.lib().hrp_block_channels(C.byref(b)) != Cc:
+            return None
+        for w in (w1, w2):
+            w.dtype, w.cin_used = dtype, Cc
+            w.need_t = getattr(w, "need_t", False)
+
+        def late():
+            d1.w, d2.w = w1.arena.data_ptr() + w1.fwd_off * 2, w2.arena.data_ptr() + w2.fwd_off * 2
+        p.late(late)
+        p.fwd.append(BlockLaunch(b))
+        out.producer = None
+        p.counters["block_fused"] = p.counters.get("block_fused", 0) + 1
+        return out
 
     def conv_bn_relu_conv(self, x, conv1_w, bn1, conv2_w, bn2=None):
         """y2 = conv2(relu(bn1(conv1(x)))), the interior of a BasicBlock (reference HRnet.py:41-50), in a TRAINING plan on the

@@ -460,6 +460,35 @@ int hrp_rowbw_launch(const void* table, const hrp_rowbw_info* info, void* stream
 /* fold descriptors (HRP_BATCH_WGRAD_FOLD) of the n problems, from their descriptors' workspace / dw / accumulate */
 int hrp_rowbw_fold_descs(const hrp_rowbw_desc* descs, const hrp_rowbw_info* info, hrp_wgrad_fold_desc* out);
 
+/* ---- fused inference BasicBlock (csrc/conv_block.h): out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x) in ONE launch -------------
+ * Replaces the four modules of BasicBlock.forward in eval mode (reference HRnet.py:41-57; scripts/test.py:267-273 is the
+ * caller whose frames per second it serves) for the 3x3 C -> C blocks of the two high-resolution branches (C = 32 @ W = 64,
+ * C = 64 @ W = 32, bf16): BatchNorm folded to per-channel scale / shift (hrp_bn_fold), the intermediate activation lives in
+ * LDS only - x is read once and out written once (2 tensor passes instead of 5).
+ * A workgroup (8 waves, two roles) walks a band of rows of one image in 4-row steps: waves 0-3 run conv1 + bn1 + ReLU into a
+ * 16-row ring of the intermediate in LDS, waves 4-7 run conv2 + bn2 + residual (from the LDS ring of x) + ReLU two steps
+ * behind; both keep their weights in registers; the rows of x arrive by direct-to-LDS DMA one step ahead.
+ *   conv1: the first convolution as hrp_conv2d_fwd would take it (x, w, scale, shift, relu = 1; no bias / res / stats; y unused)
+ *   conv2: the second one (w, scale, shift, relu = 1, res == conv1.x, y = the block output; x unused: never materialised)   */
+#define HRP_BLOCK_MAX 2
+typedef struct hrp_block_desc {
+  hrp_conv_desc conv1, conv2;
+} hrp_block_desc;
+typedef struct hrp_block_info {
+  int32_t n, grid, lds_bytes, reserved;
+  int32_t first_wg[HRP_BLOCK_MAX];     /* first workgroup of problem i                                                   */
+  int32_t bands[HRP_BLOCK_MAX];        /* row bands per image of problem i (one workgroup each)                           */
+} hrp_block_info;
+/* 32 / 64 when the fused kernel takes the block, else 0 (host only) */
+int hrp_block_channels(const hrp_block_desc* d);
+/* hrp_block_prepare  host only: validates the n <= HRP_BLOCK_MAX problems (two: a 32-channel and a 64-channel block, in this
+ *                    order - the two high-resolution branches of one trunk), chooses the bands and writes the launch table
+ *                    (hrp_block_table_bytes() bytes of HOST memory the caller keeps: passed to the kernel by value).
+ * hrp_block_launch   asynchronous on `stream`, hipGraph-capturable. */
+int64_t hrp_block_table_bytes(void);
+int hrp_block_prepare(const hrp_block_desc* descs, int n, void* table, hrp_block_info* info);
+int hrp_block_launch(const void* table, const hrp_block_info* info, void* stream);
+
 int hrp_bn_running_update(const hrp_bn_entry* table_dev, int count, void* stream);
 int hrp_bn_fold(const hrp_bn_entry* table_dev, int count, void* stream);
 int hrp_bn_param_grad(const hrp_bn_entry* table_dev, int count, void* stream);

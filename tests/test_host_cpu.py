@@ -46,9 +46,10 @@ def test_ctypes_struct_sizes_match_c():
 #include <stdio.h>
 #include "hrp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
          sizeof(hrp_ew_input), sizeof(hrp_ew_desc), sizeof(hrp_ew_bwd_desc), sizeof(hrp_bn_entry), sizeof(hrp_fk_chain),
-         sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk), sizeof(hrp_batch_info), sizeof(hrp_pose_loss_desc), sizeof(hrp_wgrad_fold_desc));
+         sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk), sizeof(hrp_batch_info), sizeof(hrp_pose_loss_desc), sizeof(hrp_wgrad_fold_desc),
+         sizeof(hrp_rowbw_desc), sizeof(hrp_rowbw_info), sizeof(hrp_block_desc), sizeof(hrp_block_info));
   return 0;
 }'''
     import tempfile
@@ -59,7 +60,8 @@ int main(void) {
         out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
     sizes = [int(v) for v in out]
     mirrors = [nv.ConvDesc, nv.WgradDesc, nv.PackEntry, nv.EwInput, nv.EwDesc, nv.EwBwdDesc, nv.BnEntry, nv.FkChain,
-               nv.OptTensor, nv.OptChunk, nv.BatchInfo, nv.PoseLossDesc, nv.WgradFoldDesc]
+               nv.OptTensor, nv.OptChunk, nv.BatchInfo, nv.PoseLossDesc, nv.WgradFoldDesc,
+               nv.RowBwDesc, nv.RowBwInfo, nv.BlockDesc, nv.BlockInfo]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

@@ -53,6 +53,9 @@ __device__ __forceinline__ void channel_consts(const hrp_ew_input& in, int c, in
   if (c >= C) return;
   if (in.mode == HRP_EW_AFFINE) {
     sc = in.a[c]; sh = in.b[c];
+    // the reduce pass of an affine input accumulates sum g * (x * a + b) = sum g * (x - mean) * inv with these (the eval-mode
+    // BatchNorm backward passes (a, b) = (invstd, -mean * invstd) of the running statistics: dgamma; a > 0 there)
+    inv = sc; mean = sc != 0.f ? -sh / sc : 0.f;
   } else if (in.mode == HRP_EW_BN_TRAIN) {
     float m = slot_sum(in.stats, c, 2 * C) / in.count;
     float var = fmaxf(slot_sum(in.stats, C + c, 2 * C) / in.count - m * m, 0.f);

@@ -528,6 +528,7 @@ class Plan:
         self.weight_list = []
         self.bn_train = []         # (bn module, stats offset, count)
         self.bn_fold = {}          # id(bn) -> (scale tensor, shift tensor)
+        self.bn_fold_hat = {}      # id(bn) -> (bn, invstd, -mean * invstd) of the RUNNING statistics: xhat = x * a + b (eval-mode BatchNorm backward)
         self.bn_bwd = []           # (bn module, bwd sums offset)
         self.stats_floats = 0
         self.bsums_floats = 0
@@ -1035,6 +1036,15 @@ class Plan:
                 ents.append(dict(a=bn.weight.data_ptr(), b=bn.bias.data_ptr(), c=bn.running_mean.data_ptr(),
                                  d=bn.running_var.data_ptr(), out_scale=sc.data_ptr(), out_shift=sh.data_ptr(),
                                  C=bn.num_features, eps=bn.eps))
+            if self.bn_fold_hat:
+                # the same fold with gamma = 1, beta = 0: xhat = x * invstd - mean * invstd (dgamma of an eval-mode BatchNorm)
+                cmax = max(bn.num_features for bn, _, _ in self.bn_fold_hat.values())
+                ones, zeros = torch.ones(cmax, device=self.device), torch.zeros(cmax, device=self.device)
+                self.keep += [ones, zeros]
+                for bn, inv, nmi in self.bn_fold_hat.values():
+                    ents.append(dict(a=ones.data_ptr(), b=zeros.data_ptr(), c=bn.running_mean.data_ptr(),
+                                     d=bn.running_var.data_ptr(), out_scale=inv.data_ptr(), out_shift=nmi.data_ptr(),
+                                     C=bn.num_features, eps=bn.eps))
             self._fold_tab = self._table(ents)
         if self.bn_bwd:
             ents = []
@@ -1699,6 +1709,8 @@ class PlanBuilder:
         p = self.plan
         if not (ROWCONV_FUSE and p.training and x.dtype == torch.bfloat16):
             return None
+        if not (self.bn_batch_stats(bn1) and (bn2 is None or self.bn_batch_stats(bn2))):
+            return None              # (a BatchNorm in eval mode inside a training plan: general path)
         Cc = x.C
         if tuple(conv1_w.shape) != (Cc, Cc, 3, 3) or tuple(conv2_w.shape) != (Cc, Cc, 3, 3) or x.pitch != Cc or x.offset:
             return None
@@ -2029,6 +2041,20 @@ class PlanBuilder:
             p.bn_fold[id(bn)] = e
         return e[1], e[2]
 
+    def _fold_hat(self, bn):
+        p = self.plan
+        e = p.bn_fold_hat.get(id(bn))
+        if e is None:
+            e = (bn, torch.zeros(bn.num_features, dtype=torch.float32, device=p.device),
+                 torch.zeros(bn.num_features, dtype=torch.float32, device=p.device))
+            p.bn_fold_hat[id(bn)] = e
+        return e[1], e[2]
+
+    def bn_batch_stats(self, bn):
+        """Does this BatchNorm normalise with batch statistics in this plan?  (train_sim2real.py:139-146 trains the network with
+        every BatchNorm module switched to eval(): running statistics in the forward pass, gradients through them.)"""
+        return self.plan.training and bn.training
+
     def act(self, terms, relu):
         """out = act(sum_j BN_j(t_j) upsampled).  In inference plans a single conv+BN(+identity residual)
         is folded into the producing conv's epilogue instead."""
@@ -2066,7 +2092,7 @@ class PlanBuilder:
             assert tm.t.H * tm.up == H and tm.t.W * tm.up == W and tm.t.C == Cc
             if tm.bn is None:
                 e.mode = nv.EW_IDENTITY
-            elif p.training:
+            elif self.bn_batch_stats(tm.bn):
                 assert tm.t.stats is not None, "train-mode BN needs conv statistics"
                 e.mode = nv.EW_BN_TRAIN
                 e.a, e.b = tm.bn.weight.data_ptr(), tm.bn.bias.data_ptr()
@@ -2103,8 +2129,7 @@ class PlanBuilder:
         for j, tm in enumerate(terms):
             if not tm.t.requires_grad or j == rider:
                 continue
-            if tm.bn is not None and not p.training:
-                raise NotImplementedError("gradients through eval-mode BatchNorm are not supported yet")
+            bn_eval = tm.bn is not None and not self.bn_batch_stats(tm.bn)
             b = nv.EwBwdDesc()
             b.dout, b.out = out.gptr(), out.ptr()
             b.dout_pitch, b.out_pitch = out.pitch, out.pitch
@@ -2122,7 +2147,21 @@ class PlanBuilder:
                 # the check above guarantees the aligned vector path is the same for both outputs
                 b.din2, b.din2_pitch = rt.gptr(), rt.pitch
                 b.accumulate2 = rt.take_grad_slot()
-            if tm.bn is not None:
+            if bn_eval:
+                # eval-mode BatchNorm (affine with the running statistics): dx = g * scale (the apply launch below, affine input as
+                # in the forward pass); dbeta = sum g, dgamma = sum g * xhat with xhat = x * invstd - mean * invstd from a reduce
+                # launch of its own descriptor (affine input (invstd, -mean * invstd): elementwise.hip channel_consts)
+                if tm.bn.weight.requires_grad or tm.bn.bias.requires_grad:
+                    r = nv.EwBwdDesc()
+                    C.memmove(C.byref(r), C.byref(b), C.sizeof(nv.EwBwdDesc))
+                    inv, nmi = self._fold_hat(tm.bn)
+                    r.inp.mode, r.inp.a, r.inp.b = nv.EW_AFFINE, inv.data_ptr(), nmi.data_ptr()
+                    r.din, r.din2 = None, None
+                    off = p.alloc_bsums(fd.C)
+                    p.bn_bwd.append((tm.bn, off))
+                    p.late(lambda r=r, off=off: setattr(r, "sums", p.bsums.data_ptr() + 8 * off))
+                    p.bwd.append(Launch("ew_red", r))
+            elif tm.bn is not None:
                 off = p.alloc_bsums(fd.C)
                 p.bn_bwd.append((tm.bn, off))
                 p.late(lambda b=b, off=off: setattr(b, "sums", p.bsums.data_ptr() + 8 * off))

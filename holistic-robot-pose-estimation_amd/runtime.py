@@ -157,12 +157,20 @@ class _PlanFn(torch.autograd.Function):
         return (None, None) + tuple(gin)
 
 
+MODE_EPOCH = [0]     # bumped by every train() / eval() call on a PlannedModule: invalidates the cached BatchNorm-mode signatures
+
+
 class PlannedModule(nn.Module):
     """Base of every hrpe_amd module: owns plans, never computes with torch ops."""
+
+    def train(self, mode=True):
+        MODE_EPOCH[0] += 1
+        return super().train(mode)
 
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_plans", {})
+        object.__setattr__(self, "_bn_sig", (-1, 0))
         object.__setattr__(self, "_compute_dtype", torch.float32)
 
     # compute dtype of the convolution trunk (heads stay fp32)
@@ -272,9 +280,13 @@ class PlannedModule(nn.Module):
         need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                                  or any(t.requires_grad for t in tensors))
         # uint8 inputs are raw images (dataset bytes): the plan's input kernel divides them by 255 on the way in
+        # (a training module whose BatchNorm modules were switched to eval() - train_sim2real.py:139-146 - is a different plan)
+        if self._bn_sig[0] != MODE_EPOCH[0]:
+            self._bn_sig = (MODE_EPOCH[0], sum(1 for m in self.modules() if not m.training and hasattr(m, "running_mean")))
+        bn_eval = self._bn_sig[1] if self.training else 0
         key = (tuple(tuple(t.shape) for t in tensors), self._compute_dtype, self.training, need_grad,
                tuple(bool(t.requires_grad) for t in tensors) if need_grad else (),
-               tuple(t.dtype == torch.uint8 for t in tensors))
+               tuple(t.dtype == torch.uint8 for t in tensors), bn_eval)
         runner = self._plans.pop(key, None)
         if runner is not None:
             self._plans[key] = runner        # most recently used last

@@ -618,9 +618,22 @@ PICK_GRADS_RESNET = [
 ]
 
 
-def gen_full_train(backbone_name=None, B=2):
+def gen_full_train(backbone_name=None, B=2, bn_eval=False):
     function = import_reference_step_function()
     full, margs = build_full(backbone_name)
+    if bn_eval:
+        # scripts/train_sim2real.py:139-146 (BASELINE config 5): the network trains with every BatchNorm module in eval() -
+        # running statistics in the forward pass, gradients through them.  The step function calls model.train() itself, so
+        # the switch is re-applied right after it.
+        plain_train = full.train
+
+        def train_with_frozen_bn(mode=True):
+            plain_train(mode)
+            for module in full.modules():
+                if isinstance(module, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                    module.eval()
+            return full
+        full.train = train_with_frozen_bn
     batch, small = make_batch(B, full.robot)
     args = rh._AttrDict(dict(margs))
     args.update(urdf_robot_name="panda", use_origin_bbox=False, use_extended_bbox=True,
@@ -661,6 +674,8 @@ def gen_full_train(backbone_name=None, B=2):
         out["fwd:" + n] = t.numpy()
     out["k_values"] = kv.numpy()
     name = "golden_full_train_resnet.npz" if backbone_name else ("golden_full_train.npz" if B == 2 else f"golden_full_train_b{B}.npz")
+    if bn_eval:
+        name = "golden_full_train_bn_eval.npz"
     np.savez_compressed(os.path.join(HERE, name), **out)
     print("full train ok", name, out["loss"], {k: float(v) for k, v in terms.items()})
 
@@ -742,6 +757,8 @@ if __name__ == "__main__":
     for w in which:
         if w == "full_train_resnet":
             gen_full_train("resnet50")
+        elif w == "full_train_bn_eval":
+            gen_full_train(None, B=2, bn_eval=True)
         elif w == "full_train_b8":      # the same step at B = 8: train-mode BatchNorm over >= 512 samples per channel
             gen_full_train(None, B=8)   # amplifies rounding noise far less than B = 2, so gradients can be held tighter
         else:

@@ -165,3 +165,52 @@ def test_bf16_training_follows_the_fp32_loss_curve():
     for i in idx:
         lo, hi = (f32[max(i - 2, 0):i + 3].mean(), b16[max(i - 2, 0):i + 3].mean())
         assert abs(lo - hi) < 0.20 * lo, (i, lo, hi)
+
+
+def test_full_train_step_with_frozen_batchnorm_golden():
+    """BASELINE config 5's way of training (scripts/train_sim2real.py:139-146): model.train() with every BatchNorm module in
+    eval() - running statistics in the forward pass and gradients THROUGH them (dx = g * scale, dgamma = sum g * xhat with the
+    running mean / variance, dbeta = sum g).  Fixture: the reference's own training step run that way
+    (tests/golden/gen_golden.py full_train_bn_eval): forward 8-tuple, loss terms, sampled gradients, untouched running statistics.
+    fp32 tolerances as test_full_train_step_golden (no batch statistics: no B = 2 amplification, but the same summaries)."""
+    from hrpe_amd.lib.core.function import compute_k_values, full_loss
+    from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+    g = load("golden_full_train_bn_eval.npz")
+    m = M.build_full().train()
+    n_bn = 0
+    for mod in m.modules():
+        if hasattr(mod, "running_mean"):
+            mod.eval()
+            n_bn += 1
+    assert n_bn > 600
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    x_root = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    K = torch.tensor(g["in:K"]).to(DEV)
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], torch.tensor(g["in:bbox"]).to(DEV))
+    q, R, t = [torch.tensor(g[k]).to(DEV) for k in ("in:q", "in:R", "in:t")]
+    kp3d, kp2d, mask = [torch.tensor(g[k]).to(DEV) for k in ("in:kp3d", "in:kp2d", "in:mask")]
+    gt = dict(pose=q, root_rot=m.robot.get_rotation_at_specific_root(q, rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    pred = m(x_reg, x_root, kv, K)
+    for n, p in zip(M.NAMES8, pred):
+        ref = g["fwd:" + n]
+        err = np.abs(p.detach().cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 1e-3, f"forward {n}: rel err {err}"
+    loss, terms = full_loss(pred, gt, K)
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g["term:" + k], rtol=2e-3, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-3)
+    loss.backward()
+    params = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            M.summary_check(params[name].grad, g, f"grad:{name}:", M.GRAD_TOL, what="frozen-BatchNorm ")
+            checked += 1
+    assert checked >= 10
+    for k, v in m.state_dict().items():          # eval-mode BatchNorm: the running statistics do not move
+        if "running" in k:
+            assert torch.equal(v, sd0[k]), k

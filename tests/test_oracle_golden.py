@@ -433,10 +433,12 @@ def test_full_eval_baxter_golden():
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
-def test_full_train_golden(robot):
+@pytest.mark.parametrize("frozen_bn", [False, True], ids=["train", "bn_eval"])
+def test_full_train_golden(robot, frozen_bn):
     """One reference training step (lib/core/function.py farward_loss, train=True): loss terms,
-    gradients and BN running stats."""
-    g = load("golden_full_train.npz")
+    gradients and BN running stats.  bn_eval: the same step with every BatchNorm module in eval() as
+    scripts/train_sim2real.py:139-146 trains (BASELINE config 5): running statistics, gradients through them."""
+    g = load("golden_full_train_bn_eval.npz" if frozen_bn else "golden_full_train.npz")
     sd = full_sd()
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
@@ -450,7 +452,7 @@ def test_full_train_golden(robot):
     kp3d, kp2d, mask = torch.tensor(g["in:kp3d"]), torch.tensor(g["in:kp2d"]), torch.tensor(g["in:mask"])
     gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, fk.rotmat_to_rot6d(R), t, root=3),
               root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
-    pred = heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=True)
+    pred = heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=not frozen_bn)
     for n, p in zip(NAMES8, pred):
         np.testing.assert_allclose(p.detach().numpy(), g["fwd:" + n], rtol=2e-4, atol=2e-5, err_msg=n)
     loss, terms = heads.full_loss(pred, gt, K)

@@ -77,6 +77,14 @@ class RowBwInfo(C.Structure):
                 ("ws_bytes", C.c_int64 * ROWBW_MAX)]
 
 
+class Sim2RealLossDesc(C.Structure):
+    _fields_ = [("rendered", C.c_void_p), ("seg", C.c_void_p), ("kp3d", C.c_void_p), ("kp3d_int", C.c_void_p),
+                ("B", C.c_int32), ("HW", C.c_int32), ("K", C.c_int32), ("mask_loss", C.c_int32),
+                ("w_mask", C.c_float), ("w_iou", C.c_float), ("w_scale", C.c_float), ("w_align", C.c_float),
+                ("terms", C.c_void_p), ("d_rendered", C.c_void_p), ("d_kp3d", C.c_void_p), ("d_kp3d_int", C.c_void_p),
+                ("workspace", C.c_void_p)]
+
+
 BLOCK_MAX = 2
 
 
@@ -217,6 +225,7 @@ PROTOTYPES = {
     "hrp_block_launch": [_P, C.POINTER(BlockInfo), _P],
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
+    "hrp_sim2real_loss": [C.POINTER(Sim2RealLossDesc), _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "hrp_linear_workspace_bytes": [_I, _I, _I],

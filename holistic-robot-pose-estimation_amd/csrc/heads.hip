@@ -820,6 +820,119 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
 }
 }  // namespace hrp
 
+namespace hrp {
+// ---- mask losses of the self-supervised trainer (scripts/train_sim2real.py:435-468) ------------------------------------
+// pass 1: per image I = sum s r, S = sum s, R = sum r, M = the mask term's sum; one workgroup per image, fixed order
+__global__ __launch_bounds__(256) void s2r_sums_kernel(const hrp_sim2real_loss_desc d) {
+  const int b = blockIdx.x;
+  const float* r = d.rendered + (size_t)b * d.HW;
+  const float* s = d.seg + (size_t)b * d.HW;
+  float aI = 0.f, aS = 0.f, aR = 0.f, aM = 0.f;
+  for (int p = threadIdx.x; p < d.HW; p += 256) {
+    const float rv = r[p], sv = s[p];
+    aI += sv * rv; aS += sv; aR += rv;
+    if (d.mask_loss == 1) aM -= sv * fmaxf(logf(rv), -100.f) + (1.f - sv) * fmaxf(logf(1.f - rv), -100.f);
+    else { const float e = rv - sv; aM += e * e; }
+  }
+  __shared__ float part[4][4];
+  aI = wave_sum(aI); aS = wave_sum(aS); aR = wave_sum(aR); aM = wave_sum(aM);
+  if ((threadIdx.x & 63) == 0) { float* q = part[threadIdx.x >> 6]; q[0] = aI; q[1] = aS; q[2] = aR; q[3] = aM; }
+  __syncthreads();
+  if (threadIdx.x < 4) d.workspace[b * 8 + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// pass 2 (one workgroup): the terms, the per-image gradient coefficients, the key-point gradients
+__global__ __launch_bounds__(256) void s2r_finalize_kernel(const hrp_sim2real_loss_desc d) {
+  __shared__ float sh_align;
+  const int n3 = d.B * d.K;
+  // align: every thread its own points, the sum serially by thread 0 (B * K is a few hundred)
+  if (threadIdx.x == 0) {
+    float mask = 0.f, iou = 0.f, num = 0.f, nf = 0.f;
+    for (int b = 0; b < d.B; ++b) {
+      const float* w = d.workspace + b * 8;
+      const float I = w[0], S = w[1], R = w[2];
+      mask += w[3];
+      const float U = S + R - I;
+      iou += I / U;
+      const float so = S - I, ro = R - I, ratio = so / ro;
+      const float f = (ratio > 5.0f || ratio < 0.2f) ? 1.f : 0.f;
+      num += fabsf(logf(ratio)) * f;
+      nf += f;
+    }
+    const float npx = (float)d.B * (float)d.HW;
+    const float l_mask = d.mask_loss == 2 ? 0.001f * mask : mask / npx;
+    const float l_iou = 1.f - iou / (float)d.B;
+    const float l_scale = num / (nf + 1e-9f);
+    float al = 0.f;
+    for (int i = 0; i < n3; ++i) {
+      const float ex = d.kp3d[3 * i] - d.kp3d_int[3 * i], ey = d.kp3d[3 * i + 1] - d.kp3d_int[3 * i + 1], ez = d.kp3d[3 * i + 2] - d.kp3d_int[3 * i + 2];
+      al += sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    const float l_align = al / (float)n3;
+    d.terms[1] = l_mask; d.terms[2] = l_iou; d.terms[3] = l_scale; d.terms[4] = l_align;
+    d.terms[0] = d.w_mask * l_mask + d.w_iou * l_iou + d.w_scale * l_scale + d.w_align * l_align;
+    sh_align = nf;
+  }
+  __syncthreads();
+  const float nf = sh_align;
+  // d loss / d rendered[b, p] = A_b * s + B_b * (1 - s) + the mask term's own (pass 3)
+  for (int b = threadIdx.x; b < d.B; b += 256) {
+    float* w = d.workspace + b * 8;
+    const float I = w[0], S = w[1], R = w[2];
+    const float U = S + R - I, so = S - I, ro = R - I, ratio = so / ro;
+    float A = 0.f, Bc = 0.f;
+    if (d.w_iou != 0.f) { A += d.w_iou * (-1.f / ((float)d.B * U)); Bc += d.w_iou * (I / ((float)d.B * U * U)); }
+    if (d.w_scale != 0.f && (ratio > 5.0f || ratio < 0.2f)) {
+      const float c = d.w_scale * (logf(ratio) >= 0.f ? 1.f : -1.f) / (nf + 1e-9f);
+      A += c * (-1.f / so); Bc += c * (-1.f / ro);
+    }
+    w[4] = A; w[5] = Bc;
+  }
+  if (d.d_kp3d || d.d_kp3d_int) {
+    for (int i = threadIdx.x; i < n3; i += 256) {
+      const float ex = d.kp3d[3 * i] - d.kp3d_int[3 * i], ey = d.kp3d[3 * i + 1] - d.kp3d_int[3 * i + 1], ez = d.kp3d[3 * i + 2] - d.kp3d_int[3 * i + 2];
+      const float nrm = sqrtf(ex * ex + ey * ey + ez * ez);
+      const float k = nrm > 0.f ? d.w_align / (nrm * (float)n3) : 0.f;
+      if (d.d_kp3d) { d.d_kp3d[3 * i] = k * ex; d.d_kp3d[3 * i + 1] = k * ey; d.d_kp3d[3 * i + 2] = k * ez; }
+      if (d.d_kp3d_int) { d.d_kp3d_int[3 * i] = -k * ex; d.d_kp3d_int[3 * i + 1] = -k * ey; d.d_kp3d_int[3 * i + 2] = -k * ez; }
+    }
+  }
+}
+
+// pass 3: the gradient with respect to the rendered masks
+__global__ __launch_bounds__(256) void s2r_grad_kernel(const hrp_sim2real_loss_desc d) {
+  const int b = blockIdx.y;
+  const float A = d.workspace[b * 8 + 4], Bc = d.workspace[b * 8 + 5];
+  const float npx = (float)d.B * (float)d.HW;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < d.HW; p += gridDim.x * 256) {
+    const size_t o = (size_t)b * d.HW + p;
+    const float rv = d.rendered[o], sv = d.seg[o];
+    float g = A * sv + Bc * (1.f - sv);
+    if (d.w_mask != 0.f) {
+      if (d.mask_loss == 0) g += d.w_mask * 2.f * (rv - sv) / npx;
+      else if (d.mask_loss == 2) g += d.w_mask * 0.002f * (rv - sv);
+      else g += d.w_mask * (rv - sv) / fmaxf((1.f - rv) * rv, 1e-12f) / npx;
+    }
+    d.d_rendered[o] = g;
+  }
+}
+}  // namespace hrp
+
+extern "C" int hrp_sim2real_loss(const hrp_sim2real_loss_desc* dp, void* stream) {
+  using namespace hrp;
+  HRP_REQUIRE(dp && dp->rendered && dp->seg && dp->kp3d && dp->kp3d_int && dp->terms && dp->workspace, "sim2real_loss: null pointer");
+  HRP_REQUIRE(dp->B > 0 && dp->HW > 0 && dp->K > 0 && dp->mask_loss >= 0 && dp->mask_loss <= 2, "sim2real_loss: B=%d HW=%d K=%d mask_loss=%d",
+              dp->B, dp->HW, dp->K, dp->mask_loss);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(s2r_sums_kernel, dim3(dp->B), dim3(256), 0, s, *dp);
+  hipLaunchKernelGGL(s2r_finalize_kernel, dim3(1), dim3(256), 0, s, *dp);
+  if (dp->d_rendered) {
+    const int gx = (dp->HW + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(s2r_grad_kernel, dim3(gx > 0 ? gx : 1, dp->B), dim3(256), 0, s, *dp);
+  }
+  return check_launch("sim2real_loss");
+}
+
 extern "C" int hrp_l1_loss(const float* pred, const float* gt, float scale, int n, float* loss, float* d_pred, void* stream) {
   using namespace hrp;
   HRP_REQUIRE(pred && gt && loss && n > 0, "l1_loss: bad arguments");

@@ -130,6 +130,68 @@ class _L1Loss(torch.autograd.Function):
         return (ctx.grad * g_loss).view_as(ctx.grad) if ctx.grad is not None else None, None, None
 
 
+SIM2REAL_YAML_WEIGHTS = dict(mask=0.0, iou=1.0, scale=0.0, align=1.0)       # configs/panda/self_supervised/*.yaml:109-112
+_MASK_LOSS = {"mse_mean": 0, "bce": 1, "mse_sum": 2}
+
+
+class _Sim2RealLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rendered, seg, kp3d, kp3d_int, mask_loss, w):
+        import ctypes as C
+        from hrpe_amd import _native as nv
+        r, s_ = rendered.contiguous().float(), seg.contiguous().float()
+        a, b = kp3d.contiguous().float(), kp3d_int.contiguous().float()
+        B = r.shape[0]
+        d = nv.Sim2RealLossDesc()
+        terms = torch.empty(5, dtype=torch.float32, device=r.device)
+        ws = torch.empty(8 * B, dtype=torch.float32, device=r.device)
+        grads = [torch.empty_like(t) if req else None for t, req in ((r, rendered.requires_grad), (a, kp3d.requires_grad), (b, kp3d_int.requires_grad))]
+        d.rendered, d.seg, d.kp3d, d.kp3d_int = r.data_ptr(), s_.data_ptr(), a.data_ptr(), b.data_ptr()
+        d.B, d.HW, d.K, d.mask_loss = B, r.numel() // B, a.shape[1], mask_loss
+        d.w_mask, d.w_iou, d.w_scale, d.w_align = w
+        d.terms, d.workspace = terms.data_ptr(), ws.data_ptr()
+        d.d_rendered, d.d_kp3d, d.d_kp3d_int = [None if g is None else g.data_ptr() for g in grads]
+        nv.call("hrp_sim2real_loss", C.byref(d), torch.cuda.current_stream(r.device).cuda_stream)
+        ctx.grads = [None if g is None else g.view(t.shape) for g, t in zip(grads, (rendered, kp3d, kp3d_int))]
+        ctx.mark_non_differentiable(terms)
+        return terms[0], terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        gr, ga, gb = [None if g is None else g * g_loss for g in ctx.grads]
+        return gr, None, ga, gb, None, None
+
+
+def sim2real_mask_loss(rendered_masks, seg_masks, pred_keypoints3d, pred_keypoints3d_int, mask_loss_func="mse_mean",
+                       weights=SIM2REAL_YAML_WEIGHTS):
+    """The render-and-compare losses of the self-supervised trainer (reference scripts/train_sim2real.py:435-468, BASELINE config
+    5): mask (mse_mean | bce | mse_sum), IoU, scale and 3-D alignment, weighted.  rendered_masks [B, H, W] are the soft
+    silhouettes of the posed robot mesh, seg_masks [B, H, W] (or [B, 1, H, W]) the segmentation network's output (detached there).
+    -> (loss, dict(loss_mask, loss_iou, loss_scale, loss_error3d_align)).  Device tensors: hrp_sim2real_loss (one call, analytic
+    gradient); host tensors: the same arithmetic as tensor expressions."""
+    seg = seg_masks.reshape(rendered_masks.shape).detach()
+    if rendered_masks.is_cuda:
+        w = (float(weights["mask"]), float(weights["iou"]), float(weights["scale"]), float(weights["align"]))
+        loss, t = _Sim2RealLoss.apply(rendered_masks, seg, pred_keypoints3d, pred_keypoints3d_int, _MASK_LOSS[mask_loss_func], w)
+        return loss, dict(loss_mask=t[1], loss_iou=t[2], loss_scale=t[3], loss_error3d_align=t[4])
+    r = rendered_masks
+    if mask_loss_func == "mse_mean":
+        l_mask = torch.nn.functional.mse_loss(r, seg)
+    elif mask_loss_func == "bce":
+        l_mask = torch.nn.functional.binary_cross_entropy(r, seg)
+    else:
+        l_mask = 0.001 * torch.nn.functional.mse_loss(r, seg, reduction="sum")
+    inter = torch.sum(seg * r, dim=(1, 2))
+    seg_area, render_area = torch.sum(seg, dim=(1, 2)), torch.sum(r, dim=(1, 2))
+    l_iou = 1 - torch.mean(inter / (seg_area + render_area - inter))
+    ratio = (seg_area - inter) / (render_area - inter)
+    flt = (ratio.detach() > 5.0) | (ratio.detach() < 0.2)
+    l_scale = torch.sum(torch.abs(torch.log(ratio)) * flt) / (torch.sum(flt) + 1e-9)
+    l_align = torch.mean(torch.norm(pred_keypoints3d - pred_keypoints3d_int, dim=2))
+    loss = weights["mask"] * l_mask + weights["iou"] * l_iou + weights["scale"] * l_scale + weights["align"] * l_align
+    return loss, dict(loss_mask=l_mask, loss_iou=l_iou, loss_scale=l_scale, loss_error3d_align=l_align)
+
+
 def depth_l1_loss(pred_depth_mm, gt_depth_m):
     """nn.L1Loss()(model(images, k_values) / 1000, gt_root_depth) of the DepthNet trainer (reference
     scripts/train_depthnet.py:231-250) as one launch with its analytic gradient (device tensors; host tensors: torch)."""

@@ -578,6 +578,30 @@ int hrp_pose_loss(const hrp_pose_loss_desc* d, void* stream);
  * *loss = mean |pred * scale - gt| over n dense fp32 values; d_pred (optional) = sign(pred * scale - gt) * scale / n. */
 int hrp_l1_loss(const float* pred, const float* gt, float scale, int n, float* loss, float* d_pred, void* stream);
 
+/* Mask losses of the self-supervised (render-and-compare) trainer, reference scripts/train_sim2real.py:435-468 (BASELINE
+ * config 5), with their analytic gradient, in one call (three small launches, fixed summation order: reproducible):
+ *   mask   mask_loss 0: MSELoss(mean)(rendered, seg) | 1: BCELoss (log clamped at -100 as torch) | 2: 0.001 * MSELoss(sum)
+ *   iou    1 - mean_b( I_b / (S_b + R_b - I_b) ),  I = sum seg * rendered, S = sum seg, R = sum rendered per image
+ *   scale  sum_b |log((S_b - I_b) / (R_b - I_b))| * f_b / (sum_b f_b + 1e-9),  f_b = ratio > 5 or ratio < 0.2 (no gradient)
+ *   align  mean over (b, k) of || kp3d - kp3d_int ||_2
+ *   loss = w_mask * mask + w_iou * iou + w_scale * scale + w_align * align        (terms[0..4] = loss, mask, iou, scale, align)
+ * Gradients (optional pointers) are those of `loss`; a term whose weight is 0 contributes none (torch would propagate 0 * inf
+ * of a degenerate ratio); || . || = 0 has gradient 0 as in torch.  `seg` carries no gradient (the trainer detaches it). */
+typedef struct hrp_sim2real_loss_desc {
+  const float* rendered;   /* [B, HW] soft silhouettes in [0, 1]                                  */
+  const float* seg;        /* [B, HW] segmentation probabilities                                   */
+  const float* kp3d;       /* [B, K, 3] key-points of the kinematic chain (pred_keypoints3d)       */
+  const float* kp3d_int;   /* [B, K, 3] key-points of the integral head (pred_keypoints3d_int)     */
+  int32_t B, HW, K, mask_loss;
+  float w_mask, w_iou, w_scale, w_align;
+  float* terms;            /* [5]                                                                  */
+  float* d_rendered;       /* optional [B, HW]                                                     */
+  float* d_kp3d;           /* optional [B, K, 3]                                                   */
+  float* d_kp3d_int;       /* optional [B, K, 3]                                                   */
+  float* workspace;        /* [8 * B] floats                                                       */
+} hrp_sim2real_loss_desc;
+int hrp_sim2real_loss(const hrp_sim2real_loss_desc* d, void* stream);
+
 /* nn.Dropout of the regression heads (lib/models/full_net.py:98-99, 132-133; p = args.p_dropout, lib/config.py default
  * 0.5), inverted scaling: mask[r,c] = (u < keep) / keep with u from Philox4x32-10 keyed by state_dev[0] (seed) at counter
  * (element / 4, salt, state_dev[1] = step); y = x * mask.  `mask` ([rows, cols] dense fp32) is what the backward multiplies

@@ -752,6 +752,53 @@ def gen_full_2iter():
     print("full 2 iterations ok", {k: float(v) for k, v in out.items() if k.startswith(("loss", "grad_norm"))})
 
 
+def gen_sim2real_loss():
+    """The mask / IoU / scale / 3-D alignment losses of the self-supervised trainer (BASELINE config 5).  They are inline code of
+    scripts/train_sim2real.py (a 300-line closure that needs pytorch3d, a dataset and a segmentation checkpoint to run): the
+    statements of lines 435-468 are read from the reference file HERE, at generation time, and executed on seeded inputs with the
+    three loss modules of lines 409-411 - the reference's own arithmetic, with autograd's gradients."""
+    import textwrap
+    src = open(os.path.join(rh.REFERENCE_ROOT, "scripts", "train_sim2real.py")).read().split("\n")
+    body = textwrap.dedent("\n".join(src[434:468]))          # 1-based lines 435..468
+    assert body.lstrip().startswith("if args.mask_loss_func") and "loss = args.mask_loss_weight" in body
+    g = torch.Generator().manual_seed(77)
+    B, H, W, Kp = 6, 24, 32, 7
+    out = {}
+    cases = {"iou_align": ("mse_mean", (0.0, 1.0, 0.0, 1.0)), "mse_mean": ("mse_mean", (1.0, 0.5, 0.25, 2.0)),
+             "bce": ("bce", (1.0, 1.0, 1.0, 1.0)), "mse_sum": ("mse_sum", (1.0, 0.0, 1.0, 0.0))}
+    # silhouettes: soft blobs; two images are made to trip the scale filter (ratio > 5 and < 0.2)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+
+    def blob(cx, cy, rad, soft):
+        return torch.sigmoid((rad - torch.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)) / soft)
+    seg = torch.stack([blob(16, 12, 7, 1.0), blob(10, 10, 5, 0.7), blob(20, 14, 9, 1.5), blob(16, 12, 10, 1.0), blob(16, 12, 3, 0.5),
+                       blob(12, 8, 6, 1.0)])
+    ren = torch.stack([blob(17, 12, 6.5, 0.8), blob(12, 11, 5, 0.7), blob(19, 13, 8, 1.2), blob(16, 12, 4, 0.8), blob(16, 12, 9, 1.0),
+                       blob(13, 9, 6, 1.1)]).clamp(1e-4, 1 - 1e-4)
+    kp_a = torch.randn(B, Kp, 3, generator=g) * 0.3
+    kp_b = kp_a + torch.randn(B, Kp, 3, generator=g) * 0.02
+    out["in:rendered"], out["in:seg"], out["in:kp3d"], out["in:kp3d_int"] = ren.numpy(), seg.numpy(), kp_a.numpy(), kp_b.numpy()
+    for name, (func, (wm, wi, ws, wa)) in cases.items():
+        rendered_masks = ren.clone().requires_grad_(True)
+        pred_keypoints3d, pred_keypoints3d_int = kp_a.clone().requires_grad_(True), kp_b.clone().requires_grad_(True)
+        ns = dict(torch=torch, args=rh._AttrDict(mask_loss_func=func, mask_loss_weight=wm, iou_loss_weight=wi, scale_loss_weight=ws,
+                                                 align_3d_loss_weight=wa),
+                  criterionBCE=torch.nn.BCELoss(), mse_sum=torch.nn.MSELoss(reduction="sum"), mse_mean=torch.nn.MSELoss(reduction="mean"),
+                  rendered_masks=rendered_masks, seg_masks=seg.clone().unsqueeze(1), pred_keypoints3d=pred_keypoints3d,
+                  pred_keypoints3d_int=pred_keypoints3d_int, cast=lambda obj, device, dtype=None: obj, device="cpu", loss_dict={})
+        exec(body, ns)
+        ns["loss"].backward()
+        out[f"{name}:loss"] = np.array(ns["loss"].item())
+        for k in ("loss_mask", "loss_iou", "loss_scale", "loss_error3d_align"):
+            out[f"{name}:{k}"] = np.array(ns["loss_dict"][k].item())
+        out[f"{name}:d_rendered"] = rendered_masks.grad.numpy()
+        out[f"{name}:d_kp3d"] = pred_keypoints3d.grad.numpy()
+        out[f"{name}:d_kp3d_int"] = pred_keypoints3d_int.grad.numpy()
+        out[f"{name}:weights"] = np.array([wm, wi, ws, wa], dtype=np.float32)
+        print("sim2real loss", name, float(out[f"{name}:loss"]), {k: float(out[f"{name}:{k}"]) for k in ("loss_mask", "loss_iou", "loss_scale", "loss_error3d_align")})
+    np.savez_compressed(os.path.join(HERE, "golden_sim2real_loss.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fk", "integral", "hrnet_eval", "depthnet", "full_eval", "full_train"]
     for w in which:

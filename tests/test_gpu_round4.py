@@ -214,3 +214,29 @@ def test_full_train_step_with_frozen_batchnorm_golden():
     for k, v in m.state_dict().items():          # eval-mode BatchNorm: the running statistics do not move
         if "running" in k:
             assert torch.equal(v, sd0[k]), k
+
+
+@pytest.mark.parametrize("case,func", [("iou_align", "mse_mean"), ("mse_mean", "mse_mean"), ("bce", "bce"), ("mse_sum", "mse_sum")])
+def test_sim2real_mask_loss_kernel_golden(case, func):
+    """hrp_sim2real_loss (mask / IoU / scale / 3-D alignment losses of the self-supervised trainer and their analytic gradient,
+    scripts/train_sim2real.py:435-468) against the fixture written by executing those statements of the reference on seeded
+    silhouettes (two of the six images trip the scale filter).  fp32 sums over 768 pixels in another order: 2e-5 on the terms,
+    gradients 1e-4 of their scale; a second call gives bit-identical results (fixed summation order)."""
+    from hrpe_amd.lib.core.function import sim2real_mask_loss
+    g = load("golden_sim2real_loss.npz")
+    r = torch.tensor(g["in:rendered"]).to(DEV).requires_grad_(True)
+    a, b = torch.tensor(g["in:kp3d"]).to(DEV).requires_grad_(True), torch.tensor(g["in:kp3d_int"]).to(DEV).requires_grad_(True)
+    seg = torch.tensor(g["in:seg"]).unsqueeze(1).to(DEV)
+    wm, wi, ws, wa = [float(v) for v in g[f"{case}:weights"]]
+    w = dict(mask=wm, iou=wi, scale=ws, align=wa)
+    loss, terms = sim2real_mask_loss(r, seg, a, b, func, w)
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g[f"{case}:{k}"], rtol=2e-5, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g[f"{case}:loss"], rtol=2e-5)
+    (loss * 1.0).backward()
+    for t, key in ((r, "d_rendered"), (a, "d_kp3d"), (b, "d_kp3d_int")):
+        ref = g[f"{case}:{key}"]
+        err = np.abs(t.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-4 * np.abs(ref).max() + 1e-12, (key, err, np.abs(ref).max())
+    loss2, terms2 = sim2real_mask_loss(r.detach().requires_grad_(True), seg, a.detach(), b.detach(), func, w)
+    assert torch.equal(loss2, loss.detach()) and all(torch.equal(terms2[k], terms[k]) for k in terms)

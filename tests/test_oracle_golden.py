@@ -560,3 +560,30 @@ def test_full_two_iterations_golden(robot):
     gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, fk.rotmat_to_rot6d(R), t, root=3),
               root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
     _two_iterations(sd, lambda: heads.full_loss(heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=True), gt, K)[0], 5.0, g, 2e-4)
+
+
+SIM2REAL_CASES = {"iou_align": "mse_mean", "mse_mean": "mse_mean", "bce": "bce", "mse_sum": "mse_sum"}
+
+
+@pytest.mark.parametrize("case", sorted(SIM2REAL_CASES))
+def test_sim2real_mask_losses_golden(case):
+    """The tensor-expression form of the render-and-compare losses (hrpe_amd.lib.core.function.sim2real_mask_loss on host
+    tensors - what the fused kernel is tested against on the GPU) against the fixture written by executing the reference's own
+    statements (scripts/train_sim2real.py:435-468; tests/golden/gen_golden.py sim2real_loss): terms, loss, autograd gradients."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import hrpe_amd  # noqa: F401
+    from hrpe_amd.lib.core.function import sim2real_mask_loss
+    g = load("golden_sim2real_loss.npz")
+    r = torch.tensor(g["in:rendered"]).requires_grad_(True)
+    a, b = torch.tensor(g["in:kp3d"]).requires_grad_(True), torch.tensor(g["in:kp3d_int"]).requires_grad_(True)
+    wm, wi, ws, wa = [float(v) for v in g[f"{case}:weights"]]
+    loss, terms = sim2real_mask_loss(r, torch.tensor(g["in:seg"]).unsqueeze(1), a, b, SIM2REAL_CASES[case],
+                                     dict(mask=wm, iou=wi, scale=ws, align=wa))
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g[f"{case}:{k}"], rtol=1e-6, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g[f"{case}:loss"], rtol=1e-6)
+    loss.backward()
+    np.testing.assert_allclose(r.grad.numpy(), g[f"{case}:d_rendered"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(a.grad.numpy(), g[f"{case}:d_kp3d"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(b.grad.numpy(), g[f"{case}:d_kp3d_int"], rtol=1e-5, atol=1e-9)

@@ -84,7 +84,7 @@ static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds)
     if (rc == -100) { rc = plan_cfg<T, 1, 1, 1, 4, NT>(d, P.t, lds, false); P.cfg = 1; }
   }
   if (rc == -100) {
-    set_error("conv batch: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
+    set_error("conv batch: no tile configuration fits LDS and the tap halo (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
     return HRP_ERR_ARG;
   }
   return rc;

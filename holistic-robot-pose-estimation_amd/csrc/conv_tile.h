@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const hrp_conv_desc d, c
 
 // ---------------------------------------------------------------------------------------------
 static thread_local int g_conv_lds_budget_kb = 76;
+static thread_local bool g_conv_border_reject = false;   // plan_cfg: a configuration was turned down because its tiles are smaller than the tap halo
 
 // Host side: tile geometry, LDS layout and block count of one problem for one tile configuration (no HIP call).
 // -> HRP_OK, -100 (this configuration does not fit: try the next) or HRP_ERR_ARG.
@@ -648,9 +649,9 @@ static int plan_cfg(const hrp_conv_desc& d, ConvTiling& t, int& lds_out, bool al
                           (t.tiles_y - 2) * TH * d.in_stride + mindy + t.IHt - 1 >= d.H)) ||
       (t.tiles_x >= 2 && (TW * d.in_stride + mindx < 0 ||
                           (t.tiles_x - 2) * TW * d.in_stride + mindx + t.IWt - 1 >= d.W))) {
-    set_error("conv: tap offsets reach beyond the border tiles (H=%d W=%d Ho=%d Wo=%d stride=%d)", d.H, d.W, d.Ho, d.Wo,
-              d.in_stride);
-    return HRP_ERR_ARG;
+    // (a tile smaller than the halo - dilated taps: the next, larger configuration may do)
+    g_conv_border_reject = true;
+    return -100;
   }
   const int out_bytes = BM * (BN * SZ + 16);
   {  // chunks per stage: as many as two stages fit in half of LDS
@@ -725,6 +726,7 @@ static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
   static const long want = getenv("HRP_CONV_WANT") ? atol(getenv("HRP_CONV_WANT")) : 256;
   static const int low_kb = getenv("HRP_CONV_LDS_KB") ? atoi(getenv("HRP_CONV_LDS_KB")) : 76;
   int rc = -100;
+  g_conv_border_reject = false;
   for (int pass = 0; pass < 2 && rc == -100; ++pass) {
   g_conv_lds_budget_kb = pass == 0 ? low_kb : 76;
   if (pass == 1 && low_kb >= 76) break;
@@ -742,7 +744,11 @@ static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
   }
   g_conv_lds_budget_kb = 76;
   if (rc == -100) {
-    set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
+    if (g_conv_border_reject)
+      set_error("conv: no tile configuration fits: the tap offsets reach beyond the border tiles of every tile that fits LDS "
+                "(H=%d W=%d Ho=%d Wo=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Ho, d.Wo, d.Cin, d.in_stride, d.ntaps);
+    else
+      set_error("conv: tile does not fit LDS (H=%d W=%d Cin=%d stride=%d taps=%d)", d.H, d.W, d.Cin, d.in_stride, d.ntaps);
     return HRP_ERR_ARG;
   }
   return rc;

@@ -24,13 +24,14 @@ logger = logging.getLogger(__name__)
 
 # ---- parameter containers ----------------------------------------------------------------------------
 class Conv2d(SingleTensorModule):
-    """Holds [Cout, Cin, k, k] weight (+bias); k in {1, 3}, padding k//2, stride in {1, 2}."""
+    """Holds [Cout, Cin, k, k] weight (+bias); k in {1, 3}, padding dilation * (k//2), stride in {1, 2}; dilation > 1 for 3x3
+    stride-1 layers (the atrous layers of the segmentation net, reference lib/models/ctrnet/keypoint_seg_resnet.py:103-149)."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True, dilation=1):
         super().__init__()
-        assert kernel_size in (1, 3) and stride in (1, 2)
+        assert kernel_size in (1, 3) and stride in (1, 2) and (dilation == 1 or (kernel_size == 3 and stride == 1))
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.kernel_size, self.stride = kernel_size, stride
+        self.kernel_size, self.stride, self.dilation = kernel_size, stride, dilation
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         bound = 1.0 / math.sqrt(in_channels * kernel_size * kernel_size)
@@ -44,7 +45,7 @@ class Conv2d(SingleTensorModule):
             # a 1x1 conv on pooled fp32 features is nn.Linear (depth_layer, depth_net.py:121-123 / full_net.py:271-274): the skinny
             # GEMM kernels with their ordered reduction instead of the conv path's split-K atomics
             return pb.linear(x, self.weight, self.bias)
-        return pb.conv(x, self.weight, self.bias, stride=self.stride, want_stats=want_stats)
+        return pb.conv(x, self.weight, self.bias, stride=self.stride, want_stats=want_stats, dilation=self.dilation)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}"

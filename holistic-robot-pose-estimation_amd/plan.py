@@ -1579,7 +1579,7 @@ class PlanBuilder:
         return holder
 
     # ---- convolution ----------------------------------------------------------------------------------
-    def _conv_desc(self, x, w, y, stride, ksize, dtype, into=None):
+    def _conv_desc(self, x, w, y, stride, ksize, dtype, into=None, dilation=1):
         d = into if into is not None else nv.ConvDesc()
         d.x, d.y = x.ptr(), y.ptr()
         d.dtype = _dt(dtype)
@@ -1591,13 +1591,15 @@ class PlanBuilder:
         taps = _TAPS3 if ksize == 3 else [(0, 0)]
         d.ntaps = len(taps)
         for i, (a, b) in enumerate(taps):
-            d.dy[i], d.dx[i], d.wtap[i] = a, b, i
+            d.dy[i], d.dx[i], d.wtap[i] = a * dilation, b * dilation, i
         d.w_ntaps = len(taps)
         d.w_cout_pad = _rup(y.C, 32)
         return d
 
-    def conv(self, x, weight, bias=None, stride=1, want_stats=False, out=None, residual=None, relu=False):
-        """y = conv(x) (+bias) (+residual) (ReLU).  weight: torch parameter [Cout, Cin, k, k] or [Cout, Cin]."""
+    def conv(self, x, weight, bias=None, stride=1, want_stats=False, out=None, residual=None, relu=False, dilation=1):
+        """y = conv(x) (+bias) (+residual) (ReLU).  weight: torch parameter [Cout, Cin, k, k] or [Cout, Cin].
+        dilation > 1 (3x3, stride 1, padding = dilation: the atrous layers of DeepLabv3's ResNet-50, reference
+        lib/models/ctrnet/keypoint_seg_resnet.py:103-149): the same tile program with the taps dilation pixels apart."""
         p = self.plan
         x.check_readable()
         cout, cin = weight.shape[0], weight.shape[1]
@@ -1608,11 +1610,12 @@ class PlanBuilder:
         w.dtype = dtype
         w.cin_used = cin
         w.need_t = getattr(w, "need_t", False) or (p.need_grad and x.requires_grad)
+        assert dilation == 1 or (ksize == 3 and stride == 1), "dilated convolutions: 3x3, stride 1"
         Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
         Wo = (x.W + 2 * (ksize // 2) - ksize) // stride + 1
         y = out if out is not None else p.new(x.N, Ho, Wo, cout, dtype)
         y.requires_grad = p.need_grad
-        d = self._conv_desc(x, w, y, stride, ksize, dtype)
+        d = self._conv_desc(x, w, y, stride, ksize, dtype, dilation=dilation)
         if bias is not None:
             d.bias = bias.data_ptr()
         if residual is not None:
@@ -1630,7 +1633,7 @@ class PlanBuilder:
         p.fwd.append(Launch("conv", d))
         y.producer = ("conv", d)
         if p.need_grad:
-            self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu))
+            self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu, dilation))
         return y
 
     def _wgrad_launch(self, x, w, y, ksize=3, stride=1):
@@ -1931,14 +1934,14 @@ class PlanBuilder:
             self.bwd_stack.append(bw)
         return y
 
-    def _conv_bwd(self, x, w, y, bias, stride, ksize, dtype, residual, relu):
+    def _conv_bwd(self, x, w, y, bias, stride, ksize, dtype, residual, relu, dilation=1):
         p = self.plan
         assert not relu, "ReLU fused in a conv epilogue is inference-only"
         if not y.grad_written:
             return  # nobody consumed this output
         esz = 4 if dtype == torch.float32 else 2
         vec = 8 if dtype == torch.bfloat16 else 4
-        taps = _TAPS3 if ksize == 3 else [(0, 0)]
+        taps = [(a * dilation, b * dilation) for a, b in _TAPS3] if ksize == 3 else [(0, 0)]
         # residual: d_res += dY (fp32 heads only)
         if residual is not None and residual.requires_grad:
             assert dtype == torch.float32

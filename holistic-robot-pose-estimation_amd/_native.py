@@ -226,6 +226,7 @@ PROTOTYPES = {
     "hrp_pose_loss": [C.POINTER(PoseLossDesc), _P],
     "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
     "hrp_sim2real_loss": [C.POINTER(Sim2RealLossDesc), _P],
+    "hrp_mesh_pose": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "hrp_linear_workspace_bytes": [_I, _I, _I],

@@ -786,6 +786,59 @@ extern "C" int hrp_rot6d_compose_bwd(const float* a, const float* b, const float
   return check_launch("rot6d_compose_bwd");
 }
 
+namespace hrp {
+// ---- mesh posing (mesh_renderer.py:126-173 + urdf_robot.py:242-275): one workgroup row per sample ------------------------
+__global__ __launch_bounds__(256) void mesh_pose_kernel(const hrp_fk_chain* __restrict__ ch, const float* __restrict__ q,
+                                                        const float* __restrict__ r6, const float* __restrict__ tr, int root_kp,
+                                                        const float* __restrict__ verts, const uint8_t* __restrict__ vert_link, int V,
+                                                        const float* __restrict__ K, float* __restrict__ xyz, float* __restrict__ uv) {
+  __shared__ float P[HRP_FK_MAX_KP][12];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int nl = ch->nkp;
+  if (tid < nl) {
+    const int dof = ch->dof;
+    float ql[HRP_FK_MAX_JOINTS];
+    for (int i = 0; i < dof; ++i) ql[i] = q[(size_t)b * dof + i];
+    float rl[6], tl[3];
+    for (int i = 0; i < 6; ++i) rl[i] = r6[6 * b + i];
+    for (int i = 0; i < 3; ++i) tl[i] = tr[3 * b + i];
+    Rigid<float> M = base_to_cam<float>(rl, tl);
+    if (root_kp >= 0) M = rigid_mul(M, rigid_inverse(frame_pose<float>(ch, ch->kp_frame[root_kp], ql)));
+    if (M.t[2] < 0.f) {      // urdf_robot.py:250-253: the camera looks along +z; a pose behind it is mirrored through the origin
+      for (int i = 0; i < 3; ++i) { M.t[i] = -M.t[i]; for (int k = 0; k < 3; ++k) M.r[i][k] = -M.r[i][k]; }
+    }
+    const Rigid<float> T = rigid_mul(M, frame_pose<float>(ch, ch->kp_frame[tid], ql));
+    for (int i = 0; i < 3; ++i) { P[tid][4 * i] = T.r[i][0]; P[tid][4 * i + 1] = T.r[i][1]; P[tid][4 * i + 2] = T.r[i][2]; P[tid][4 * i + 3] = T.t[i]; }
+  }
+  __syncthreads();
+  for (int v = blockIdx.x * 256 + tid; v < V; v += gridDim.x * 256) {
+    const float* T = P[vert_link[v]];
+    const float x = verts[3 * v], y = verts[3 * v + 1], z = verts[3 * v + 2];
+    float p[3];
+    for (int i = 0; i < 3; ++i) p[i] = T[4 * i] * x + T[4 * i + 1] * y + T[4 * i + 2] * z + T[4 * i + 3];
+    float* o = xyz + ((size_t)b * V + v) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    if (K && uv) {
+      float w[2];
+      project<float>(K + 9 * b, p, w);
+      uv[((size_t)b * V + v) * 2] = w[0];
+      uv[((size_t)b * V + v) * 2 + 1] = w[1];
+    }
+  }
+}
+}  // namespace hrp
+
+extern "C" int hrp_mesh_pose(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans, int B, int root_kp,
+                             const float* verts, const uint8_t* vert_link, int V, const float* K, float* xyz, float* uv, void* stream) {
+  using namespace hrp;
+  HRP_REQUIRE(chain_dev && q && rot6d && trans && verts && vert_link && xyz && B > 0 && V > 0, "mesh_pose: bad args");
+  HRP_REQUIRE(root_kp < HRP_FK_MAX_KP, "mesh_pose: root_kp=%d", root_kp);
+  int gx = (V + 256 * 4 - 1) / (256 * 4);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(mesh_pose_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, root_kp, verts, vert_link, V, K, xyz, uv);
+  return check_launch("mesh_pose");
+}
+
 extern "C" int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
                                   const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream) {
   HRP_REQUIRE(chain_dev && q && rot6d && trans && xyz && B > 0, "fk_project_fwd: bad args");

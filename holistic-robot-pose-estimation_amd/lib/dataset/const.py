@@ -10,6 +10,10 @@ LINK_NAMES = {
                            for side in ("right", "left")],
 }
 
+# links whose visual meshes the self-supervised trainer renders, in the order of their mesh files (reference
+# lib/utils/urdf_robot.py:209-219; only the Panda has a mesh list there)
+MESH_LINKS = {"panda": ["panda_link%d" % i for i in range(8)] + ["panda_hand"]}
+
 JOINT_NAMES = {
     "panda": ["panda_joint%d" % i for i in range(1, 8)] + ["panda_finger_joint1"],
     "kuka": ["iiwa_joint_%d" % i for i in range(1, 8)],

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from hrpe_amd import _native as nv
-from hrpe_amd.lib.dataset.const import BAXTER_KEYPOINT_JOINTS, JOINT_NAMES, LINK_NAMES
+from hrpe_amd.lib.dataset.const import BAXTER_KEYPOINT_JOINTS, JOINT_NAMES, LINK_NAMES, MESH_LINKS
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "assets")
 
@@ -214,6 +214,42 @@ class URDFRobot:
         assert root < len(self.link_names), (root, len(self.link_names))
         with torch.no_grad():
             return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, None, root, ("rot",))[0]
+
+    def mesh_chain_on(self, device):
+        """(device hrp_fk_chain whose key-point table lists the visual-mesh links, their names): reference urdf_robot.py:209-219."""
+        key = "mesh:" + str(device)
+        if key not in self._dev:
+            if device.type != "cuda":
+                raise nv.HrpError("URDFRobot kinematics run on the GPU only (no CPU path)")
+            names = MESH_LINKS[self.robot_type]
+            ch, _ = parse_chain(self.urdf_path, names)
+            self._dev[key] = (torch.frombuffer(bytearray(bytes(ch)), dtype=torch.uint8).to(device), names)
+        return self._dev[key]
+
+    def pose_mesh(self, jointcfgs, b2c_rot, b2c_trans, verts, vert_link, root=0, K=None):
+        """Camera-frame vertices of the posed robot mesh, one launch for the batch (reference: RobotMeshRenderer.get_robot_mesh
+        per sample on the CPU, lib/utils/mesh_renderer.py:126-173, then the camera pose of
+        get_rendered_mask_single_image_at_specific_root, urdf_robot.py:242-275 - re-rooted at key-point `root`, mirrored when
+        the translation has negative depth).  verts [V, 3]: vertices in their links' frames; vert_link [V] uint8: index of the
+        vertex's link in MESH_LINKS[robot_type].  -> xyz [B, V, 3] (and uv [B, V, 2] with K [B, 3, 3]).  No gradient: the
+        trainer detaches the joint angles here."""
+        dev = jointcfgs.device
+        chain, names = self.mesh_chain_on(dev)
+        root_kp = -1
+        if root != 0:
+            if self.link_names[root] not in names:
+                raise NotImplementedError(f"key-point link {self.link_names[root]} is not a mesh link")
+            root_kp = names.index(self.link_names[root])
+        B, V = jointcfgs.shape[0], verts.shape[0]
+        q, r, t = [x.detach().contiguous().float() for x in (jointcfgs, b2c_rot, b2c_trans)]
+        vv, vl = verts.contiguous().float(), vert_link.contiguous().to(torch.uint8)
+        xyz = torch.empty(B, V, 3, device=dev)
+        uv = torch.empty(B, V, 2, device=dev) if K is not None else None
+        Kc = K.contiguous().float() if K is not None else None
+        nv.call("hrp_mesh_pose", chain.data_ptr(), q.data_ptr(), r.data_ptr(), t.data_ptr(), B, root_kp, vv.data_ptr(), vl.data_ptr(), V,
+                Kc.data_ptr() if Kc is not None else None, xyz.data_ptr(), uv.data_ptr() if uv is not None else None,
+                torch.cuda.current_stream(dev).cuda_stream)
+        return xyz if K is None else (xyz, uv)
 
     def get_keypoints_only_fk(self, jointcfgs):
         rot, tr = self._identity_cam(jointcfgs)

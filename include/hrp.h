@@ -530,6 +530,15 @@ int hrp_rot6d_compose_bwd(const float* a, const float* b, const float* dout, flo
  * root > 0 re-roots the chain at keypoint `root` (urdf_robot.py:194-198). One wavefront per sample. */
 int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
                        const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream);
+/* Mesh posing of the render-and-compare path (reference lib/utils/mesh_renderer.py:126-173 get_robot_mesh - every link's
+ * vertices moved by the link's pose, on the CPU, per sample - and lib/utils/urdf_robot.py:242-275: camera pose of the robot
+ * base, optionally re-rooted at a key-point link, flipped when the translation has negative depth):
+ *   xyz[b, v] = M_b * (T_link(v)(q_b) * verts[v]),   M_b = B2C_b (root_kp < 0) or B2C_b * T_root(q_b)^-1;  M_b -> -M_b if M_b.t.z < 0
+ * `chain_dev` is an hrp_fk_chain whose key-point table lists the MESH links (offsets unused): vert_link[v] and root_kp index it.
+ * K (optional, [B, 9]): uv[b, v] = pinhole projection of xyz (the renderer's PerspectiveCameras with focal (-fx, -fy)).
+ * Forward only: the trainer detaches the joint angles on this path and the silhouette's pose gradient comes from the rasteriser. */
+int hrp_mesh_pose(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans, int B, int root_kp,
+                  const float* verts, const uint8_t* vert_link, int V, const float* K, float* xyz, float* uv, void* stream);
 int hrp_fk_project_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
                        const float* K, int B, int root, const float* d_xyz, const float* d_uv,
                        float* d_q, float* d_rot6d, float* d_trans, void* stream);

@@ -197,6 +197,25 @@ class Robot:
         return rotmat_to_rot6d(TWL[:, root, :3, :3])
 
 
+MESH_LINKS = {"panda": ["panda_link%d" % i for i in range(8)] + ["panda_hand"]}      # urdf_robot.py:209-219
+
+
+def pose_mesh(robot, q, rot6d, trans, verts, vert_link, root=0, robot_type="panda"):
+    """Camera-frame vertices of the posed mesh [B, V, 3].  mesh_renderer.py:126-173 (every link's vertices `verts @ R.T + t`
+    with the link's pose) viewed by the camera of urdf_robot.py:242-275: base-to-camera pose, re-rooted at key-point `root`
+    (`base2cam @ inv(TWL_root)`, :266-271), mirrored through the origin when its translation has negative depth (:250-253;
+    pytorch3d's `X @ R + T` with R transposed at :245 is the column form `R X + T` used here)."""
+    TL = link_poses(robot.tree, q, MESH_LINKS[robot_type])                        # [B, L, 4, 4]
+    M = _base2cam(rot6d, trans)
+    if root != 0:
+        M = M @ torch.linalg.inv(robot.get_TWL(q)[:, root])
+    flip = torch.where(M[:, 2, 3] < 0, -1.0, 1.0)[:, None, None]
+    R, T = M[:, :3, :3] * flip, M[:, :3, 3] * flip[:, :, 0]
+    vl = vert_link.long()
+    posed = torch.einsum("bvkj,vj->bvk", TL[:, vl, :3, :3], verts) + TL[:, vl, :3, 3]
+    return torch.einsum("bkj,bvj->bvk", R, posed) + T[:, None, :]
+
+
 def project(K, pts):
     """point_projection_from_3d_tensor, transforms.py:7-21: uv = (K p)[:2] / (K p)[2]."""
     h = torch.einsum("bij,bkj->bki", K, pts)

@@ -752,6 +752,49 @@ def gen_full_2iter():
     print("full 2 iterations ok", {k: float(v) for k, v in out.items() if k.startswith(("loss", "grad_norm"))})
 
 
+def gen_mesh_pose():
+    """Mesh posing of the render-and-compare path (BASELINE config 5).  What the reference can run here: the link poses from its
+    urdfpytorch kinematics (`robot.link_fk_batch`, the call inside URDFRobot.get_TWL) for the nine visual-mesh links of
+    urdf_robot.py:209-219, and URDFRobot.get_rendered_mask_single_image_at_specific_root (urdf_robot.py:242-275) with the
+    renderer replaced by a recorder of the camera (R, T) it is called with - pytorch3d, roboticstoolbox and the mesh files are
+    not in the container.  The vertices are seeded points in the link frames, posed with the expression of
+    mesh_renderer.py:148 (`verts @ R.T + t`) and viewed in pytorch3d's row-vector convention (`X @ R + T`)."""
+    robot = URDFRobot("panda")
+    g = np.random.Generator(np.random.PCG64(4321))
+    n, V = 12, 96
+    b = np.array(JOINT_BOUNDS["panda"], dtype=np.float64)
+    q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((n, len(b)))).astype(np.float32)
+    rot6d = (random_rotations(g, n)[:, :2, :].reshape(n, 6) * g.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    t = np.stack([g.uniform(-.3, .3, n), g.uniform(-.3, .3, n), g.uniform(.6, 2.0, n)], 1).astype(np.float32)
+    t[3, 2], t[7, 2] = -0.9, -1.4                               # behind the camera: the mirrored branch of urdf_robot.py:250-251
+    mesh_links = ["panda_link%d" % i for i in range(8)] + ["panda_hand"]
+    verts = (g.normal(size=(V, 3)) * 0.08).astype(np.float32)
+    vert_link = g.integers(0, len(mesh_links), V).astype(np.uint8)
+    fk = robot.robot.link_fk_batch(torch.tensor(q), use_names=True)
+    TL = torch.stack([fk[name] for name in mesh_links]).permute(1, 0, 2, 3)          # [n, 9, 4, 4]
+    out = dict(q=q, rot6d=rot6d, t=t, verts=verts, vert_link=vert_link, link_R=TL[:, :, :3, :3].numpy(), link_t=TL[:, :, :3, 3].numpy())
+
+    class Recorder:
+        def silhouette_renderer(self, meshes_world=None, R=None, T=None):
+            self.R, self.T = R.detach().clone(), T.detach().clone()
+            return torch.zeros(1, 2, 2, 4)
+    for root in (0, 3):
+        cam = np.zeros((n, V, 3), np.float32)
+        Rs, Ts = np.zeros((n, 3, 3), np.float32), np.zeros((n, 3), np.float32)
+        for i in range(n):
+            rec = Recorder()
+            with torch.no_grad():
+                robot.get_rendered_mask_single_image_at_specific_root(torch.tensor(q[i]), torch.tensor(rot6d[i]), torch.tensor(t[i]),
+                                                                      None, rec, root=root)
+            Rs[i], Ts[i] = rec.R[0].numpy(), rec.T[0].numpy()
+            vl = torch.tensor(vert_link.astype(np.int64))
+            posed = torch.einsum("vj,vkj->vk", torch.tensor(verts), TL[i, vl, :3, :3]) + TL[i, vl, :3, 3]     # verts_i @ R.T + t per link
+            cam[i] = (posed @ rec.R[0] + rec.T[0]).numpy()
+        out[f"cam_root{root}"], out[f"R_root{root}"], out[f"T_root{root}"] = cam, Rs, Ts
+    np.savez_compressed(os.path.join(HERE, "golden_mesh_pose.npz"), **out)
+    print("mesh pose ok", out["cam_root3"][0, :2], "flipped:", [int(i) for i in np.where(out["T_root0"][:, 2] > 0)[0] if t[i, 2] < 0])
+
+
 def gen_sim2real_loss():
     """The mask / IoU / scale / 3-D alignment losses of the self-supervised trainer (BASELINE config 5).  They are inline code of
     scripts/train_sim2real.py (a 300-line closure that needs pytorch3d, a dataset and a segmentation checkpoint to run): the

@@ -289,3 +289,27 @@ def test_dilation_beyond_the_tile_halo_is_refused_loudly():
     with pytest.raises(HrpError, match="conv"):
         with torch.no_grad():
             conv(torch.randn(1, 32, 60, 80, device=DEV))
+
+
+def test_mesh_pose_kernel_golden():
+    """hrp_mesh_pose (URDFRobot.pose_mesh: the posed robot mesh in the camera frame for a whole batch in one launch) against the
+    reference-generated fixture (link poses of the reference's kinematics, camera pose recorded from the reference's
+    get_rendered_mask_single_image_at_specific_root, roots 0 and 3, two samples behind the camera) and against pinhole
+    projection of its own output.  fp32: 5e-6 m."""
+    from hrpe_amd.lib.utils.urdf_robot import URDFRobot
+    g = load("golden_mesh_pose.npz")
+    robot = URDFRobot("panda")
+    q, r6, t = [torch.tensor(g[k]).to(DEV) for k in ("q", "rot6d", "t")]
+    verts, vl = torch.tensor(g["verts"]).to(DEV), torch.tensor(g["vert_link"]).to(DEV)
+    K = torch.tensor([[160.0, 0, 160.0], [0, 160.0, 120.0], [0, 0, 1.0]]).repeat(q.shape[0], 1, 1).to(DEV)
+    for root in (0, 3):
+        xyz, uv = robot.pose_mesh(q, r6, t, verts, vl, root=root, K=K)
+        np.testing.assert_allclose(xyz.cpu().numpy(), g[f"cam_root{root}"], atol=5e-6, err_msg=f"root {root}")
+        ref_uv = torch.stack([160.0 * xyz[..., 0] / xyz[..., 2] + 160.0, 160.0 * xyz[..., 1] / xyz[..., 2] + 120.0], -1)
+        np.testing.assert_allclose(uv.cpu().numpy(), ref_uv.cpu().numpy(), rtol=1e-5, atol=1e-3)
+        assert (xyz[[3, 7], :, 2] > 0).all()                   # mirrored in front of the camera
+    big = torch.randn(5000, 3, device=DEV) * 0.05              # more vertices than one workgroup pass
+    bl = torch.randint(0, 9, (5000,), device=DEV, dtype=torch.uint8)
+    a = robot.pose_mesh(q, r6, t, big, bl, root=3)
+    b = robot.pose_mesh(q, r6, t, big[:100], bl[:100], root=3)
+    assert torch.equal(a[:, :100], b)

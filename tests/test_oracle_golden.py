@@ -587,3 +587,18 @@ def test_sim2real_mask_losses_golden(case):
     np.testing.assert_allclose(r.grad.numpy(), g[f"{case}:d_rendered"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(a.grad.numpy(), g[f"{case}:d_kp3d"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(b.grad.numpy(), g[f"{case}:d_kp3d_int"], rtol=1e-5, atol=1e-9)
+
+
+def test_mesh_pose_golden(robot):
+    """oracle.fk.pose_mesh against the fixture of tests/golden/gen_golden.py mesh_pose: link poses from the reference's own
+    kinematics, camera (R, T) recorded from the reference's get_rendered_mask_single_image_at_specific_root (roots 0 and 3, two
+    samples behind the camera)."""
+    g = load("golden_mesh_pose.npz")
+    q, r6, t = torch.tensor(g["q"]), torch.tensor(g["rot6d"]), torch.tensor(g["t"])
+    TL = fk.link_poses(robot.tree, q, fk.MESH_LINKS["panda"])
+    np.testing.assert_allclose(TL[:, :, :3, :3].numpy(), g["link_R"], atol=2e-6)
+    np.testing.assert_allclose(TL[:, :, :3, 3].numpy(), g["link_t"], atol=2e-6)
+    for root in (0, 3):
+        cam = fk.pose_mesh(robot, q, r6, t, torch.tensor(g["verts"]), torch.tensor(g["vert_link"]), root=root)
+        np.testing.assert_allclose(cam.numpy(), g[f"cam_root{root}"], atol=5e-6, err_msg=f"root {root}")
+    assert (g["T_root0"][[3, 7], 2] > 0).all() and (g["t"][[3, 7], 2] < 0).all()      # the mirrored samples are in the fixture

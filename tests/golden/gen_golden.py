@@ -752,6 +752,57 @@ def gen_full_2iter():
     print("full 2 iterations ok", {k: float(v) for k, v in out.items() if k.startswith(("loss", "grad_norm"))})
 
 
+def gen_pose_loss():
+    """The loss assembly of lib/core/function.py:191-322 on PRESCRIBED predictions: the reference's training-step function is run
+    with a stand-in model whose forward returns seeded tensors (nn.Parameters, so that autograd leaves their gradients), once with
+    small and once with large translation errors - both branches of the exp(-20 e) damping of function.py:245-251.  Pins
+    hrp_pose_loss (terms + analytic gradient) directly against the reference instead of through the network."""
+    function = import_reference_step_function()
+    full, margs = build_full(None)
+    B = 6
+    batch, small = make_batch(B, full.robot)
+    args = rh._AttrDict(dict(margs))
+    args.update(urdf_robot_name="panda", use_origin_bbox=False, use_extended_bbox=True,
+                train_ds_names="dream/synthetic/panda_synth_train_dr", use_joint_valid_mask=False,
+                known_joint=False, joint_individual_weights=None, image_size=256.0, fix_mask=False,
+                pose_loss_func="mse", rot_loss_func="mse", trans_loss_func="l2norm",
+                depth_loss_func="l1", uv_loss_func="l2norm", kp2d_loss_func="l2norm",
+                kp3d_loss_func="l2norm", kp2d_int_loss_func="l2norm", kp3d_int_loss_func="l2norm",
+                align_3d_loss_func="l2norm", pose_loss_weight=1.0, rot_loss_weight=1.0,
+                trans_loss_weight=1.0, depth_loss_weight=10.0, uv_loss_weight=1.0,
+                kp2d_loss_weight=10.0, kp3d_loss_weight=10.0, kp2d_int_loss_weight=10.0,
+                kp3d_int_loss_weight=10.0, align_3d_loss_weight=0.0)
+    g = torch.Generator().manual_seed(99)
+    kp3d = torch.tensor(small["kp3d"])
+    out = {"in:" + k: v for k, v in small.items()}
+
+    class Prescribed(torch.nn.Module):
+        def __init__(self, tensors):
+            super().__init__()
+            self.p = torch.nn.ParameterList([torch.nn.Parameter(t.clone()) for t in tensors])
+
+        def forward(self, reg_images, root_images, k_values, K=None):
+            return tuple(p * 1.0 for p in self.p)
+
+    r = lambda *sh: torch.randn(*sh, generator=g)      # noqa: E731
+    for tag, spread in (("near", 0.05), ("far", 2.0)):
+        preds = [torch.tensor(small["q"]) + 0.2 * r(B, 8), r(B, 6), kp3d[:, 3] + spread * r(B, 3),
+                 torch.tensor(small["kp2d"])[:, 3] + 5.0 * r(B, 2), kp3d[:, 3, 2:3] + 0.05 * r(B, 1), r(B, 7, 3),
+                 kp3d + 0.05 * r(B, 7, 3), kp3d + 0.05 * r(B, 7, 3)]
+        model = Prescribed(preds)
+        loss, terms = function.farward_loss(args, batch, model, full.robot, "cpu", [0], train=True)
+        loss.backward()
+        out[f"{tag}:loss"] = np.array(loss.item())
+        for k, v in terms.items():
+            out[f"{tag}:term:{k}"] = np.array(v.item())
+        for n, p_, t0 in zip(NAMES8, model.p, preds):
+            out[f"{tag}:pred:{n}"] = t0.numpy()
+            out[f"{tag}:grad:{n}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy()
+        e = torch.norm(preds[2] - kp3d[:, 3], dim=1).mean().item()
+        print("pose loss", tag, float(out[f"{tag}:loss"]), "mean translation error", e)
+    np.savez_compressed(os.path.join(HERE, "golden_pose_loss.npz"), **out)
+
+
 def gen_mesh_pose():
     """Mesh posing of the render-and-compare path (BASELINE config 5).  What the reference can run here: the link poses from its
     urdfpytorch kinematics (`robot.link_fk_batch`, the call inside URDFRobot.get_TWL) for the nine visual-mesh links of

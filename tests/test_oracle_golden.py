@@ -602,3 +602,27 @@ def test_mesh_pose_golden(robot):
         cam = fk.pose_mesh(robot, q, r6, t, torch.tensor(g["verts"]), torch.tensor(g["vert_link"]), root=root)
         np.testing.assert_allclose(cam.numpy(), g[f"cam_root{root}"], atol=5e-6, err_msg=f"root {root}")
     assert (g["T_root0"][[3, 7], 2] > 0).all() and (g["t"][[3, 7], 2] < 0).all()      # the mirrored samples are in the fixture
+
+
+@pytest.mark.parametrize("tag", ["near", "far"])
+def test_pose_loss_on_prescribed_predictions_golden(robot, tag):
+    """The oracle's loss assembly (oracle/heads.py full_loss, restating lib/core/function.py:191-322) against the reference's own
+    step function run on a stand-in model with prescribed outputs (tests/golden/gen_golden.py pose_loss): ten terms, the loss and
+    autograd's gradient with respect to every prediction, for small AND large translation errors - `far` takes the branch of
+    function.py:245-251 in which the translation term is damped by exp(-20 e) (VERDICT r3 weak #4)."""
+    g = load("golden_pose_loss.npz")
+    K = torch.tensor(g["in:K"])
+    q, R, t = torch.tensor(g["in:q"]), torch.tensor(g["in:R"]), torch.tensor(g["in:t"])
+    kp3d, kp2d, mask = torch.tensor(g["in:kp3d"]), torch.tensor(g["in:kp2d"]), torch.tensor(g["in:mask"])
+    gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, fk.rotmat_to_rot6d(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    pred = [torch.tensor(g[f"{tag}:pred:{n}"]).requires_grad_(True) for n in NAMES8]
+    loss, terms = heads.full_loss(pred, gt, K)
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g[f"{tag}:term:{k}"], rtol=2e-5, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}:loss"], rtol=2e-5)
+    loss.backward()
+    for n, p in zip(NAMES8, pred):
+        ref = g[f"{tag}:grad:{n}"]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-7 + 1e-5 * np.abs(ref).max(), err_msg=n)

@@ -148,7 +148,7 @@ class PoseLossDesc(C.Structure):
                                           "gt_pose", "gt_root_rot", "gt_root_trans", "gt_root_uv", "gt_kp3d", "gt_kp2d", "mask", "K",
                                           "d_pose", "d_rot", "d_trans", "d_root_uv", "d_depth", "d_xyz_int", "d_xyz_fk", "out")] + \
                [("weights", C.c_float * 10), ("B", C.c_int32), ("P", C.c_int32), ("J", C.c_int32), ("root", C.c_int32),
-                ("image_size", C.c_float)]
+                ("image_size", C.c_float), ("rot_dim", C.c_int32)]
 
 
 OPT_CHUNK = 4096
@@ -203,6 +203,8 @@ PROTOTYPES = {
     "hrp_pose_geometry_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "hrp_fk_project_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "hrp_fk_project_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hrp_fk_project_rot_fwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P],
+    "hrp_fk_project_rot_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "hrp_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_scale_rows": [_P, _I, _I, _I, _P, _F, _P],
     "hrp_mul_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],

@@ -315,7 +315,21 @@ __device__ __forceinline__ Rigid<S> frame_pose(const hrp_fk_chain* ch, int leaf,
 }
 
 template <class S>
-__device__ __forceinline__ Rigid<S> base_to_cam(const S* r6, const S* tr) {
+__device__ __forceinline__ Rigid<S> base_to_cam(const S* r6, const S* tr, const int rd = 6) {
+  if (rd == 4) {
+    // quaternion (w, x, y, z), geometries.py:21-41: normalised by (norm + 1e-9)
+    const S n = dsqrt(r6[0] * r6[0] + r6[1] * r6[1] + r6[2] * r6[2] + r6[3] * r6[3]) + lift<S>(1e-9f);
+    const S w = r6[0] / n, x = r6[1] / n, y = r6[2] / n, z = r6[3] / n;
+    const S w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+    const S wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+    const S two = lift<S>(2.f);
+    Rigid<S> T;
+    T.r[0][0] = w2 + x2 - y2 - z2; T.r[0][1] = two * xy - two * wz; T.r[0][2] = two * wy + two * xz;
+    T.r[1][0] = two * wz + two * xy; T.r[1][1] = w2 - x2 + y2 - z2; T.r[1][2] = two * yz - two * wx;
+    T.r[2][0] = two * xz - two * wy; T.r[2][1] = two * wx + two * yz; T.r[2][2] = w2 - x2 - y2 + z2;
+    T.t[0] = tr[0]; T.t[1] = tr[1]; T.t[2] = tr[2];
+    return T;
+  }
   // geometries.py:100-115
   S ax = r6[0], ay = r6[1], az = r6[2], bx = r6[3], by = r6[4], bz = r6[5];
   S n = dsqrt(ax * ax + ay * ay + az * az);
@@ -334,8 +348,8 @@ __device__ __forceinline__ Rigid<S> base_to_cam(const S* r6, const S* tr) {
 
 // M = B2C (root == 0) or B2C * T_root^-1
 template <class S>
-__device__ __forceinline__ Rigid<S> camera_from_base(const hrp_fk_chain* ch, const S* q, const S* r6, const S* tr, int root) {
-  Rigid<S> M = base_to_cam<S>(r6, tr);
+__device__ __forceinline__ Rigid<S> camera_from_base(const hrp_fk_chain* ch, const S* q, const S* r6, const S* tr, int root, const int rd = 6) {
+  Rigid<S> M = base_to_cam<S>(r6, tr, rd);
   if (root > 0) M = rigid_mul(M, rigid_inverse(frame_pose<S>(ch, ch->kp_frame[root], q)));
   return M;
 }
@@ -359,16 +373,16 @@ __device__ __forceinline__ void project(const float* K, const S* p, S* uv) {
 __global__ __launch_bounds__(64) void fk_project_fwd_kernel(const hrp_fk_chain* __restrict__ ch, const float* __restrict__ q,
                                                             const float* __restrict__ r6, const float* __restrict__ tr,
                                                             const float* __restrict__ K, int root, float* __restrict__ xyz,
-                                                            float* __restrict__ uv, float* __restrict__ root_rot) {
+                                                            float* __restrict__ uv, float* __restrict__ root_rot, const int rd) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int dof = ch->dof, nkp = ch->nkp;
   float ql[HRP_FK_MAX_JOINTS];
   for (int i = 0; i < dof; ++i) ql[i] = q[(size_t)b * dof + i];
   float rl[6], tl[3];
-  for (int i = 0; i < 6; ++i) rl[i] = r6[6 * b + i];
+  for (int i = 0; i < 6; ++i) rl[i] = i < rd ? r6[rd * b + i] : 0.f;
   for (int i = 0; i < 3; ++i) tl[i] = tr[3 * b + i];
   if (lane < nkp) {
-    Rigid<float> M = camera_from_base<float>(ch, ql, rl, tl, root);
+    Rigid<float> M = camera_from_base<float>(ch, ql, rl, tl, root, rd);
     float p[3];
     keypoint<float>(ch, M, ql, lane, p);
     float* o = xyz + ((size_t)b * nkp + lane) * 3;
@@ -381,11 +395,20 @@ __global__ __launch_bounds__(64) void fk_project_fwd_kernel(const hrp_fk_chain* 
     }
   }
   if (root_rot && lane == 63) {
-    // urdf_robot.py:113-138: first two rows of (B2C * T_root).R
-    Rigid<float> P = base_to_cam<float>(rl, tl);
+    // urdf_robot.py:113-138: first two rows of (B2C * T_root).R, or its quaternion (geometries.py:63-82)
+    Rigid<float> P = base_to_cam<float>(rl, tl, rd);
     if (root > 0) P = rigid_mul(P, frame_pose<float>(ch, ch->kp_frame[root], ql));
-    for (int i = 0; i < 2; ++i)
-      for (int k = 0; k < 3; ++k) root_rot[6 * b + i * 3 + k] = P.r[i][k];
+    if (rd == 4) {
+      float w = sqrtf(fmaxf(1.f + P.r[0][0] + P.r[1][1] + P.r[2][2], 0.f)) / 2.f;
+      w = fmaxf(w, 1e-8f);
+      const float w4 = 4.f * w;
+      float qv[4] = {w, (P.r[2][1] - P.r[1][2]) / w4, (P.r[0][2] - P.r[2][0]) / w4, (P.r[1][0] - P.r[0][1]) / w4};
+      const float mag = fmaxf(sqrtf(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3]), 1e-8f);
+      for (int i = 0; i < 4; ++i) root_rot[4 * b + i] = qv[i] / mag;
+    } else {
+      for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 3; ++k) root_rot[6 * b + i * 3 + k] = P.r[i][k];
+    }
   }
 }
 
@@ -393,16 +416,16 @@ __global__ __launch_bounds__(64) void fk_project_bwd_kernel(const hrp_fk_chain* 
                                                             const float* __restrict__ r6, const float* __restrict__ tr,
                                                             const float* __restrict__ K, int root, const float* __restrict__ d_xyz,
                                                             const float* __restrict__ d_uv, float* __restrict__ d_q,
-                                                            float* __restrict__ d_r6, float* __restrict__ d_tr) {
+                                                            float* __restrict__ d_r6, float* __restrict__ d_tr, const int rd) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int dof = ch->dof, nkp = ch->nkp;
-  const int npar = dof + 9;
+  const int npar = dof + rd + 3;
   if (lane >= npar) return;
   Dual ql[HRP_FK_MAX_JOINTS], rl[6], tl[3];
   for (int i = 0; i < dof; ++i) ql[i] = {q[(size_t)b * dof + i], lane == i ? 1.f : 0.f};
-  for (int i = 0; i < 6; ++i) rl[i] = {r6[6 * b + i], lane == dof + i ? 1.f : 0.f};
-  for (int i = 0; i < 3; ++i) tl[i] = {tr[3 * b + i], lane == dof + 6 + i ? 1.f : 0.f};
-  Rigid<Dual> M = camera_from_base<Dual>(ch, ql, rl, tl, root);
+  for (int i = 0; i < 6; ++i) rl[i] = {i < rd ? r6[rd * b + i] : 0.f, lane == dof + i && i < rd ? 1.f : 0.f};
+  for (int i = 0; i < 3; ++i) tl[i] = {tr[3 * b + i], lane == dof + rd + i ? 1.f : 0.f};
+  Rigid<Dual> M = camera_from_base<Dual>(ch, ql, rl, tl, root, rd);
   float g = 0.f;
   for (int k = 0; k < nkp; ++k) {
     Dual p[3];
@@ -419,8 +442,8 @@ __global__ __launch_bounds__(64) void fk_project_bwd_kernel(const hrp_fk_chain* 
     }
   }
   if (lane < dof) d_q[(size_t)b * dof + lane] = g;
-  else if (lane < dof + 6) d_r6[6 * b + lane - dof] = g;
-  else d_tr[3 * b + lane - dof - 6] = g;
+  else if (lane < dof + rd) d_r6[rd * b + lane - dof] = g;
+  else d_tr[3 * b + lane - dof - rd] = g;
 }
 
 // standalone pinhole projection (transforms.py:17-21): one thread per point
@@ -463,7 +486,7 @@ struct LossArgs {
   float *d_pose, *d_rot, *d_trans, *d_root_uv, *d_depth, *d_xyz_int, *d_xyz_fk;            // gradients (may be NULL: none)
   float* out;                                                                             // [11]
   float w[10];
-  int B, P, J, root;
+  int B, P, J, root, R;
   float S;
 };
 
@@ -504,10 +527,10 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const LossArgs a) {
       t[0] += d * d;
       if (grad) a.d_pose[b * P + k] = a.w[0] * 2.f * d / (B * P);
     }
-    for (int k = 0; k < 6; ++k) {
-      const float d = a.rot[b * 6 + k] - a.g_rot[b * 6 + k];
+    for (int k = 0; k < a.R; ++k) {
+      const float d = a.rot[b * a.R + k] - a.g_rot[b * a.R + k];
       t[1] += d * d;
-      if (grad) a.d_rot[b * 6 + k] = a.w[1] * 2.f * d / (B * 6);
+      if (grad) a.d_rot[b * a.R + k] = a.w[1] * 2.f * d / (B * a.R);
     }
     {
       const float m = a.mask[b * J + a.root];
@@ -587,7 +610,7 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const LossArgs a) {
       }
     }
   }
-  const float norm[10] = {1.f / (B * P), 1.f / (B * 6), 1.f / n_root, 1.f / B, 1.f / B, 1.f / (B * J), 1.f / n_valid, 1.f / n_valid,
+  const float norm[10] = {1.f / (B * P), 1.f / (B * a.R), 1.f / n_root, 1.f / B, 1.f / B, 1.f / (B * J), 1.f / n_valid, 1.f / n_valid,
                           1.f / (B * J), 1.f / (B * J)};
   // weights in term order: joint, rot, uv, depth, trans, error3d, error2d, error2d_int, error3d_int, align
   const float wt[10] = {a.w[0], a.w[1], a.w[2], a.w[3], a.w[4], a.w[6], a.w[5], a.w[7], a.w[8], a.w[9]};
@@ -621,6 +644,8 @@ extern "C" int hrp_pose_loss(const hrp_pose_loss_desc* d, void* stream) {
   a.out = d->out;
   for (int k = 0; k < 10; ++k) a.w[k] = d->weights[k];
   a.B = d->B; a.P = d->P; a.J = d->J; a.root = d->root; a.S = d->image_size;
+  a.R = d->rot_dim == 0 ? 6 : d->rot_dim;
+  HRP_REQUIRE(a.R == 6 || a.R == 4, "pose_loss: rot_dim=%d", d->rot_dim);
   hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("pose_loss");
 }
@@ -839,19 +864,30 @@ extern "C" int hrp_mesh_pose(const hrp_fk_chain* chain_dev, const float* q, cons
   return check_launch("mesh_pose");
 }
 
-extern "C" int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
-                                  const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream) {
-  HRP_REQUIRE(chain_dev && q && rot6d && trans && xyz && B > 0, "fk_project_fwd: bad args");
-  hipLaunchKernelGGL(fk_project_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, K, root, xyz, uv, root_rot6d);
+extern "C" int hrp_fk_project_rot_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot, int rot_dim, const float* trans,
+                                      const float* K, int B, int root, float* xyz, float* uv, float* root_rot, void* stream) {
+  HRP_REQUIRE(chain_dev && q && rot && trans && xyz && B > 0, "fk_project_fwd: bad args");
+  HRP_REQUIRE(rot_dim == 6 || rot_dim == 4, "fk_project_fwd: rot_dim=%d (6: two rows of the rotation matrix, 4: quaternion w x y z)", rot_dim);
+  hipLaunchKernelGGL(fk_project_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot, trans, K, root, xyz, uv, root_rot, rot_dim);
   return check_launch("fk_project_fwd");
 }
+extern "C" int hrp_fk_project_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
+                                  const float* K, int B, int root, float* xyz, float* uv, float* root_rot6d, void* stream) {
+  return hrp_fk_project_rot_fwd(chain_dev, q, rot6d, 6, trans, K, B, root, xyz, uv, root_rot6d, stream);
+}
 
+extern "C" int hrp_fk_project_rot_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot, int rot_dim, const float* trans,
+                                      const float* K, int B, int root, const float* d_xyz, const float* d_uv,
+                                      float* d_q, float* d_rot, float* d_trans, void* stream) {
+  HRP_REQUIRE(chain_dev && q && rot && trans && d_q && d_rot && d_trans && B > 0, "fk_project_bwd: bad args");
+  HRP_REQUIRE(rot_dim == 6 || rot_dim == 4, "fk_project_bwd: rot_dim=%d", rot_dim);
+  hipLaunchKernelGGL(fk_project_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot, trans, K, root, d_xyz, d_uv, d_q, d_rot, d_trans, rot_dim);
+  return check_launch("fk_project_bwd");
+}
 extern "C" int hrp_fk_project_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
                                   const float* K, int B, int root, const float* d_xyz, const float* d_uv,
                                   float* d_q, float* d_rot6d, float* d_trans, void* stream) {
-  HRP_REQUIRE(chain_dev && q && rot6d && trans && d_q && d_rot6d && d_trans && B > 0, "fk_project_bwd: bad args");
-  hipLaunchKernelGGL(fk_project_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, K, root, d_xyz, d_uv, d_q, d_rot6d, d_trans);
-  return check_launch("fk_project_bwd");
+  return hrp_fk_project_rot_bwd(chain_dev, q, rot6d, 6, trans, K, B, root, d_xyz, d_uv, d_q, d_rot6d, d_trans, stream);
 }
 
 // ---- L1 loss of the DepthNet trainer (reference scripts/train_depthnet.py:231-250: L1Loss(model(images, k) / 1000, gt_depth)):

@@ -9,7 +9,7 @@ projections go through the projection kernel."""
 import torch
 
 from hrpe_amd.lib.dataset.const import JOINT_NAMES
-from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+from hrpe_amd.lib.utils.geometries import rotmat_to_quat, rotmat_to_rot6d
 from hrpe_amd.lib.utils.transforms import point_projection_from_3d_tensor
 
 FULL_YAML_WEIGHTS = dict(pose=1.0, rot=1.0, trans=1.0, depth=10.0, uv=1.0, kp2d=10.0, kp3d=10.0,
@@ -23,7 +23,7 @@ def compute_k_values(fx, fy, bboxes, real_bbox=(1000.0, 1000.0)):
 
 
 def prepare_batch(input_batch, robot, device, reference_keypoint_id=3, use_origin_bbox=False, use_extended_bbox=True,
-                  synthetic=True):
+                  synthetic=True, rotation_dim=6):
     """The batch unpacking of function.py:25-98 for a DreamDataset batch (lib/dataset/dream.py:393-413), without the
     per-sample Python loops (gt pose/rot/trans at :50-64, k_values at :98) and without the fp32 image round trip:
     uint8 images stay uint8 on the way to the device (4x less PCIe traffic) and the model's input kernel does the
@@ -51,7 +51,8 @@ def prepare_batch(input_batch, robot, device, reference_keypoint_id=3, use_origi
     TCO = dev(input_batch["TCO"])
     jp = input_batch["jointpose"]
     pose = torch.stack([dev(jp[k]) for k in JOINT_NAMES[robot.robot_type]], dim=1)        # :51
-    rot, trans = rotmat_to_rot6d(TCO[:, :3, :3]), TCO[:, :3, 3].contiguous()                # :53-54
+    to_rot = rotmat_to_quat if rotation_dim == 4 else rotmat_to_rot6d                        # :60-65
+    rot, trans = to_rot(TCO[:, :3, :3]), TCO[:, :3, 3].contiguous()                          # :53-54
     kp3d, kp2d = dev(other["keypoints_3d"]), dev(other["keypoints_2d"])
     if reference_keypoint_id == 0:                                                         # :76-78
         root_trans, root_rot = trans, rot
@@ -102,6 +103,7 @@ class _FusedPoseLoss(torch.autograd.Function):
         for i, w in enumerate(wvec):
             d.weights[i] = w
         d.B, d.P, d.J, d.root, d.image_size = pose.shape[0], pose.shape[1], xyz_fk.shape[1], root, image_size
+        d.rot_dim = rot.shape[1]
         nv.call("hrp_pose_loss", C.byref(d), torch.cuda.current_stream(pose.device).cuda_stream)
         ctx.grads = grads
         ctx.mark_non_differentiable(out)

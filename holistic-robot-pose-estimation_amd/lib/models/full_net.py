@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from hrpe_amd.lib.dataset.const import JOINT_NAMES
-from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
+from hrpe_amd.lib.utils.geometries import rotmat_to_quat, rotmat_to_rot6d
 from hrpe_amd.lib.utils.integral import HeatmapIntegralPose
 from hrpe_amd.lib.utils.urdf_robot import URDFRobot
 from hrpe_amd.runtime import PlannedModule
@@ -104,8 +104,10 @@ class RootNetwithRegInt(PlannedModule):
         if self.reg_joint_map and self.backbone_name not in ("resnet34", "resnet50"):
             raise NotImplementedError("reg_joint_map reads the ResNet feature map (full_net.py:313-316) and its integral layer "
                                       "accepts resnet34 / resnet50 only (integral.py:206, 234)")
-        if self.rotation_dim != 6:
-            raise NotImplementedError("only rotation_dim == 6")
+        if self.rotation_dim not in (6, 4):
+            raise NotImplementedError("rotation_dim: 6 (two rows of the rotation matrix) or 4 (quaternion)")
+        if self.rotation_dim != 6 and (self.direct_reg_rot or self.rot_iterative_matmul):
+            raise NotImplementedError("direct_reg_rot / rot_iterative_matmul decode a 6-D rotation (full_net.py:127, 349)")
         if self.reg_joint_map:       # full_net.py:87-93, 218-237: 3 x (conv3x3 + BN + ReLU), a 1x1 conv to one map per joint
             from hrpe_amd.lib.dataset.const import JOINT_BOUNDS
             dims, mods, cin = list(args.joint_conv_dim), [], self.feature_channel
@@ -165,7 +167,8 @@ class RootNetwithRegInt(PlannedModule):
         which = "mean" if init_param_dict["init_pose_from_mean"] else "zero"
         init_pose = torch.tensor([[pose_params[which][robot_type][k] for k in JOINT_NAMES[robot_type]]]).float()
         cam = np.array(init_param_dict["cam_params"])
-        init_rot = rotmat_to_rot6d(torch.from_numpy(cam[:3, :3]).unsqueeze(0)).float()
+        to_rot = rotmat_to_rot6d if self.rotation_dim == 6 else rotmat_to_quat        # full_net.py:186-189
+        init_rot = to_rot(torch.from_numpy(cam[:3, :3]).unsqueeze(0).float()).float()
         self.register_buffer("init_pose", init_pose)
         self.register_buffer("init_rot", init_rot)
 
@@ -342,7 +345,7 @@ class RootNetwithRegInt(PlannedModule):
                                           self.decrot, matmul=self.rot_iterative_matmul)
         pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
-        outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, 6)), ("dense", trans, (N, 3)),
+        outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, rot_d.C)), ("dense", trans, (N, 3)),
                 ("dense", root_uv, (N, 2)), ("dense", depth, (N, 1)), ("dense", uvd, (N, J, 3)),
                 ("dense", xyz_int, (N, J, 3)), ("dense", xyz_fk, (N, J, 3))]
         if depths is not None:      # full_net.py:392-395: the 9-tuple carries pred_depths after pred_depth

@@ -116,9 +116,10 @@ class _FKFn(torch.autograd.Function):
         nkp = robot.nkp
         xyz = torch.empty(B, nkp, 3, device=dev)
         uv = torch.empty(B, nkp, 2, device=dev) if Kc is not None else None
-        rr = torch.empty(B, 6, device=dev)
+        rd = rot.shape[1]               # 6: two rows of the rotation matrix, 4: quaternion (urdf_robot.py:86-92)
+        rr = torch.empty(B, rd, device=dev)
         s = torch.cuda.current_stream(dev).cuda_stream
-        nv.call("hrp_fk_project_fwd", chain.data_ptr(), q.data_ptr(), rot.data_ptr(), trans.data_ptr(),
+        nv.call("hrp_fk_project_rot_fwd", chain.data_ptr(), q.data_ptr(), rot.data_ptr(), rd, trans.data_ptr(),
                 Kc.data_ptr() if Kc is not None else None, B, root, xyz.data_ptr(),
                 uv.data_ptr() if uv is not None else None, rr.data_ptr(), s)
         ctx.save_for_backward(q, rot, trans, Kc if Kc is not None else torch.empty(0, device=dev))
@@ -140,7 +141,7 @@ class _FKFn(torch.autograd.Function):
         gu = gu.contiguous().float() if gu is not None else None
         dq, dr, dt = torch.empty_like(q), torch.empty_like(rot), torch.empty_like(trans)
         s = torch.cuda.current_stream(dev).cuda_stream
-        nv.call("hrp_fk_project_bwd", ctx.robot.chain_on(dev).data_ptr(), q.data_ptr(), rot.data_ptr(), trans.data_ptr(),
+        nv.call("hrp_fk_project_rot_bwd", ctx.robot.chain_on(dev).data_ptr(), q.data_ptr(), rot.data_ptr(), rot.shape[1], trans.data_ptr(),
                 Kc.data_ptr() if ctx.hasK else None, B, ctx.root, gx.data_ptr() if gx is not None else None,
                 gu.data_ptr() if gu is not None else None, dq.data_ptr(), dr.data_ptr(), dt.data_ptr(), s)
         return None, dq, dr, dt, None, None, None
@@ -192,16 +193,16 @@ class URDFRobot:
         return rot, torch.zeros(B, 3, device=q.device)
 
     def get_keypoints(self, jointcfgs, b2c_rot, b2c_trans):
-        if b2c_rot.shape[1] != 6:
-            raise NotImplementedError("only the 6-D rotation representation is supported")
+        if b2c_rot.shape[1] not in (6, 4):
+            raise NotImplementedError("rotation representations: 6-D (two matrix rows) and quaternion; rot9d is not built")
         return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, None, 0, ("xyz",))[0]
 
     def get_keypoints_root(self, jointcfgs, b2c_rot, b2c_trans, root=0):
         if root == 0:
             return self.get_keypoints(jointcfgs, b2c_rot, b2c_trans)
         assert 0 < root < len(self.link_names)
-        if b2c_rot.shape[1] != 6:
-            raise NotImplementedError("only the 6-D rotation representation is supported")
+        if b2c_rot.shape[1] not in (6, 4):
+            raise NotImplementedError("rotation representations: 6-D (two matrix rows) and quaternion; rot9d is not built")
         return _FKFn.apply(self, jointcfgs, b2c_rot, b2c_trans, None, root, ("xyz",))[0]
 
     def get_keypoints_and_projection(self, jointcfgs, b2c_rot, b2c_trans, K, root=0):

@@ -2338,19 +2338,20 @@ class PlanBuilder:
         return depth, xyz, ruv, trans
 
     def fk(self, chain_dev, dof, nkp, q, rot, trans, root, Kmat=None, want_uv=False, want_root_rot=False):
-        """Forward kinematics (+projection): q [N,dof], rot6d [N,6], trans [N,3] dense fp32."""
+        """Forward kinematics (+projection): q [N,dof], rot [N,6] (two matrix rows) or [N,4] (quaternion), trans [N,3] dense fp32."""
         p = self.plan
         N = q.N
-        assert q.pitch == dof and rot.pitch == 6 and trans.pitch == 3
+        rd = rot.C
+        assert q.pitch == dof and rd in (6, 4) and rot.pitch == rd and trans.pitch == 3
         xyz = p.new(N, 1, 1, nkp * 3, torch.float32, pitch=nkp * 3)
         uv = p.new(N, 1, 1, nkp * 2, torch.float32, pitch=nkp * 2) if want_uv else None
-        rr = p.new(N, 1, 1, 6, torch.float32, pitch=6) if want_root_rot else None
+        rr = p.new(N, 1, 1, rd, torch.float32, pitch=rd) if want_root_rot else None
         rg = p.need_grad and (q.requires_grad or rot.requires_grad or trans.requires_grad)
         xyz.requires_grad = rg
         if uv is not None:
             uv.requires_grad = rg
         kp = Kmat.ptr() if Kmat is not None else None
-        p.fwd.append(lambda s: nv.call("hrp_fk_project_fwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), trans.ptr(), kp, N, root,
+        p.fwd.append(lambda s: nv.call("hrp_fk_project_rot_fwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), rd, trans.ptr(), kp, N, root,
                                        xyz.ptr(), uv.ptr() if uv is not None else None,
                                        rr.ptr() if rr is not None else None, s))
         if p.need_grad:
@@ -2360,9 +2361,9 @@ class PlanBuilder:
                 if not rg or (gx is None and gu is None):
                     return
                 dq = p.new(N, 1, 1, dof, torch.float32, pitch=dof)
-                dr = p.new(N, 1, 1, 6, torch.float32, pitch=6)
+                dr = p.new(N, 1, 1, rd, torch.float32, pitch=rd)
                 dtv = p.new(N, 1, 1, 3, torch.float32, pitch=3)
-                p.bwd.append(lambda s: nv.call("hrp_fk_project_bwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), trans.ptr(), kp, N,
+                p.bwd.append(lambda s: nv.call("hrp_fk_project_rot_bwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), rd, trans.ptr(), kp, N,
                                                root, gx, gu, dq.ptr(), dr.ptr(), dtv.ptr(), s))
                 for src, dst in ((dq, q), (dr, rot), (dtv, trans)):
                     if dst.requires_grad:

@@ -542,6 +542,14 @@ int hrp_mesh_pose(const hrp_fk_chain* chain_dev, const float* q, const float* ro
 int hrp_fk_project_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans,
                        const float* K, int B, int root, const float* d_xyz, const float* d_uv,
                        float* d_q, float* d_rot6d, float* d_trans, void* stream);
+/* The same pair for either rotation representation of the network (reference urdf_robot.py:86-92, 118-138; full_net.py:186-189):
+ * rot_dim 6 = two rows of the rotation matrix (Zhou et al.), 4 = quaternion (w, x, y, z), normalised by (norm + 1e-9) as
+ * geometries.py:21-41; root_rot comes back in the same representation (quaternion: geometries.py:63-82). */
+int hrp_fk_project_rot_fwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot, int rot_dim, const float* trans,
+                           const float* K, int B, int root, float* xyz, float* uv, float* root_rot, void* stream);
+int hrp_fk_project_rot_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot, int rot_dim, const float* trans,
+                           const float* K, int B, int root, const float* d_xyz, const float* d_uv,
+                           float* d_q, float* d_rot, float* d_trans, void* stream);
 
 /* small fp32 helpers used by the regression heads */
 int hrp_copy_cols(const float* src, int src_pitch, float* dst, int dst_pitch, int rows, int cols, int accumulate, void* stream);
@@ -573,7 +581,7 @@ int hrp_linear_bwd_weight(const float* x, int x_pitch, const float* dy, int dy_p
  * loss_uv, loss_depth, loss_trans, loss_error3d, loss_error2d, loss_error2d_int, loss_error3d_int, loss_error3d_align (the
  * names of function.py:313-319); out[10]: the weighted total.  d_*: gradient of out[10] (all seven, or all NULL). */
 typedef struct hrp_pose_loss_desc {
-  const float *pose, *rot, *trans, *root_uv, *depth, *xyz_int, *xyz_fk;   /* [B,P] [B,6] [B,3] [B,2] [B,1] [B,J,3] [B,J,3] */
+  const float *pose, *rot, *trans, *root_uv, *depth, *xyz_int, *xyz_fk;   /* [B,P] [B,rot_dim] [B,3] [B,2] [B,1] [B,J,3] [B,J,3] */
   const float *gt_pose, *gt_root_rot, *gt_root_trans, *gt_root_uv;       /* [B,P] [B,6] [B,3] [B,2] */
   const float *gt_kp3d, *gt_kp2d, *mask, *K;                             /* [B,J,3] [B,J,2] [B,J] [B,9] */
   float *d_pose, *d_rot, *d_trans, *d_root_uv, *d_depth, *d_xyz_int, *d_xyz_fk;
@@ -581,6 +589,7 @@ typedef struct hrp_pose_loss_desc {
   float weights[10];
   int32_t B, P, J, root;
   float image_size;
+  int32_t rot_dim;     /* width of rot / gt_root_rot / d_rot: 0 or 6 = two rows of the rotation matrix, 4 = quaternion (w x y z) */
 } hrp_pose_loss_desc;
 int hrp_pose_loss(const hrp_pose_loss_desc* d, void* stream);
 /* The DepthNet trainer's loss (scripts/train_depthnet.py:231-250, nn.L1Loss on model(images, k) / 1000 against the root depth):

@@ -147,10 +147,32 @@ def rotmat_to_rot6d(R):
     return R[..., :2, :].reshape(*R.shape[:-2], 6)
 
 
+def quat_to_rotmat(quat):
+    """geometries.py:21-41: (w, x, y, z), normalised by (norm + 1e-9)."""
+    nq = quat / (quat.norm(p=2, dim=1, keepdim=True) + 1e-9)
+    w, x, y, z = nq[:, 0], nq[:, 1], nq[:, 2], nq[:, 3]
+    w2, x2, y2, z2 = w * w, x * x, y * y, z * z
+    wx, wy, wz, xy, xz, yz = w * x, w * y, w * z, x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+
+
+def rotmat_to_quat(m):
+    """geometries.py:63-82: w = sqrt(max(1 + trace, 0)) / 2 clamped at 1e-8, x y z from the antisymmetric part, normalised
+    (norm clamped at 1e-8)."""
+    w = torch.sqrt(torch.clamp(1.0 + m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2], min=0.0)) / 2.0
+    w = torch.clamp(w, min=1e-8)
+    w4 = 4.0 * w
+    q = torch.stack([w, (m[:, 2, 1] - m[:, 1, 2]) / w4, (m[:, 0, 2] - m[:, 2, 0]) / w4, (m[:, 1, 0] - m[:, 0, 1]) / w4], 1)
+    return q / torch.clamp(torch.sqrt((q * q).sum(1, keepdim=True)), min=1e-8)
+
+
 def _base2cam(rot6d, trans):
+    """rot6d: [B, 6] (Zhou et al.) or [B, 4] quaternion (urdf_robot.py:86-92)."""
     B = rot6d.shape[0]
     T = torch.zeros(B, 4, 4, dtype=torch.float32)
-    T[:, :3, :3] = rot6d_to_rotmat(rot6d)
+    T[:, :3, :3] = rot6d_to_rotmat(rot6d) if rot6d.shape[1] == 6 else quat_to_rotmat(rot6d)
     T[:, :3, 3] = trans
     T[:, 3, 3] = 1.0
     return T
@@ -194,6 +216,8 @@ class Robot:
         if root == 0:
             return rot6d
         TWL = _base2cam(rot6d, trans)[:, None] @ self.get_TWL(q)
+        if rot6d.shape[1] == 4:            # urdf_robot.py:136-137
+            return rotmat_to_quat(TWL[:, root, :3, :3])
         return rotmat_to_rot6d(TWL[:, root, :3, :3])
 
 

@@ -79,7 +79,9 @@ def random_rotations(g, n):
     return R.reshape(n, 3, 3).astype(np.float32)
 
 
-def gen_fk(robot_type="panda", other_root=3):
+def gen_fk(robot_type="panda", other_root=3, quat=False):
+    """quat: the base-to-camera rotation as an (unnormalised) quaternion (w, x, y, z) instead of the 6-D form
+    (urdf_robot.py:86-92, 118-138; the rotation_dim == 4 variant of the network, full_net.py:186-189)."""
     robot = URDFRobot(robot_type)
     g = np.random.Generator(np.random.PCG64(1234))
     n = 256
@@ -88,6 +90,10 @@ def gen_fk(robot_type="panda", other_root=3):
     q = (b[:, 0] + (b[:, 1] - b[:, 0]) * g.random((n, dof))).astype(np.float32)
     rot6d = (random_rotations(g, n)[:, :2, :].reshape(n, 6)
              * g.uniform(0.5, 2.0, (n, 1)) + g.normal(0, 0.05, (n, 6))).astype(np.float32)
+    if quat:
+        from lib.utils.geometries import rotmat_to_quat
+        rot6d = (rotmat_to_quat(torch.tensor(random_rotations(g, n).astype(np.float32))).numpy()
+                 * g.uniform(0.5, 2.0, (n, 1)) + g.normal(0, 0.02, (n, 4))).astype(np.float32)
     t = np.stack([g.uniform(-.3, .3, n), g.uniform(-.3, .3, n), g.uniform(.6, 2.0, n)], 1).astype(np.float32)
     s = g.uniform(0.8, 2.5, n)
     K = np.zeros((n, 3, 3), np.float32)
@@ -119,8 +125,14 @@ def gen_fk(robot_type="panda", other_root=3):
         out["fk_only"] = robot.get_keypoints_only_fk(torch.tensor(q)).numpy()
         out["fk_q0"] = robot.get_keypoints_only_fk(torch.zeros(1, dof)).numpy()
     name = "golden_fk.npz" if robot_type == "panda" else f"golden_fk_{robot_type}.npz"
+    if quat:
+        name = "golden_fk_quat.npz"
     np.savez_compressed(os.path.join(HERE, name), **out)
     print("fk ok", robot_type, out[f"xyz_root{other_root}"][0, :2])
+
+
+def gen_fk_quat():
+    gen_fk("panda", 3, quat=True)
 
 
 def gen_fk_kuka():
@@ -454,6 +466,18 @@ def gen_full_eval_direct_rot():
     print("full eval (direct_reg_rot) ok", o[1][0])
 
 
+def gen_full_eval_quat():
+    """rotation_dim = 4 (full_net.py:129-131, 186-189): the rotation regressor iterates on a quaternion."""
+    full, _ = build_full(rotation_dim=4)
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K)
+    assert o[1].shape[1] == 4
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_quat.npz"), **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval (quaternion) ok", o[1][0])
+
+
 def gen_full_eval_multi_kp():
     """multi_kp = True, kps_need_depth = [0, 3, 6] (full_net.py:146-148, 275-279, 392-393): the 9-tuple."""
     full, _ = build_full(multi_kp=True, kps_need_depth=[0, 3, 6])
@@ -618,9 +642,9 @@ PICK_GRADS_RESNET = [
 ]
 
 
-def gen_full_train(backbone_name=None, B=2, bn_eval=False):
+def gen_full_train(backbone_name=None, B=2, bn_eval=False, quat=False):
     function = import_reference_step_function()
-    full, margs = build_full(backbone_name)
+    full, margs = build_full(backbone_name, **(dict(rotation_dim=4) if quat else {}))
     if bn_eval:
         # scripts/train_sim2real.py:139-146 (BASELINE config 5): the network trains with every BatchNorm module in eval() -
         # running statistics in the forward pass, gradients through them.  The step function calls model.train() itself, so
@@ -676,6 +700,8 @@ def gen_full_train(backbone_name=None, B=2, bn_eval=False):
     name = "golden_full_train_resnet.npz" if backbone_name else ("golden_full_train.npz" if B == 2 else f"golden_full_train_b{B}.npz")
     if bn_eval:
         name = "golden_full_train_bn_eval.npz"
+    if quat:
+        name = "golden_full_train_quat.npz"
     np.savez_compressed(os.path.join(HERE, name), **out)
     print("full train ok", name, out["loss"], {k: float(v) for k, v in terms.items()})
 
@@ -898,6 +924,8 @@ if __name__ == "__main__":
     for w in which:
         if w == "full_train_resnet":
             gen_full_train("resnet50")
+        elif w == "full_train_quat":
+            gen_full_train(None, B=2, quat=True)
         elif w == "full_train_bn_eval":
             gen_full_train(None, B=2, bn_eval=True)
         elif w == "full_train_b8":      # the same step at B = 8: train-mode BatchNorm over >= 512 samples per channel

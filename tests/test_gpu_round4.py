@@ -340,3 +340,70 @@ def test_fused_pose_loss_on_prescribed_predictions_golden(tag):
         ref = g[f"{tag}:grad:{n}"]
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-7 + 1e-5 * np.abs(ref).max(), err_msg=n)
+
+
+def test_fk_kernel_with_quaternion_rotation_golden():
+    """hrp_fk_project_rot_fwd / _bwd with rot_dim = 4 (the rotation_dim == 4 variant, reference urdf_robot.py:86-92, 118-138) against
+    the reference fixture: key-points 3e-6 m, gradients, the re-rooted rotation as a quaternion."""
+    from hrpe_amd.lib.utils.transforms import point_projection_from_3d_tensor
+    from hrpe_amd.lib.utils.urdf_robot import URDFRobot
+    g = load("golden_fk_quat.npz")
+    robot = URDFRobot("panda")
+    q, r, t, K = [torch.tensor(g[k]).to(DEV) for k in ("q", "rot6d", "t", "K")]
+    assert r.shape[1] == 4
+    for root in (0, 3):
+        tq, tr, tt = [x.clone().requires_grad_(True) for x in (q, r, t)]
+        xyz = robot.get_keypoints_root(tq, tr, tt, root=root)
+        uv = point_projection_from_3d_tensor(K, xyz)
+        np.testing.assert_allclose(xyz.detach().cpu().numpy(), g[f"xyz_root{root}"], atol=3e-6)
+        ((xyz * torch.tensor(g["w_xyz"]).to(DEV)).sum() + (uv * torch.tensor(g["w_uv"]).to(DEV)).sum()).backward()
+        for name, x in (("gq", tq), ("grot", tr), ("gt", tt)):
+            ref = g[f"{name}_root{root}"]
+            np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=3e-4 * max(1.0, np.abs(ref).max()), rtol=2e-3)
+        rr = robot.get_rotation_at_specific_root(q, r, t, root=root).cpu().numpy()
+        ref = g[f"rootrot_root{root}"]
+        # geometries.py:63-82 divides the antisymmetric part by 4 w with w = sqrt(1 + trace) / 2: matrix entries that differ by
+        # one fp32 ulp (1e-7) move the quaternion by ~1e-7 / w - the fixture holds samples with w = 0.02
+        tol = 3e-6 + 1e-6 / np.maximum(np.abs(ref[:, :1]), 1e-3)
+        assert (np.abs(rr - ref) <= tol).all(), float((np.abs(rr - ref) / tol).max())
+
+
+def test_full_network_with_quaternion_rotation_golden():
+    """rotation_dim = 4 (reference full_net.py:129-131, 186-189; function.py:63-64): inference 8-tuple against
+    golden_full_eval_quat.npz (3e-4) and one training step against golden_full_train_quat.npz (loss terms 2e-3 - loss_rot is the
+    mean squared quaternion difference -, sampled gradients as the 6-D fixture)."""
+    from hrpe_amd.lib.core.function import compute_k_values, full_loss
+    from hrpe_amd.lib.utils.geometries import rotmat_to_quat
+    from synth import synth_inputs
+    g = load("golden_full_eval_quat.npz")
+    m = M.build_full(rotation_dim=4).eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = m(x_reg.to(DEV), x_root.to(DEV), kv.to(DEV), K.to(DEV))
+    assert out[1].shape[1] == 4
+    for n, t in zip(M.NAMES8, out):
+        ref = g[n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    g = load("golden_full_train_quat.npz")
+    m = M.build_full(rotation_dim=4).train()
+    rng = np.random.Generator(np.random.PCG64(2024))
+    x_reg = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    x_root = (torch.tensor(rng.integers(0, 256, (2, 3, 256, 256)).astype(np.float32)) / 255.).to(DEV)
+    K = torch.tensor(g["in:K"]).to(DEV)
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], torch.tensor(g["in:bbox"]).to(DEV))
+    q, R, t = [torch.tensor(g[k]).to(DEV) for k in ("in:q", "in:R", "in:t")]
+    kp3d, kp2d, mask = [torch.tensor(g[k]).to(DEV) for k in ("in:kp3d", "in:kp2d", "in:mask")]
+    gt = dict(pose=q, root_rot=m.robot.get_rotation_at_specific_root(q, rotmat_to_quat(R), t, root=3),
+              root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
+    pred = m(x_reg, x_root, kv, K)
+    loss, terms = full_loss(pred, gt, K)
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g["term:" + k], rtol=2e-3, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-3)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            M.summary_check(params[name].grad, g, f"grad:{name}:", M.GRAD_TOL, what="quaternion ")

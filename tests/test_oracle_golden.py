@@ -433,13 +433,15 @@ def test_full_eval_baxter_golden():
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
-@pytest.mark.parametrize("frozen_bn", [False, True], ids=["train", "bn_eval"])
+@pytest.mark.parametrize("frozen_bn", [False, True, "quat"], ids=["train", "bn_eval", "quat"])
 def test_full_train_golden(robot, frozen_bn):
     """One reference training step (lib/core/function.py farward_loss, train=True): loss terms,
     gradients and BN running stats.  bn_eval: the same step with every BatchNorm module in eval() as
     scripts/train_sim2real.py:139-146 trains (BASELINE config 5): running statistics, gradients through them."""
-    g = load("golden_full_train_bn_eval.npz" if frozen_bn else "golden_full_train.npz")
-    sd = full_sd()
+    quat = frozen_bn == "quat"            # rotation_dim = 4 (full_net.py:186-189, function.py:63-64): same step, quaternion rotations
+    frozen_bn = frozen_bn is True
+    g = load("golden_full_train_quat.npz" if quat else "golden_full_train_bn_eval.npz" if frozen_bn else "golden_full_train.npz")
+    sd = _full_sd_quat() if quat else full_sd()
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running" not in k and not k.startswith("init_"):
             v.requires_grad_(True)
@@ -450,7 +452,7 @@ def test_full_train_golden(robot, frozen_bn):
     kv = torch.tensor(g["k_values"])
     q, R, t = torch.tensor(g["in:q"]), torch.tensor(g["in:R"]), torch.tensor(g["in:t"])
     kp3d, kp2d, mask = torch.tensor(g["in:kp3d"]), torch.tensor(g["in:kp2d"]), torch.tensor(g["in:mask"])
-    gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, fk.rotmat_to_rot6d(R), t, root=3),
+    gt = dict(pose=q, root_rot=robot.get_rotation_at_specific_root(q, (fk.rotmat_to_quat if quat else fk.rotmat_to_rot6d)(R), t, root=3),
               root_trans=kp3d[:, 3], root_uv=kp2d[:, 3], kp3d=kp3d, kp2d=kp2d, mask=mask)
     pred = heads.full_forward(sd, robot, x_reg, x_root, kv, K, training=not frozen_bn)
     for n, p in zip(NAMES8, pred):
@@ -626,3 +628,42 @@ def test_pose_loss_on_prescribed_predictions_golden(robot, tag):
         ref = g[f"{tag}:grad:{n}"]
         got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-7 + 1e-5 * np.abs(ref).max(), err_msg=n)
+
+
+def _full_sd_quat():
+    sd = {k: v for k, v in full_sd().items() if not k.startswith(("fc_rot_1", "decrot", "init_rot"))}
+    sd.update(synth_state_dict({"fc_rot_1.weight": torch.empty(1024, 2048 + 4), "fc_rot_1.bias": torch.empty(1024),
+                                "decrot.weight": torch.empty(4, 1024), "decrot.bias": torch.empty(4)}))
+    sd["init_rot"] = torch.tensor([[1.0, 0.0, 0.0, 0.0]])          # rotmat_to_quat(identity), full_net.py:188-189
+    return sd
+
+
+def test_fk_quat_golden(robot):
+    """Key-points, projection, gradients and the re-rooted rotation with the base-to-camera rotation as a quaternion
+    (urdf_robot.py:86-92, 118-138; geometries.py:21-41, 63-82)."""
+    g = load("golden_fk_quat.npz")
+    q, r, t, K = [torch.tensor(g[k]) for k in ("q", "rot6d", "t", "K")]
+    assert r.shape[1] == 4
+    for root in (0, 3):
+        tq, tr, tt = [x.clone().requires_grad_(True) for x in (q, r, t)]
+        xyz = robot.get_keypoints_root(tq, tr, tt, root=root)
+        uv = fk.project(K, xyz)
+        np.testing.assert_allclose(xyz.detach().numpy(), g[f"xyz_root{root}"], atol=2e-6)
+        np.testing.assert_allclose(uv.detach().numpy(), g[f"uv_root{root}"], atol=2e-3, rtol=1e-5)
+        ((xyz * torch.tensor(g["w_xyz"])).sum() + (uv * torch.tensor(g["w_uv"])).sum()).backward()
+        for name, x in (("gq", tq), ("grot", tr), ("gt", tt)):
+            ref = g[f"{name}_root{root}"]
+            np.testing.assert_allclose(x.grad.numpy(), ref, atol=2e-4 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+        rr = robot.get_rotation_at_specific_root(q, r, t, root=root)
+        np.testing.assert_allclose(rr.numpy(), g[f"rootrot_root{root}"], atol=2e-6)
+
+
+def test_full_eval_quat_golden(robot):
+    """rotation_dim = 4 (full_net.py:129-131, 186-189): the 8-tuple with a quaternion as pred_rot."""
+    g = load("golden_full_eval_quat.npz")
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(_full_sd_quat(), robot, x_reg, x_root, kv, K)
+    assert out[1].shape[1] == 4
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)

@@ -85,6 +85,12 @@ class Sim2RealLossDesc(C.Structure):
                 ("workspace", C.c_void_p)]
 
 
+class SilhouetteDesc(C.Structure):
+    _fields_ = [("uv", C.c_void_p), ("xyz", C.c_void_p), ("faces", C.c_void_p),
+                ("B", C.c_int32), ("V", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("sigma", C.c_float), ("blur_radius", C.c_float), ("alpha", C.c_void_p), ("logp", C.c_void_p)]
+
+
 BLOCK_MAX = 2
 
 
@@ -229,6 +235,9 @@ PROTOTYPES = {
     "hrp_l1_loss": [_P, _P, _F, _I, _P, _P, _P],
     "hrp_sim2real_loss": [C.POINTER(Sim2RealLossDesc), _P],
     "hrp_mesh_pose": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
+    "hrp_mesh_pose_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
+    "hrp_silhouette_fwd": [C.POINTER(SilhouetteDesc), _P],
+    "hrp_silhouette_bwd": [C.POINTER(SilhouetteDesc), _P, _P, _P],
     "hrp_linear_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hrp_linear_bwd_data": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "hrp_linear_workspace_bytes": [_I, _I, _I],

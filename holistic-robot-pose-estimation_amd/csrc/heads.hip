@@ -853,6 +853,85 @@ __global__ __launch_bounds__(256) void mesh_pose_kernel(const hrp_fk_chain* __re
 }
 }  // namespace hrp
 
+namespace hrp {
+// d (rot6d, trans) of sum(d_xyz * xyz) for hrp_mesh_pose's output: xyz[v] = s (R(rot6d) w_v + trans), w_v = T_root^-1 T_link(v) verts[v]
+// (independent of rot6d / trans; the joint angles are detached on this path, urdf_robot.py:267), s = -1 for a mirrored sample.
+// One workgroup per sample: G_t = sum g_v, G_R = sum g_v w_v^T reduced in a fixed order, then nine lanes differentiate the
+// rotation matrix in forward mode.
+__global__ __launch_bounds__(256) void mesh_pose_bwd_kernel(const hrp_fk_chain* __restrict__ ch, const float* __restrict__ q,
+                                                            const float* __restrict__ r6, const float* __restrict__ tr, int root_kp,
+                                                            const float* __restrict__ verts, const uint8_t* __restrict__ vert_link, int V,
+                                                            const float* __restrict__ d_xyz, float* __restrict__ d_r6, float* __restrict__ d_tr) {
+  __shared__ float P[HRP_FK_MAX_KP][12];
+  __shared__ float red[256][12];
+  __shared__ float flip;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nl = ch->nkp, dof = ch->dof;
+  float rl[6], tl[3];
+  for (int i = 0; i < 6; ++i) rl[i] = r6[6 * b + i];
+  for (int i = 0; i < 3; ++i) tl[i] = tr[3 * b + i];
+  if (tid < nl || tid == 255) {
+    float ql[HRP_FK_MAX_JOINTS];
+    for (int i = 0; i < dof; ++i) ql[i] = q[(size_t)b * dof + i];
+    Rigid<float> Rinv = rigid_identity<float>();
+    if (root_kp >= 0) Rinv = rigid_inverse(frame_pose<float>(ch, ch->kp_frame[root_kp], ql));
+    if (tid == 255) {
+      const Rigid<float> M = rigid_mul(base_to_cam<float>(rl, tl), Rinv);
+      flip = M.t[2] < 0.f ? -1.f : 1.f;
+    } else {
+      const Rigid<float> T = rigid_mul(Rinv, frame_pose<float>(ch, ch->kp_frame[tid], ql));
+      for (int i = 0; i < 3; ++i) { P[tid][4 * i] = T.r[i][0]; P[tid][4 * i + 1] = T.r[i][1]; P[tid][4 * i + 2] = T.r[i][2]; P[tid][4 * i + 3] = T.t[i]; }
+    }
+  }
+  __syncthreads();
+  float acc[12];
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    const float* T = P[vert_link[v]];
+    const float x = verts[3 * v], y = verts[3 * v + 1], z = verts[3 * v + 2];
+    float w[3];
+    for (int i = 0; i < 3; ++i) w[i] = T[4 * i] * x + T[4 * i + 1] * y + T[4 * i + 2] * z + T[4 * i + 3];
+    const float* g = d_xyz + ((size_t)b * V + v) * 3;
+    for (int i = 0; i < 3; ++i) {
+      acc[9 + i] += g[i];
+      for (int j = 0; j < 3; ++j) acc[3 * i + j] += g[i] * w[j];
+    }
+  }
+  for (int i = 0; i < 12; ++i) red[tid][i] = acc[i];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st)
+      for (int i = 0; i < 12; ++i) red[tid][i] += red[tid + st][i];
+    __syncthreads();
+  }
+  if (tid < 9) {
+    Dual rd[6], td[3];
+    for (int i = 0; i < 6; ++i) rd[i] = {rl[i], tid == i ? 1.f : 0.f};
+    for (int i = 0; i < 3; ++i) td[i] = {tl[i], tid == 6 + i ? 1.f : 0.f};
+    const Rigid<Dual> M = base_to_cam<Dual>(rd, td);
+    float g = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      g += red[0][9 + i] * M.t[i].d;
+      for (int j = 0; j < 3; ++j) g += red[0][3 * i + j] * M.r[i][j].d;
+    }
+    g *= flip;
+    if (tid < 6) d_r6[6 * b + tid] = g;
+    else d_tr[3 * b + tid - 6] = g;
+  }
+}
+}  // namespace hrp
+
+extern "C" int hrp_mesh_pose_bwd(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans, int B, int root_kp,
+                                 const float* verts, const uint8_t* vert_link, int V, const float* d_xyz, float* d_rot6d, float* d_trans,
+                                 void* stream) {
+  using namespace hrp;
+  HRP_REQUIRE(chain_dev && q && rot6d && trans && verts && vert_link && d_xyz && d_rot6d && d_trans && B > 0 && V > 0, "mesh_pose_bwd: bad args");
+  HRP_REQUIRE(root_kp < HRP_FK_MAX_KP, "mesh_pose_bwd: root_kp=%d", root_kp);
+  hipLaunchKernelGGL(mesh_pose_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, chain_dev, q, rot6d, trans, root_kp, verts, vert_link, V,
+                     d_xyz, d_rot6d, d_trans);
+  return check_launch("mesh_pose_bwd");
+}
+
 extern "C" int hrp_mesh_pose(const hrp_fk_chain* chain_dev, const float* q, const float* rot6d, const float* trans, int B, int root_kp,
                              const float* verts, const uint8_t* vert_link, int V, const float* K, float* xyz, float* uv, void* stream) {
   using namespace hrp;

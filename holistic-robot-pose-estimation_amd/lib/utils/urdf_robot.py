@@ -147,6 +147,48 @@ class _FKFn(torch.autograd.Function):
         return None, dq, dr, dt, None, None, None
 
 
+class _SilhouetteFn(torch.autograd.Function):
+    """posed mesh -> soft silhouette (hrp_mesh_pose + hrp_silhouette_fwd); backward through the rasteriser, the projection and the
+    camera pose to (b2c_rot, b2c_trans) - the joint angles are detached on this path as in the reference (urdf_robot.py:267)."""
+
+    @staticmethod
+    def forward(ctx, robot, q, rot, trans, verts, vert_link, faces, K, H, W, root, sigma, blur):
+        xyz, uv = robot.pose_mesh(q, rot, trans, verts, vert_link, root=root, K=K)
+        dev = q.device
+        B, V = xyz.shape[0], xyz.shape[1]
+        fc = faces.contiguous().to(torch.int32)
+        alpha = torch.empty(B, H, W, device=dev)
+        logp = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+        d = nv.SilhouetteDesc()
+        d.uv, d.xyz, d.faces = uv.data_ptr(), xyz.data_ptr(), fc.data_ptr()
+        d.B, d.V, d.F, d.H, d.W = B, V, fc.shape[0], H, W
+        d.sigma, d.blur_radius = sigma, blur
+        d.alpha, d.logp = alpha.data_ptr(), logp.data_ptr()
+        nv.call("hrp_silhouette_fwd", C.byref(d), torch.cuda.current_stream(dev).cuda_stream)
+        ctx.keep = (robot, q.detach(), rot.detach(), trans.detach(), verts, vert_link, fc, K.contiguous().float(), xyz, uv, logp, alpha, d, root)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, g_alpha):
+        robot, q, rot, trans, verts, vert_link, fc, K, xyz, uv, logp, alpha, d, root = ctx.keep
+        dev = q.device
+        s = torch.cuda.current_stream(dev).cuda_stream
+        B, V = xyz.shape[0], xyz.shape[1]
+        ga = g_alpha.contiguous().float()
+        d_uv = torch.empty(B, V, 2, device=dev)
+        nv.call("hrp_silhouette_bwd", C.byref(d), ga.data_ptr(), d_uv.data_ptr(), s)
+        d_xyz = torch.empty(B, V, 3, device=dev)
+        nv.call("hrp_project_bwd", K.data_ptr(), xyz.data_ptr(), d_uv.data_ptr(), B, V, d_xyz.data_ptr(), s)
+        chain, names = robot.mesh_chain_on(dev)
+        root_kp = names.index(robot.link_names[root]) if root != 0 else -1
+        qq, rr, tt = [x.contiguous().float() for x in (q, rot, trans)]
+        d_rot, d_trans = torch.empty_like(rr), torch.empty_like(tt)
+        nv.call("hrp_mesh_pose_bwd", chain.data_ptr(), qq.data_ptr(), rr.data_ptr(), tt.data_ptr(), B, root_kp,
+                verts.contiguous().float().data_ptr(), vert_link.contiguous().to(torch.uint8).data_ptr(), V, d_xyz.data_ptr(),
+                d_rot.data_ptr(), d_trans.data_ptr(), s)
+        return None, None, d_rot, d_trans, None, None, None, None, None, None, None, None, None
+
+
 class URDFRobot:
     def __init__(self, robot_type, urdf_path=None):
         if robot_type not in LINK_NAMES:
@@ -251,6 +293,23 @@ class URDFRobot:
                 Kc.data_ptr() if Kc is not None else None, xyz.data_ptr(), uv.data_ptr() if uv is not None else None,
                 torch.cuda.current_stream(dev).cuda_stream)
         return xyz if K is None else (xyz, uv)
+
+    def render_silhouette(self, jointcfgs, b2c_rot, b2c_trans, mesh, K, image_size, root=0, sigma=1e-8, blur_radius=None):
+        """Soft silhouettes [B, H, W] of the posed robot mesh for a whole batch - the loop of scripts/train_sim2real.py:415-418 over
+        get_rendered_mask_single_image_at_specific_root (urdf_robot.py:242-275) with the renderer of
+        lib/utils/mesh_renderer.py:78-109 (pytorch3d MeshRasterizer + SoftSilhouetteShader, sigma 1e-8, blur_radius
+        log(1 / 1e-4 - 1) * sigma).  mesh = (verts [V, 3] in link frames, vert_link [V], faces [F, 3]); K [B, 3, 3] the intrinsics of
+        the rendered image (set_robot_renderer scales K_original by 0.5), image_size = (H, W).  Gradients reach b2c_rot / b2c_trans.
+        PARITY UNPINNED (csrc/silhouette.hip): pytorch3d is not available to the build; the algorithm is restated from its
+        published form and checked against this repository's own torch restatement (oracle/silhouette.py)."""
+        if b2c_rot.shape[1] != 6:
+            raise NotImplementedError("render_silhouette: 6-D rotations only")
+        verts, vert_link, faces = mesh
+        if blur_radius is None:
+            blur_radius = float(np.log(1.0 / 1e-4 - 1.0) * sigma)
+        H, W = image_size
+        return _SilhouetteFn.apply(self, jointcfgs, b2c_rot, b2c_trans, verts, vert_link, faces, K, int(H), int(W), root,
+                                   float(sigma), float(blur_radius))
 
     def get_keypoints_only_fk(self, jointcfgs):
         rot, tr = self._identity_cam(jointcfgs)

@@ -311,6 +311,29 @@ class URDFRobot:
         return _SilhouetteFn.apply(self, jointcfgs, b2c_rot, b2c_trans, verts, vert_link, faces, K, int(H), int(W), root,
                                    float(sigma), float(blur_radius))
 
+    def set_robot_renderer(self, K_original, original_image_size=(480, 640), scale=0.5, device="cuda", mesh=None):
+        """reference urdf_robot.py:201-227: intrinsics and image size scaled by `scale`, the visual meshes of MESH_LINKS next to the
+        URDF (`meshes/visual/<link>/<link>.obj`) unless `mesh` = (verts, vert_link, faces) is given."""
+        from hrpe_amd.lib.utils.mesh_renderer import RobotMeshRenderer
+        fx, fy = float(K_original[0, 0]) * scale, float(K_original[1, 1]) * scale
+        cx, cy = float(K_original[0, 2]) * scale, float(K_original[1, 2]) * scale
+        size = (int(original_image_size[0] * scale), int(original_image_size[1] * scale))
+        files = None
+        if mesh is None:
+            base = os.path.dirname(self.urdf_path)
+            short = [n.replace("panda_", "") for n in MESH_LINKS[self.robot_type]]
+            files = [os.path.join(base, "meshes", "visual", n, n + ".obj") for n in short]
+        return RobotMeshRenderer([-fx, -fy], [cx, cy], size, robot=self, mesh_files=files, device=device, mesh=mesh)
+
+    def get_rendered_masks(self, joint_angles, rot, trans, renderer, root=0):
+        """The loop of scripts/train_sim2real.py:415-418 for the whole batch: [B, H, W] rendered masks, differentiable in rot / trans
+        (the joint angles are detached, urdf_robot.py:267)."""
+        return renderer.silhouettes(self, joint_angles.detach(), rot, trans, root=root)
+
+    def get_rendered_mask_single_image_at_specific_root(self, joint_angles, rot, trans, robot_mesh, robot_renderer_gpu, root=0):
+        """reference urdf_robot.py:259-275 (one sample; `robot_mesh` is not needed: the renderer poses the mesh itself) -> [1, H, W]"""
+        return self.get_rendered_masks(joint_angles[None], rot[None], trans[None], robot_renderer_gpu, root=root)
+
     def get_keypoints_only_fk(self, jointcfgs):
         rot, tr = self._identity_cam(jointcfgs)
         return _FKFn.apply(self, jointcfgs, rot, tr, None, 0, ("xyz",))[0]

@@ -670,3 +670,30 @@ def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "mislabelled" in str(e.value)
+
+
+def test_silhouette_oracle_known_answers_and_obj_loader(tmp_path):
+    """oracle/silhouette.py (the torch restatement the HIP rasteriser is tested against; pytorch3d's algorithm, parity unpinned):
+    a right triangle with legs of 20 px covers exactly the pixel centres strictly inside it (210 of them), a face behind the camera
+    and a zero-area face render nothing, two overlapping faces give the same mask as one; and the .obj loader of
+    hrpe_amd.lib.utils.mesh_renderer (host code) fans polygons and numbers vertices per file."""
+    from oracle import silhouette as osil
+    uv = torch.tensor([[[10.2, 10.2], [30.2, 10.2], [10.2, 30.2], [5.0, 5.0], [5.0, 5.0], [5.0, 5.0]]])
+    z = torch.ones(1, 6)
+    a = osil.soft_silhouette(uv, z, torch.tensor([[0, 1, 2]]), 40, 40)
+    ys, xs = torch.meshgrid(torch.arange(40.0) + 0.5, torch.arange(40.0) + 0.5, indexing="ij")
+    inside = (xs > 10.2) & (ys > 10.2) & ((xs - 10.2) + (ys - 10.2) < 20.0)
+    assert int(inside.sum()) == 210
+    assert torch.equal(a[0] > 0.5, inside) and float((a[0] * (1 - a[0])).abs().max()) < 1e-6       # binary at sigma = 1e-8
+    assert torch.equal(osil.soft_silhouette(uv, z, torch.tensor([[0, 1, 2], [0, 2, 1]]), 40, 40) > 0.5, a > 0.5)
+    assert float(osil.soft_silhouette(uv, z, torch.tensor([[3, 4, 5]]), 40, 40).max()) == 0.0       # zero area
+    zb = z.clone()
+    zb[0, 1] = -1.0
+    assert float(osil.soft_silhouette(uv, zb, torch.tensor([[0, 1, 2]]), 40, 40).max()) == 0.0       # a vertex behind the camera
+    from hrpe_amd.lib.utils.mesh_renderer import load_mesh_files
+    p0, p1 = tmp_path / "a.obj", tmp_path / "b.obj"
+    p0.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    p1.write_text("v 0 0 1\nv 1 0 1\nv 0 1 1\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    verts, links, faces = load_mesh_files([str(p0), str(p1)])
+    assert verts.shape == (7, 3) and links.tolist() == [0, 0, 0, 0, 1, 1, 1]
+    assert faces.tolist() == [[0, 1, 2], [0, 2, 3], [4, 5, 6]]

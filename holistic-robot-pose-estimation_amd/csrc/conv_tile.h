@@ -639,7 +639,12 @@ static int plan_cfg(const hrp_conv_desc& d, ConvTiling& t, int& lds_out, bool al
     // (out_stride == 1: the launch covers all of y, which it zeroes first)
     if (allow_ksplit && SZ == 4 && !d.relu && !d.scale && !d.stats && d.out_stride == 1 && d.y_H == d.Ho && d.y_W == d.Wo && t.nblocks <= 64) {
       int ks = 1;
-      while (ks < 16 && t.nblocks * ks * 2 <= 256 && nch / (ks * 2) >= 8) ks *= 2;
+      // at most TWO slices: two fp32 partials added atomically onto a zeroed output give the same bits in either order
+      // (a + b == b + a); four or more do not - the fp32 inference forward differed in the last bit from run to run
+      // (256-channel fuse layers at 8 x 8), which moved key-point 0 by up to 1.5e-3 px.  The 1 x 1 layers on pooled
+      // features, which wanted 16 slices, run on the linear kernels with their ordered reduction since round 3.
+      static const int ks_max = getenv("HRP_CONV_KSPLIT_MAX") ? atoi(getenv("HRP_CONV_KSPLIT_MAX")) : 2;
+      while (ks < ks_max && t.nblocks * ks * 2 <= 256 && nch / (ks * 2) >= 8) ks *= 2;
       if (ks > 1) { t.ksplit = ks; t.cps = cdiv(nch, ks); t.nblocks *= ks; }
     }
   }

@@ -407,3 +407,20 @@ def test_full_network_with_quaternion_rotation_golden():
         if key.startswith("grad:") and key.endswith(":val"):
             name = key.split(":")[1]
             M.summary_check(params[name].grad, g, f"grad:{name}:", M.GRAD_TOL, what="quaternion ")
+
+
+def test_fp32_inference_is_bit_reproducible():
+    """Two fresh fp32 models, the same inputs: identical 8-tuples, bit for bit.  (Until round 4 the 256-channel fuse layers at 8 x 8
+    ran the conv path's split-K with FOUR atomically added fp32 partials - the order of the additions moved key-point 0 by up to
+    1.5e-3 px from run to run and made test_fp32_keypoints_within_the_reference_fp32_noise_floor fail one run in six; the split
+    is capped at two slices now, whose sum does not depend on the order.)"""
+    from synth import synth_inputs
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    outs = []
+    for _ in range(3):
+        m = M.build_full().eval()
+        with torch.no_grad():
+            outs.append([t.clone() for t in m(x_reg, x_root, kv, K)])
+    for o in outs[1:]:
+        for n, a, b in zip(M.NAMES8, o, outs[0]):
+            assert torch.equal(a, b), n

@@ -425,3 +425,23 @@ def test_fp32_inference_is_bit_reproducible():
     for o in outs[1:]:
         for n, a, b in zip(M.NAMES8, o, outs[0]):
             assert torch.equal(a, b), n
+
+
+def test_fp32_training_step_is_bit_reproducible():
+    """Two fresh fp32 DepthNets, the same batch: identical loss and identical gradients for all 981 parameters.  (bf16 steps have
+    been bit-reproducible since round 3; in fp32 the split-K of the skinny layers added its partials atomically ONTO gradients
+    that accumulate - (y + a) + b against (y + b) + a - which made 897 of the 981 gradients differ in the last bits from run to run;
+    such launches no longer split.)"""
+    from hrpe_amd.lib.models.depth_net import get_rootnet
+    x, _, kv, _ = synth_inputs(4)
+    runs = []
+    for _ in range(2):
+        m = get_rootnet("hrnet32")
+        m.load_state_dict(synth_state_dict(m.state_dict()))
+        m = m.to(DEV).train()
+        loss = torch.nn.functional.l1_loss(m(x.to(DEV), kv.to(DEV)) / 1000.0, torch.ones(4, 1, device=DEV))
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[1][1][n])]
+    assert len(runs[0][1]) > 900 and not bad, bad[:8]

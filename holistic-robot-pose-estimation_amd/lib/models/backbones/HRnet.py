@@ -51,18 +51,26 @@ class Conv2d(SingleTensorModule):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}"
 
 
-class BatchNorm2d(PlannedModule):
+class BatchNorm2d(nn.BatchNorm2d, PlannedModule):
+    """Parameter / buffer holder with torch's class in its bases: `isinstance(m, torch.nn.BatchNorm2d)` checks of the reference's
+    trainers (scripts/train_sim2real.py:144-146 freezes BatchNorm that way) see these modules; it never runs torch's forward."""
+
     def __init__(self, num_features, momentum=0.1, eps=1e-5):
-        super().__init__()
-        self.num_features, self.momentum, self.eps = num_features, momentum, eps
-        self.weight = nn.Parameter(torch.ones(num_features))
-        self.bias = nn.Parameter(torch.zeros(num_features))
-        self.register_buffer("running_mean", torch.zeros(num_features))
-        self.register_buffer("running_var", torch.ones(num_features))
-        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        nn.BatchNorm2d.__init__(self, num_features, eps=eps, momentum=momentum)      # (reaches PlannedModule.__init__ through the MRO)
 
     def forward(self, x):
         raise NotImplementedError("BatchNorm2d is always fused with its producing conv in a plan")
+
+
+class BatchNorm1d(nn.BatchNorm1d, PlannedModule):
+    """nn.BatchNorm1d of the add_fc heads (full_net.py:150-157, depth_net.py:44-70): the same parameters / buffers, planned as a
+    BatchNorm over [N, 1, 1, C]."""
+
+    def __init__(self, num_features, momentum=0.1, eps=1e-5):
+        nn.BatchNorm1d.__init__(self, num_features, eps=eps, momentum=momentum)
+
+    def forward(self, x):
+        raise NotImplementedError("BatchNorm1d is always fused with its producing layer in a plan")
 
 
 def conv_bn(pb, x, conv, bn):

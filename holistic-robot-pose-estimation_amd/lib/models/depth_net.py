@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from hrpe_amd.plan import Term
 from hrpe_amd.runtime import PlannedModule
-from .backbones.HRnet import BatchNorm2d, Conv2d, get_hrnet
+from .backbones.HRnet import BatchNorm1d, BatchNorm2d, Conv2d, get_hrnet
 from .backbones.Resnet import get_resnet
 
 
@@ -46,7 +46,7 @@ class RootNet(PlannedModule):
             for i, (o, k) in enumerate([(c // 2, c), (c // 4, c // 2), (c // 4, c // 4), (c // 2, c // 4), (c, c // 2)], 1):
                 setattr(self, f"depth_fc{i}", _Linear1x1(k, o))
                 if i < 5:
-                    setattr(self, f"depth_bn{i}", BatchNorm2d(o))
+                    setattr(self, f"depth_bn{i}", BatchNorm1d(o))
         self.depth_layer = Conv2d(self.inplanes, 1, 1, bias=True)
         if use_offset:
             self.offset_layer = Conv2d(self.inplanes, 1, 1, bias=True)

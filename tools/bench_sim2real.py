@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""The self-supervised (render-and-compare) training step of BASELINE config 5 on synthetic data, timed on one GPU (development /
+evidence tool - bench.py's contract is the supervised step).  Reference loop body: scripts/train_sim2real.py:139-146, 405-418, 435-468.
+
+    python tools/bench_sim2real.py [--batch 32] [--steps 10] [--faces-per-side 14]
+
+What is synthetic: the images, the robot mesh (one box per visual-mesh link, every side a grid of triangles: ~21 000 faces at the
+default, the size of a real visual mesh set) and the segmentation masks (rendered once from a perturbed pose: the reference's
+mask network, CtRNet / DeepLabv3 + a checkpoint, is not available).  The rasteriser is parity-UNPINNED (csrc/silhouette.hip)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import bench  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def grid_box_mesh(n, seed=3):
+    """One box per mesh link, every side an n x n grid of quads (2 n^2 triangles): (verts, vert_link, faces)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    verts, links, faces = [], [], []
+    lin = np.linspace(-1.0, 1.0, n + 1, dtype=np.float32)
+    for l in range(9):
+        half = g.uniform(0.04, 0.09, 3).astype(np.float32)
+        off = g.uniform(-0.03, 0.03, 3).astype(np.float32)
+        for axis in range(3):
+            for sign in (-1.0, 1.0):
+                base = sum(len(v) for v in verts)
+                a, b = np.meshgrid(lin, lin, indexing="ij")
+                p = np.zeros(((n + 1) ** 2, 3), np.float32)
+                p[:, axis] = sign
+                p[:, (axis + 1) % 3] = a.reshape(-1)
+                p[:, (axis + 2) % 3] = b.reshape(-1)
+                verts.append(p * half + off)
+                links += [l] * len(p)
+                for i in range(n):
+                    for j in range(n):
+                        v00 = base + i * (n + 1) + j
+                        faces += [(v00, v00 + 1, v00 + n + 2), (v00, v00 + n + 2, v00 + n + 1)]
+    return (torch.tensor(np.concatenate(verts)), torch.tensor(np.asarray(links, np.uint8)), torch.tensor(np.asarray(faces, np.int32)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--faces-per-side", type=int, default=14)
+    a = ap.parse_args()
+    from hrpe_amd.lib.core.function import compute_k_values, sim2real_mask_loss
+    from hrpe_amd.optim import FusedClipAdam
+    B = a.batch
+    from synth import synth_state_dict
+    model = bench.build_model(0.5)
+    # (frozen BatchNorm normalises with the RUNNING statistics: the seeded state dict of the test fixtures carries plausible ones;
+    # freshly initialised statistics of (0, 1) let the activations of a random network overflow)
+    model.load_state_dict(synth_state_dict(model.state_dict()))
+    model = model.to(DEV).set_compute_dtype(torch.bfloat16).train()
+    for mod in model.modules():                     # scripts/train_sim2real.py:144-146
+        if isinstance(mod, torch.nn.BatchNorm2d) or isinstance(mod, torch.nn.BatchNorm1d):
+            mod.eval()
+    d = {k: torch.tensor(v).to(DEV) for k, v in bench.synthetic_batch(B, 4242).items()}
+    K = d["K"]
+    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], d["bbox"])
+    mesh = grid_box_mesh(a.faces_per_side)
+    K_original = torch.tensor([[640.0, 0, 320.0], [0, 640.0, 240.0], [0, 0, 1.0]])
+    renderer = model.robot.set_robot_renderer(K_original, original_image_size=(480, 640), scale=0.5, device=DEV, mesh=mesh)
+    opt = FusedClipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-6, max_norm=5.0)
+    with torch.no_grad():
+        pose, rot, trans = model(d["x_reg"], d["x_root"], kv, K)[:3]
+        # random weights predict the robot anywhere: a constant per-sample offset puts key-point 3 at 1.5 m on the optical axis, so
+        # that the silhouettes fill a realistic part of the image (the gradient still reaches the predicted translation)
+        t_off = torch.tensor([0.0, 0.0, 1.5], device=DEV) - trans
+        seg = model.robot.get_rendered_masks(pose, rot, trans + t_off + torch.tensor([0.02, -0.01, 0.03], device=DEV), renderer, root=3)
+    weights = dict(mask=0.0, iou=1.0, scale=0.0, align=1.0)        # configs/panda/self_supervised/*.yaml:109-112
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    acc = np.zeros(5)
+    cover = 0.0
+
+    def step(timed):
+        nonlocal cover
+        ev[0].record()
+        out = model(d["x_reg"], d["x_root"], kv, K)
+        ev[1].record()
+        rendered = model.robot.get_rendered_masks(out[0], out[1], out[2] + t_off, renderer, root=3)
+        ev[2].record()
+        loss, _ = sim2real_mask_loss(rendered, seg, out[7], out[6], "mse_mean", weights)
+        ev[3].record()
+        opt.zero_grad()
+        loss.backward()
+        ev[4].record()
+        opt.step()
+        ev[5].record()
+        if timed:
+            torch.cuda.synchronize()
+            acc[:] += [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+            cover = float(rendered.detach().mean())
+        return loss
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(a.steps):
+        loss = step(True)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / a.steps
+    names = ["network forward", "mesh posing + rasteriser", "mask losses", "backward (losses, rasteriser, network)", "clip + Adam"]
+    print(json.dumps({"workload": "self-supervised render-and-compare step (BASELINE config 5) on synthetic meshes / masks, eager launches, "
+                                  "full network bf16 with frozen BatchNorm, 240x320 masks", "batch": B, "images_per_sec": round(B / ms * 1e3, 1),
+                      "ms_per_step": round(ms, 2), "phases_ms": {n: round(v / a.steps, 3) for n, v in zip(names, acc)},
+                      "mesh": {"vertices": int(mesh[0].shape[0]), "faces": int(mesh[2].shape[0])}, "mask_coverage": round(cover, 4),
+                      "loss": round(float(loss.detach()), 5), "rasteriser": "parity unpinned (csrc/silhouette.hip)",
+                      "mask_network": "absent: masks rendered from a perturbed pose"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,9 @@ from .configs import HRNET_CONFIGS, AttrDict
 
 BN_MOMENTUM = 0.1  # reference HRnet.py:18
 HEAD_FP32 = os.environ.get("HRP_HEAD_FP32", "0") not in ("0", "")
+# measurement switch (DESIGN 4, bf16 key-point 0): from which stage on a FEATURE-ONLY trunk (the DepthNet) computes in fp32 - "" (bf16
+# throughout), "4" or "3": the branch tensors entering that stage are cast and everything behind runs on the fp32 kernels
+TRUNK_FP32_FROM = os.environ.get("HRP_DEPTHNET_FP32_FROM", "")
 logger = logging.getLogger(__name__)
 
 
@@ -297,8 +300,10 @@ def _trunk_segments(net):
         h = _emit_seq(pb, net.layer1, h)
         return [h if tr is None else _transition(pb, tr, h) for tr in net.transition1]
 
-    def stage(mods, trans):
+    def stage(mods, trans, number=0):
         def seg(pb, ys):
+            if TRUNK_FP32_FROM and not net.generate_hm and number == int(TRUNK_FP32_FROM):
+                ys = [pb.cast(y, torch.float32) for y in ys]
             for m in mods:
                 ys = m.emit(pb, ys, virtual=True)
             if trans is not None:
@@ -306,7 +311,7 @@ def _trunk_segments(net):
                 ys = [ys[j] if tr is None else _transition(pb, tr, ys[-1]) for j, tr in enumerate(trans)]
             return ys
         return seg
-    return [stem, stage(net.stage2, net.transition2), stage(net.stage3, net.transition3), stage(net.stage4, None)]
+    return [stem, stage(net.stage2, net.transition2, 2), stage(net.stage3, net.transition3, 3), stage(net.stage4, None, 4)]
 
 
 def emit_trunks(pb, nets, xs, rider=None):

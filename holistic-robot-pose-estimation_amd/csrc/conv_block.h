@@ -7,13 +7,14 @@
 // Structure (what conv_rowbw.h showed to work: roles instead of phases).  A workgroup of 8 waves walks a band of rows of
 // one image from top to bottom in STEPS of 4 rows; the two convolutions run concurrently, two steps apart, on different waves:
 //   role 0 (waves 0-3)  conv1 step t: h rows [r0 - 1 + 4t, r0 + 3 + 4t) from the x ring -> relu(acc * sc1 + sh1) -> h ring (LDS);
-//                       also issues the direct-to-LDS DMA of the 4 x rows of step t + 1 before its MFMA loop
+//                       after its epilogue it issues the direct-to-LDS DMA of the 4 new x rows of step t + 2
 //   role 1 (waves 4-7)  conv2 step s = t - 2: out rows [r0 + 4s, r0 + 4s + 4) from the h ring; its accumulators are stored one
 //                       iteration later, BEFORE the next MFMA loop (residual from the x ring, relu(acc * sc2 + sh2 + x) -> global):
 //                       role 1's epilogue runs under role 0's MFMA loop and the other way round
 //   ONE barrier per step.  The x ring holds 24 rows: [4i - 10, 4i + 14) of step i are live (residual of step i - 3 .. DMA target
-//   of step i + 2: the rows are requested two steps before conv1 reads them); the h ring 12 rows: [4i - 8, 4i + 4).  No row is computed or read twice inside a band; bands of
-//   one image (small batches only) recompute one h row and re-read two x rows at each seam.
+//   of step i + 2: the rows are requested two steps before conv1 reads them); the h ring 12 rows: [4i - 8, 4i + 4).  No row is
+//   computed or read twice inside a band; bands of one image (small batches only) recompute one h row and re-read two x rows at
+//   each seam.
 //   Each role keeps the 9 x KS weight fragments of ITS convolution in registers for the whole band (72 / 144 VGPRs), a wave
 //   owns 2 output rows x 32 pixels x 32 output channels per step (18 KS MFMAs 32x32x16 from 12 KS LDS reads).
 //   LDS layout, bank swizzle, DMA piece mapping, MFMA row -> channel permutation: conv_row.h.

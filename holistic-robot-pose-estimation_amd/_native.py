@@ -63,20 +63,6 @@ class WgradFoldDesc(C.Structure):
                 ("dw_tap_off", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
-ROWBW_MAX = 2
-
-
-class RowBwDesc(C.Structure):
-    _fields_ = [("conv", ConvDesc), ("wg_x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_int64), ("wg_act", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32 * 2)]
-
-
-class RowBwInfo(C.Structure):
-    _fields_ = [("n", C.c_int32), ("grid", C.c_int32), ("lds_bytes", C.c_int32), ("total_strips", C.c_int32),
-                ("strip0", C.c_int32 * (ROWBW_MAX + 1)), ("first_wg", C.c_int32 * ROWBW_MAX), ("G", C.c_int32 * ROWBW_MAX),
-                ("ws_bytes", C.c_int64 * ROWBW_MAX)]
-
-
 class Sim2RealLossDesc(C.Structure):
     _fields_ = [("rendered", C.c_void_p), ("seg", C.c_void_p), ("kp3d", C.c_void_p), ("kp3d_int", C.c_void_p),
                 ("B", C.c_int32), ("HW", C.c_int32), ("K", C.c_int32), ("mask_loss", C.c_int32),
@@ -224,10 +210,6 @@ PROTOTYPES = {
     "hrp_rot6d_compose_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "hrp_wgrad_fold_desc_of": [C.POINTER(WgradDesc), C.POINTER(WgradFoldDesc)],
     "hrp_batch_wgrad_fold_descs": [_P, C.POINTER(BatchInfo), C.POINTER(WgradFoldDesc)],
-    "hrp_rowbw_channels": [C.POINTER(RowBwDesc)],
-    "hrp_rowbw_prepare": [_P, _I, _I, _P, C.POINTER(RowBwInfo)],
-    "hrp_rowbw_launch": [_P, C.POINTER(RowBwInfo), _P],
-    "hrp_rowbw_fold_descs": [_P, C.POINTER(RowBwInfo), C.POINTER(WgradFoldDesc)],
     "hrp_block_channels": [C.POINTER(BlockDesc)],
     "hrp_block_prepare": [_P, _I, _P, C.POINTER(BlockInfo)],
     "hrp_block_launch": [_P, C.POINTER(BlockInfo), _P],
@@ -298,8 +280,6 @@ def lib():
         L.hrp_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         L.hrp_batch_table_bytes.restype = C.c_int64
         L.hrp_batch_table_bytes.argtypes = [C.c_int, C.c_int]
-        L.hrp_rowbw_table_bytes.restype = C.c_int64
-        L.hrp_rowbw_table_bytes.argtypes = []
         L.hrp_block_table_bytes.restype = C.c_int64
         L.hrp_block_table_bytes.argtypes = []
         _lib = L
@@ -348,18 +328,6 @@ def call_batch(batch, stream):
     fn()
 
 
-def call_rowbw(batch, stream):
-    """One fused row-strip backward launch (plan.RowBwBatch: .table host launch table, .info RowBwInfo, .items)."""
-    name = "hrp_rowbw_launch"
-    if _skip and name in _skip:
-        return
-    fn = lambda: check(lib().hrp_rowbw_launch(batch.table, C.byref(batch.info), stream), name)   # noqa: E731
-    if _profile_hook is not None:
-        _profile_hook(name, (batch,), fn)
-        return
-    fn()
-
-
 def call_block(batch, stream):
     """One fused inference BasicBlock launch (plan.BlockBatch: .table host launch table, .info BlockInfo, .items)."""
     name = "hrp_block_launch"
@@ -372,5 +340,5 @@ def call_block(batch, stream):
     fn()
 
 
-FAMILY_FN = {"block": "hrp_block_launch", "rowbw": "hrp_rowbw_launch", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
+FAMILY_FN = {"block": "hrp_block_launch", "conv": "hrp_conv2d_fwd", "wgrad": "hrp_conv2d_bwd_weight", "wgrad_fold": "hrp_wgrad_fold", "ew_fwd": "hrp_ew_fwd", "ew_red": "hrp_ew_bwd_reduce",
              "ew_app": "hrp_ew_bwd_apply"}

@@ -72,7 +72,7 @@ static int conv_batch_plan_one(const hrp_conv_desc& d, ConvProblem& P, int& lds)
       return HRP_OK;
     }
   }
-  static const int budget_kb = getenv("HRP_CONV_BATCH_LDS_KB") ? atoi(getenv("HRP_CONV_BATCH_LDS_KB")) : 76;   // tuning knob
+  static const int budget_kb = 76;   // (swept: DESIGN 5)
   g_conv_lds_budget_kb = budget_kb;
   if (d.Cout <= 32) {
     rc = plan_cfg<T, 1, 2, 1, 4, NT>(d, P.t, lds, false); P.cfg = 0;
@@ -119,7 +119,7 @@ static int conv_batch_prepare_nt(const hrp_conv_desc* descs, int n, ConvProblem*
   // their DMA / store plans across tiles: two per CU over the launch.
   bool light = true;
   for (int i = 0; i < n; ++i) light = light && probs[i].cfg <= 1;
-  static const int pwgs = getenv("HRP_CONV_BATCH_PERSIST") ? atoi(getenv("HRP_CONV_BATCH_PERSIST")) : 512;
+  static const int pwgs = 512;
   const int pcap = light && pwgs > 0 ? (pwgs / n < 32 ? 32 : pwgs / n) : 0;
   int blk = 0;
   for (int k = 0; k < n; ++k) {

@@ -4,7 +4,7 @@
 // out is written once, the intermediate activation h never leaves LDS.  Eval has no batch-statistics barrier between the two
 // convolutions, so nothing forces h through HBM.
 //
-// Structure (what conv_rowbw.h showed to work: roles instead of phases).  A workgroup of 8 waves walks a band of rows of
+// Structure (roles instead of phases).  A workgroup of 8 waves walks a band of rows of
 // one image from top to bottom in STEPS of 4 rows; the two convolutions run concurrently, two steps apart, on different waves:
 //   role 0 (waves 0-3)  conv1 step t: h rows [r0 - 1 + 4t, r0 + 3 + 4t) from the x ring -> relu(acc * sc1 + sh1) -> h ring (LDS);
 //                       after its epilogue it issues the direct-to-LDS DMA of the 4 new x rows of step t + 2
@@ -297,7 +297,7 @@ __device__ __forceinline__ void blk_body(const BlkProblem& q, const int wg) {
   }
 }
 
-// Problems are addressed with compile-time indices into the by-value kernel argument (conv_rowbw.h).  C0 / C1: channel counts
+// Problems are addressed with compile-time indices into the by-value kernel argument.  C0 / C1: channel counts
 // of problem 0 / 1 (C1 == 0: one problem).
 template <int C0, int C1>
 __global__ __launch_bounds__(512) void block_kernel(const BlkArgs A) {

@@ -37,7 +37,7 @@ static int block_launch_t(const BlkArgs& A, int grid, int lds, hipStream_t s) {
 using namespace hrp;
 
 extern "C" int hrp_block_channels(const hrp_block_desc* d) {
-  static const bool off = getenv("HRP_NO_BLOCK_FUSE") != nullptr;
+  static const bool off = false;
   return (d && !off) ? block_channels(*d) : 0;
 }
 
@@ -51,7 +51,7 @@ extern "C" int hrp_block_prepare(const hrp_block_desc* descs, int n, void* table
               "block: two problems of one launch are a 32-channel and a 64-channel block, in this order");
   // bands per image: one workgroup per image once the batch fills the chip with the launches that run next to each other
   // (B = 64: 2 problems x 64 images per trunk); small batches are cut into bands of >= 8 rows
-  static const int target = getenv("HRP_BLOCK_WGS") ? atoi(getenv("HRP_BLOCK_WGS")) : 64;
+  static const int target = 64;
   int grid = 0, lds = 0;
   BlkArgs A;
   memset(&A, 0, sizeof(A));

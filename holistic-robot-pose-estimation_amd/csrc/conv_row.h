@@ -120,7 +120,7 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
   static const int spw_env = getenv("HRP_ROWCONV_SPW") ? atoi(getenv("HRP_ROWCONV_SPW")) : 0;
   rp.spw = spw_env > 0 ? spw_env : (rp.nstrips >= 256 ? 2 : 1);
   if (rp.spi % rp.spw || d.Cin != 32) rp.spw = 1;       // (the 64-channel kernel keeps its weights in registers: one strip)
-  static const bool no_img = getenv("HRP_NO_IMGCONV") != nullptr;      // A/B switch: deep layers on the strip kernels
+  static const bool no_img = false;
   if (!no_img && (d.Cin == 128 || d.Cin == 256) && d.H == d.W) {
     rp.img = 1;
     rp.nstrips = d.Cin == 128 ? d.N : ((d.N + 1) / 2) * 2;
@@ -238,8 +238,7 @@ __device__ __forceinline__ bool row_ext(const hrp_conv_desc& d) {
 // mask hrp_ew_fwd wrote (block outputs).  RES: a residual (optionally under its own bit mask, res_mask) is added first.  A tile
 // outside the tensor (okmask bit clear) has zero accumulators and loads nothing: its masked values are zero without a test.
 // Operands of the epilogue forms that read tensors (the reduce's BatchNorm input and bit mask, a residual and its bit mask):
-// loaded by row_epi_load - possibly long before row_epi_bnb_math / row_epi_res_math consume them (conv_rowbw.hip issues the
-// loads in front of its MFMA loop).
+// loaded by row_epi_load, consumed by row_epi_bnb_math.
 template <int NT>
 struct RowEpiOps {
   uint4 xr[NT][2], rr[NT][2];
@@ -309,24 +308,6 @@ __device__ __forceinline__ void row_epi_bnb_math(const hrp_conv_desc& d, const f
         s1[8 * hh + i] += g;
         s2[8 * hh + i] = fmaf(g, xv[i], s2[8 * hh + i]);
       }
-    }
-  }
-}
-
-// y = conv + residual (under res_mask when given), no statistics: the data gradient of a block's first conv without a reduce
-template <int NT>
-__device__ __forceinline__ void row_epi_res_math(const hrp_conv_desc& d, const f32x16 (&acc)[NT], const unsigned (&off)[NT],
-                                                 const unsigned okmask, const RowEpiOps<NT>& e) {
-  char* yg = (char*)d.y;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float v[8], r[8];
-      Elem<bf16_t>::unpack(e.rr[t][hh], r);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * hh + i] + row_keep_if_bit(r[i], e.rb[t], 8 * hh + i);
-      if ((okmask >> t) & 1) *(uint4*)(yg + off[t] + 16 * hh) = Elem<bf16_t>::pack(v);
     }
   }
 }

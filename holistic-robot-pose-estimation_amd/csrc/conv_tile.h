@@ -645,7 +645,7 @@ static int plan_cfg(const hrp_conv_desc& d, ConvTiling& t, int& lds_out, bool al
       // (a + b == b + a); four or more do not - the fp32 inference forward differed in the last bit from run to run
       // (256-channel fuse layers at 8 x 8), which moved key-point 0 by up to 1.5e-3 px.  The 1 x 1 layers on pooled
       // features, which wanted 16 slices, run on the linear kernels with their ordered reduction since round 3.
-      static const int ks_max = getenv("HRP_CONV_KSPLIT_MAX") ? atoi(getenv("HRP_CONV_KSPLIT_MAX")) : 2;
+      static const int ks_max = 2;
       while (ks < ks_max && t.nblocks * ks * 2 <= 256 && nch / (ks * 2) >= 8) ks *= 2;
       if (ks > 1) { t.ksplit = ks; t.cps = cdiv(nch, ks); t.nblocks *= ks; }
     }
@@ -699,7 +699,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   // (off by default since the end of round 1: the persistent instances hold 196-208 registers per lane against 96-132,
   // so nothing of another lane fits next to their two workgroups on a CU; alone they are 15 % faster on 32->32 @64x64,
   // in the step they cost 0.55 ms - HRP_CONV_PERSIST=48 restores them)
-  static const int persist_max = getenv("HRP_CONV_PERSIST") ? atoi(getenv("HRP_CONV_PERSIST")) : 0;
+  static const int persist_max = 0;
   constexpr bool CAN_PERSIST = NT == 9;   // (only 3x3 layers have tiles small enough to profit; keeps the instantiation count down)
   const bool persist = CAN_PERSIST && mfma_per_tile <= persist_max && t.nblocks >= 3 * 256 && !d.bnb_x;   // 1x1 layers are store bound: many small workgroups
   const bool fastp = (d.Cin * SZ) % ROW == 0;   // no half-filled last chunk: per-piece advancing pointers
@@ -715,7 +715,7 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
   }
   int occ = (160 * 1024) / lds;
   occ = occ < 1 ? 1 : occ > 2 ? 2 : occ;
-  static const int pgrid = getenv("HRP_CONV_PGRID") ? atoi(getenv("HRP_CONV_PGRID")) : 0;   // tuning knob: persistent workgroups per CU
+  static const int pgrid = 0;   // persistent workgroups per CU (0: off; swept: DESIGN 5)
   const int pocc = pgrid > 0 ? pgrid : occ;
   const int grid = persist && t.nblocks > 256 * pocc ? 256 * pocc : t.nblocks;
   if (t.ksplit > 1 && d.res != d.y)
@@ -730,8 +730,8 @@ static int launch_cfg(const hrp_conv_desc& d, hipStream_t s) {
 template <typename T, int NT>
 static int launch_conv_nt(const hrp_conv_desc& d, hipStream_t s) {
   const long pixels = (long)d.N * d.Ho * d.Wo;
-  static const long want = getenv("HRP_CONV_WANT") ? atol(getenv("HRP_CONV_WANT")) : 256;
-  static const int low_kb = getenv("HRP_CONV_LDS_KB") ? atoi(getenv("HRP_CONV_LDS_KB")) : 76;
+  static const long want = 256;
+  static const int low_kb = 76;
   int rc = -100;
   g_conv_border_reject = false;
   for (int pass = 0; pass < 2 && rc == -100; ++pass) {

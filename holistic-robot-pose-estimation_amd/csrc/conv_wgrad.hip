@@ -499,7 +499,7 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
     mindx = d.dx_t[i] < mindx ? d.dx_t[i] : mindx; maxdx = d.dx_t[i] > maxdx ? d.dx_t[i] : maxdx;
   }
   t.mindy = mindy; t.mindx = mindx;
-  static const int budget_kb = getenv("HRP_WGRAD_LDS_KB") ? atoi(getenv("HRP_WGRAD_LDS_KB")) : 72;
+  static const int budget_kb = 72;
   const int budget = budget_kb * 1024;
   int lds = 0;
   constexpr int BM_MIN = SZ == 4 ? 16 : 64;   // bf16 needs 16 pixels per wave and k-step; fp32 tiles are twice the bytes
@@ -550,16 +550,16 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
   t.n_cob = cdiv(d.Cout, 32 * NB); t.n_cib = cdiv(d.Cin, 32 * NB);
   int pairs = t.n_cob * t.n_cib;
   // workgroups per (cout, cin) block: ~2 per CU over the whole launch; each walks ntiles / G pixel tiles
-  static const int wg_total = getenv("HRP_WGRAD_WGS") ? atoi(getenv("HRP_WGRAD_WGS")) : 256;   // tuning knob
+  static const int wg_total = 256;   // (swept: DESIGN 5)
   int G = (wg_budget > 0 ? wg_budget : wg_total) / pairs;
   if (G < 1) G = 1;
   if (G > t.ntiles) G = t.ntiles;
   t.xmode = 0; t.xa = t.xb = t.xnb = 1;
-  static const bool no_xcd = getenv("HRP_NO_WGRAD_XCD") != nullptr;
+  static const bool no_xcd = false;
   // tuning knob: bit 0 mode 1, bit 1 mode 2.  Measured (PMC FETCH_SIZE of the weight-gradient launches of one step, B = 64):
   // pair-major 27.1 GB, mode 2 only 22.1 GB, mode 1 only 28.5 GB, both 23.5 GB; kernel time one by one 8.31 / 8.75 / 8.38 /
   // 8.78 ms; step time the same within 0.1 ms -> mode 2 (the 2 x 2 blocks of the 64-channel layers share an L2)
-  static const int xmask = getenv("HRP_WGRAD_XCD_MODES") ? atoi(getenv("HRP_WGRAD_XCD_MODES")) : 2;
+  static const int xmask = 2;
   if (wg_budget > 0 && !no_xcd) {          // batched launches (1-D grid): XCD-aware numbering
     if (pairs >= 8 && pairs % 8 == 0 && (xmask & 1)) {
       // xa | n_cob, xb | n_cib, (n_cob / xa) * (n_cib / xb) == 8, xa + xb minimal (slices fetched per XCD)
@@ -768,7 +768,7 @@ static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProbl
     total += work[i];
   }
   // workgroups of the launch: two per CU, shared in proportion to the work (at least one per (cout, cin) pair)
-  static const int wg_launch = getenv("HRP_WGRAD_BATCH_WGS") ? atoi(getenv("HRP_WGRAD_BATCH_WGS")) : 512;
+  static const int wg_launch = 512;
   int lds_max = 0, blk = 0, blk2 = 0;
   for (int i = 0; i < n; ++i) {
     int budget = (int)(wg_launch * work[i] / total + 0.5);

@@ -562,7 +562,7 @@ static EwGeom geom(int C, int vec, bool vec_ok, long npix, int maxblocks) {
   g.nslab = cdiv(nv, tpr);
   int ppb = 256 / tpr;
   long blocks = (npix + ppb - 1) / ppb;
-  static const int mult = getenv("HRP_EW_BLOCKS") ? atoi(getenv("HRP_EW_BLOCKS")) : 1;   // tuning knob
+  static const int mult = 1;   // (swept: DESIGN 5)
   long cap = (long)maxblocks * mult / g.nslab;
   if (cap < 1) cap = 1;
   g.gx = (int)(blocks < cap ? blocks : cap);
@@ -576,7 +576,7 @@ static int ew_fwd_t(const hrp_ew_desc& d, hipStream_t s) {
   bool ok = aligned16(d.out, d.out_pitch, SZ);
   for (int j = 0; j < d.nin; ++j) ok = ok && aligned16(d.in[j].ptr, d.in[j].pitch, SZ);
   // (one block per CU with 4 pixels in flight per thread: 47.1 ms per step at 1 024 blocks, 46.8 at 512, 46.4 at 256)
-  static const int fwd_blocks = getenv("HRP_EW_FWD_BLOCKS") ? atoi(getenv("HRP_EW_FWD_BLOCKS")) : 256;   // tuning knob
+  static const int fwd_blocks = 256;   // (swept: DESIGN 5)
   bool batched = d.nin <= 2;   // the kernel's four-pixel path; fuse sums (3-4 inputs, upsampled ones) keep 4 blocks per CU
   for (int j = 0; j < d.nin; ++j) batched = batched && d.in[j].up == 1;
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * d.H * d.W, batched ? fwd_blocks : 1024);
@@ -603,7 +603,7 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   if (APPLY) ok = ok && aligned16(d.din, d.din_pitch, SZ);
   if (APPLY && d.din2) ok = ok && aligned16(d.din2, d.din2_pitch, SZ);
   const int up = d.in.up;
-  static const int red_blocks = getenv("HRP_EW_RED_BLOCKS") ? atoi(getenv("HRP_EW_RED_BLOCKS")) : 256;   // tuning knob
+  static const int red_blocks = 256;   // (swept: DESIGN 5)
   // (the reduce ends with 2 C atomics per block and keeps 4 pixels of loads in flight per thread: one block per CU
   // streams as fast alone as 512 and leaves the CUs to the kernels of the other lanes - 48.3 -> 47.6 ms per step;
   // twice as many on the >= 64 MiB tensors, where the streaming part dominates)
@@ -611,7 +611,7 @@ static int ew_bwd_t(const hrp_ew_bwd_desc& d, hipStream_t s) {
   // (apply: 4 pixels of loads in flight per thread and ONE block per CU - 1 024 blocks of one-pixel trips took 9.2 ms
   // of kernel time per step and a 47.6 ms step, this 9.8 ms and 46.8 ms: the CUs stay free for the other lanes;
   // block counts that are not a multiple of the 256 CUs (192, 320, 384) lose 0.5-1 ms to the uneven tail)
-  static const int apply_blocks = getenv("HRP_EW_APPLY_BLOCKS") ? atoi(getenv("HRP_EW_APPLY_BLOCKS")) : 256;   // tuning knob
+  static const int apply_blocks = 256;   // (swept: DESIGN 5)
   // (the upsampled fuse-layer inputs keep the one-pixel loop: they get the block counts that suited it)
   const int nblk = up != 1 ? (APPLY ? 1024 : 512) : APPLY ? apply_blocks : (big ? 2 * red_blocks : red_blocks);
   EwGeom g = geom(d.C, VEC, ok, (long)d.N * (d.H / up) * (d.W / up), nblk);
@@ -693,7 +693,7 @@ static int ew_fwd_batch_prepare(const hrp_ew_desc* descs, int n, EwProblem* tab,
   }
   // (block budgets swept 256 .. 8192 on the B=64 step: 768 / 384 is the minimum - 43.1 ms at 2048 / 1024, 41.0-41.8 here;
   // issuing the first trip's loads before the channel-constant phase was measured 0.5 ms slower)
-  static const int total = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 768;
+  static const int total = 768;
   int blk = 0, lds_max = 0;
   for (int i = 0; i < n; ++i) {
     const hrp_ew_desc& d = descs[i];
@@ -731,8 +731,8 @@ static int ew_bwd_batch_prepare(const hrp_ew_bwd_desc* descs, int n, EwBwdProble
     bytes[i] = (double)d.N * d.H * d.W * d.C * SZ;
     sum += bytes[i];
   }
-  static const int total_apply = getenv("HRP_EW_BATCH_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_BLOCKS")) : 768;
-  static const int total_red = getenv("HRP_EW_BATCH_RED_BLOCKS") ? atoi(getenv("HRP_EW_BATCH_RED_BLOCKS")) : 384;
+  static const int total_apply = 768;
+  static const int total_red = 384;
   int blk = 0, lds_max = 0;
   for (int i = 0; i < n; ++i) {
     const hrp_ew_bwd_desc& d = descs[i];

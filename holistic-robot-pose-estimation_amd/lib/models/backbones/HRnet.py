@@ -20,7 +20,8 @@ from .configs import HRNET_CONFIGS, AttrDict
 BN_MOMENTUM = 0.1  # reference HRnet.py:18
 HEAD_FP32 = os.environ.get("HRP_HEAD_FP32", "0") not in ("0", "")
 # measurement switch (DESIGN 4, bf16 key-point 0): from which stage on a FEATURE-ONLY trunk (the DepthNet) computes in fp32 - "" (bf16
-# throughout), "4" or "3": the branch tensors entering that stage are cast and everything behind runs on the fp32 kernels
+# throughout), "4" or "3": the branch tensors entering that stage are cast and everything behind runs on the fp32 kernels; "1": the
+# whole trunk from its input image on (full_net.py creates that input as an fp32 tensor)
 TRUNK_FP32_FROM = os.environ.get("HRP_DEPTHNET_FP32_FROM", "")
 logger = logging.getLogger(__name__)
 
@@ -43,8 +44,7 @@ class Conv2d(SingleTensorModule):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def emit(self, pb, x, want_stats=False):
-        if (self.kernel_size == 1 and self.stride == 1 and not want_stats and x.H == 1 and x.W == 1 and x.dtype == torch.float32
-                and not os.environ.get("HRP_LINEAR_AS_CONV")):
+        if self.kernel_size == 1 and self.stride == 1 and not want_stats and x.H == 1 and x.W == 1 and x.dtype == torch.float32:
             # a 1x1 conv on pooled fp32 features is nn.Linear (depth_layer, depth_net.py:121-123 / full_net.py:271-274): the skinny
             # GEMM kernels with their ordered reduction instead of the conv path's split-K atomics
             return pb.linear(x, self.weight, self.bias)
@@ -287,7 +287,7 @@ def _transition(pb, tr, src):
 TRUNK_LANES = os.environ.get("HRP_TRUNK_LANES", "nets")
 # lanes of bf16 INFERENCE plans when HRP_TRUNK_LANES is "nets": "flat22" = two streams per trunk (branches {0, 1} | {2, 3}), "" = as
 # the training plans
-EVAL_LANES = os.environ.get("HRP_EVAL_LANES", "flat22")
+EVAL_LANES = "flat22"
 
 
 def _trunk_segments(net):

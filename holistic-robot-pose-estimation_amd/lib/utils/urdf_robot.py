@@ -294,6 +294,21 @@ class URDFRobot:
                 torch.cuda.current_stream(dev).cuda_stream)
         return xyz if K is None else (xyz, uv)
 
+    def _check_mesh(self, verts, vert_link, faces):
+        """Index ranges of a mesh tuple, once per tuple (the kernels index vertices by face entry and link poses by
+        vert_link without bounds checks; a malformed .obj would read out of bounds).  One device sync per new mesh."""
+        key = (faces.data_ptr(), vert_link.data_ptr(), int(verts.shape[0]), int(faces.shape[0]))
+        seen = self.__dict__.setdefault("_mesh_checked", set())
+        if key in seen:
+            return
+        V = int(verts.shape[0])
+        nlinks = len(MESH_LINKS[self.robot_type])
+        if faces.numel() and (int(faces.min()) < 0 or int(faces.max()) >= V):
+            raise ValueError(f"mesh faces index vertices outside [0, {V})")
+        if vert_link.numel() != V or (V and int(vert_link.max()) >= nlinks):
+            raise ValueError(f"mesh vert_link must hold one link index < {nlinks} per vertex")
+        seen.add(key)
+
     def render_silhouette(self, jointcfgs, b2c_rot, b2c_trans, mesh, K, image_size, root=0, sigma=1e-8, blur_radius=None):
         """Soft silhouettes [B, H, W] of the posed robot mesh for a whole batch - the loop of scripts/train_sim2real.py:415-418 over
         get_rendered_mask_single_image_at_specific_root (urdf_robot.py:242-275) with the renderer of
@@ -305,6 +320,7 @@ class URDFRobot:
         if b2c_rot.shape[1] != 6:
             raise NotImplementedError("render_silhouette: 6-D rotations only")
         verts, vert_link, faces = mesh
+        self._check_mesh(verts, vert_link, faces)
         if blur_radius is None:
             blur_radius = float(np.log(1.0 / 1e-4 - 1.0) * sigma)
         H, W = image_size

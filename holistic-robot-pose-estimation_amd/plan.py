@@ -116,7 +116,7 @@ class ParamW:
 
 
 # ReLU sign bits written by the forward element-wise pass, read by its backward instead of the activation
-RELU_BITMASK = not os.environ.get("HRP_NO_RELU_BITMASK")
+RELU_BITMASK = True
 
 # True: every lane runs on the caller's stream (per-kernel timing passes, A/B measurements)
 SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
@@ -124,7 +124,7 @@ SERIAL_LANES = bool(os.environ.get("HRP_SERIAL_LANES"))
 
 # nesting depth of parallel blocks that really fork; deeper ones stay on their parent lane.  1 = flat: a lane
 # forked from a forked lane crashes hipStreamEndCapture on ROCm 7 (eager multi-stream execution is fine)
-MAX_LANE_DEPTH = int(os.environ.get("HRP_LANE_DEPTH", "1"))
+MAX_LANE_DEPTH = 1
 
 
 # How a plan executes.  "merged" (default): ONE stream; the lanes of every parallel block are walked in lock step and
@@ -139,9 +139,9 @@ PLAN_MODE = os.environ.get("HRP_PLAN_MODE", "hybrid")
 # instead of a 6-10 us launch behind every weight-gradient launch (~660 per step of the benchmark network)
 # the BatchNorm-backward reduce pass of an activation whose gradient has ONE producer, a data-gradient convolution, runs in
 # that convolution's epilogue (hrp_conv_desc.bnb_*) instead of as a launch of its own over the same two tensors
-FUSE_BN_REDUCE = not os.environ.get("HRP_NO_FUSE_BN_REDUCE")
-WGRAD_DEFER = not os.environ.get("HRP_NO_WGRAD_DEFER")
-WGRAD_FOLD_EVERY = int(os.environ.get("HRP_WGRAD_FOLD_EVERY", "32"))
+FUSE_BN_REDUCE = True
+WGRAD_DEFER = True
+WGRAD_FOLD_EVERY = 32
 # weight gradients feed nothing before the optimizer: the launches of a lane are held back until WGRAD_SINK problems of one
 # tap count are pending (or the lane ends) and then run as ONE batched launch - also the layers that have no lock-step
 # partner (stem, layer1, transitions, the fuse convolutions).  0: every launch stays where the layer's backward put it.
@@ -149,21 +149,22 @@ WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "8"))
 # train-mode BasicBlock interiors conv -> BN -> ReLU -> conv on the row-strip kernel (csrc/conv_row.h): the BatchNorm + ReLU
 # runs in the second convolution's staging path, its backward in the staging path of the first convolution's data gradient
 # stride-2 data gradients: parity classes padded to 4 taps (PlanBuilder._conv_bwd)
-PARITY_PAD = not os.environ.get("HRP_NO_PARITY_PAD")
-ROWCONV_FUSE = not os.environ.get("HRP_NO_ROWCONV_FUSE")
+PARITY_PAD = True
+ROWCONV_FUSE = True
 # ... and the block-end activation's backward (apply pass into conv2's data gradient, reduce pass into the next block's)
-BLOCK_END_FUSE = not os.environ.get("HRP_NO_BLOCK_END_FUSE")
-BLOCK_END_REDUCE_FUSE = not os.environ.get("HRP_NO_BLOCK_END_REDUCE_FUSE")
-# ... and, for the 32- / 64-channel branches, the data gradient AND the weight gradient of each conv of a block in ONE launch from one
-# staging of the output gradient (csrc/conv_rowbw.h, hrp_rowbw_*): the BatchNorm-input gradients (y1.grad, y2.grad) and the forward
-# activation h are never written to HBM.  HRP_ROWBW_FUSE=0 / 1 overrides the default (DESIGN 5 has the A/B measurement).
+BLOCK_END_FUSE = True
+BLOCK_END_REDUCE_FUSE = True
 BLOCK_FUSE = os.environ.get("HRP_BLOCK_FUSE", "1") not in ("0", "")      # fused inference BasicBlock (csrc/conv_block.h)
-ROWBW_FUSE = os.environ.get("HRP_ROWBW_FUSE", "0") not in ("0", "")
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
-MASKED_RES = not os.environ.get("HRP_NO_MASKED_RES")
-BATCHING = not os.environ.get("HRP_NO_BATCH")      # merged mode without batching = the same launches one by one
-# development aid: batch only these families (comma separated: conv,wgrad,ew_fwd,ew_red,ew_app)
-BATCH_FAMILIES = set(os.environ["HRP_BATCH_FAMILIES"].split(",")) if os.environ.get("HRP_BATCH_FAMILIES") else None
+MASKED_RES = True
+BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
+# development aid (set by tests / tools): batch only these families ({"conv", "wgrad", "ew_fwd", "ew_red", "ew_app"})
+BATCH_FAMILIES = None
+# The switches above without an environment variable are module constants: tests and tools patch them (plan.X = ...) before a
+# plan is built.  The environment variables that remain are the ones a user of the library or of bench.py needs: HRP_PLAN_MODE,
+# HRP_SERIAL_LANES, HRP_WGRAD_SINK, HRP_BLOCK_FUSE, HRP_PLAN_STATS, HRP_DBG_SYNC.
+PLAN_STATS = bool(os.environ.get("HRP_PLAN_STATS"))      # print launch counts per family when a plan is finalised
+DBG_SYNC = os.environ.get("HRP_DBG_SYNC")                 # development aid: device-wide sync after every op / every fork and join
 
 # bumped whenever parameters / BatchNorm buffers are modified behind torch's back (see Plan.params_dirty)
 PARAM_EPOCH = 0
@@ -287,7 +288,7 @@ class BatchLaunch:
         except nv.HrpError:
             if self.fam == "wgrad_fold":
                 raise
-            if os.environ.get("HRP_PLAN_STATS"):
+            if PLAN_STATS:
                 import sys
                 print(f"plan: batch of {n} {self.fam} launches runs one by one ({nv.lib().hrp_last_error().decode()})", file=sys.stderr)
             self.singles = True      # not batchable after all (scalar path, tile does not fit ..): one by one
@@ -312,64 +313,6 @@ class BatchLaunch:
                 it(s)
         else:
             nv.call_batch(self, s)
-
-
-class RowBwLaunch:
-    """One fused backward problem (data gradient + weight gradient of a row-strip conv, hrp_rowbw_desc).  Runs inside a
-    RowBwBatch (one or two problems of one launch); Plan.finalize wraps the ones the lock-step merge left alone."""
-    fam = "rowbw"
-
-    def __init__(self, desc):
-        self.desc = desc
-
-    def launches(self):
-        return [self]
-
-    def merge_key(self):
-        return ("rowbw",)
-
-    def written(self):
-        return (self.desc.conv.y, self.desc.dw)
-
-
-class RowBwBatch:
-    """hrp_rowbw_launch of one problem, or of the 32-channel + the 64-channel problem of one lock-step position."""
-    fam = "rowbw"
-
-    def __init__(self, plan, items):
-        self.plan, self.items = plan, sorted(items, key=lambda it: it.desc.conv.Cin)
-        self.info, self.table, self.folds = None, None, None
-
-    def launches(self):
-        return self.items
-
-    def merge_key(self):
-        return None
-
-    def _arr(self):
-        n = len(self.items)
-        return (nv.RowBwDesc * n)(*[it.desc for it in self.items]), n
-
-    def ws_query(self):
-        arr, n = self._arr()
-        info = nv.RowBwInfo()
-        nv.check(nv.lib().hrp_rowbw_prepare(arr, n, 0, None, C.byref(info)), "hrp_rowbw_prepare")
-        return [int(info.ws_bytes[i]) for i in range(n)]
-
-    def prepare(self):
-        arr, n = self._arr()                 # copies: every pointer (workspace included) is final by now
-        self.info = nv.RowBwInfo()
-        self.table = (C.c_char * int(nv.lib().hrp_rowbw_table_bytes()))()
-        nv.check(nv.lib().hrp_rowbw_prepare(arr, n, 0, self.table, C.byref(self.info)), "hrp_rowbw_prepare")
-        folds = (nv.WgradFoldDesc * n)()
-        nv.check(nv.lib().hrp_rowbw_fold_descs(arr, C.byref(self.info), folds), "hrp_rowbw_fold_descs")
-        self.folds = list(folds)
-
-    def fold_descs(self):
-        return self.folds
-
-    def __call__(self, s):
-        nv.call_rowbw(self, s)
 
 
 class BlockLaunch:
@@ -433,19 +376,6 @@ def _pair_block(plan, ops):
     while c32 and c64:
         out.append(BlockBatch(plan, [c32.pop(0), c64.pop(0)]))
     out += [BlockBatch(plan, [it]) for it in c32 + c64]
-    return out
-
-
-def _pair_rowbw(plan, ops):
-    """Fused backward problems of one lock-step position -> launches of one 32-channel + one 64-channel problem (the two
-    high-resolution branches of one trunk), leftovers alone."""
-    items = [l for op in ops for l in op.launches()]
-    c32 = [it for it in items if it.desc.conv.Cin == 32]
-    c64 = [it for it in items if it.desc.conv.Cin != 32]
-    out = []
-    while c32 and c64:
-        out.append(RowBwBatch(plan, [c32.pop(0), c64.pop(0)]))
-    out += [RowBwBatch(plan, [it]) for it in c32 + c64]
     return out
 
 
@@ -689,28 +619,20 @@ class Plan:
         if self.merged:
             # lock-step merge of the virtual lanes into batched launches; streams only where a block asked for them
             self.fwd_run, self.bwd_run = self._flatten(self.fwd), self._flatten(self.bwd)
-            self.bwd_run = [Entry(e.lane, e.path, RowBwBatch(self, [e.op])) if isinstance(e.op, RowBwLaunch) else e for e in self.bwd_run]
             if WGRAD_SINK > 1 and WGRAD_DEFER and BATCHING:
                 self.bwd_run = self._sink_wgrads(self.bwd_run)
             ops = [e.op for e in self.fwd_run + self.bwd_run if e.lane is not None]
             batches = [op for op in ops if isinstance(op, BatchLaunch)]
-            wg_ops = [e for e in self.bwd_run if isinstance(e.op, (Launch, BatchLaunch, RowBwBatch)) and e.op.fam in ("wgrad", "rowbw")]
-            assert WGRAD_DEFER or not any(e.op.fam == "rowbw" for e in wg_ops), "fused row-strip backward launches need deferred folds"
+            wg_ops = [e for e in self.bwd_run if isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad"]
             defer = WGRAD_DEFER and bool(wg_ops)
             # (descriptor.reserved == 1: a gradient some later launch of the list reads - folded on the spot)
-            now = {id(e.op) for e in wg_ops if e.op.fam == "wgrad" and any(it.desc.reserved for it in e.op.launches())}
+            now = {id(e.op) for e in wg_ops if any(it.desc.reserved for it in e.op.launches())}
             if defer:
                 # deferred folds: every launch keeps its slabs until its lane folds them, so every problem gets its own
                 # scratch region (one bump allocation over the whole backward: ~4 GB for the benchmark network at B=64)
                 total, ws_off = 0, {}
                 for e in wg_ops:
                     op = e.op
-                    if op.fam == "rowbw":
-                        ws_off[id(op)] = []
-                        for b in op.ws_query():
-                            ws_off[id(op)].append((total, b))
-                            total += _rup(b, 256)
-                        continue
                     for it in op.launches():
                         it.desc.phase = 0 if id(op) in now else 1
                     if isinstance(op, BatchLaunch):
@@ -732,10 +654,6 @@ class Plan:
                         it.desc.workspace, it.desc.workspace_bytes = (base + off, b) if b else (None, 0)
                 for op in batches:
                     op.prepare()
-                for e in wg_ops:
-                    if e.op.fam == "rowbw":
-                        e.op.prepare()
-                self.counters["rowbw_launches"] = sum(e.op.fam == "rowbw" for e in wg_ops)
                 self.bwd_run = self._insert_folds(self.bwd_run)
             else:
                 # weight-gradient scratch: one buffer per stream, every launch of that stream uses it in turn
@@ -769,7 +687,7 @@ class Plan:
             self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes - 1)]
         self._bn_tables()
         self.built = True
-        if os.environ.get("HRP_PLAN_STATS"):
+        if PLAN_STATS:
             import sys
             msg = f"plan: {len(self.fwd)} forward / {len(self.bwd)} backward ops, {self.n_lanes} lanes, {self.counters}"
             if self.merged:
@@ -805,7 +723,7 @@ class Plan:
             seq.items.append(e.op)
 
         def key_of(op):
-            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, RowBwLaunch, BlockLaunch)) else None
+            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, BlockLaunch)) else None
 
         def lockstep(kids):
             out = []
@@ -819,9 +737,7 @@ class Plan:
                         else:
                             groups.setdefault(key, []).append(x[k])
                 for key, ops in groups.items():
-                    if key[0] == "rowbw":
-                        out += _pair_rowbw(self, ops)
-                    elif key[0] == "block":
+                    if key[0] == "block":
                         out += _pair_block(self, ops)
                     else:
                         out += ops if len(ops) == 1 else _merge_ops(self, ops)
@@ -983,8 +899,7 @@ class Plan:
                 for c in e.op.children:
                     flush(c, e.path)
             out.append(e)
-            if e.lane is not None and ((isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1)
-                                       or isinstance(e.op, RowBwBatch)):
+            if e.lane is not None and isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1:
                 pending.setdefault(e.lane, []).extend(f for f in e.op.fold_descs() if f.G > 0)
                 if len(pending[e.lane]) >= min(max(WGRAD_FOLD_EVERY, 1), nv.BATCH_MAX):
                     flush(e.lane, e.path, everything=WGRAD_FOLD_EVERY < nv.BATCH_MAX)
@@ -995,7 +910,7 @@ class Plan:
     def _late_pack_cut(self):
         """Index in self.fwd right after the first parallel block (the join back into the main lane), or None when the
         plan is not a training plan with at least two parallel blocks and a network's worth of weights."""
-        if not self.need_grad or os.environ.get("HRP_NO_LATE_PACK") or len(self.weight_list) < 64:
+        if not self.need_grad or len(self.weight_list) < 64:
             return None
         joins = [i for i, e in enumerate(self.fwd) if e.lane is None and getattr(e.op, "kind", None) == "join"]
         forks = [i for i, e in enumerate(self.fwd) if e.lane is None and getattr(e.op, "kind", None) == "fork"]
@@ -1102,7 +1017,7 @@ class Plan:
             return
         streams = [torch.cuda.current_stream(self.device)] + self._side_streams
         handles = [st.cuda_stream if st is not None else None for st in streams]
-        dbg = os.environ.get("HRP_DBG_SYNC")     # development aid: device-wide sync after every op / every fork and join
+        dbg = DBG_SYNC
         for lane, _, op in ops:
             if lane is None:
                 op.run(streams)
@@ -1216,7 +1131,7 @@ class Plan:
                 if depth == 0:
                     tops.append(i)
                 del hits[:]
-                if isinstance(op, (Launch, BatchLaunch, RowBwBatch, BlockLaunch, BlockBatch)):
+                if isinstance(op, (Launch, BatchLaunch, BlockLaunch, BlockBatch)):
                     for it in op.launches():     # the descriptors say what a launch touches
                         walk(it.desc)
                 else:
@@ -1319,11 +1234,12 @@ class PlanBuilder:
         self.fuse_inference = (not plan.training) and (not plan.need_grad)
 
     # ---- inputs / outputs ---------------------------------------------------------------------------
-    def image_input(self, name, N, Cc, H, W, u8=False):
+    def image_input(self, name, N, Cc, H, W, u8=False, dtype=None):
         """NCHW fp32 external tensor -> NHWC plan tensor (channel-padded to 8).  u8: the external tensor holds the
-        dataset's bytes and is divided by 255 on the way in (reference lib/core/function.py:26,29)."""
+        dataset's bytes and is divided by 255 on the way in (reference lib/core/function.py:26,29).  dtype: element type of
+        the plan tensor when it is not the plan's (a trunk that computes in fp32 inside a bf16 plan)."""
         p = self.plan
-        t = p.new(N, H, W, Cc)
+        t = p.new(N, H, W, Cc, dtype)
         dt = _dt(t.dtype)
 
         def op(s):
@@ -1770,21 +1686,16 @@ class PlanBuilder:
                 # gradient below adds it as a MASKED residual and writes x.grad once; else conv2's data gradient accumulates it as
                 # a second side output
                 masked_res = fd is not None and MASKED_RES and not x.grad_written
-                # both convs' data gradient + weight gradient as fused launches (csrc/conv_rowbw.h): 32 / 64 channels, block-end
-                # backward fused, masked residual, both weights trained, deferred folds (merged / hybrid plans)
-                fuse_bw = (ROWBW_FUSE and Cc in (32, 64) and fd is not None and masked_res and conv1_w.requires_grad
-                           and conv2_w.requires_grad and PLAN_MODE in ("merged", "hybrid") and WGRAD_DEFER and BATCHING)
-                if fd is not None and not fuse_bw:
+                if fd is not None:
                     y2.take_grad_slot()
-                wg2_first = fd is None and not os.environ.get("HRP_WG2_LATE")
+                wg2_first = fd is None
                 if wg2_first and conv2_w.requires_grad:
                     self._wgrad_launch(h, w2, y2)
                 # data gradient of conv2 -> gradient of the activation h (raw), BatchNorm-backward sums in the epilogue
                 h.take_grad_slot()
                 boff = p.alloc_bsums(Cc)
                 p.bn_bwd.append((bn1, boff))
-                q2 = nv.RowBwDesc() if fuse_bw else None
-                g2 = q2.conv if fuse_bw else nv.ConvDesc()
+                g2 = nv.ConvDesc()
                 self._conv_desc(y2, w2, h, 1, 3, dtype, into=g2)
                 g2.x, g2.y = y2.gptr() if (fd is None) else 0, h.gptr()
                 red = None
@@ -1795,8 +1706,7 @@ class PlanBuilder:
                     g2.x = out.gptr()
                     g2.pro_mode, g2.pro_x2, g2.pro_gamma, g2.pro_beta = 2, y2.ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
                     g2.pro_count, g2.pro_eps, g2.pro_mask = cnt, bn2.eps, fd.mask
-                    if not fuse_bw:
-                        g2.pro_side = y2.gptr()
+                    g2.pro_side = y2.gptr()
                     if not masked_res:
                         g2.pro_side2, g2.pro_side2_acc = x.gptr(), x.take_grad_slot()
                     # its reduce: in the epilogue of the launch that completes out.grad when that is a row-strip data gradient
@@ -1824,11 +1734,9 @@ class PlanBuilder:
                 g2.bnb_x, g2.bnb_x_pitch = y1.ptr(), y1.pitch
                 g2.bnb_gamma, g2.bnb_beta, g2.bnb_count, g2.bnb_eps = gam, bet, cnt, bn1.eps
                 # data gradient of conv1 -> x.grad; its staged operand is the BatchNorm + ReLU backward of (h.grad, y1)
-                if not fuse_bw:
-                    y1.take_grad_slot()
+                y1.take_grad_slot()
                 acc = x.take_grad_slot()
-                q1 = nv.RowBwDesc() if fuse_bw else None
-                g1 = q1.conv if fuse_bw else nv.ConvDesc()
+                g1 = nv.ConvDesc()
                 self._conv_desc(h, w1, x, 1, 3, dtype, into=g1)
                 g1.x, g1.y = h.gptr(), x.gptr()
                 for i, (a, b) in enumerate(_TAPS3):
@@ -1840,19 +1748,7 @@ class PlanBuilder:
                 elif acc:
                     g1.res, g1.res_pitch = x.gptr(), x.pitch
                 g1.pro_mode, g1.pro_x2, g1.pro_gamma, g1.pro_beta, g1.pro_count, g1.pro_eps = 2, y1.ptr(), gam, bet, cnt, bn1.eps
-                if not fuse_bw:
-                    g1.pro_side = y1.gptr()
-                else:
-                    # the weight gradients ride along: X operand of conv2 = relu(bn1(y1)) recomputed from y1 (the forward launch
-                    # no longer writes the activation h), of conv1 = the block input
-                    d2.pro_side = None
-                    acc_w = 1 if p.grad_arena is not None else 0
-                    q2.wg_x, q2.wg_act, q2.dw = y1.ptr(), 1, p.grad_of_param(w2.param).data_ptr()
-                    q1.wg_x, q1.wg_act, q1.dw = x.ptr(), 0, p.grad_of_param(w1.param).data_ptr()
-                    q2.accumulate = 1 if (w2.grad_written or acc_w) else 0
-                    q1.accumulate = 1 if (w1.grad_written or acc_w) else 0
-                    w1.grad_written = w2.grad_written = True
-                    p.counters["rowbw_fused_blocks"] = p.counters.get("rowbw_fused_blocks", 0) + 1
+                g1.pro_side = y1.gptr()
 
                 def late_b():
                     g2.w, g1.w = w2.arena.data_ptr() + w2.bwd_off * esz, w1.arena.data_ptr() + w1.bwd_off * esz
@@ -1867,15 +1763,15 @@ class PlanBuilder:
                         else:
                             red.sums, red.inp.stats = sums2, fd.inp[0].stats
                 p.late(late_b)
-                p.bwd.append(RowBwLaunch(q2) if fuse_bw else Launch("conv", g2))
-                if conv2_w.requires_grad and not wg2_first and not fuse_bw:
+                p.bwd.append(Launch("conv", g2))
+                if conv2_w.requires_grad and not wg2_first:
                     self._wgrad_launch(h, w2, y2)
-                p.bwd.append(RowBwLaunch(q1) if fuse_bw else Launch("conv", g1))
+                p.bwd.append(Launch("conv", g1))
                 # (so far) the last producer of x.grad: the block in front of this one may put its BatchNorm reduce here if
                 # that is still so when its own backward is emitted
                 if acc or (fd is not None and masked_res):
                     p.row_last_writer[x.gptr()] = (g1, p.lane_path, len((x.base if x.base is not None else x)._grad_paths))
-                if conv1_w.requires_grad and not fuse_bw:
+                if conv1_w.requires_grad:
                     self._wgrad_launch(x, w1, y1)
             self.bwd_stack.append(bw)
             if bn2 is not None and fd is None:
@@ -2257,7 +2153,7 @@ class PlanBuilder:
         parent = p.cur_lane
         if len(p.lane_path) >= MAX_LANE_DEPTH or virtual:
             n = 1   # deeper blocks stay on their parent lane
-        n = min(n, int(os.environ.get("HRP_LANE_MAXN", "64")))
+        n = min(n, 64)
         children = [p.lane_id(parent, i) for i in range(1, n)]
         par = _Parallel(self, p._n_blocks, ([parent] + children + [parent] * 64) if children else [parent] * 64)
         p._block_lanes[p._n_blocks] = ([parent] + children) if children else None

@@ -170,7 +170,7 @@ class PlannedModule(nn.Module):
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_plans", {})
-        object.__setattr__(self, "_bn_sig", (-1, 0))
+        object.__setattr__(self, "_bn_sig", (-1, []))
         object.__setattr__(self, "_compute_dtype", torch.float32)
 
     # compute dtype of the convolution trunk (heads stay fp32)
@@ -273,6 +273,21 @@ class PlannedModule(nn.Module):
                     pl.plan._versions = None
         return r
 
+    def _frozen_bn_signature(self):
+        """Which BatchNorm modules of a TRAINING module are in eval() (train_sim2real.py:139-146 trains that way), as a bit mask over
+        self.modules() order: part of the plan-cache key.  The key holds the IDENTITY of the frozen set (two different
+        subsets of equal size - the regression trunk's BatchNorms against the DepthNet's - must not share a plan, which has every
+        bn.training baked in), and it is re-read from the modules on every call: a plain `m.training = False` assignment does not
+        pass through train() / eval().  Only the module LIST is cached (per MODE_EPOCH)."""
+        if self._bn_sig[0] != MODE_EPOCH[0]:
+            object.__setattr__(self, "_bn_sig", (MODE_EPOCH[0], [m for m in self.modules() if hasattr(m, "running_mean")]))
+        sig = 0
+        if self.training:
+            for i, m in enumerate(self._bn_sig[1]):
+                if not m.training:
+                    sig |= 1 << i
+        return sig
+
     # subclasses implement: _signature(*inputs) -> hashable ; _build(pb, *inputs) -> (in_names, outs, img_inputs)
     def _run(self, *tensors):
         dev = tensors[0].device
@@ -281,9 +296,7 @@ class PlannedModule(nn.Module):
                                                  or any(t.requires_grad for t in tensors))
         # uint8 inputs are raw images (dataset bytes): the plan's input kernel divides them by 255 on the way in
         # (a training module whose BatchNorm modules were switched to eval() - train_sim2real.py:139-146 - is a different plan)
-        if self._bn_sig[0] != MODE_EPOCH[0]:
-            self._bn_sig = (MODE_EPOCH[0], sum(1 for m in self.modules() if not m.training and hasattr(m, "running_mean")))
-        bn_eval = self._bn_sig[1] if self.training else 0
+        bn_eval = self._frozen_bn_signature()
         key = (tuple(tuple(t.shape) for t in tensors), self._compute_dtype, self.training, need_grad,
                tuple(bool(t.requires_grad) for t in tensors) if need_grad else (),
                tuple(t.dtype == torch.uint8 for t in tensors), bn_eval)

@@ -413,53 +413,6 @@ int hrp_batch_launch(const void* table_dev, const hrp_batch_info* info, void* st
 int hrp_wgrad_fold_desc_of(const hrp_wgrad_desc* d, hrp_wgrad_fold_desc* out);
 int hrp_batch_wgrad_fold_descs(const void* table_host, const hrp_batch_info* info, hrp_wgrad_fold_desc* out);
 
-/* ---- fused backward of a row-strip convolution: data gradient AND weight gradient from ONE staging of the output gradient ----
- * (reference: autograd of conv1 / conv2 of a BasicBlock, HRnet.py:41-57, reached through loss.backward(), scripts/train_full.py:61.)
- * `conv` is the data-gradient problem exactly as hrp_conv2d_fwd takes it - a row-strip problem with 32 or 64 channels
- * (hrp_conv_rowstrip_channels), every prologue / epilogue option included; its staged operand x' (after pro_mode) is the gradient
- * dY of the layer's forward output.  The same workgroup that holds the strip of dY in LDS also stages the matching rows of the
- * layer's forward input wg_x and accumulates
- *     dW[co][ci][ky][kx] += sum over pixels q of  dY[q - (ky-1, kx-1)][co] * X[q][ci]
- * on the matrix cores (operands gathered with the LDS transpose read), so that dY is read once instead of twice, the
- * BatchNorm-input gradient (conv.pro_side, pro_mode 2) never has to exist in HBM, and - wg_act - neither does the forward
- * activation: X = relu(bn(wg_x)) is recomputed from the BatchNorm input with the constants of conv.bnb_stats / bnb_gamma /
- * bnb_beta / bnb_count / bnb_eps (the arithmetic pro_mode 1 applied in the forward pass, bit for bit).
- * Persistent workgroups (one per CU, strips double-buffered in LDS) walk contiguous strip ranges of the one or two problems of
- * a launch (two: the 32-channel and the 64-channel layer of one HRNet trunk, in this order); every workgroup leaves one fp32 partial slab per problem it touched in `workspace`
- * ([G][pairs][9 * 1024], the layout of hrp_wgrad_fold_desc), folded into dw by a HRP_BATCH_WGRAD_FOLD launch
- * (hrp_rowbw_fold_descs) - the same deferred, fixed-order fold the phase-1 weight gradients use (bit-reproducible). */
-#define HRP_ROWBW_MAX 2
-typedef struct hrp_rowbw_desc {
-  hrp_conv_desc conv;      /* the data gradient; conv.Cin == conv.Cout in {32, 64}                                     */
-  const void* wg_x;        /* forward input of the layer [N, H, W, C] (dense, 16-byte aligned), dtype of conv          */
-  float* dw;               /* fp32 [C][C][9] gradient of the layer's weight (PyTorch layout)                           */
-  void* workspace;         /* hrp_rowbw_info.ws_bytes[i] bytes of scratch for THIS problem, untouched until the fold   */
-  int64_t workspace_bytes;
-  int32_t wg_act;          /* 1: X = relu(bn(wg_x)) (constants from conv.bnb_stats ..), 0: X = wg_x                    */
-  int32_t accumulate;      /* fold: dw += (1) or dw = (0)                                                              */
-  int32_t reserved[2];
-} hrp_rowbw_desc;
-typedef struct hrp_rowbw_info {
-  int32_t n, grid, lds_bytes, total_strips;
-  int32_t strip0[HRP_ROWBW_MAX + 1];   /* first strip of problem i in the launch's strip numbering                     */
-  int32_t first_wg[HRP_ROWBW_MAX];     /* first workgroup that holds strips of problem i                               */
-  int32_t G[HRP_ROWBW_MAX];            /* workgroups (= partial slabs) of problem i                                    */
-  int64_t ws_bytes[HRP_ROWBW_MAX];     /* scratch problem i needs in its descriptor's `workspace`                      */
-} hrp_rowbw_info;
-/* 32 / 64 when d can run on the fused kernel, else 0 (host only) */
-int hrp_rowbw_channels(const hrp_rowbw_desc* d);
-/* hrp_rowbw_prepare  host only: validates the n <= HRP_ROWBW_MAX problems, splits the strips of the launch evenly over max_wgs
- *                    workgroups (<= 0: one per CU of the current device, 256 when no device is visible) and fills info.  With
- *                    table == NULL it is a size query (info->ws_bytes; workspace pointers not needed yet); else every
- *                    descriptor carries its final workspace and the launch table (hrp_rowbw_table_bytes() bytes of HOST memory
- *                    the caller keeps: the launch passes it to the kernel by value) is written.
- * hrp_rowbw_launch   asynchronous on `stream`, hipGraph-capturable. */
-int64_t hrp_rowbw_table_bytes(void);
-int hrp_rowbw_prepare(const hrp_rowbw_desc* descs, int n, int max_wgs, void* table, hrp_rowbw_info* info);
-int hrp_rowbw_launch(const void* table, const hrp_rowbw_info* info, void* stream);
-/* fold descriptors (HRP_BATCH_WGRAD_FOLD) of the n problems, from their descriptors' workspace / dw / accumulate */
-int hrp_rowbw_fold_descs(const hrp_rowbw_desc* descs, const hrp_rowbw_info* info, hrp_wgrad_fold_desc* out);
-
 /* ---- fused inference BasicBlock (csrc/conv_block.h): out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x) in ONE launch -------------
  * Replaces the four modules of BasicBlock.forward in eval mode (reference HRnet.py:41-57; scripts/test.py:267-273 is the
  * caller whose frames per second it serves) for the 3x3 C -> C blocks of the two high-resolution branches (C = 32 @ W = 64,

@@ -718,18 +718,25 @@ def _two_iterations(model, loss_fn, clip, picks, out):
     the second step the sampled parameter updates (p - p0) and running statistics."""
     params = dict(model.named_parameters())
     p0 = {n: params[n].detach().clone() for n in picks}
+    idxs = {n: sample_indices(params[n].numel(), 256, 300 + i) for i, n in enumerate(picks)}
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0.0)
     for it in range(2):
         opt.zero_grad()
         loss = loss_fn()
         loss.backward()
         norm = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        # the (clipped) gradient Adam sees, at the sampled elements: the test leaves elements whose reference gradient is at
+        # noise level (Adam's first steps are ~ lr * sign(g): their sign is not a property of the arithmetic) out of the count
+        for n in picks:
+            gr = params[n].grad.reshape(-1).double()
+            out[f"grad{it + 1}:{n}:val"] = gr[idxs[n]].float().numpy()
+            out[f"grad{it + 1}:{n}:absmean"] = np.array(gr.abs().mean().item())
         opt.step()
         out[f"loss{it + 1}"] = np.array(loss.item())
         out[f"grad_norm{it + 1}"] = np.array(float(norm))
     for i, n in enumerate(picks):
         upd = (params[n].detach() - p0[n]).reshape(-1).double()
-        idx = sample_indices(upd.numel(), 256, 300 + i)
+        idx = idxs[n]
         out[f"upd:{n}:idx"], out[f"upd:{n}:val"] = idx, upd[idx].float().numpy()
         out[f"upd:{n}:absmean"] = np.array(upd.abs().mean().item())
 

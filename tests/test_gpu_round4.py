@@ -5,9 +5,9 @@
   fixtures the reference itself wrote (tests/golden/gen_golden.py depthnet_2iter / full_2iter): forward -> loss -> backward ->
   clip -> Adam -> forward with repacked weights and updated running statistics, end to end, with hrpe_amd.optim.FusedClipAdam
   and with torch.optim.Adam + clip_grad_norm_.  fp32 tolerances: loss 1e-3 (relative), gradient norm 2e-2, parameter updates:
-  median error < 5 % of the mean update (Adam's first steps are ~ lr * sign(g): single elements with noise-level gradients may
-  land on the other side, at most 10 % of the samples may miss by more than half a step - measured 4-5 % on the stem
-  convolution, whose fp32 gradient at B = 4 differs in the last bits from run to run).
+  median error < 5 % of the mean update; Adam's first steps are ~ lr * sign(g), so elements whose reference gradient (recorded in
+  the fixture since round 5) is below 5 % of the tensor's mean |g| are left out, and at most 2 % of the remaining samples may
+  miss by more than half a step.
 * The benchmarked bf16 configuration: end-to-end key-point error in pixels, gated per key-point.
 """
 import os
@@ -26,6 +26,9 @@ DEV = "cuda:0"
 
 def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+GRAD_FLOOR = 0.05
 
 
 def two_iterations(model, loss_fn, clip, g, fused):
@@ -51,7 +54,17 @@ def two_iterations(model, loss_fn, clip, g, fused):
         upd = (named[n].detach() - p0[n]).reshape(-1).cpu()[g[f"upd:{n}:idx"]].numpy()
         err = np.abs(upd - g[f"upd:{n}:val"])
         am = g[f"upd:{n}:absmean"]
-        assert np.median(err) < 0.05 * am and np.mean(err > 0.5 * am) < 0.10, (n, float(np.median(err)), float(am), float(np.mean(err > 0.5 * am)))
+        # Adam's first steps move an element by ~ lr * sign(g): an element whose REFERENCE gradient is at noise level (below
+        # GRAD_FLOOR of the tensor's mean |g| in either iteration; the fp32 gradients of this 330-layer chain carry ~1e-2 of
+        # relative rounding noise, test_gpu_model.py) has no well-defined sign and is left out; of the others at most 2 % may
+        # miss by more than half a step (round 4 allowed 10 % of ALL elements)
+        ok = np.ones(err.shape, bool)
+        for it in (1, 2):
+            ok &= np.abs(g[f"grad{it}:{n}:val"]) >= GRAD_FLOOR * g[f"grad{it}:{n}:absmean"]
+        assert np.median(err) < 0.05 * am, (n, float(np.median(err)), float(am))
+        if ok.sum() >= 32:
+            miss = float(np.mean(err[ok] > 0.5 * am))
+            assert miss <= 0.02, (n, miss, int(ok.sum()), float(am))
     sd = model.state_dict()
     for key in g.files:
         if key.startswith("buf:") and "num_batches" not in key:
@@ -122,9 +135,9 @@ def test_bf16_keypoint_error_is_gated_per_keypoint():
     assert by_kp2[0] < 1.3 and max(by_kp2[1:]) < 0.5, by_kp2
 
 
-def _train_curve(dtype, steps, B=8):
-    """`steps` training steps of the full network (synthetic batch of bench.py, the loss of lib/core/function.py:191-322, clip 5 + Adam
-    1e-4, no dropout) -> losses.  Same seeded weights and batch for every call."""
+def _train_curve(dtype, steps, B=8, nbatches=4):
+    """`steps` training steps of the full network (synthetic batches of bench.py, the loss of lib/core/function.py:191-322, clip 5 +
+    Adam 1e-4, no dropout) over `nbatches` DIFFERENT batches visited in turn -> losses.  Same seeded weights and batches for every call."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -132,17 +145,21 @@ def _train_curve(dtype, steps, B=8):
     from hrpe_amd.lib.utils.geometries import rotmat_to_rot6d
     from hrpe_amd.optim import FusedClipAdam
     m = M.build_full().set_compute_dtype(dtype).train()
-    d = {k: torch.tensor(v).to(DEV) for k, v in bench.synthetic_batch(B, 4242).items()}
-    K = d["K"]
-    kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], d["bbox"])
-    rot6 = rotmat_to_rot6d(d["R"])
-    with torch.no_grad():
-        kp3d, kp2d = m.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
-        gt = dict(pose=d["q"], root_rot=m.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
-                  root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7, device=DEV))
+    batches = []
+    for b in range(nbatches):
+        d = {k: torch.tensor(v).to(DEV) for k, v in bench.synthetic_batch(B, 4242 + 17 * b).items()}
+        K = d["K"]
+        kv = compute_k_values(K[:, 0, 0], K[:, 1, 1], d["bbox"])
+        rot6 = rotmat_to_rot6d(d["R"])
+        with torch.no_grad():
+            kp3d, kp2d = m.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
+            gt = dict(pose=d["q"], root_rot=m.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
+                      root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7, device=DEV))
+        batches.append((d, kv, K, gt))
     opt = FusedClipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-4, max_norm=5.0)
     losses = []
-    for _ in range(steps):
+    for it in range(steps):
+        d, kv, K, gt = batches[it % nbatches]
         opt.zero_grad()
         loss, _ = full_loss(m(d["x_reg"], d["x_root"], kv, K), gt, K)
         loss.backward()
@@ -152,20 +169,22 @@ def _train_curve(dtype, steps, B=8):
 
 
 def test_bf16_training_follows_the_fp32_loss_curve():
-    """60 optimizer steps in fp32 and in bf16 from the same weights on the same batch (the cosine-0.65 gate on
-    bf16 trunk gradients was the only evidence that bf16 training is sound).  The bf16 loss must fall like the fp32 loss: both end
-    below 40 % of their first value and the curves stay within 20 % of each other at every 10th step (measured: fp32 66.0 -> 21.6,
-    bf16 66.1 -> 23.9: the bf16 run trails by 11 % at step 60)."""
-    f32 = _train_curve(torch.float32, 60)
-    b16 = _train_curve(torch.bfloat16, 60)
-    idx = list(range(0, 60, 10)) + [59]
-    print("\nstep   fp32      bf16")
+    """80 optimizer steps in fp32 and in bf16 from the same weights over the same FOUR batches visited in turn (one
+    memorised batch and a 20 % band were evidence of "not broken", not of parity).  The bf16 loss must fall like the fp32 loss: both
+    end below 60 % of their first epoch, and the curves - averaged over one pass through the four batches - stay within 10 % of each
+    other at every 10th step."""
+    n = 80
+    f32 = _train_curve(torch.float32, n)
+    b16 = _train_curve(torch.bfloat16, n)
+    ep = lambda v, i: v[i:i + 4].mean()      # noqa: E731  (one pass over the four batches)
+    idx = list(range(0, n - 3, 8))
+    print("\nstep   fp32      bf16   (means over 4 consecutive steps)")
     for i in idx:
-        print(f"{i:4d} {f32[i]:9.4f} {b16[i]:9.4f}")
-    assert f32[-1] < 0.40 * f32[0] and b16[-1] < 0.40 * b16[0], (f32[0], f32[-1], b16[0], b16[-1])
+        print(f"{i:4d} {ep(f32, i):9.4f} {ep(b16, i):9.4f}")
+    assert ep(f32, n - 4) < 0.60 * ep(f32, 0) and ep(b16, n - 4) < 0.60 * ep(b16, 0), (ep(f32, 0), ep(f32, n - 4), ep(b16, 0), ep(b16, n - 4))
     for i in idx:
-        lo, hi = (f32[max(i - 2, 0):i + 3].mean(), b16[max(i - 2, 0):i + 3].mean())
-        assert abs(lo - hi) < 0.20 * lo, (i, lo, hi)
+        lo, hi = ep(f32, i), ep(b16, i)
+        assert abs(lo - hi) < 0.10 * lo, (i, lo, hi)
 
 
 def test_full_train_step_with_frozen_batchnorm_golden():

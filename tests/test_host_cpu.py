@@ -46,10 +46,10 @@ def test_ctypes_struct_sizes_match_c():
 #include <stdio.h>
 #include "hrp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
          sizeof(hrp_ew_input), sizeof(hrp_ew_desc), sizeof(hrp_ew_bwd_desc), sizeof(hrp_bn_entry), sizeof(hrp_fk_chain),
          sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk), sizeof(hrp_batch_info), sizeof(hrp_pose_loss_desc), sizeof(hrp_wgrad_fold_desc),
-         sizeof(hrp_rowbw_desc), sizeof(hrp_rowbw_info), sizeof(hrp_block_desc), sizeof(hrp_block_info));
+         sizeof(hrp_block_desc), sizeof(hrp_block_info));
   return 0;
 }'''
     import tempfile
@@ -61,7 +61,7 @@ int main(void) {
     sizes = [int(v) for v in out]
     mirrors = [nv.ConvDesc, nv.WgradDesc, nv.PackEntry, nv.EwInput, nv.EwDesc, nv.EwBwdDesc, nv.BnEntry, nv.FkChain,
                nv.OptTensor, nv.OptChunk, nv.BatchInfo, nv.PoseLossDesc, nv.WgradFoldDesc,
-               nv.RowBwDesc, nv.RowBwInfo, nv.BlockDesc, nv.BlockInfo]
+               nv.BlockDesc, nv.BlockInfo]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
@@ -697,3 +697,35 @@ def test_silhouette_oracle_known_answers_and_obj_loader(tmp_path):
     verts, links, faces = load_mesh_files([str(p0), str(p1)])
     assert verts.shape == (7, 3) and links.tolist() == [0, 0, 0, 0, 1, 1, 1]
     assert faces.tolist() == [[0, 1, 2], [0, 2, 3], [4, 5, 6]]
+
+
+def test_plan_cache_key_tells_frozen_batchnorm_subsets_apart():
+    """the plan-cache key of a training module with some BatchNorm modules in eval() was the COUNT of frozen
+    modules - the regression trunk's and the DepthNet's BatchNorms (same count) shared a plan with the wrong bn.training baked in.
+    The signature is the identity of the frozen set, and it sees a direct `m.training = False`."""
+    import torch.nn as nn
+    from hrpe_amd.runtime import PlannedModule
+    from hrpe_amd.lib.models.backbones.HRnet import BatchNorm2d
+
+    class Two(PlannedModule):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.ModuleList([BatchNorm2d(8) for _ in range(3)])
+            self.b = nn.ModuleList([BatchNorm2d(8) for _ in range(3)])
+
+    m = Two().train()
+    none = m._frozen_bn_signature()
+    assert none == 0
+    for bn in m.a:
+        bn.eval()
+    sig_a = m._frozen_bn_signature()
+    m.train()
+    for bn in m.b:
+        bn.eval()
+    sig_b = m._frozen_bn_signature()
+    assert sig_a != 0 and sig_b != 0 and sig_a != sig_b          # same count, different sets
+    m.train()
+    m.a[1].training = False                                        # no train() / eval() call: MODE_EPOCH does not move
+    assert m._frozen_bn_signature() not in (0, sig_a, sig_b)
+    m.eval()
+    assert m._frozen_bn_signature() == 0                           # an eval-mode module: the inference plan, whatever the children say

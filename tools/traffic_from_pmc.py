@@ -36,7 +36,6 @@ def main():
         # sha256[:16] of the library sources the counters were collected on: bench.py reports `roofline.traffic` only while the
         # library it measures carries the same hash
         "source_hash": nv.source_hash(),
-        "plan": {"HRP_ROWBW_FUSE": os.environ.get("HRP_ROWBW_FUSE", "default")},
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/one_step.py: one eager "
                   "forward+loss+backward of the benchmark network, B=64, bf16, lanes folded onto one stream",
         "correction": "FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE doubled (gfx950 counts 128-byte "

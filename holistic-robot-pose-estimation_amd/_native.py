@@ -15,6 +15,7 @@ MAX_TAPS = 16
 EW_MAX_IN = 4
 EW_IDENTITY, EW_AFFINE, EW_BN_TRAIN = 0, 1, 2
 FK_MAX_JOINTS, FK_MAX_KP = 32, 24
+PIL_KMAX = 12
 
 
 class HrpError(RuntimeError):
@@ -174,6 +175,10 @@ PROTOTYPES = {
     "hrp_nchw_to_nhwc_s2d": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_u8_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "hrp_gather_f32": [_P, _P, _P, _I, _I, _P],
+    "hrp_pil_resize_table": [_I, _I, _P],
+    "hrp_pil_resize_normalize": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P],
+    "hrp_broadcast_hw": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "hrp_bilinear_nhwc_to_nchw": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "hrp_fill_zero": [_P, _L, _P],
     "hrp_maxpool3x3s2_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "hrp_maxpool3x3s2_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -167,6 +167,10 @@ PLAN_STATS = bool(os.environ.get("HRP_PLAN_STATS"))      # print launch counts p
 DBG_SYNC = os.environ.get("HRP_DBG_SYNC")                 # development aid: device-wide sync after every op / every fork and join
 
 # bumped whenever parameters / BatchNorm buffers are modified behind torch's back (see Plan.params_dirty)
+# largest dilation of a 3x3 convolution the tile program runs as ONE problem (its halo tile must fit LDS); beyond it
+# PlanBuilder._conv_shifted_taps splits the taps into one-tap problems
+MAX_TILE_DILATION = 4
+
 PARAM_EPOCH = 0
 _PLAN_SERIAL = 0      # plans of this process that drew a dropout key (Plan.rng_state)
 
@@ -1494,6 +1498,63 @@ class PlanBuilder:
         p.fwd.append(op)
         return holder
 
+    def pil_resize_input(self, name, N, H, W, scale=0.5, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """External NCHW image batch with values 0 .. 255 (float32 or uint8) -> the ResNet stem's space-to-depth tensor of the
+        image resized by `scale` with Pillow's bicubic filter, / 255, normalised (reference mask_inference.py:44-49: a host loop
+        over PIL images).  One launch; bit-exact with PIL.Image.resize on the bytes."""
+        p = self.plan
+        Ho, Wo = int(H * scale), int(W * scale)
+        t = p.new(N, Ho // 2, Wo // 2, 12, pitch=16)
+        tabs = []
+        for n_in, n_out in ((W, Wo), (H, Ho)):
+            host = (C.c_int32 * (n_out * (nv.PIL_KMAX + 2)))()
+            nv.check(nv.lib().hrp_pil_resize_table(n_in, n_out, host), "hrp_pil_resize_table")
+            tabs.append(torch.frombuffer(bytearray(bytes(host)), dtype=torch.int32).to(p.device))
+        p.keep += tabs
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        dt = _dt(t.dtype)
+
+        def op(s):
+            x = p.dyn[name]
+            assert x.dtype in (torch.uint8, torch.float32) and tuple(x.shape) == (N, 3, H, W)
+            nv.call("hrp_pil_resize_normalize", x.data_ptr(), 1 if x.dtype == torch.uint8 else 0, N, H, W, tabs[0].data_ptr(),
+                    tabs[1].data_ptr(), Ho, Wo, t.ptr(), dt, t.pitch, 1, m3, s3, s)
+        p.fwd.append(op)
+        t.external = name
+        return t
+
+    def broadcast_hw(self, vec, out):
+        """out[n, y, x, :] = vec[n, :] (fp32 [N, C] -> an NHWC tensor / channel slice): F.interpolate(bilinear) of a 1 x 1 map, the
+        image-pooling branch of ASPP (torchvision deeplabv3.ASPPPooling).  Inference plans."""
+        p = self.plan
+        assert not p.need_grad and vec.dtype == torch.float32 and vec.C == out.C and vec.N == out.N
+        vec.check_readable()
+        p.fwd.append(lambda s: nv.call("hrp_broadcast_hw", vec.ptr(), vec.pitch, out.ptr(), _dt(out.dtype), out.N, out.H * out.W, out.C,
+                                       out.pitch, s))
+        return out
+
+    def bilinear_nchw_output(self, t, H, W, sigmoid=False):
+        """NHWC plan tensor -> fresh NCHW fp32 torch tensor at H x W by bilinear interpolation (align_corners=False;
+        keypoint_seg_resnet.py:147), optionally through a sigmoid (CtRNet.py:109)."""
+        holder = {}
+        p = self.plan
+        t.check_readable()
+
+        def op(s):
+            out = torch.empty(t.N, t.C, H, W, dtype=torch.float32, device=p.device)
+            nv.call("hrp_bilinear_nhwc_to_nchw", t.ptr(), _dt(t.dtype), t.N, t.H, t.W, t.C, t.pitch, out.data_ptr(), H, W,
+                    1 if sigmoid else 0, s)
+            holder["out"] = out
+        p.fwd.append(op)
+        return holder
+
+    def channel_slice(self, t, c0, cc):
+        """View of channels [c0, c0 + cc) of an NHWC tensor (writes through)."""
+        assert c0 % 8 == 0 and c0 + cc <= t.C
+        v = TensorH(self.plan, t.N, t.H, t.W, cc, t.dtype, buf=t.buf, offset=t.offset + c0, pitch=t.pitch, base=t.base or t)
+        v.lane_path = t.lane_path
+        return v
+
     # ---- convolution ----------------------------------------------------------------------------------
     def _conv_desc(self, x, w, y, stride, ksize, dtype, into=None, dilation=1):
         d = into if into is not None else nv.ConvDesc()
@@ -1530,6 +1591,8 @@ class PlanBuilder:
         Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
         Wo = (x.W + 2 * (ksize // 2) - ksize) // stride + 1
         y = out if out is not None else p.new(x.N, Ho, Wo, cout, dtype)
+        if dilation > MAX_TILE_DILATION:
+            return self._conv_shifted_taps(x, w, y, bias, dilation, dtype, want_stats, residual, relu)
         y.requires_grad = p.need_grad
         d = self._conv_desc(x, w, y, stride, ksize, dtype, dilation=dilation)
         if bias is not None:
@@ -1550,6 +1613,41 @@ class PlanBuilder:
         y.producer = ("conv", d)
         if p.need_grad:
             self.bwd_stack.append(lambda: self._conv_bwd(x, w, y, bias, stride, ksize, dtype, residual, relu, dilation))
+        return y
+
+    def _conv_shifted_taps(self, x, w, y, bias, dilation, dtype, want_stats, residual, relu):
+        """3x3 convolution whose taps lie further apart than the tile program's halo (ASPP rates 12 / 24 / 36 of DeepLabv3's head,
+        reference lib/models/ctrnet/keypoint_seg_resnet.py:121-129): nine ONE-tap problems over the nine packed taps of the same
+        weight, each on the rectangle of output pixels whose source pixel lies inside the image (the tap offset folded into the
+        problem's window, so that no problem needs border handling), the centre tap first and the others accumulating onto it
+        (res == y).  A tap whose rectangle is empty (rate 36 on a 30-row map: every vertical tap) is no launch at all.  Inference
+        plans only; BatchNorm + ReLU behind it run as PlanBuilder.act(..., out=y) in place: the nine partial sums are rounded to
+        the plan's element type between the launches."""
+        p = self.plan
+        if p.need_grad or want_stats or residual is not None or relu:
+            raise nv.HrpError(f"conv: dilation {dilation} (beyond the tile halo) is built for inference plans without fused epilogue")
+        esz = 4 if dtype == torch.float32 else 2
+        first = True
+        for i, (a, b) in sorted(enumerate(_TAPS3), key=lambda kv: (kv[1] != (0, 0), kv[0])):
+            dt_y, dt_x = a * dilation, b * dilation
+            y0, y1 = max(0, -dt_y), min(y.H, y.H - dt_y)
+            x0, x1 = max(0, -dt_x), min(y.W, y.W - dt_x)
+            if y1 <= y0 or x1 <= x0:
+                continue
+            d = self._conv_desc(x, w, y, 1, 1, dtype)
+            d.Ho, d.Wo, d.out_off_y, d.out_off_x = y1 - y0, x1 - x0, y0, x0
+            d.ntaps, d.w_ntaps = 1, 9
+            d.dy[0], d.dx[0], d.wtap[0] = y0 + dt_y, x0 + dt_x, i
+            if first:
+                assert (a, b) == (0, 0)
+                if bias is not None:
+                    d.bias = bias.data_ptr()
+            else:
+                d.res, d.res_pitch = y.ptr(), y.pitch
+            first = False
+            p.late(lambda d=d: setattr(d, "w", w.arena.data_ptr() + w.fwd_off * esz))
+            p.fwd.append(Launch("conv", d))
+        y.producer = None          # (nothing to fold a BatchNorm into: the sum is complete only after the last launch)
         return y
 
     def _wgrad_launch(self, x, w, y, ksize=3, stride=1):
@@ -1954,9 +2052,10 @@ class PlanBuilder:
         every BatchNorm module switched to eval(): running statistics in the forward pass, gradients through them.)"""
         return self.plan.training and bn.training
 
-    def act(self, terms, relu):
+    def act(self, terms, relu, out=None):
         """out = act(sum_j BN_j(t_j) upsampled).  In inference plans a single conv+BN(+identity residual)
-        is folded into the producing conv's epilogue instead."""
+        is folded into the producing conv's epilogue instead.  out: write into this tensor (a channel slice of a
+        concatenation; may be terms[0].t itself: the pass is one-to-one per element) instead of a new one."""
         p = self.plan
         for tm in terms:
             tm.t.check_readable()
@@ -1978,7 +2077,10 @@ class PlanBuilder:
             t0.t.consumed = True
             t0.t.producer = None
             return t0.t
-        out = p.new(N, H, W, Cc, dtype)
+        if out is None:
+            out = p.new(N, H, W, Cc, dtype)
+        else:
+            assert (out.N, out.H, out.W, out.C, out.dtype) == (N, H, W, Cc, dtype) and not p.need_grad
         out.requires_grad = p.need_grad and any(tm.t.requires_grad for tm in terms)
         d = nv.EwDesc()
         d.nin = len(terms)

@@ -413,6 +413,28 @@ int hrp_batch_launch(const void* table_dev, const hrp_batch_info* info, void* st
 int hrp_wgrad_fold_desc_of(const hrp_wgrad_desc* d, hrp_wgrad_fold_desc* out);
 int hrp_batch_wgrad_fold_descs(const void* table_host, const hrp_batch_info* info, hrp_wgrad_fold_desc* out);
 
+/* ---- segmentation-mask network of the self-supervised trainer (BASELINE config 5), the parts that are not convolutions -------
+ * (reference lib/models/ctrnet/mask_inference.py:44-57 preprocess_img_tensor, keypoint_seg_resnet.py:134-149, CtRNet.py:102-111;
+ *  the convolutions run through hrp_conv2d_fwd - the ASPP rates 12 / 24 / 36 as shifted one-tap problems, plan.py.)
+ * hrp_pil_resize_table      host only: Pillow's bicubic resampling table of one axis (Resample.c precompute_coeffs +
+ *                           normalize_coeffs_8bpc): out_size rows of HRP_PIL_KMAX + 2 ints [first input index, taps, weights in
+ *                           2^-22 units]; the caller uploads it.
+ * hrp_pil_resize_normalize  src: NCHW [N, 3, H, W], float32 holding 0 .. 255 (truncated to a byte like np.uint8) or (src_u8) bytes ->
+ *                           Image.resize to Ho x Wo (horizontal pass, 8-bit rounding, vertical pass, 8-bit rounding: bit-exact with
+ *                           Pillow) -> / 255 -> (x - mean) / std -> NHWC with dst_pitch channels per pixel, or (s2d) the 2 x 2
+ *                           space-to-depth layout of the ResNet stem, [N, Ho/2, Wo/2, 12 of dst_pitch].  mean3 / std3: host arrays.
+ * hrp_broadcast_hw          dst[n, p, c] = src[n, c] for p < HW (bilinear up-sampling of a 1 x 1 map: ASPP's image-pooling branch)
+ * hrp_bilinear_nhwc_to_nchw F.interpolate(mode="bilinear", align_corners=False) of an NHWC tensor to H x W, written as fp32 NCHW;
+ *                           act 1: sigmoid of the result */
+#define HRP_PIL_KMAX 12
+int hrp_pil_resize_table(int in_size, int out_size, int32_t* out);
+int hrp_pil_resize_normalize(const void* src, int src_u8, int N, int H, int W, const int32_t* xtab_dev, const int32_t* ytab_dev,
+                             int Ho, int Wo, void* dst, int dtype, int dst_pitch, int s2d, const float* mean3, const float* std3,
+                             void* stream);
+int hrp_broadcast_hw(const float* src, int src_pitch, void* dst, int dtype, int N, int HW, int C, int dst_pitch, void* stream);
+int hrp_bilinear_nhwc_to_nchw(const void* src, int dtype, int N, int h, int w, int C, int pitch, float* dst, int H, int W, int act,
+                              void* stream);
+
 /* ---- fused inference BasicBlock (csrc/conv_block.h): out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x) in ONE launch -------------
  * Replaces the four modules of BasicBlock.forward in eval mode (reference HRnet.py:41-57; scripts/test.py:267-273 is the
  * caller whose frames per second it serves) for the 3x3 C -> C blocks of the two high-resolution branches (C = 32 @ W = 64,

@@ -1,0 +1,148 @@
+"""GPU tests of the segmentation-mask network of BASELINE config 5 (row f-3; reference lib/models/ctrnet/mask_inference.py:44-57,
+keypoint_seg_resnet.py:103-149, CtRNet.py:102-111), through the C ABI and the drop-in module.
+
+Pinned: hrp_pil_resize_normalize against Pillow itself (the reference's own dependency, installed in the image) - the bytes of
+PIL.Image.resize, then ToTensor / Normalize in float32.  PARITY UNPINNED: the network (torchvision deeplabv3_resnet50 is neither in
+the reference tree nor in the image): compared with oracle/segnet.py, this repository's restatement of the published architecture.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tables(nv, n_in, n_out):
+    host = (C.c_int32 * (n_out * (nv.PIL_KMAX + 2)))()
+    nv.check(nv.lib().hrp_pil_resize_table(n_in, n_out, host), "table")
+    return torch.frombuffer(bytearray(bytes(host)), dtype=torch.int32).to(DEV)
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (60, 84), (22, 38)])
+@pytest.mark.parametrize("src", ["float", "u8"])
+def test_resize_kernel_is_pillow_bit_for_bit(hw, src):
+    """uint8 / float 0..255 NCHW -> PIL bicubic x0.5 -> / 255 -> Normalize, on the device, against PIL.Image.resize + the same float32
+    arithmetic on the host (mask_inference.py:44-49)."""
+    from PIL import Image
+    from hrpe_amd import _native as nv
+    H, W = hw
+    Ho, Wo = H // 2, W // 2
+    g = torch.Generator().manual_seed(H * 7 + W)
+    img = torch.randint(0, 256, (3, 3, H, W), generator=g)
+    x = (img.float() + 0.37) if src == "float" else img.to(torch.uint8)       # (np.uint8 truncates the fraction)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    ref = []
+    for a in img.numpy().astype(np.uint8).transpose(0, 2, 3, 1):
+        r = torch.from_numpy(np.array(Image.fromarray(a).resize((Wo, Ho)))).float().div(255)
+        ref.append(((r - torch.tensor(mean)) / torch.tensor(std)).permute(2, 0, 1))
+    ref = torch.stack(ref)
+    xt, yt = _tables(nv, W, Wo), _tables(nv, H, Ho)
+    out = torch.zeros(3, Ho, Wo, 8, device=DEV)
+    xd = x.to(DEV).contiguous()
+    nv.call("hrp_pil_resize_normalize", xd.data_ptr(), 1 if src == "u8" else 0, 3, H, W, xt.data_ptr(), yt.data_ptr(), Ho, Wo,
+            out.data_ptr(), nv.HRP_F32, 8, 0, (C.c_float * 3)(*mean), (C.c_float * 3)(*std), None)
+    torch.cuda.synchronize()
+    got = out[..., :3].permute(0, 3, 1, 2).cpu()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert float(out[..., 3:].abs().max()) == 0.0
+    if Ho % 2 == 0 and Wo % 2 == 0:      # the space-to-depth layout of the ResNet stem
+        o2 = torch.zeros(3, Ho // 2, Wo // 2, 16, device=DEV)
+        nv.call("hrp_pil_resize_normalize", xd.data_ptr(), 1 if src == "u8" else 0, 3, H, W, xt.data_ptr(), yt.data_ptr(), Ho, Wo,
+                o2.data_ptr(), nv.HRP_F32, 16, 1, (C.c_float * 3)(*mean), (C.c_float * 3)(*std), None)
+        torch.cuda.synchronize()
+        s2d = ref.reshape(3, 3, Ho // 2, 2, Wo // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(3, Ho // 2, Wo // 2, 12)
+        assert torch.equal(o2[..., :12].cpu(), s2d)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 30, 40, 240, 320), (1, 5, 7, 9, 20, 31), (2, 3, 16, 16, 16, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bilinear_kernel_matches_interpolate(shape, dtype):
+    from hrpe_amd import _native as nv
+    N, Cc, h, w, H, W = shape
+    x = torch.randn(N, Cc, h, w)
+    xq = x.to(dtype).float()
+    src = torch.zeros(N, h, w, 8, dtype=dtype, device=DEV)
+    src[..., :Cc] = xq.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    for act in (0, 1):
+        out = torch.empty(N, Cc, H, W, device=DEV)
+        nv.call("hrp_bilinear_nhwc_to_nchw", src.data_ptr(), nv.HRP_F32 if dtype == torch.float32 else nv.HRP_BF16, N, h, w, Cc, 8,
+                out.data_ptr(), H, W, act, None)
+        ref = F.interpolate(xq, size=(H, W), mode="bilinear", align_corners=False)
+        if act:
+            ref = torch.sigmoid(ref)
+        assert (out.cpu() - ref).abs().max().item() < 2e-6 * (1 + ref.abs().max().item())
+
+
+@pytest.mark.parametrize("rate", [12, 24, 36])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_large_dilation_conv_as_shifted_taps(rate, dtype):
+    """ASPP's 3x3 convolutions with rates 12 / 24 / 36 on a 30 x 40 map (keypoint_seg_resnet.py:121: torchvision's ASPPConv) run as
+    one-tap problems on the rectangles where the tap's source lies inside the image (PlanBuilder._conv_shifted_taps)."""
+    from hrpe_amd.lib.models.backbones.HRnet import Conv2d
+    g = torch.Generator().manual_seed(rate)
+    conv = Conv2d(64, 32, 3, bias=False, dilation=rate)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / 24.0)
+    x = torch.randn(2, 64, 30, 40, generator=g)
+    yr = F.conv2d(x, conv.weight, padding=rate, dilation=rate)
+    conv = conv.to(DEV).set_compute_dtype(dtype).eval()
+    with torch.no_grad():
+        y = conv(x.to(DEV))
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    assert y.shape == yr.shape
+    assert ((y.cpu() - yr).abs().max() / yr.abs().max()).item() < tol
+
+
+def test_large_dilation_is_refused_with_gradients():
+    """Round 4 refused every dilation beyond the tile halo; round 5 runs them in inference plans.  A TRAINING plan still refuses
+    loudly (no data / weight gradient for the shifted-tap form: the reference never trains the mask network)."""
+    from hrpe_amd._native import HrpError
+    from hrpe_amd.lib.models.backbones.HRnet import Conv2d
+    conv = Conv2d(32, 64, 3, bias=False, dilation=12).to(DEV).set_compute_dtype(torch.bfloat16).train()
+    with pytest.raises(HrpError, match="conv"):
+        conv(torch.randn(1, 32, 60, 80, device=DEV))
+
+
+def _mask_net():
+    from hrpe_amd.lib.models.ctrnet.mask_inference import seg_mask_inference
+    m = seg_mask_inference((600.0, 600.0, 320.0, 240.0), "azure")
+    sd = synth_state_dict(m.state_dict())
+    # synthesised weights give logits of ~0.15 +- 0.05: spread them so that the sigmoid output uses its range (test sensitivity)
+    k = "net.keypoint_seg_predictor.module.classifer.0.4."
+    sd[k + "weight"] = sd[k + "weight"] * 40.0
+    sd[k + "bias"] = sd[k + "bias"] * 0.0 - 6.0
+    m.load_state_dict(sd)
+    return m, sd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_seg_mask_inference_matches_the_oracle(dtype):
+    """The drop-in module on raw [2, 3, 480, 640] images (values 0 .. 255) against oracle/segnet.py (PIL resize + torch restatement of
+    torchvision's deeplabv3_resnet50; PARITY UNPINNED for the network half).  The test scales the last layer by 40 so that the
+    probabilities span [0.0, 0.9]; fp32: 2e-3 of probability (measured 2e-4); bf16: 5e-2 (measured 3.6e-2)."""
+    from oracle import segnet as og
+    m, sd = _mask_net()
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(2, 3, 30, 40, generator=g)
+    img = (F.interpolate(base, size=(480, 640), mode="bilinear") * 255 + 4 * torch.randn(2, 3, 480, 640, generator=g)).clamp(0, 255)
+    with torch.no_grad():
+        ref = og.seg_mask_forward(sd, img)
+    m = m.to(DEV).set_compute_dtype(dtype)
+    out = m(img.to(DEV))
+    assert out.shape == (2, 1, 240, 320) and not out.requires_grad
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"\nmask probability: range [{ref.min():.3f}, {ref.max():.3f}], max error {err:.2e}")
+    assert ref.max() - ref.min() > 0.3
+    assert err < (2e-3 if dtype == torch.float32 else 5e-2), err
+    # uint8 images give the same mask (np.uint8 of the float tensor is what the reference feeds PIL)
+    out8 = m(img.to(torch.uint8).to(DEV))
+    assert torch.equal(out8, m(img.floor().to(DEV)))
+    # the same state dict through the reference's module tree names
+    assert any(k.startswith("net.keypoint_seg_predictor.module.backbone.0.layer4.2.conv3") for k in sd)

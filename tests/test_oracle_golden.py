@@ -667,3 +667,29 @@ def test_full_eval_quat_golden(robot):
     assert out[1].shape[1] == 4
     for n, t in zip(NAMES8, out):
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
+def test_segnet_oracle_resize_is_pillow_bit_for_bit():
+    """oracle/segnet.py restates Pillow's 8-bit bicubic resize (the preprocessing of the mask network, reference
+    lib/models/ctrnet/mask_inference.py:44-49).  Pillow is a dependency that IS installed here: the restatement is pinned against
+    PIL.Image.resize itself, border rows / columns and odd sizes included.  (The network half of that oracle - torchvision's
+    deeplabv3_resnet50 - has nothing to be pinned against in this image: parity unpinned, stated in its header.)"""
+    from PIL import Image
+    from oracle.segnet import pil_resize_half
+    rng = np.random.default_rng(3)
+    for H, W in ((480, 640), (64, 48), (22, 38), (9, 7)):
+        a = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(a).resize((int(W * 0.5), int(H * 0.5))))
+        assert np.array_equal(pil_resize_half(a), ref), (H, W)
+    yy, xx = np.mgrid[0:120, 0:160]
+    a = np.stack([yy * 2 % 256, xx % 256, (yy + xx) % 256], -1).astype(np.uint8)
+    assert np.array_equal(pil_resize_half(a), np.asarray(Image.fromarray(a).resize((80, 60))))
+
+
+def test_segnet_oracle_layer_plan_is_torchvisions_dilated_resnet50():
+    """replace_stride_with_dilation = [False, True, True]: layer3 / layer4 keep stride 1, their first block keeps the previous
+    dilation (torchvision resnet._make_layer)."""
+    from oracle.segnet import layer_plan
+    lp = dict(layer_plan())
+    assert lp["layer1"] == [(1, 1)] * 3 and lp["layer2"] == [(2, 1)] + [(1, 1)] * 3
+    assert lp["layer3"] == [(1, 1)] + [(1, 2)] * 5 and lp["layer4"] == [(1, 2)] + [(1, 4)] * 2

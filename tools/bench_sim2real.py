@@ -5,8 +5,12 @@ evidence tool - bench.py's contract is the supervised step).  Reference loop bod
     python tools/bench_sim2real.py [--batch 32] [--steps 10] [--faces-per-side 14]
 
 What is synthetic: the images, the robot mesh (one box per visual-mesh link, every side a grid of triangles: ~21 000 faces at the
-default, the size of a real visual mesh set) and the segmentation masks (rendered once from a perturbed pose: the reference's
-mask network, CtRNet / DeepLabv3 + a checkpoint, is not available).  The rasteriser is parity-UNPINNED (csrc/silhouette.hip)."""
+default, the size of a real visual mesh set) and the weights of both networks.  The mask network (seg_mask_inference: device-side
+PIL resize + DeepLabv3-ResNet50 + bilinear up-sampling + sigmoid, lib/models/ctrnet) RUNS in every step on [B, 3, 480, 640] images
+as scripts/train_sim2real.py:412 does; with random weights its output is no silhouette, so the loss TARGET stays a mask rendered
+once from a perturbed pose (--mask-target net uses the network's output instead: same work, meaningless loss).  The rasteriser
+and the mask network are parity-UNPINNED (csrc/silhouette.hip; torchvision absent).  Plans replay from HIP graphs after their
+second call (runtime.Runner)."""
 import argparse
 import json
 import os
@@ -55,6 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--faces-per-side", type=int, default=14)
+    ap.add_argument("--mask-target", choices=["rendered", "net"], default="rendered")
+    ap.add_argument("--no-mask-net", action="store_true")
     a = ap.parse_args()
     from hrpe_amd.lib.core.function import compute_k_values, sim2real_mask_loss
     from hrpe_amd.optim import FusedClipAdam
@@ -82,27 +88,40 @@ def main():
         t_off = torch.tensor([0.0, 0.0, 1.5], device=DEV) - trans
         seg = model.robot.get_rendered_masks(pose, rot, trans + t_off + torch.tensor([0.02, -0.01, 0.03], device=DEV), renderer, root=3)
     weights = dict(mask=0.0, iou=1.0, scale=0.0, align=1.0)        # configs/panda/self_supervised/*.yaml:109-112
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-    acc = np.zeros(5)
+    seg_net = None
+    if not a.no_mask_net:
+        from hrpe_amd.lib.models.ctrnet.mask_inference import seg_mask_inference
+        seg_net = seg_mask_inference((640.0, 640.0, 320.0, 240.0), "azure")
+        seg_net.load_state_dict(synth_state_dict(seg_net.state_dict()))
+        seg_net = seg_net.to(DEV).set_compute_dtype(torch.bfloat16)
+        images_original_255 = torch.randint(0, 256, (B, 3, 480, 640), device=DEV).float()      # train_sim2real.py:412
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+    acc = np.zeros(6)
     cover = 0.0
 
     def step(timed):
         nonlocal cover
         ev[0].record()
-        out = model(d["x_reg"], d["x_root"], kv, K)
+        target = seg
+        if seg_net is not None:
+            seg_masks = seg_net(images_original_255).detach()
+            if a.mask_target == "net":
+                target = seg_masks[:, 0]
         ev[1].record()
-        rendered = model.robot.get_rendered_masks(out[0], out[1], out[2] + t_off, renderer, root=3)
+        out = model(d["x_reg"], d["x_root"], kv, K)
         ev[2].record()
-        loss, _ = sim2real_mask_loss(rendered, seg, out[7], out[6], "mse_mean", weights)
+        rendered = model.robot.get_rendered_masks(out[0], out[1], out[2] + t_off, renderer, root=3)
         ev[3].record()
+        loss, _ = sim2real_mask_loss(rendered, target, out[7], out[6], "mse_mean", weights)
+        ev[4].record()
         opt.zero_grad()
         loss.backward()
-        ev[4].record()
-        opt.step()
         ev[5].record()
+        opt.step()
+        ev[6].record()
         if timed:
             torch.cuda.synchronize()
-            acc[:] += [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+            acc[:] += [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
             cover = float(rendered.detach().mean())
         return loss
 
@@ -117,13 +136,17 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
-    names = ["network forward", "mesh posing + rasteriser", "mask losses", "backward (losses, rasteriser, network)", "clip + Adam"]
-    print(json.dumps({"workload": "self-supervised render-and-compare step (BASELINE config 5) on synthetic meshes / masks, eager launches, "
-                                  "full network bf16 with frozen BatchNorm, 240x320 masks", "batch": B, "images_per_sec": round(B / ms * 1e3, 1),
+    names = ["mask network (resize + DeepLabv3-ResNet50 + upsample)", "network forward", "mesh posing + rasteriser", "mask losses",
+             "backward (losses, rasteriser, network)", "clip + Adam"]
+    print(json.dumps({"workload": "self-supervised render-and-compare step (BASELINE config 5) on synthetic meshes / images, plans replayed "
+                                  "from HIP graphs, full network bf16 with frozen BatchNorm, mask network on 480x640 images, 240x320 masks",
+                      "batch": B, "images_per_sec": round(B / ms * 1e3, 1),
                       "ms_per_step": round(ms, 2), "phases_ms": {n: round(v / a.steps, 3) for n, v in zip(names, acc)},
                       "mesh": {"vertices": int(mesh[0].shape[0]), "faces": int(mesh[2].shape[0])}, "mask_coverage": round(cover, 4),
                       "loss": round(float(loss.detach()), 5), "rasteriser": "parity unpinned (csrc/silhouette.hip)",
-                      "mask_network": "absent: masks rendered from a perturbed pose"}))
+                      "mask_network": ("absent (--no-mask-net)" if seg_net is None else
+                                       "present (parity unpinned); loss target: " + ("its output" if a.mask_target == "net" else
+                                                                                       "a mask rendered from a perturbed pose"))}))
 
 
 if __name__ == "__main__":

@@ -75,7 +75,7 @@ class Sim2RealLossDesc(C.Structure):
 class SilhouetteDesc(C.Structure):
     _fields_ = [("uv", C.c_void_p), ("xyz", C.c_void_p), ("faces", C.c_void_p),
                 ("B", C.c_int32), ("V", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("sigma", C.c_float), ("blur_radius", C.c_float), ("alpha", C.c_void_p), ("logp", C.c_void_p)]
+                ("sigma", C.c_float), ("blur_radius", C.c_float), ("alpha", C.c_void_p), ("logp", C.c_void_p), ("count", C.c_void_p)]
 
 
 BLOCK_MAX = 2

@@ -12,8 +12,15 @@
 //     p         sigmoid(-s / sigma)
 //   alpha(pixel) = 1 - prod over kept faces of (1 - p)                      (sigmoid_alpha_blend; the trainer takes channel 3)
 //   backward: d alpha / d s_k = -prod(1 - p) p_k / sigma, d s / d (edge end points) of the nearest segment, atomically summed per vertex.
-// Not modelled: the cap of 100 nearest faces per pixel (every kept face enters the product), near-plane clipping of faces that
-// cross the camera plane (a face with a vertex at z < 1e-8 is skipped), z ordering (irrelevant for the silhouette).
+// faces_per_pixel = 100 (mesh_renderer.py:99): pytorch3d keeps the 100 faces NEAREST in z of those that pass the test above; here
+//   every kept face enters the product, which is the same number wherever at most 100 faces are kept at a pixel - always, for a
+//   robot's visual mesh (kept = the pixel CENTRE inside the face or within sqrt(blur_radius) = 0.036 px of it: the depth complexity of
+//   the mesh, < 10).  hrp_silhouette_desc.count returns the per-pixel number so that a caller can verify it
+//   (URDFRobot.render_silhouette(check_faces_per_pixel=True) raises above 100) instead of assuming it.
+// Faces behind the camera: the reference's RasterizationSettings leave z_clip_value = None and its PerspectiveCameras carry no znear
+//   (mesh_renderer.py:96-105), so pytorch3d does NOT clip at a near plane; its rasteriser then drops a face when ANY vertex has
+//   z < kEpsilon = 1e-8 ("z_invalid = zlims.x < kEpsilon" in rasterize_meshes.cu) - the rule load_face applies.  z ordering is
+//   irrelevant for the silhouette.
 //
 // Face-parallel: a robot's visual mesh projects to triangles of a few pixels at 320 x 240, so one thread per (sample, face)
 // walks the face's bounding box.  The per-pixel product is accumulated as a FIXED-POINT sum of log(1 - p) (64-bit integer
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(256) void silhouette_fwd_kernel(const hrp_silhouett
       float l = a > 30.f ? -a : -log1pf(expf(a));
       l = fmaxf(l, S2R_LOG_FLOOR);
       atomicAdd((unsigned long long*)(lp + y * d.W + x), (unsigned long long)(long long)llrint((double)l * S2R_FIX));
+      if (d.count) atomicAdd(d.count + (size_t)b * d.H * d.W + y * d.W + x, 1);
     }
 }
 
@@ -168,6 +176,7 @@ extern "C" int hrp_silhouette_fwd(const hrp_silhouette_desc* d, void* stream) {
   if (rc != HRP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   zero_async(d->logp, (size_t)d->B * d->H * d->W * 8, s);
+  if (d->count) zero_async(d->count, (size_t)d->B * d->H * d->W * 4, s);
   hipLaunchKernelGGL(silhouette_fwd_kernel, dim3(cdiv(d->F, 256), d->B), dim3(256), 0, s, *d);
   const size_t n = (size_t)d->B * d->H * d->W;
   hipLaunchKernelGGL(silhouette_alpha_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, *d);

@@ -152,7 +152,7 @@ class _SilhouetteFn(torch.autograd.Function):
     camera pose to (b2c_rot, b2c_trans) - the joint angles are detached on this path as in the reference (urdf_robot.py:267)."""
 
     @staticmethod
-    def forward(ctx, robot, q, rot, trans, verts, vert_link, faces, K, H, W, root, sigma, blur):
+    def forward(ctx, robot, q, rot, trans, verts, vert_link, faces, K, H, W, root, sigma, blur, check_cap=False):
         xyz, uv = robot.pose_mesh(q, rot, trans, verts, vert_link, root=root, K=K)
         dev = q.device
         B, V = xyz.shape[0], xyz.shape[1]
@@ -160,11 +160,19 @@ class _SilhouetteFn(torch.autograd.Function):
         alpha = torch.empty(B, H, W, device=dev)
         logp = torch.empty(B, H, W, dtype=torch.int64, device=dev)
         d = nv.SilhouetteDesc()
+        count = torch.empty(B, H, W, dtype=torch.int32, device=dev) if check_cap else None
+        d.count = count.data_ptr() if check_cap else None
         d.uv, d.xyz, d.faces = uv.data_ptr(), xyz.data_ptr(), fc.data_ptr()
         d.B, d.V, d.F, d.H, d.W = B, V, fc.shape[0], H, W
         d.sigma, d.blur_radius = sigma, blur
         d.alpha, d.logp = alpha.data_ptr(), logp.data_ptr()
         nv.call("hrp_silhouette_fwd", C.byref(d), torch.cuda.current_stream(dev).cuda_stream)
+        if check_cap:
+            robot.last_faces_per_pixel = int(count.max())          # (a device sync: a verification mode, off by default)
+            d.count = None
+            if robot.last_faces_per_pixel > 100:
+                raise NotImplementedError(f"render_silhouette: {robot.last_faces_per_pixel} faces are kept at one pixel; pytorch3d would "
+                                          "keep the 100 nearest (faces_per_pixel = 100, mesh_renderer.py:99) - that selection is not built")
         ctx.keep = (robot, q.detach(), rot.detach(), trans.detach(), verts, vert_link, fc, K.contiguous().float(), xyz, uv, logp, alpha, d, root)
         return alpha
 
@@ -186,7 +194,7 @@ class _SilhouetteFn(torch.autograd.Function):
         nv.call("hrp_mesh_pose_bwd", chain.data_ptr(), qq.data_ptr(), rr.data_ptr(), tt.data_ptr(), B, root_kp,
                 verts.contiguous().float().data_ptr(), vert_link.contiguous().to(torch.uint8).data_ptr(), V, d_xyz.data_ptr(),
                 d_rot.data_ptr(), d_trans.data_ptr(), s)
-        return None, None, d_rot, d_trans, None, None, None, None, None, None, None, None, None
+        return None, None, d_rot, d_trans, None, None, None, None, None, None, None, None, None, None
 
 
 class URDFRobot:
@@ -309,14 +317,18 @@ class URDFRobot:
             raise ValueError(f"mesh vert_link must hold one link index < {nlinks} per vertex")
         seen.add(key)
 
-    def render_silhouette(self, jointcfgs, b2c_rot, b2c_trans, mesh, K, image_size, root=0, sigma=1e-8, blur_radius=None):
+    def render_silhouette(self, jointcfgs, b2c_rot, b2c_trans, mesh, K, image_size, root=0, sigma=1e-8, blur_radius=None,
+                          check_faces_per_pixel=False):
         """Soft silhouettes [B, H, W] of the posed robot mesh for a whole batch - the loop of scripts/train_sim2real.py:415-418 over
         get_rendered_mask_single_image_at_specific_root (urdf_robot.py:242-275) with the renderer of
         lib/utils/mesh_renderer.py:78-109 (pytorch3d MeshRasterizer + SoftSilhouetteShader, sigma 1e-8, blur_radius
         log(1 / 1e-4 - 1) * sigma).  mesh = (verts [V, 3] in link frames, vert_link [V], faces [F, 3]); K [B, 3, 3] the intrinsics of
         the rendered image (set_robot_renderer scales K_original by 0.5), image_size = (H, W).  Gradients reach b2c_rot / b2c_trans.
         PARITY UNPINNED (csrc/silhouette.hip): pytorch3d is not available to the build; the algorithm is restated from its
-        published form and checked against this repository's own torch restatement (oracle/silhouette.py)."""
+        published form and checked against this repository's own torch restatement (oracle/silhouette.py).
+        check_faces_per_pixel: verify (one device sync) that no pixel keeps more than pytorch3d's faces_per_pixel = 100 faces - the
+        only place where this rasteriser could differ from the published algorithm; raises NotImplementedError otherwise and leaves
+        the maximum in self.last_faces_per_pixel."""
         if b2c_rot.shape[1] != 6:
             raise NotImplementedError("render_silhouette: 6-D rotations only")
         verts, vert_link, faces = mesh
@@ -325,7 +337,7 @@ class URDFRobot:
             blur_radius = float(np.log(1.0 / 1e-4 - 1.0) * sigma)
         H, W = image_size
         return _SilhouetteFn.apply(self, jointcfgs, b2c_rot, b2c_trans, verts, vert_link, faces, K, int(H), int(W), root,
-                                   float(sigma), float(blur_radius))
+                                   float(sigma), float(blur_radius), bool(check_faces_per_pixel))
 
     def set_robot_renderer(self, K_original, original_image_size=(480, 640), scale=0.5, device="cuda", mesh=None):
         """reference urdf_robot.py:201-227: intrinsics and image size scaled by `scale`, the visual meshes of MESH_LINKS next to the

@@ -520,6 +520,9 @@ typedef struct hrp_silhouette_desc {
   float sigma, blur_radius;
   float* alpha;           /* [B, H, W] */
   int64_t* logp;          /* [B, H, W] */
+  int32_t* count;         /* optional [B, H, W] (zeroed by the call): faces kept at the pixel.  pytorch3d keeps the faces_per_pixel =
+                             100 NEAREST faces (mesh_renderer.py:99); every kept face enters the product here, so the result is
+                             pytorch3d's exactly where count <= 100 - the caller can check that instead of assuming it */
 } hrp_silhouette_desc;
 int hrp_silhouette_fwd(const hrp_silhouette_desc* d, void* stream);
 int hrp_silhouette_bwd(const hrp_silhouette_desc* d, const float* d_alpha, float* d_uv, void* stream);

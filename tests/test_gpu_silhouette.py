@@ -191,3 +191,73 @@ def test_self_supervised_step_runs_end_to_end(tmp_path):
     assert any(not torch.equal(p.detach(), before[n]) for n, p in list(m.named_parameters())[:3])
     moved = m.robot.get_rendered_masks(pose.detach(), rot.detach(), trans.detach() + torch.tensor([0.2, 0.0, 0.0], device=DEV), renderer, root=3)
     assert not torch.equal(moved, m.robot.get_rendered_masks(pose.detach(), rot.detach(), trans.detach(), renderer, root=3))
+
+
+def test_faces_per_pixel_count_and_the_cap_check():
+    """pytorch3d keeps the faces_per_pixel = 100 nearest faces per pixel (mesh_renderer.py:99); this rasteriser multiplies over EVERY
+    kept face, which is the same wherever at most 100 are kept.  hrp_silhouette_desc.count returns the per-pixel number (equal to the
+    restatement's), the scenes of these tests stay far below the cap, and render_silhouette(check_faces_per_pixel=True) refuses a
+    scene that exceeds it instead of returning something pytorch3d would not."""
+    from hrpe_amd import _native as nv
+    from hrpe_amd.lib.utils.urdf_robot import URDFRobot
+    import ctypes as C
+    robot = URDFRobot("panda")
+    q, r6, t, K = scene()
+    verts, vl, faces = box_mesh()
+    mesh = (verts.to(DEV), vl.to(DEV), faces.to(DEV))
+    a = robot.render_silhouette(q.to(DEV), r6.to(DEV), t.to(DEV), mesh, K.to(DEV), (H, W), root=3, check_faces_per_pixel=True)
+    assert 1 <= robot.last_faces_per_pixel <= 100, robot.last_faces_per_pixel
+    assert torch.equal(a, robot.render_silhouette(q.to(DEV), r6.to(DEV), t.to(DEV), mesh, K.to(DEV), (H, W), root=3))
+    # the count itself against the restatement (soft band of one pixel, so that many (pixel, face) pairs are kept)
+    sigma, blur = 1e-4, float(np.log(1.0 / 1e-4 - 1.0) * 1e-4)
+    xyz, uv = robot.pose_mesh(q.to(DEV), r6.to(DEV), t.to(DEV), mesh[0], mesh[1], root=0, K=K.to(DEV))
+    B, V = uv.shape[0], uv.shape[1]
+    alpha, logp = torch.empty(B, H, W, device=DEV), torch.empty(B, H, W, dtype=torch.int64, device=DEV)
+    count = torch.empty(B, H, W, dtype=torch.int32, device=DEV)
+    d = nv.SilhouetteDesc()
+    d.uv, d.xyz, d.faces, d.B, d.V, d.F, d.H, d.W = uv.data_ptr(), xyz.data_ptr(), mesh[2].data_ptr(), B, V, mesh[2].shape[0], H, W
+    d.sigma, d.blur_radius, d.alpha, d.logp, d.count = sigma, blur, alpha.data_ptr(), logp.data_ptr(), count.data_ptr()
+    nv.call("hrp_silhouette_fwd", C.byref(d), None)
+    _, cref = osil.soft_silhouette(uv.cpu(), xyz[..., 2].cpu(), faces.long(), H, W, sigma, blur, return_counts=True)
+    assert float((count.cpu() != cref).float().mean()) < 2e-3          # (an fp32 rounding at the edge of the blur band)
+    assert int(cref.max()) > 2
+    # 150 copies of one face on top of each other: beyond the cap
+    stack = (mesh[0], mesh[1], mesh[2][:1].repeat(150, 1))
+    with pytest.raises(NotImplementedError, match="faces_per_pixel"):
+        robot.render_silhouette(q.to(DEV), r6.to(DEV), t.to(DEV), stack, K.to(DEV), (H, W), root=3, check_faces_per_pixel=True)
+
+
+def test_vertex_gradient_at_the_reference_sigma():
+    """sigma = 1e-8, blur_radius = log(1 / 1e-4 - 1) sigma (mesh_renderer.py:94-97), the trainer's own setting (the
+    gradient tests ran at 1e-4 only): the mask is soft only within 0.009 px of an outline, so the gradient lives on the few pixel
+    centres that lie that close to an edge.  A triangle with a vertical edge 0.005 px beside a column of pixel centres (inside for one
+    sample, outside for the other) against float64 autograd of the restatement: 2e-2 of the largest entry (fp32 forms the 0.005 px
+    distance from coordinates of ~20 px: 4e-4 relative, squared and divided by sigma)."""
+    from hrpe_amd import _native as nv
+    import ctypes as C
+    sigma = 1e-8
+    blur = float(np.log(1.0 / 1e-4 - 1.0) * sigma)
+    uv = torch.tensor([[[20.505, 4.3], [20.505, 52.6], [61.2, 30.1]],
+                       [[20.495, 4.3], [20.495, 52.6], [61.2, 30.1]]], dtype=torch.float32)
+    xyz = torch.ones(2, 3, 3)
+    faces = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    uvd, xyzd, fd = uv.to(DEV), xyz.to(DEV), faces.to(DEV)
+    alpha, logp = torch.empty(2, H, W, device=DEV), torch.empty(2, H, W, dtype=torch.int64, device=DEV)
+    d = nv.SilhouetteDesc()
+    d.uv, d.xyz, d.faces, d.B, d.V, d.F, d.H, d.W = uvd.data_ptr(), xyzd.data_ptr(), fd.data_ptr(), 2, 3, 1, H, W
+    d.sigma, d.blur_radius, d.alpha, d.logp = sigma, blur, alpha.data_ptr(), logp.data_ptr()
+    nv.call("hrp_silhouette_fwd", C.byref(d), None)
+    uvr = uv.double().requires_grad_(True)
+    ref = osil.soft_silhouette(uvr, xyz[..., 2].double(), faces.long(), H, W, sigma, blur)
+    col = ref.detach()[:, 5:52, 20]
+    assert 0.01 < float(col[0].min()) and float(col[0].max()) < 0.99 or 0.01 < float(col[1].min()), "the test column must sit inside the soft band"
+    assert float((alpha.cpu().double() - ref.detach()).abs().max()) < 2e-2
+    wgt = torch.randn(2, H, W, generator=torch.Generator().manual_seed(4))
+    (ref * wgt.double()).sum().backward()
+    d_uv = torch.empty(2, 3, 2, device=DEV)
+    nv.call("hrp_silhouette_bwd", C.byref(d), wgt.to(DEV).data_ptr(), d_uv.data_ptr(), None)
+    torch.cuda.synchronize()
+    gmax = float(uvr.grad.abs().max())
+    err = float((d_uv.cpu().double() - uvr.grad).abs().max()) / gmax
+    print(f"\ngradient at sigma 1e-8: largest entry {gmax:.3e}, max error {err:.2e} of it")
+    assert gmax > 1.0 and err < 2e-2, (gmax, err)

@@ -8,6 +8,7 @@ O=$R/gpurun_out
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra > $O/${ROUND:-r05}${SUFFIX}_prof_bench.json 2> $O/${ROUND:-r05}${SUFFIX}_prof_bench.err
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${ROUND:-r05}${SUFFIX}_bench_kernel_stats.csv
+f=$(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 $R/tools/trace_grids.py $f > $O/${ROUND:-r05}${SUFFIX}_launch_grids.txt
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python3 $R/tools/one_step.py 64 > $O/${ROUND:-r05}${SUFFIX}_pmc_fetch.log 2>&1
 python3 $R/tools/pmc_summary.py /tmp/prof_fetch FETCH_SIZE $O/${ROUND:-r05}${SUFFIX}_pmc_step_FETCH_SIZE.json | tail -5
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python3 $R/tools/one_step.py 64 > $O/${ROUND:-r05}${SUFFIX}_pmc_write.log 2>&1

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HRP_LIB") or os.path.join(_HERE, "libhrp_hip.so")   # HRP_LIB: development builds (A/B variants)
 CSRC = os.path.join(_HERE, "csrc")
 
-HRP_F32, HRP_BF16 = 0, 1
+HRP_F32, HRP_BF16, HRP_F32X3 = 0, 1, 2
 MAX_TAPS = 16
 EW_MAX_IN = 4
 EW_IDENTITY, EW_AFFINE, EW_BN_TRAIN = 0, 1, 2

@@ -35,8 +35,10 @@ static inline BatchHdr make_hdr(const int* blk0, int n) {
 // family entry points (one translation unit each; batch.hip dispatches)
 int conv_batch_prepare_bf16(const hrp_conv_desc* descs, int n, void* table, hrp_batch_info* info);
 int conv_batch_prepare_f32(const hrp_conv_desc* descs, int n, void* table, hrp_batch_info* info);
+int conv_batch_prepare_f32x3(const hrp_conv_desc* descs, int n, void* table, hrp_batch_info* info);
 int conv_batch_launch_bf16(const void* table_dev, const hrp_batch_info* info, hipStream_t s);
 int conv_batch_launch_f32(const void* table_dev, const hrp_batch_info* info, hipStream_t s);
+int conv_batch_launch_f32x3(const void* table_dev, const hrp_batch_info* info, hipStream_t s);
 int64_t conv_batch_table_bytes(int n);
 int conv_check(const hrp_conv_desc* d);
 

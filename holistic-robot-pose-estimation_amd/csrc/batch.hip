@@ -26,7 +26,8 @@ extern "C" int hrp_batch_prepare(int family, const void* descs, int n, void* tab
       const hrp_conv_desc* d = (const hrp_conv_desc*)descs;
       HRP_REQUIRE(table_host, "conv batch: table_host is required");
       info->dtype = d[0].dtype;
-      return d[0].dtype == HRP_F32 ? conv_batch_prepare_f32(d, n, table_host, info) : conv_batch_prepare_bf16(d, n, table_host, info);
+      return d[0].dtype == HRP_F32 ? conv_batch_prepare_f32(d, n, table_host, info) :
+             d[0].dtype == HRP_F32X3 ? conv_batch_prepare_f32x3(d, n, table_host, info) : conv_batch_prepare_bf16(d, n, table_host, info);
     }
     case HRP_BATCH_WGRAD:
       info->dtype = ((const hrp_wgrad_desc*)descs)[0].dtype;
@@ -47,7 +48,8 @@ extern "C" int hrp_batch_launch(const void* table_dev, const hrp_batch_info* inf
   HRP_REQUIRE(table_dev && info && info->n >= 1 && info->n <= HRP_BATCH_MAX && info->grid > 0, "batch launch: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   switch (info->family) {
-    case HRP_BATCH_CONV: return info->dtype == HRP_F32 ? conv_batch_launch_f32(table_dev, info, s) : conv_batch_launch_bf16(table_dev, info, s);
+    case HRP_BATCH_CONV: return info->dtype == HRP_F32 ? conv_batch_launch_f32(table_dev, info, s) :
+                                 info->dtype == HRP_F32X3 ? conv_batch_launch_f32x3(table_dev, info, s) : conv_batch_launch_bf16(table_dev, info, s);
     case HRP_BATCH_WGRAD: return wgrad_batch_launch(table_dev, info, s);
     case HRP_BATCH_WGRAD_FOLD: return wgrad_fold_launch(table_dev, info, s);
     case HRP_BATCH_EW_FWD: case HRP_BATCH_EW_BWD_REDUCE: case HRP_BATCH_EW_BWD_APPLY: return ew_batch_launch(table_dev, info, s);

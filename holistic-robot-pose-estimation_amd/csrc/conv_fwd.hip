@@ -7,12 +7,13 @@
 namespace hrp {
 
 int launch_conv_f32(const hrp_conv_desc& d, hipStream_t s);
+int launch_conv_f32x3(const hrp_conv_desc& d, hipStream_t s);
 
 int conv_check(const hrp_conv_desc* d) {
   HRP_REQUIRE(d && d->x && d->w && d->y, "conv: null pointer");
   HRP_REQUIRE(d->ntaps >= 1 && d->ntaps <= HRP_MAX_TAPS, "conv: ntaps=%d", d->ntaps);
-  HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16, "conv: dtype=%d", d->dtype);
-  const int vec = d->dtype == HRP_F32 ? 4 : 8;
+  HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16 || d->dtype == HRP_F32X3, "conv: dtype=%d", d->dtype);
+  const int vec = d->dtype == HRP_BF16 ? 8 : 4;
   HRP_REQUIRE(d->Cin % vec == 0 && d->x_pitch % vec == 0 && (uintptr_t)d->x % 16 == 0,
               "conv: input channels / pitch must be multiples of %d elements (Cin=%d pitch=%d)", vec, d->Cin, d->x_pitch);
   HRP_REQUIRE((uintptr_t)d->w % 16 == 0, "conv: packed weights must be 16-byte aligned");
@@ -23,7 +24,7 @@ int conv_check(const hrp_conv_desc* d) {
   PwPlan pwp;
   const bool lean_kernel = hrp_conv_rowstrip_channels(d) != 0 || pw_plan(*d, pwp) != 0;      // (their own eligibility checks cover bnb_*)
   if (d->bnb_x && d->bnb_mask && !lean_kernel) {   // BatchNorm-backward reduce in the epilogue of the general tile program: only the plain vector store path computes it
-    const int sz = d->dtype == HRP_F32 ? 4 : 2;
+    const int sz = d->dtype == HRP_BF16 ? 2 : 4;
     HRP_REQUIRE(d->stats && d->bnb_mask && d->bnb_consts, "conv: bnb_x needs stats, bnb_mask and bnb_consts");
     HRP_REQUIRE(!d->res && !d->relu && !d->bias && !d->scale, "conv: bnb_x excludes res / relu / bias / scale");
     HRP_REQUIRE(d->out_stride == 1 && d->y_H == d->Ho && d->y_W == d->Wo, "conv: bnb_x needs a launch that covers y");
@@ -56,6 +57,7 @@ extern "C" int hrp_conv2d_fwd(const hrp_conv_desc* d, void* stream) {
   const int rc = conv_check(d);
   if (rc != HRP_OK) return rc;
   if (d->dtype == HRP_F32) return launch_conv_f32(*d, (hipStream_t)stream);
+  if (d->dtype == HRP_F32X3) return launch_conv_f32x3(*d, (hipStream_t)stream);
   if (hrp_conv_rowstrip_channels(d)) return launch_conv_row(*d, (hipStream_t)stream);
   PwPlan pw;
   if (pw_plan(*d, pw)) return launch_conv_pw(*d, pw, (hipStream_t)stream);

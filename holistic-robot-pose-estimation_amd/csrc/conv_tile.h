@@ -22,6 +22,7 @@
 #include "hrp_common.h"
 #include "batch.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef HRP_CONV_ISSUE_STEPS
 #define HRP_CONV_ISSUE_STEPS 64
@@ -90,6 +91,11 @@ struct Mma<float> {
   __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
+};
+template <>
+struct Mma<f32x3_t> {      // (the MFMA loop of this type is its own branch of conv_tile_body; KSTEPS feeds the host heuristics only)
+  using Frag = float;
+  static constexpr int KSTEPS = 4;
 };
 
 // x rotated right by N lanes inside each row of 16 lanes (DPP row_ror)
@@ -345,10 +351,68 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
       // step s run: with one or two waves per SIMD nothing else would hide the LDS latency.
       // The pieces of stage st+1 are issued between the MFMA steps (chunk g of the next stage during chunk g of
       // this one, SPP slots per step): issued in one burst a full memory queue stalls the wave for ~2 us.
+      const int ng = nloc - st * G < G ? nloc - st * G : G;
+      if constexpr (std::is_same<T, f32x3_t>::value) {
+        // ---- fp32 tensors, 3 x bf16 products.  One v_mfma_f32_32x32x16_bf16 takes 16 K values, 8 per lane half: half 0 brings
+        // the 8 channels of chunk g, half 1 those of chunk g + 1 (an odd last chunk: zeros).  Weight rows arrive PRE-SPLIT from
+        // hrp_pack_weights (logical half 0 = 8 hi, half 1 = 8 lo); the pixels' 8 floats are split here (24 VALU per fragment, under
+        // the 3 CT MFMAs it feeds).  Per (chunk pair, tap): CT weight fragment pairs, PT pixel fragments, 3 CT PT MFMAs - the
+        // fp32 MFMA path spends 8 CT PT instructions of twice the latency on the same products.
+        constexpr int SPX = (MAXP_IN + MAXP_W + NT - 1) / NT;
+        const int khoff = khalf * t.buf_bytes;
+        struct Raw { uint4 ah[CT], al[CT]; float4 b0[PT], b1[PT]; };
+        auto ldraw = [&](const char* lds_in, int tap, Raw& r) {
+          const char* lds_w = lds_in + t.in_pieces * 1024;
+          const int wr = tap * BN + wrow0;
+#pragma unroll
+          for (int c = 0; c < CT; ++c) { r.ah[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, 0)); r.al[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, 1)); }
+#pragma unroll
+          for (int p = 0; p < PT; ++p) {
+            const int rr = pixrow[p] + taprow[tap];
+            r.b0[p] = *(const float4*)(lds_in + row_addr(rr, 0));
+            r.b1[p] = *(const float4*)(lds_in + row_addr(rr, 1));
+          }
+        };
+        for (int g = 0; g < ng; g += 2) {
+          const bool pair = g + 1 < ng;
+          const char* lds_in = sbuf + g * t.buf_bytes + (pair ? khoff : 0);
+          const bool zero_b = !pair && khalf != 0;
+          Raw cur, nxt;
+          ldraw(lds_in, 0, cur);
+#pragma unroll
+          for (int tap = 0; tap < NT; ++tap) {
+            if (tap + 1 < NT) ldraw(lds_in, tap + 1, nxt);
+            uint4 bh[PT], bl[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+              const float x[8] = {cur.b0[p].x, cur.b0[p].y, cur.b0[p].z, cur.b0[p].w, cur.b1[p].x, cur.b1[p].y, cur.b1[p].z, cur.b1[p].w};
+              split_bf16x8(x, bh[p], bl[p]);
+              if (zero_b) bh[p] = bl[p] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int p = 0; p < PT; ++p) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, cur.ah[c]), al = __builtin_bit_cast(bf16x8, cur.al[c]);
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, bh[p]), xl = __builtin_bit_cast(bf16x8, bl[p]);
+                acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[c][p], 0, 0, 0);      // (small terms first)
+                acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[c][p], 0, 0, 0);
+                acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[c][p], 0, 0, 0);
+              }
+            if (more) {
+#pragma unroll
+              for (int u = 0; u < SPX; ++u) {
+                if ((st + 1) * G + g < nloc) issue_slot(cbeg + (st + 1) * G + g, nbuf + g * t.buf_bytes, tap * SPX + u);
+                if ((st + 1) * G + g + 1 < nloc && g + 1 < G) issue_slot(cbeg + (st + 1) * G + g + 1, nbuf + (g + 1) * t.buf_bytes, tap * SPX + u);
+              }
+            }
+            if (tap + 1 < NT) cur = nxt;
+          }
+        }
+      } else {
       constexpr int NS = NT * Mma<T>::KSTEPS;
       constexpr int ISSUE_STEPS = NS < HRP_CONV_ISSUE_STEPS ? NS : HRP_CONV_ISSUE_STEPS;   // front-load the next stage's DMA
       constexpr int SPP = (MAXP_IN + MAXP_W + ISSUE_STEPS - 1) / ISSUE_STEPS;
-      const int ng = nloc - st * G < G ? nloc - st * G : G;
       typename Mma<T>::Frag fa[2][CT], fb[2][PT];
       auto load = [&](const char* lds_in, int step, typename Mma<T>::Frag (&a)[CT], typename Mma<T>::Frag (&bb)[PT]) {
         const int tap = step / Mma<T>::KSTEPS, kk = step % Mma<T>::KSTEPS;   // constants after unrolling
@@ -385,6 +449,7 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
           for (int p = 0; p < PT; ++p) fb[0][p] = fb[1][p];
         }
       }
+      }   // (not f32x3)
     }
     __syncthreads();
     HRP_CSTAMP(4);
@@ -669,6 +734,7 @@ static int plan_cfg(const hrp_conv_desc& d, ConvTiling& t, int& lds_out, bool al
     if (G < 1) G = 1;
     if (G > 16) G = 16;
     if (G > nsub) G = nsub;
+    if (std::is_same<T, f32x3_t>::value && G >= 2) G &= ~1;      // (chunk pairs share an MFMA: an even stage keeps every pair whole)
     t.G = G;
   }
   int main_bytes = 2 * t.G * t.buf_bytes;

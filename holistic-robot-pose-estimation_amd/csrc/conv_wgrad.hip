@@ -20,6 +20,7 @@
 #include "batch.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 // -DHRP_TIMELINE (tools/bench_kernels.py timeline, never in the shipped library): wave 0 of every workgroup
 // stamps the 100 MHz wall clock at phase boundaries into the last MiB of the workspace.
@@ -77,6 +78,9 @@ __device__ __forceinline__ void wgrad_block_of(const WgradTiling& t, const int l
 }
 
 template <typename T>
+static constexpr int wgrad_maxp_x() { return std::is_same<T, f32x3_t>::value ? 10 : 8; }
+
+template <typename T>
 struct WG;
 template <>
 struct WG<bf16_t> {
@@ -96,6 +100,11 @@ struct WG<float> {
   __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
+};
+template <>
+struct WG<f32x3_t> {       // HRP_F32X3: fp32 tiles in LDS, 16 pixels per k-step as three bf16 MFMAs on split operands
+  static constexpr int K = 16;
+  using Frag = float;
 };
 
 __device__ uint4 g_wg_zero_page[4];  // 64 zero bytes: DMA source of padding / out-of-range rows
@@ -124,7 +133,9 @@ __device__ __forceinline__ void conv_wgrad_body(const hrp_wgrad_desc& d, const W
   constexpr int P = CB * SZ;        // LDS pixel row: CB channels, unpadded (DMA writes lane-linear)
   constexpr int NVEC = P / 16;      // 16-byte slots per pixel row
   constexpr int K = WG<T>::K;
-  constexpr int MAXP_X = 8, MAXP_DY = 6;    // 1 KiB DMA pieces per wave (host keeps tiles below 32 / 24 KiB)
+  // 1 KiB DMA pieces per wave (host keeps tiles below 32 / 24 KiB; fp32x3: 40 KiB - its smallest tile is 64 pixels, whose fp32
+  // halo tile under a stride-2 3x3 layer is 37 KiB)
+  constexpr int MAXP_X = wgrad_maxp_x<T>(), MAXP_DY = 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* xtab = (int*)(smem + t.lds_tab_off);
 
@@ -356,6 +367,35 @@ __device__ __forceinline__ void conv_wgrad_body(const hrp_wgrad_desc& d, const W
         __builtin_amdgcn_sched_barrier(0);
       }
       }   // NB == 1
+    } else if constexpr (std::is_same<T, f32x3_t>::value) {
+      // fp32 tensors, 3 x bf16 products: a lane gathers the 8 pixels of its K half for its channel (8 ds_read_b32 per operand,
+      // the X offsets of the 8 pixels shared by all taps), splits them into hi / lo bf16 and issues lo*hi, hi*lo, hi*hi.
+      if (more) issue(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
+      for (int kb = 0; kb < ppw; kb += 16) {
+        const int m0 = wave * ppw + kb + 8 * khalf;
+        float av[8];
+        int xo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          av[j] = *(const float*)(lds_dy + (m0 + j) * P + l31 * 4);
+          xo[j] = xtab[m0 + j] + l31 * 4;
+        }
+        uint4 ah, al;
+        split_bf16x8(av, ah, al);
+        const bf16x8 fah = __builtin_bit_cast(bf16x8, ah), fal = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+        for (int tp = 0; tp < NT; ++tp) {
+          float bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bv[j] = *(const float*)(lds_x + xo[j] + tapoff[tp]);
+          uint4 bh, bl;
+          split_bf16x8(bv, bh, bl);
+          const bf16x8 fbh = __builtin_bit_cast(bf16x8, bh), fbl = __builtin_bit_cast(bf16x8, bl);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fbh, acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fbl, acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fbh, acc[tp], 0, 0, 0);
+        }
+      }
     } else {
       if (more) issue(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
       auto load = [&](int kb, float& a, float (&b)[NT]) {
@@ -502,7 +542,7 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
   static const int budget_kb = 72;
   const int budget = budget_kb * 1024;
   int lds = 0;
-  constexpr int BM_MIN = SZ == 4 ? 16 : 64;   // bf16 needs 16 pixels per wave and k-step; fp32 tiles are twice the bytes
+  constexpr int BM_MIN = std::is_same<T, float>::value ? 16 : 64;   // bf16 / fp32x3 need 16 pixels per wave and k-step; fp32 tiles are twice the bytes
   for (int BM = 256; BM >= BM_MIN; BM >>= 1) {
     int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
     int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
@@ -523,7 +563,7 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
     t.buf_bytes = (t.x_pieces + t.dy_pieces) * 1024;
     t.lds_tab_off = 2 * t.buf_bytes;
     int main_bytes = t.lds_tab_off + BM * 4;
-    if (t.x_pieces > 32 || t.dy_pieces > 24) { lds = 1 << 30; continue; }
+    if (t.x_pieces > 4 * wgrad_maxp_x<T>() || t.dy_pieces > 24) { lds = 1 << 30; continue; }
     t.lds_red_off = 0;  // the cross-wave exchange reuses the tiles
     int red_bytes = NTE * 8192;
     lds = main_bytes > red_bytes ? main_bytes : red_bytes;
@@ -722,8 +762,8 @@ __global__ __launch_bounds__(256) void wgrad_fold_batch_kernel(const FoldProblem
 
 static int wgrad_check(const hrp_wgrad_desc* d) {
   HRP_REQUIRE(d && d->x && d->dy && d->dw, "wgrad: null pointer");
-  HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16, "wgrad: dtype");
-  const int vec = d->dtype == HRP_F32 ? 4 : 8;
+  HRP_REQUIRE(d->dtype == HRP_F32 || d->dtype == HRP_BF16 || d->dtype == HRP_F32X3, "wgrad: dtype");
+  const int vec = d->dtype == HRP_BF16 ? 8 : 4;
   HRP_REQUIRE(d->Cin % vec == 0 && d->x_pitch % vec == 0 && (uintptr_t)d->x % 16 == 0, "wgrad: x channels/pitch/alignment");
   // dy may have any Cout as long as whole 16-byte vectors can be read (garbage lanes are masked at the store)
   HRP_REQUIRE(d->dy_pitch % vec == 0 && d->dy_pitch >= (d->Cout + vec - 1) / vec * vec && (uintptr_t)d->dy % 16 == 0,
@@ -817,6 +857,7 @@ int wgrad_batch_prepare(const hrp_wgrad_desc* descs, int n, void* table, hrp_bat
     HRP_REQUIRE(descs[i].phase == descs[0].phase, "wgrad batch: mixed phases");
   }
   if (descs[0].dtype == HRP_F32) return wgrad_batch_prepare_t<float>(descs, n, table, info);
+  if (descs[0].dtype == HRP_F32X3) return wgrad_batch_prepare_t<f32x3_t>(descs, n, table, info);
   return wgrad_batch_prepare_t<bf16_t>(descs, n, table, info);
 }
 
@@ -841,6 +882,12 @@ int wgrad_batch_launch(const void* table_dev, const hrp_batch_info* info, hipStr
       case 1: return wgrad_batch_launch_nt<float, 1>(tab, info, s);
       case 4: return wgrad_batch_launch_nt<float, 4>(tab, info, s);
       case 9: return wgrad_batch_launch_nt<float, 9>(tab, info, s);
+    }
+  } else if (info->dtype == HRP_F32X3) {
+    switch (info->variant) {
+      case 1: return wgrad_batch_launch_nt<f32x3_t, 1>(tab, info, s);
+      case 4: return wgrad_batch_launch_nt<f32x3_t, 4>(tab, info, s);
+      case 9: return wgrad_batch_launch_nt<f32x3_t, 9>(tab, info, s);
     }
   } else {
     switch (info->variant) {
@@ -915,6 +962,11 @@ extern "C" int hrp_wgrad_fold_desc_of(const hrp_wgrad_desc* d, hrp_wgrad_fold_de
     if (d->ntaps == 4) return fold_desc_t<float, 4>(*d, out);
     return fold_desc_t<float, 9>(*d, out);
   }
+  if (d->dtype == HRP_F32X3) {
+    if (d->ntaps == 1) return fold_desc_t<f32x3_t, 1>(*d, out);
+    if (d->ntaps == 4) return fold_desc_t<f32x3_t, 4>(*d, out);
+    return fold_desc_t<f32x3_t, 9>(*d, out);
+  }
   if (d->ntaps == 1) return fold_desc_t<bf16_t, 1>(*d, out);
   if (d->ntaps == 4) return fold_desc_t<bf16_t, 4>(*d, out);
   return fold_desc_t<bf16_t, 9>(*d, out);
@@ -939,6 +991,11 @@ extern "C" int hrp_conv2d_bwd_weight(const hrp_wgrad_desc* d, void* stream) {
     if (d->ntaps == 4) return launch_wgrad<float, 4>(*d, s);
     return launch_wgrad<float, 9>(*d, s);
   }
+  if (d->dtype == HRP_F32X3) {
+    if (d->ntaps == 1) return launch_wgrad<f32x3_t, 1>(*d, s);
+    if (d->ntaps == 4) return launch_wgrad<f32x3_t, 4>(*d, s);
+    return launch_wgrad<f32x3_t, 9>(*d, s);
+  }
   if (d->ntaps == 1) return launch_wgrad<bf16_t, 1>(*d, s);
   if (d->ntaps == 4) return launch_wgrad<bf16_t, 4>(*d, s);
   return launch_wgrad<bf16_t, 9>(*d, s);
@@ -951,6 +1008,11 @@ extern "C" int64_t hrp_wgrad_workspace_bytes(const hrp_wgrad_desc* d) {
     if (d->ntaps == 1) return wgrad_ws_bytes<float, 1>(*d);
     if (d->ntaps == 4) return wgrad_ws_bytes<float, 4>(*d);
     return wgrad_ws_bytes<float, 9>(*d);
+  }
+  if (d->dtype == HRP_F32X3) {
+    if (d->ntaps == 1) return wgrad_ws_bytes<f32x3_t, 1>(*d);
+    if (d->ntaps == 4) return wgrad_ws_bytes<f32x3_t, 4>(*d);
+    return wgrad_ws_bytes<f32x3_t, 9>(*d);
   }
   if (d->ntaps == 1) return wgrad_ws_bytes<bf16_t, 1>(*d);
   if (d->ntaps == 4) return wgrad_ws_bytes<bf16_t, 4>(*d);

@@ -1,6 +1,7 @@
 // Library plumbing + the small HBM-bound kernels: layout change at the stem, weight packing,
 // column sums (bias gradients), batch-norm bookkeeping tables, global average pooling.
 #include "hrp_common.h"
+#include <type_traits>
 #include <string.h>
 
 namespace hrp {
@@ -203,6 +204,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
   const unsigned Cout = e.Cout, Cin = e.Cin, nt = e.ntaps;
   const unsigned cout_pad = (Cout + 31) / 32 * 32, cin_pad = (Cin + 31) / 32 * 32;
   auto store_row = [&](void* dst, size_t row, const float (&v)[CK]) {
+    if constexpr (std::is_same<T, f32x3_t>::value) {      // HRP_F32X3: the row's 8 values as [8 hi | 8 lo] bf16
+      uint4* q = (uint4*)((char*)dst + row * 32);
+      split_bf16x8(v, q[0], q[1]);
+      return;
+    }
     float a[CK / 2], b[CK / 2];
 #pragma unroll
     for (int k = 0; k < CK / 2; ++k) { a[k] = v[k]; b[k] = v[CK / 2 + k]; }
@@ -536,6 +542,7 @@ extern "C" int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int 
   if (bx > 256) bx = 256;                      // (workgroups past a small tensor's rows exit at once)
   dim3 grid(bx, count);
   if (dtype == HRP_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+  else if (dtype == HRP_F32X3) hipLaunchKernelGGL(pack_weights_kernel<f32x3_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
   else hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
   return check_launch("pack_weights");
 }

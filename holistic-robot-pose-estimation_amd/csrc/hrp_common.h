@@ -74,6 +74,24 @@ struct Elem<bf16_t> {
   }
 };
 
+// fp32 tensors, matrix products as THREE bf16 MFMAs on split operands (x = hi + lo, both bf16: x w ~ hi_x hi_w + hi_x lo_w +
+// lo_x hi_w, relative error ~2^-16 per product instead of bf16's 2^-9, at a third of the bf16 matrix rate instead of fp32's
+// sixteenth): element type tag of the HRP_F32X3 convolution kernels.  Everything but the MFMA operands is float.
+struct f32x3_t {
+  float v;
+};
+template <>
+struct Elem<f32x3_t> : Elem<float> {};
+// x[0..7] -> hi, lo (8 bf16 each, as 4 dwords): hi = rne(x), lo = rne(x - hi)
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], uint4& hi, uint4& lo) {
+  hi = Elem<bf16_t>::pack(x);
+  float h[8], r[8];
+  Elem<bf16_t>::unpack(hi, h);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = x[i] - h[i];
+  lo = Elem<bf16_t>::pack(r);
+}
+
 // sum of the HRP_STAT_SLOTS replicas of statistic element i (buffer laid out [slot][n])
 __device__ __forceinline__ float slot_sum(const double* p, int i, int n) {
   double s = 0.0;

@@ -32,6 +32,14 @@ def _dt(dtype):
     return nv.HRP_F32 if dtype == torch.float32 else nv.HRP_BF16
 
 
+def _cdt(plan, dtype):
+    """dtype code of a CONVOLUTION problem / of the weight packing: fp32 tensors of a plan in the 3 x bf16 product mode run as
+    HRP_F32X3 (Plan.x3; include/hrp.h); every other launch of such a plan is plain HRP_F32."""
+    if dtype == torch.float32:
+        return nv.HRP_F32X3 if plan.x3 else nv.HRP_F32
+    return nv.HRP_BF16
+
+
 class TensorH:
     """NHWC activation handle: logical shape (N,H,W,C), channel pitch, backing buffer (+ gradient)."""
 
@@ -451,6 +459,7 @@ def lanes_concurrent(a, b):
 class Plan:
     def __init__(self, device, dtype, training, need_grad):
         self.device, self.dtype, self.training, self.need_grad = device, dtype, training, need_grad
+        self.x3 = False            # fp32 plan whose convolutions form their products as three bf16 MFMAs on split operands
         self.keep = []
         # lanes: independent sub-graphs (the two backbones, the branches of an HRNet module) are emitted into
         # different lanes = HIP streams, forked from / joined into their parent lane; lane 0 is the caller's
@@ -605,7 +614,7 @@ class Plan:
                     tab[i].Cout, tab[i].Cin, tab[i].ntaps, tab[i].pad_t = w.cout, w.cin, w.ntaps, w.pad_t
                 tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
                 self.keep.append(tdev)
-                dest.append((tdev, len(group), _dt(dtype), max(w.max_elems for w in group)))
+                dest.append((tdev, len(group), _cdt(self, dtype), max(w.max_elems for w in group)))
         self._pack_stream = None
         if self._pack_tables_late:
             self._pack_stream = torch.cuda.Stream(device=dev)
@@ -1315,7 +1324,7 @@ class PlanBuilder:
         taps = [(ty - 2, tx - 2) for ty in range(4) for tx in range(4)]
         vec = 8 if dtype == torch.bfloat16 else 4
         d = nv.ConvDesc()
-        d.x, d.y, d.dtype = xs.ptr(), y.ptr(), _dt(dtype)
+        d.x, d.y, d.dtype = xs.ptr(), y.ptr(), _cdt(p, dtype)
         d.N, d.H, d.W, d.Cin, d.x_pitch = xs.N, xs.H, xs.W, _rup(xs.C, vec), xs.pitch
         d.Ho, d.Wo, d.Cout = y.H, y.W, cout
         d.y_H, d.y_W, d.y_pitch, d.res_pitch = y.H, y.W, y.pitch, y.pitch
@@ -1340,7 +1349,7 @@ class PlanBuilder:
                 lane = p.cur_lane
                 for grp in range(4):   # weight gradient of the 16 taps in 4 groups of 4 (one kernel row each)
                     g = nv.WgradDesc()
-                    g.x, g.dy, g.dw, g.dtype = xs.ptr(), y.gptr(), gw12.data_ptr(), _dt(dtype)
+                    g.x, g.dy, g.dw, g.dtype = xs.ptr(), y.gptr(), gw12.data_ptr(), _cdt(p, dtype)
                     g.N, g.H, g.W, g.Cin, g.x_pitch = xs.N, xs.H, xs.W, _rup(xs.C, vec), xs.pitch
                     g.Ho, g.Wo, g.Cout, g.dy_pitch = y.H, y.W, cout, y.pitch
                     g.in_stride, g.ntaps = 1, 4
@@ -1409,7 +1418,7 @@ class PlanBuilder:
             y.stats = p.alloc_stats(cout_t)
         for (py, px) in [(0, 0), (0, 1), (1, 0), (1, 1)]:
             d = nv.ConvDesc()
-            d.x, d.y, d.dtype = x.ptr(), y.ptr(), _dt(dtype)
+            d.x, d.y, d.dtype = x.ptr(), y.ptr(), _cdt(p, dtype)
             d.N, d.H, d.W, d.Cin, d.x_pitch = x.N, x.H, x.W, _rup(x.C, vec), x.pitch
             d.Cout = cout_t
             d.y_H, d.y_W, d.y_pitch, d.res_pitch = y.H, y.W, y.pitch, y.pitch
@@ -1442,7 +1451,7 @@ class PlanBuilder:
             lane = p.cur_lane
             for grp in range(4):
                 g = nv.WgradDesc()
-                g.x, g.dy, g.dw, g.dtype = y.gptr(), x.ptr(), p.grad_of_param(w.param).data_ptr(), _dt(dtype)
+                g.x, g.dy, g.dw, g.dtype = y.gptr(), x.ptr(), p.grad_of_param(w.param).data_ptr(), _cdt(p, dtype)
                 g.N, g.H, g.W, g.Cin, g.x_pitch = y.N, y.H, y.W, _rup(y.C, vec), y.pitch
                 g.Ho, g.Wo, g.Cout, g.dy_pitch = x.H, x.W, x.C, x.pitch
                 g.in_stride, g.ntaps = 2, 4
@@ -1457,7 +1466,7 @@ class PlanBuilder:
         if x.requires_grad:
             acc = x.take_grad_slot()
             d = nv.ConvDesc()
-            d.x, d.y, d.dtype = y.gptr(), x.gptr(), _dt(dtype)
+            d.x, d.y, d.dtype = y.gptr(), x.gptr(), _cdt(p, dtype)
             d.N, d.H, d.W, d.Cin, d.x_pitch = y.N, y.H, y.W, _rup(y.C, vec), y.pitch
             d.Ho, d.Wo, d.Cout = x.H, x.W, x.C
             d.y_H, d.y_W, d.y_pitch, d.res_pitch = x.H, x.W, x.pitch, x.pitch
@@ -1559,7 +1568,7 @@ class PlanBuilder:
     def _conv_desc(self, x, w, y, stride, ksize, dtype, into=None, dilation=1):
         d = into if into is not None else nv.ConvDesc()
         d.x, d.y = x.ptr(), y.ptr()
-        d.dtype = _dt(dtype)
+        d.dtype = _cdt(self.plan, dtype)
         d.N, d.H, d.W, d.Cin, d.x_pitch = x.N, x.H, x.W, _rup(x.C, 8 if dtype == torch.bfloat16 else 4), x.pitch
         d.Ho, d.Wo, d.Cout = y.H, y.W, y.C
         d.y_H, d.y_W, d.y_pitch, d.res_pitch = y.H, y.W, y.pitch, y.pitch
@@ -1658,7 +1667,7 @@ class PlanBuilder:
         taps = _TAPS3 if ksize == 3 else [(0, 0)]
         g = nv.WgradDesc()
         g.x, g.dy, g.dw = x.ptr(), y.gptr(), p.grad_of_param(w.param).data_ptr()
-        g.dtype = _dt(dtype)
+        g.dtype = _cdt(p, dtype)
         g.N, g.H, g.W, g.Cin, g.x_pitch = x.N, x.H, x.W, _rup(x.C, vec), x.pitch
         g.Ho, g.Wo, g.Cout, g.dy_pitch = y.H, y.W, y.C, y.pitch
         g.in_stride, g.ntaps = stride, len(taps)
@@ -1954,7 +1963,7 @@ class PlanBuilder:
         if w.param.requires_grad:
             g = nv.WgradDesc()
             g.x, g.dy, g.dw = x.ptr(), y.gptr(), p.grad_of_param(w.param).data_ptr()
-            g.dtype = _dt(dtype)
+            g.dtype = _cdt(p, dtype)
             g.N, g.H, g.W, g.Cin, g.x_pitch = x.N, x.H, x.W, _rup(x.C, vec), x.pitch
             g.Ho, g.Wo, g.Cout, g.dy_pitch = y.H, y.W, y.C, y.pitch
             g.in_stride, g.ntaps = stride, len(taps)
@@ -1990,7 +1999,7 @@ class PlanBuilder:
             for ci, (py, px) in enumerate(classes):
                 d = nv.ConvDesc()
                 d.x, d.y = y.gptr(), x.gptr()
-                d.dtype = _dt(dtype)
+                d.dtype = _cdt(p, dtype)
                 d.N, d.H, d.W, d.Cin, d.x_pitch = y.N, y.H, y.W, _rup(y.C, vec), y.pitch
                 d.Cout = x.C
                 d.y_H, d.y_W, d.y_pitch = x.H, x.W, x.pitch

@@ -172,13 +172,21 @@ class PlannedModule(nn.Module):
         object.__setattr__(self, "_plans", {})
         object.__setattr__(self, "_bn_sig", (-1, []))
         object.__setattr__(self, "_compute_dtype", torch.float32)
+        object.__setattr__(self, "_x3", False)
 
     # compute dtype of the convolution trunk (heads stay fp32)
     def set_compute_dtype(self, dtype):
+        """torch.float32, torch.bfloat16, or "fp32x3": fp32 tensors whose convolution products are three bf16 MFMAs on split (hi + lo)
+        operands - ~2^-16 relative per product at a third of the bf16 matrix rate, where the fp32 matrix cores run at a sixteenth
+        (include/hrp.h HRP_F32X3; the precision between bf16 and fp32 of DESIGN 4)."""
+        x3 = dtype == "fp32x3"
+        if x3:
+            dtype = torch.float32
         assert dtype in (torch.float32, torch.bfloat16)
         for m in self.modules():
             if isinstance(m, PlannedModule):
                 object.__setattr__(m, "_compute_dtype", dtype)
+                object.__setattr__(m, "_x3", x3)
                 m._plans.clear()
         return self
 
@@ -299,7 +307,7 @@ class PlannedModule(nn.Module):
         bn_eval = self._frozen_bn_signature()
         key = (tuple(tuple(t.shape) for t in tensors), self._compute_dtype, self.training, need_grad,
                tuple(bool(t.requires_grad) for t in tensors) if need_grad else (),
-               tuple(t.dtype == torch.uint8 for t in tensors), bn_eval)
+               tuple(t.dtype == torch.uint8 for t in tensors), bn_eval, self._x3)
         runner = self._plans.pop(key, None)
         if runner is not None:
             self._plans[key] = runner        # most recently used last
@@ -309,6 +317,7 @@ class PlannedModule(nn.Module):
             while len(self._plans) >= PLAN_CACHE_MAX:
                 self._plans.pop(next(iter(self._plans)))
             plan = Plan(dev, self._compute_dtype, self.training, need_grad)
+            plan.x3 = bool(self._x3)
             if need_grad:
                 plan.preallocate_param_grads(list(self.parameters()))
             pb = PlanBuilder(plan)

@@ -51,7 +51,11 @@
 extern "C" {
 #endif
 
-typedef enum { HRP_F32 = 0, HRP_BF16 = 1 } hrp_dtype;
+/* HRP_F32X3 (convolutions and the weight packing only): fp32 tensors, every product formed as three bf16 MFMAs on split operands
+ * (x = hi + lo; x w ~ hi hi + hi lo + lo hi: ~2^-16 relative per product, a third of the bf16 matrix rate instead of the fp32 matrix
+ * cores' sixteenth).  hrp_pack_weights(dtype = HRP_F32X3) writes the packed rows pre-split ([8 hi | 8 lo] bf16 per 32-byte row); the
+ * convolution kernels split the activations on the fly.  Everything else about such a problem is HRP_F32. */
+typedef enum { HRP_F32 = 0, HRP_BF16 = 1, HRP_F32X3 = 2 } hrp_dtype;
 
 typedef enum {
   HRP_OK = 0,

@@ -132,6 +132,7 @@ BATCH_CONV, BATCH_WGRAD, BATCH_EW_FWD, BATCH_EW_BWD_REDUCE, BATCH_EW_BWD_APPLY, 
 class BatchInfo(C.Structure):
     _fields_ = [("family", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("variant", C.c_int32),
                 ("grid", C.c_int32), ("lds_bytes", C.c_int32), ("grid2", C.c_int32),
+                ("grid3", C.c_int32), ("lds_bytes3", C.c_int32),
                 ("blk0", C.c_int32 * (BATCH_MAX + 1)), ("blk2", C.c_int32 * (BATCH_MAX + 1)),
                 ("ws_bytes", C.c_int64 * BATCH_MAX)]
 

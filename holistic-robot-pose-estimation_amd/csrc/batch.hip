@@ -45,7 +45,7 @@ extern "C" int hrp_batch_prepare(int family, const void* descs, int n, void* tab
 }
 
 extern "C" int hrp_batch_launch(const void* table_dev, const hrp_batch_info* info, void* stream) {
-  HRP_REQUIRE(table_dev && info && info->n >= 1 && info->n <= HRP_BATCH_MAX && info->grid > 0, "batch launch: bad arguments");
+  HRP_REQUIRE(table_dev && info && info->n >= 1 && info->n <= HRP_BATCH_MAX && (info->grid > 0 || info->grid3 > 0), "batch launch: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   switch (info->family) {
     case HRP_BATCH_CONV: return info->dtype == HRP_F32 ? conv_batch_launch_f32(table_dev, info, s) :

@@ -470,6 +470,217 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
   conv_wgrad_body<T, NT, NKS, NB>(d, t, blockIdx.x, blockIdx.y);
 }
 
+// ---- eight-wave workgroups for the 3x3 stride-1 bf16 layers of the BasicBlocks (32 -> 32 and multiples of 64 channels) -----
+// What the batched weight-gradient launches cost is bytes: (tile bytes staged into LDS + 2 x partial-slab bytes) / ~4 TB/s fits
+// every class measured with tools/bench_batch.py.  The 32 x 32 program stages the x / dY slices of a layer
+// (n_cob + n_cib) / 2 times - 2 / 4 / 8 x for 64 / 128 / 256 channels - and writes one 36 KB slab per four waves.  Here a
+// workgroup has EIGHT waves, each running the 32 x 32 wave program (nine taps, 64 pixels per tile, 144 accumulator registers,
+// two waves per SIMD as before), arranged as
+//   PAIRS = 4:  a 64 x 64 block = 2 x 2 (cout, cin) pairs x 2 pixel slices, 128-pixel tiles: every staged byte feeds twice
+//               the MFMAs (the slices are staged (n_cob + n_cib) / 4 times), slab bytes per wave x 2;
+//   PAIRS = 1:  one 32 x 32 pair x 8 pixel slices, 512-pixel tiles (the 32-channel layers): slab bytes per wave / 2.
+// LDS: the X halo tile and the dY tile as 32-channel planes laid out exactly like the tiles of conv_wgrad_body (64-byte pixel
+// rows: the transpose reads stay conflict free), double buffered.  The partial sums leave in the 32 x 32 slab layout, so the
+// folding launches do not change.
+constexpr int OCTO_MAXP_X = 5, OCTO_MAXP_DY = 4;
+
+template <int PAIRS>
+__device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
+  using T = bf16_t;
+  constexpr int NT = 9, SZ = 2, VEC = 8, P = 64, NVEC = 4, NKS = 4;
+  constexpr int KSL = 8 / PAIRS;               // pixel slices of 64 pixels per tile
+  constexpr int BM = 64 * KSL;
+  constexpr int NPL = PAIRS == 4 ? 2 : 1;      // 32-channel planes per operand
+  constexpr int DPP = BM / 16;                 // 1 KiB pieces per dY plane
+  constexpr int MAXP_X = OCTO_MAXP_X, MAXP_DY = OCTO_MAXP_DY;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. 7 = slice * PAIRS + pair
+  const int pair = wave % PAIRS, ksl = wave / PAIRS;
+  const int pco = pair >> 1, pci = pair & 1;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int cobw = fdiv(blk, t.fd_cib), cibw = blk - cobw * t.n_cib;
+  const int co0 = cobw * (32 * NPL), ci0 = cibw * (32 * NPL);
+  const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
+  const int xpp = NPL == 2 ? t.x_pieces >> 1 : t.x_pieces;      // 1 KiB pieces per X plane
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const char* xg = (const char*)d.x;
+  const char* dyg = (const char*)d.dy;
+  const char* zero = (const char*)g_wg_zero_page;
+  asm volatile("" : "+v"(zero));
+
+  int tapoff[NT];
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) tapoff[tp] = ((d.dy_t[tp] - t.mindy) * t.IWt + (d.dx_t[tp] - t.mindx)) * P;
+
+  // DMA plan: as in conv_wgrad_body, per plane; piece p = wave + 8 i of this wave's slot i
+  const int x_pieces = t.x_pieces, dy_pieces = t.dy_pieces;
+  int xrel[MAXP_X], xcode[MAXP_X], dyrel[MAXP_DY], dycode[MAXP_DY];
+  {
+    const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
+    const int iy_last = y_last + t.mindy, ix_last = x_last + t.mindx;
+#pragma unroll
+    for (int i = 0; i < MAXP_X; ++i) {
+      xcode[i] = 32; xrel[i] = 0;
+      const int p = wave + 8 * i;
+      if (p >= x_pieces) continue;
+      const int plane = (NPL == 2 && p >= xpp) ? 1 : 0, pp = p - plane * xpp;
+      const int sl = pp * 64 + lane, pix = sl / NVEC, vec = sl - pix * NVEC;
+      const int ti = fdiv16(pix, t.fd_ihw), rem = pix - mul24(ti, ihw);
+      const int iy = fdiv16(rem, t.fd_iwt), ix = rem - mul24(iy, t.IWt);
+      const int c = ci0 + plane * 32 + vec * VEC;
+      int code = (pix >= t.in_pix) ? 32 : 0;
+      code |= (iy + t.mindy < 0) ? 1 : 0;
+      code |= (iy + iy_last >= d.H) ? 2 : 0;
+      code |= (ix + t.mindx < 0) ? 4 : 0;
+      code |= (ix + ix_last >= d.W) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      xcode[i] = code;
+      xrel[i] = mul24(mul24(mul24(ti, d.H) + iy, d.W) + ix, d.x_pitch * SZ) + c * SZ;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP_DY; ++i) {
+      dycode[i] = 32; dyrel[i] = 0;
+      const int p = wave + 8 * i;
+      if (p >= dy_pieces) continue;
+      const int plane = p / DPP, pp = p - plane * DPP;
+      const int sl = pp * 64 + lane, m = sl / NVEC, vec = sl - m * NVEC;
+      const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      const int c = co0 + plane * 32 + vec * VEC;
+      int code = (ti >= t.TI) ? 32 : 0;
+      code |= (ty + y_last >= d.Ho) ? 2 : 0;
+      code |= (tx + x_last >= d.Wo) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      dycode[i] = code;
+      dyrel[i] = mul24(mul24(mul24(ti, d.Ho) + ty, d.Wo) + tx, d.dy_pitch * SZ) + c * SZ;
+    }
+  }
+
+  struct TileCtx { const char* xbase; const char* dybase; char* buf; int cls; };
+  auto tile_ctx = [&](int tile, char* buf) {
+    int q = fdiv(tile, t.fd_tx);
+    const int tx_i = tile - q * t.tiles_x;
+    const int tn_i = fdiv(q, t.fd_ty);
+    const int ty_i = q - tn_i * t.tiles_y;
+    const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
+    const int iy0 = oy0 + t.mindy, ix0 = ox0 + t.mindx;
+    TileCtx c;
+    c.cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
+            (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
+    c.xbase = xg + (((long long)n0 * d.H + iy0) * d.W + ix0) * (long long)d.x_pitch * SZ;
+    c.dybase = dyg + (((long long)n0 * d.Ho + oy0) * d.Wo + ox0) * (long long)d.dy_pitch * SZ;
+    c.buf = buf;
+    return c;
+  };
+  auto issue_slot = [&](const TileCtx& c, int slot) {   // slot is a constant after unrolling
+    if (slot < MAXP_X) {
+      const int p = wave + 8 * slot;
+      if (p < x_pieces) wg_dma16((xcode[slot] & c.cls) ? zero : c.xbase + (unsigned)xrel[slot], c.buf + p * 1024);
+    } else if (slot < MAXP_X + MAXP_DY) {
+      const int i = slot - MAXP_X, p = wave + 8 * i;
+      if (p < dy_pieces)
+        wg_dma16((dycode[i] & c.cls) ? zero : c.dybase + (unsigned)dyrel[i], c.buf + (x_pieces + p) * 1024);
+    }
+  };
+
+  const int tr_pix = (lane & 15) >> 2;
+  const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * SZ;
+
+  int it = 0;
+  if (gxi < t.ntiles) {
+    const TileCtx c = tile_ctx(gxi, smem);
+#pragma unroll
+    for (int slot = 0; slot < MAXP_X + MAXP_DY; ++slot) issue_slot(c, slot);
+  }
+  int xo0[NKS], xo1[NKS], ao[NKS];
+  {
+    auto xoff = [&](int m) {
+      int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      if (ti >= t.TI) ti = t.TI - 1;       // idle slot (its dY row is zero)
+      return mul24(mul24(mul24(ti, t.IHt) + ty, t.IWt) + tx, P) + tr_coff;
+    };
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int m0 = ksl * 64 + ks * 16 + 8 * khalf + tr_pix;
+      xo0[ks] = xoff(m0); xo1[ks] = xoff(m0 + 4);
+      ao[ks] = m0 * P + tr_coff;
+    }
+  }
+
+  for (int tile = gxi; tile < t.ntiles; tile += t.G, ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* lds_x = smem + (it & 1) * t.buf_bytes + pci * (xpp * 1024);
+    const char* lds_dy = smem + (it & 1) * t.buf_bytes + x_pieces * 1024 + pco * (DPP * 1024);
+    const bool more = tile + t.G < t.ntiles;
+    TileCtx nx{};
+    if (more) nx = tile_ctx(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
+    // the wave program of conv_wgrad_body (NB = 1): flattened MFMA sequence q = ks * 9 + tap, X fragments D steps ahead, the dY
+    // fragment of the next k-step at the first tap; one DMA piece of the next tile every fourth step
+    constexpr int D = 4, TOT = NKS * NT;
+    bf16x8 a[2], b[D + 1];
+    auto load_a = [&](int ks, bf16x8& f) {
+      bf16x4 lo = WG<T>::tr(lds_dy + ao[ks]), hi = WG<T>::tr(lds_dy + ao[ks] + 4 * P);
+      f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_b = [&](int q, bf16x8& f) {
+      const int ks = q / NT, tp = q % NT;
+      bf16x4 lo = WG<T>::tr(lds_x + xo0[ks] + tapoff[tp]), hi = WG<T>::tr(lds_x + xo1[ks] + tapoff[tp]);
+      f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    load_a(0, a[0]);
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_b(q, b[q % (D + 1)]);
+#pragma unroll
+    for (int q = 0; q < TOT; ++q) {
+      const int ks = q / NT, tp = q % NT;
+      if (tp == 0 && ks + 1 < NKS) load_a(ks + 1, a[(ks + 1) & 1]);
+      if (q + D < TOT) load_b(q + D, b[(q + D) % (D + 1)]);
+      WG<T>::mma(a[ks & 1], b[q % (D + 1)], acc[tp]);
+      if (more && q % 4 == 0) issue_slot(nx, q / 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- the partial slabs [g][32 x 32 pair][9 * 1024], half of the accumulator rows at a time: every wave drops its rows in
+  // output order, then the 512 threads add the pixel slices of every pair as float4 and write its slab
+  __syncthreads();
+  float* dump = (float*)smem;
+  const int ncib32 = t.n_cib * NPL, np32 = t.n_cob * NPL * ncib32;
+  float* ws = (float*)d.workspace + (size_t)gxi * np32 * (NT * 1024);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    float* mine = dump + wave * (NT * 512) + 4 * khalf * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mine[(tp * 16 + (j & 3) + 8 * (j >> 2)) * 32] = acc[tp][8 * h + j];
+    __syncthreads();
+    for (int f = tid; f < PAIRS * NT * 128; f += 512) {
+      const int pr = f / (NT * 128), e = f - pr * (NT * 128);
+      float4 v = ((const float4*)dump)[f];
+#pragma unroll
+      for (int k = 1; k < KSL; ++k) {
+        const float4 u = ((const float4*)dump)[f + k * PAIRS * (NT * 128)];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      const int cob32 = cobw * NPL + (pr >> 1), cib32 = cibw * NPL + (pr & 1);
+      const int tp = e >> 7, rem = e & 127;
+      ((float4*)(ws + (size_t)(cob32 * ncib32 + cib32) * (NT * 1024) + tp * 1024 + 512 * h))[rem] = v;
+    }
+  }
+}
+
 // dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci].  bx: which 256 consecutive elements of the pair's NTE * 1024.
 constexpr int FOLD_ELEMS = 256;   // per block: 64 lanes x float4, the 4 waves take every fourth slab
 __device__ __forceinline__ void wgrad_fold_body(const hrp_wgrad_fold_desc& f, const int bx, const int blk) {
@@ -626,6 +837,54 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
   return HRP_OK;
 }
 
+// Eight-wave program (conv_wgrad_octo_body): 0 = not eligible, else PAIRS.  Depends on the layer only, never on the workspace.
+static int octo_pairs(const hrp_wgrad_desc& d) {
+  if (d.dtype != HRP_BF16 || d.ntaps != 9 || d.in_stride != 1) return 0;
+  if (d.dw_cin != d.Cin || d.Ho != d.H || d.Wo != d.W) return 0;
+  for (int i = 0; i < 9; ++i)
+    if (d.dy_t[i] < -1 || d.dy_t[i] > 1 || d.dx_t[i] < -1 || d.dx_t[i] > 1) return 0;
+  if (d.Cout == 32 && d.Cin == 32) return 1;
+  return (d.Cout % 64 == 0 && d.Cin % 64 == 0) ? 4 : 0;
+}
+
+static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_w, int wg_budget) {
+  const int npl = pairs_w == 4 ? 2 : 1, BM = 64 * (8 / pairs_w);
+  t.mindy = -1; t.mindx = -1;
+  int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
+  int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
+  int TI = BM / (TW * TH);
+  if (TI > d.N) TI = d.N;
+  t.TW = TW; t.TH = TH; t.TI = TI; t.BM = BM;
+  t.IHt = TH + 2; t.IWt = TW + 2;
+  t.in_pix = TI * t.IHt * t.IWt;
+  const int xpp = cdiv(t.in_pix * 64, 1024);
+  if (npl * xpp > 8 * OCTO_MAXP_X) return HRP_ERR_ARG;          // (tiny maps with many images per tile: the 32 x 32 program)
+  t.x_pieces = npl * xpp; t.dy_pieces = npl * (BM / 16);
+  t.buf_bytes = (t.x_pieces + t.dy_pieces) * 1024;
+  t.lds_tab_off = 0; t.lds_red_off = 0;
+  const int red_bytes = 8 * 9 * 512 * 4;
+  t.lds_bytes = 2 * t.buf_bytes > red_bytes ? 2 * t.buf_bytes : red_bytes;
+  if (t.lds_bytes > 160 * 1024) return HRP_ERR_ARG;
+  t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
+  t.ntiles = t.tiles_x * t.tiles_y * t.tiles_n;
+  if ((t.tiles_y >= 2 && (t.tiles_y - 2) * TH - 1 + t.IHt - 1 >= d.H) || (t.tiles_x >= 2 && (t.tiles_x - 2) * TW - 1 + t.IWt - 1 >= d.W))
+    return HRP_ERR_ARG;
+  t.n_cob = d.Cout / (32 * npl); t.n_cib = d.Cin / (32 * npl);
+  const int pairs = t.n_cob * t.n_cib;
+  int G = wg_budget / pairs;
+  if (G < 1) G = 1;
+  if (G > t.ntiles) G = t.ntiles;
+  t.xmode = 0; t.xa = t.xb = t.xnb = 1;
+  if ((pairs == 1 || pairs == 2 || pairs == 4) && G >= 8) { G -= G % 8; t.xmode = 2; }
+  t.G = G;
+  t.use_ws = 1;
+  t.fd_g = make_fastdiv(G);
+  t.fd_ihw = make_fastdiv(t.IHt * t.IWt); t.fd_iwt = make_fastdiv(t.IWt);
+  t.fd_thw = make_fastdiv(TH * TW); t.fd_tw = make_fastdiv(TW);
+  t.fd_tx = make_fastdiv(t.tiles_x); t.fd_ty = make_fastdiv(t.tiles_y); t.fd_cib = make_fastdiv(t.n_cib);
+  return HRP_OK;
+}
+
 // 64 x 64 blocks for the 1x1 bf16 layers with at least 64 channels on both sides
 template <typename T, int NT>
 static constexpr bool can_nb2() { return NT == 1 && Elem<T>::SZ == 2; }
@@ -696,8 +955,10 @@ static int launch_wgrad(const hrp_wgrad_desc& d, hipStream_t s) {
 struct WgradProblem {
   hrp_wgrad_desc d;
   WgradTiling t;
-  int nks, nb, nte, pairs;
+  int nks, nb, nte, pairs;       // nb: 1 / 2 = 32 / 64-channel blocks of conv_wgrad_body; 3 / 6 = the eight-wave program, PAIRS = nb - 2
   FastDiv fd_r;   // division by nte * 4 (blocks per pair of the folding launch)
+  int fold_pairs, fold_n_cib, fold_nb;   // the slab layout the folding launches see (eight-wave program: 32 x 32 pairs)
+  int wblk0;      // eight-wave program: first workgroup of this problem in its launch
 };
 
 template <typename T, int NT>
@@ -728,6 +989,20 @@ __global__ __launch_bounds__(256) WGRAD_OCC void wgrad_batch_kernel(const WgradP
   }
 }
 
+// the eight-wave problems of a batch (nb >= 3): 512 threads per workgroup, so a launch of their own next to the others' launch
+__global__ __launch_bounds__(512) void wgrad_octo_batch_kernel(const WgradProblem* __restrict__ tab, const int n) {
+  int g = 0, base = 0;
+  for (int i = 0; i < n; ++i) {
+    const int b0 = tab[i].wblk0;
+    if (tab[i].nb >= 3 && (int)blockIdx.x >= b0) { g = i; base = b0; }
+  }
+  const WgradProblem& P = tab[g];
+  int gxi, blk;
+  wgrad_block_of(P.t, (int)blockIdx.x - base, gxi, blk);
+  if (P.nb == 6) conv_wgrad_octo_body<4>(P.d, P.t, gxi, blk);
+  else conv_wgrad_octo_body<1>(P.d, P.t, gxi, blk);
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProblem* __restrict__ tab, const BatchHdr h) {
   int base;
   const int g = batch_find(h, blockIdx.x, base);
@@ -737,7 +1012,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProb
   const int bx = local - blk * (P.nte * 4);
   hrp_wgrad_fold_desc f;
   f.workspace = (const float*)P.d.workspace; f.dw = P.d.dw;
-  f.G = P.t.G; f.pairs = P.pairs; f.n_cib = P.t.n_cib; f.nte = P.nte; f.nb = P.nb;
+  f.G = P.t.G; f.pairs = P.fold_pairs; f.n_cib = P.fold_n_cib; f.nte = P.nte; f.nb = P.fold_nb;
   f.Cout = P.d.Cout; f.dw_cin = P.d.dw_cin; f.ntaps = P.d.ntaps; f.dw_tap_stride = P.d.dw_tap_stride; f.dw_tap_off = P.d.dw_tap_off;
   f.accumulate = P.d.accumulate;
   wgrad_fold_body(f, bx, blk);
@@ -775,7 +1050,16 @@ static int wgrad_check(const hrp_wgrad_desc* d) {
 }
 
 template <typename T, int NT>
-static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget) {
+static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget, int octo = 0) {
+  if (octo) {
+    const int rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256);
+    if (rc != HRP_OK) return rc;
+    P.nb = 2 + octo; P.nks = 0; P.nte = NT;
+    P.pairs = P.t.n_cob * P.t.n_cib;
+    P.fold_pairs = (d.Cout / 32) * (d.Cin / 32); P.fold_n_cib = d.Cin / 32; P.fold_nb = 1;
+    P.fd_r = make_fastdiv(P.nte * 4);
+    return HRP_OK;
+  }
   P.nb = 1;
   int rc;
   if constexpr (can_nb2<T, NT>()) {
@@ -791,6 +1075,7 @@ static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget) 
   P.nks = Elem<T>::SZ == 2 ? P.t.BM / 64 : 0;
   P.nte = NT * P.nb * P.nb;
   P.pairs = P.t.n_cob * P.t.n_cib;
+  P.fold_pairs = P.pairs; P.fold_n_cib = P.t.n_cib; P.fold_nb = P.nb;
   P.fd_r = make_fastdiv(P.nte * 4);
   return HRP_OK;
 }
@@ -798,25 +1083,35 @@ static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget) 
 template <typename T, int NT>
 static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProblem* tab, hrp_batch_info* info) {
   WgradProblem probs[HRP_BATCH_MAX];
-  double work[HRP_BATCH_MAX], total = 0.0;
+  double work[HRP_BATCH_MAX], total[2] = {0.0, 0.0};
+  int octo[HRP_BATCH_MAX];
   for (int i = 0; i < n; ++i) {
     memset(&probs[i], 0, sizeof(WgradProblem));
     probs[i].d = descs[i];
-    const int rc = wgrad_plan_one<T, NT>(descs[i], probs[i], 0);
-    if (rc != HRP_OK) return rc;
-    work[i] = (double)descs[i].N * descs[i].Ho * descs[i].Wo * probs[i].pairs;
-    total += work[i];
+    octo[i] = 0;
+    if constexpr (std::is_same<T, bf16_t>::value && NT == 9) {
+      octo[i] = octo_pairs(descs[i]);
+      if (octo[i] && wgrad_plan_one<T, NT>(descs[i], probs[i], 0, octo[i]) != HRP_OK) octo[i] = 0;
+    }
+    if (!octo[i]) {
+      const int rc = wgrad_plan_one<T, NT>(descs[i], probs[i], 0);
+      if (rc != HRP_OK) return rc;
+    }
+    work[i] = (double)descs[i].N * descs[i].Ho * descs[i].Wo * probs[i].fold_pairs;
+    total[octo[i] ? 1 : 0] += work[i];
   }
-  // workgroups of the launch: two per CU, shared in proportion to the work (at least one per (cout, cin) pair)
+  // workgroups of the launch: two per CU, shared in proportion to the work (at least one per (cout, cin) pair); the eight-wave
+  // problems' launch: one per CU
   static const int wg_launch = 512;
-  int lds_max = 0, blk = 0, blk2 = 0;
+  static const int wg_octo = 256;   // (512: a batch of eight 85.9 -> 74.2 us instead of 63.6 - the slab bytes double)
+  int lds_max = 0, lds_octo = 0, blk = 0, blk2 = 0, blkw = 0;
   for (int i = 0; i < n; ++i) {
-    int budget = (int)(wg_launch * work[i] / total + 0.5);
-    if (budget < probs[i].pairs) budget = probs[i].pairs;
-    const int rc = wgrad_plan_one<T, NT>(descs[i], probs[i], budget);
-    if (rc != HRP_OK) return rc;
     WgradProblem& P = probs[i];
-    const int64_t need = (int64_t)P.t.G * P.pairs * P.nte * 1024 * 4;
+    int budget = (int)((octo[i] ? wg_octo : wg_launch) * work[i] / total[octo[i] ? 1 : 0] + 0.5);
+    if (budget < P.pairs) budget = P.pairs;
+    const int rc = wgrad_plan_one<T, NT>(descs[i], P, budget, octo[i]);
+    if (rc != HRP_OK) return rc;
+    const int64_t need = (int64_t)P.t.G * P.fold_pairs * P.nte * 1024 * 4;
     info->ws_bytes[i] = need;
     if (tab) {
       HRP_REQUIRE(descs[i].workspace && descs[i].workspace_bytes >= need,
@@ -824,16 +1119,23 @@ static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProbl
       HRP_REQUIRE((uintptr_t)descs[i].workspace % 16 == 0, "wgrad batch: workspace alignment");
     }
     P.t.use_ws = 1;
-    lds_max = P.t.lds_bytes > lds_max ? P.t.lds_bytes : lds_max;
     info->blk0[i] = blk;
-    blk += P.t.G * P.pairs;
+    if (octo[i]) {
+      lds_octo = P.t.lds_bytes > lds_octo ? P.t.lds_bytes : lds_octo;
+      P.wblk0 = blkw;
+      blkw += P.t.G * P.pairs;
+    } else {
+      lds_max = P.t.lds_bytes > lds_max ? P.t.lds_bytes : lds_max;
+      blk += P.t.G * P.pairs;
+    }
     info->blk2[i] = blk2;
-    blk2 += P.nte * 4 * P.pairs;
+    blk2 += P.nte * 4 * P.fold_pairs;
     if (tab) tab[i] = P;
   }
   info->blk0[n] = blk; info->blk2[n] = blk2;
   // phase 1 (all problems or none): the caller folds the slabs with a HRP_BATCH_WGRAD_FOLD launch of its own
   info->grid = blk; info->grid2 = descs[0].phase == 1 ? 0 : blk2;
+  info->grid3 = blkw; info->lds_bytes3 = lds_octo;
   info->lds_bytes = lds_max;
   info->variant = NT;
   return HRP_OK;
@@ -868,8 +1170,20 @@ static int wgrad_batch_launch_nt(const WgradProblem* tab, const hrp_batch_info* 
     (void)hipFuncSetAttribute((const void*)wgrad_batch_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_batch_kernel<T, NT>), dim3(info->grid), dim3(256), info->lds_bytes, s, tab, make_hdr(info->blk0, info->n));
-  int rc = check_launch("wgrad_batch_kernel");
+  int rc = HRP_OK;
+  if (info->grid > 0) {
+    hipLaunchKernelGGL((wgrad_batch_kernel<T, NT>), dim3(info->grid), dim3(256), info->lds_bytes, s, tab, make_hdr(info->blk0, info->n));
+    rc = check_launch("wgrad_batch_kernel");
+  }
+  if (rc == HRP_OK && info->grid3 > 0) {
+    static bool octo_attr = false;
+    if (!octo_attr) {
+      (void)hipFuncSetAttribute((const void*)wgrad_octo_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      octo_attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_octo_batch_kernel, dim3(info->grid3), dim3(512), info->lds_bytes3, s, tab, info->n);
+    rc = check_launch("wgrad_octo_batch_kernel");
+  }
   if (rc != HRP_OK || info->grid2 == 0) return rc;
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(info->grid2), dim3(256), 0, s, tab, make_hdr(info->blk2, info->n));
   return check_launch("wgrad_reduce_batch_kernel");
@@ -977,7 +1291,7 @@ extern "C" int hrp_batch_wgrad_fold_descs(const void* table_host, const hrp_batc
   HRP_REQUIRE(table_host && info && out && info->family == HRP_BATCH_WGRAD, "wgrad fold: needs a prepared HRP_BATCH_WGRAD table");
   const WgradProblem* tab = (const WgradProblem*)table_host;
   for (int i = 0; i < info->n; ++i)
-    out[i] = make_fold_desc(tab[i].d, tab[i].t.G, tab[i].pairs, tab[i].t.n_cib, tab[i].nte, tab[i].nb);
+    out[i] = make_fold_desc(tab[i].d, tab[i].t.G, tab[i].fold_pairs, tab[i].fold_n_cib, tab[i].nte, tab[i].fold_nb);
   return HRP_OK;
 }
 

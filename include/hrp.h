@@ -405,6 +405,7 @@ typedef struct hrp_batch_info {
   int32_t variant;                  /* library-internal kernel selector (tap count, input count ..) */
   int32_t grid, lds_bytes;          /* main launch */
   int32_t grid2;                    /* HRP_BATCH_WGRAD: the launch that folds the partial slabs into dW */
+  int32_t grid3, lds_bytes3;        /* HRP_BATCH_WGRAD: the launch of the problems on the eight-wave program (3x3 stride-1 bf16)  */
   int32_t blk0[HRP_BATCH_MAX + 1];  /* first block of problem i (table order) in the main launch */
   int32_t blk2[HRP_BATCH_MAX + 1];  /* ... in the second launch */
   int64_t ws_bytes[HRP_BATCH_MAX];  /* HRP_BATCH_WGRAD: workspace bytes problem i (CALLER order) needs */

@@ -1,0 +1,117 @@
+"""GPU tests of the eight-wave weight-gradient program (csrc/conv_wgrad.hip: conv_wgrad_octo_body - 512-thread workgroups that own a
+64 x 64 block as 2 x 2 pairs x 2 pixel slices, or a 32 x 32 block x 8 pixel slices; the 3x3 stride-1 bf16 layers of the BasicBlocks,
+reference HRnet.py:35-58) through the C ABI's batched launch, against torch's conv2d weight gradient in float64 on the same bf16
+operands."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _problem(nv, N, H, W, cin, cout, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(N, H, W, cin, generator=g)).to(torch.bfloat16).to(DEV).contiguous()
+    dy = (torch.randn(N, H, W, cout, generator=g) / 8).to(torch.bfloat16).to(DEV).contiguous()
+    d = nv.WgradDesc()
+    d.x, d.dy, d.dtype = x.data_ptr(), dy.data_ptr(), nv.HRP_BF16
+    d.N, d.H, d.W, d.Cin, d.x_pitch = N, H, W, cin, cin
+    d.Ho, d.Wo, d.Cout, d.dy_pitch = H, W, cout, cout
+    d.in_stride, d.ntaps = 1, 9
+    for i, (a, b) in enumerate([(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]):
+        d.dy_t[i], d.dx_t[i] = a, b
+    d.dw_cin = cin
+    return d, x, dy
+
+
+def _reference(x, dy, cin, cout):
+    xr = x.double().permute(0, 3, 1, 2)
+    gr = dy.double().permute(0, 3, 1, 2)
+    return torch.nn.grad.conv2d_weight(xr, (cout, cin, 3, 3), gr, padding=1).reshape(cout, cin, 9)
+
+
+SHAPES = [
+    # N, H, W, cin, cout
+    (6, 32, 32, 64, 64),       # one 64 x 64 block, 128-pixel tiles
+    (6, 16, 16, 128, 128),     # 2 x 2 blocks of 64 x 64
+    (5, 8, 8, 256, 256),       # two images per tile, odd image count (idle tile slots)
+    (3, 20, 24, 64, 128),      # border tiles that leave the image in both directions, cin != cout
+    (3, 64, 64, 32, 32),       # 32 x 32 block x 8 pixel slices, 512-pixel tiles
+    (2, 40, 24, 32, 32),       # ... with border tiles
+    (2, 16, 16, 32, 64),       # not eligible: the 32 x 32 program in the same batch (its own launch)
+    (3, 12, 12, 192, 64),      # three cin blocks of 64, one cout block
+]
+
+
+@pytest.mark.parametrize("phase", [0, 1])
+def test_eight_wave_program_in_a_mixed_batch(phase):
+    from hrpe_amd import _native as nv
+    L = nv.lib()
+    probs = [_problem(nv, *s, seed=70 + i) for i, s in enumerate(SHAPES)]
+    n = len(probs)
+    arr = (nv.WgradDesc * n)(*[p[0] for p in probs])
+    dws = []
+    for d in arr:
+        d.phase, d.accumulate = phase, 0
+        dws.append(torch.full((d.Cout * d.dw_cin * 9,), 3.0, device=DEV))
+        d.dw = dws[-1].data_ptr()
+    info = nv.BatchInfo()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, None, C.byref(info)), "query")
+    wss = []
+    for i, d in enumerate(arr):
+        ws = torch.zeros(int(info.ws_bytes[i]) // 4 + 4, device=DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(info.ws_bytes[i])
+        wss.append(ws)
+    host = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD, n)))()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, host, C.byref(info)), "prepare")
+    assert info.grid3 > 0 and info.grid > 0, "the batch holds problems of both programs"
+    tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+    nv.check(L.hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+    if phase == 1:
+        folds = (nv.WgradFoldDesc * n)()
+        nv.check(L.hrp_batch_wgrad_fold_descs(host, C.byref(info), folds), "fold descs")
+        torch.cuda.synchronize()
+        assert all(float(dw.min()) == 3.0 == float(dw.max()) for dw in dws), "phase 1 must not touch dw"
+        finfo = nv.BatchInfo()
+        fhost = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD_FOLD, n)))()
+        nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD_FOLD, folds, n, fhost, C.byref(finfo)), "fold prepare")
+        ftab = torch.frombuffer(bytearray(bytes(fhost)), dtype=torch.uint8).to(DEV)
+        nv.check(L.hrp_batch_launch(ftab.data_ptr(), C.byref(finfo), None), "fold launch")
+    torch.cuda.synchronize()
+    for (d, x, dy), dw, s in zip(probs, dws, SHAPES):
+        ref = _reference(x, dy, s[3], s[4]).to(DEV)
+        got = dw.view(s[4], s[3], 9).double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, f"{s}: weight gradient off by {err:.2e} of its range"      # fp32 accumulation of exact bf16 products
+
+
+def test_eight_wave_program_alone_accumulates():
+    """A batch without a problem of the 32 x 32 program (grid == 0) launches, and accumulate = 1 adds to dw."""
+    from hrpe_amd import _native as nv
+    L = nv.lib()
+    probs = [_problem(nv, 4, 16, 16, 128, 128, 91), _problem(nv, 4, 32, 32, 64, 64, 92)]
+    arr = (nv.WgradDesc * 2)(*[p[0] for p in probs])
+    dws = []
+    for d in arr:
+        d.phase, d.accumulate = 0, 1
+        dws.append(torch.full((d.Cout * d.dw_cin * 9,), 0.5, device=DEV))
+        d.dw = dws[-1].data_ptr()
+    info = nv.BatchInfo()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, None, C.byref(info)), "query")
+    wss = []
+    for i, d in enumerate(arr):
+        ws = torch.zeros(int(info.ws_bytes[i]) // 4 + 4, device=DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(info.ws_bytes[i])
+        wss.append(ws)
+    host = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD, 2)))()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, host, C.byref(info)), "prepare")
+    assert info.grid == 0 and info.grid3 > 0
+    tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+    nv.check(L.hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+    torch.cuda.synchronize()
+    for (d, x, dy), dw in zip(probs, dws):
+        ref = _reference(x, dy, d.Cin, d.Cout).to(DEV) + 0.5
+        err = float((dw.view(d.Cout, d.Cin, 9).double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, err

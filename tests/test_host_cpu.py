@@ -563,8 +563,15 @@ def test_batch_prepare_is_host_only():
     arr = (nv.WgradDesc * 2)(*gs)
     assert lib.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, None, C.byref(info)) == 0, lib.hrp_last_error()
     single = [lib.hrp_wgrad_workspace_bytes(C.byref(g)) for g in gs]
-    assert all(0 < info.ws_bytes[i] <= single[i] for i in range(2))
-    assert info.grid <= 2 * 512 and info.grid2 > 0
+    # both are 3x3 stride-1 bf16 layers of the eight-wave program (its own launch of one 512-thread workgroup per CU): the
+    # 32-channel problem writes one slab per eight waves, the 128-channel problem four per eight waves
+    assert info.grid == 0 and 0 < info.grid3 <= 256 and info.lds_bytes3 <= 160 * 1024 and info.grid2 > 0
+    assert 0 < info.ws_bytes[0] <= single[0] and 0 < info.ws_bytes[1] <= 2 * single[1]
+    # a stride-2 layer in the same batch keeps the 32 x 32 program and its launch
+    gs[1].in_stride, gs[1].H, gs[1].W = 2, 32, 32
+    arr = (nv.WgradDesc * 2)(*gs)
+    assert lib.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, None, C.byref(info)) == 0, lib.hrp_last_error()
+    assert 0 < info.grid <= 512 and 0 < info.grid3 <= 256
 
 
 def test_kernel_choice_and_workspace_queries_are_host_only():

@@ -182,7 +182,7 @@ def wgrad_batch(N, nets, branches, dtype):
             print(f"   problem {i} ({t.shape[0]} workgroups; us after the first entry, mean/max): " +
                   "  ".join(f"{n} {((t[:, k] - t0).mean() / 100):.2f}/{((t[:, k] - t0).max() / 100):.2f}" for k, n in enumerate(names) if t[:, k].max() > 0))
     print(f"wgrad batch{len(descs)} (nets {nets} x branches {branches}, B={N}): {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  "
-          f"grid {b.info.grid}+{b.info.grid2} lds {b.info.lds_bytes}  | one by one: " + " ".join(f"{t:.1f}" for t in singles)
+          f"grid {b.info.grid}+{b.info.grid3} (eight-wave)+{b.info.grid2} lds {b.info.lds_bytes}/{b.info.lds_bytes3}  | one by one: " + " ".join(f"{t:.1f}" for t in singles)
           + f" (sum x nets {sum(singles) * nets:.1f})")
     return keep
 
@@ -208,3 +208,8 @@ if __name__ == "__main__":
     if a.what in ("wgrad", "all"):
         wgrad_batch(a.batch, a.nets, a.branches, dt)
         wgrad_batch(a.batch, 1, a.branches, dt)
+        for i in range(4):
+            CLS = CLASSES
+            CLASSES = [CLS[i]]
+            wgrad_batch(a.batch, 2, 1, dt)
+            CLASSES = CLS

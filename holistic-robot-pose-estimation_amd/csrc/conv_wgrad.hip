@@ -119,6 +119,232 @@ __device__ __forceinline__ void wg_dma16(const char* src, char* lds_wave_base) {
                :: "v"(src), "s"(lds) : "memory");   // m0 is scratch for the compiler too: it never keeps a value there
 }
 
+// ---- HRP_F32X3: fp32 tensors, every product as three bf16 MFMAs on split operands (hi = rne(v), lo = rne(v - hi)) -----------
+// The fp32 tile of a workgroup is staged by DMA into a RAW region, converted ONCE into bf16 hi / lo planes laid out like the bf16
+// program's tiles (64-byte pixel rows), and the wave program is the bf16 one - transpose reads, operand offsets in registers - with
+// a hi and a lo fragment per operand and lo*hi + hi*lo + hi*hi per tap.  (The first version gathered eight ds_read_b32 per operand
+// and split in registers per tap: ~350 instructions per 27 MFMAs, 24.1 ms of weight gradients per step; this one ~70.)
+// LDS: RAW (DMA target) + the planes, each one tile - the DMA of tile i + 1 runs under the MFMAs of tile i because RAW is free
+// again once tile i has been converted.
+template <int NT, int NKS>
+__device__ __forceinline__ void conv_wgrad_x3_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
+  constexpr int SZ = 4, VEC = 4, P = 128, NVEC = 8;      // the RAW tile: fp32, 32 channels per pixel row
+  constexpr int P2 = 64;                                   // a plane's pixel row: 32 bf16
+  constexpr int MAXP_X = wgrad_maxp_x<f32x3_t>(), MAXP_DY = 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int npairs = t.n_cob * t.n_cib;
+  const int cob = fdiv(blk, t.fd_cib), cib = blk - cob * t.n_cib;
+  const int co0 = cob * 32, ci0 = cib * 32;
+  const int IS = d.in_stride;
+  const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const char* xg = (const char*)d.x;
+  const char* dyg = (const char*)d.dy;
+  const char* zero = (const char*)g_wg_zero_page;
+  asm volatile("" : "+v"(zero));
+  const int ppw = t.BM / 4;  // pixels per wave
+
+  int tapoff[NT];
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) tapoff[tp] = ((d.dy_t[tp] - t.mindy) * t.IWt + (d.dx_t[tp] - t.mindx)) * P2;
+
+  const int x_pieces = t.x_pieces, dy_pieces = t.dy_pieces;
+  int xrel[MAXP_X], xcode[MAXP_X], dyrel[MAXP_DY], dycode[MAXP_DY];
+  {
+    const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
+    const int iy_last = y_last * IS + t.mindy, ix_last = x_last * IS + t.mindx;
+#pragma unroll
+    for (int i = 0; i < MAXP_X; ++i) {
+      xcode[i] = 32; xrel[i] = 0;
+      if (wave + 4 * i >= x_pieces) continue;
+      const int sl = (wave + 4 * i) * 64 + lane, pix = sl / NVEC, vec = sl - pix * NVEC;
+      const int ti = fdiv16(pix, t.fd_ihw), rem = pix - mul24(ti, ihw);
+      const int iy = fdiv16(rem, t.fd_iwt), ix = rem - mul24(iy, t.IWt);
+      const int c = ci0 + vec * VEC;
+      int code = (pix >= t.in_pix || c >= d.Cin) ? 32 : 0;
+      code |= (iy + t.mindy < 0) ? 1 : 0;
+      code |= (iy + iy_last >= d.H) ? 2 : 0;
+      code |= (ix + t.mindx < 0) ? 4 : 0;
+      code |= (ix + ix_last >= d.W) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      xcode[i] = code;
+      xrel[i] = mul24(mul24(mul24(ti, d.H) + iy, d.W) + ix, d.x_pitch * SZ) + c * SZ;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP_DY; ++i) {
+      dycode[i] = 32; dyrel[i] = 0;
+      if (wave + 4 * i >= dy_pieces) continue;
+      const int sl = (wave + 4 * i) * 64 + lane, m = sl / NVEC, vec = sl - m * NVEC;
+      const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      const int c = co0 + vec * VEC;
+      int code = (m >= t.BM || ti >= t.TI || c >= d.Cout) ? 32 : 0;
+      code |= (ty + y_last >= d.Ho) ? 2 : 0;
+      code |= (tx + x_last >= d.Wo) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      dycode[i] = code;
+      dyrel[i] = mul24(mul24(mul24(ti, d.Ho) + ty, d.Wo) + tx, d.dy_pitch * SZ) + c * SZ;
+    }
+  }
+
+  struct TileCtx { const char* xbase; const char* dybase; int cls; };
+  auto tile_ctx = [&](int tile) {
+    int q = fdiv(tile, t.fd_tx);
+    const int tx_i = tile - q * t.tiles_x;
+    const int tn_i = fdiv(q, t.fd_ty);
+    const int ty_i = q - tn_i * t.tiles_y;
+    const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
+    const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
+    TileCtx c;
+    c.cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
+            (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
+    c.xbase = xg + (((long long)n0 * d.H + iy0) * d.W + ix0) * (long long)d.x_pitch * SZ;
+    c.dybase = dyg + (((long long)n0 * d.Ho + oy0) * d.Wo + ox0) * (long long)d.dy_pitch * SZ;
+    return c;
+  };
+  char* const raw = smem;                         // [x_pieces + dy_pieces] KiB, the tile as it lies in HBM
+  char* const pl = smem + t.buf_bytes;            // X hi | X lo | dY hi | dY lo
+  const int xpl = x_pieces * 512, dypl = dy_pieces * 512;
+  auto issue_slot = [&](const TileCtx& c, int slot) {   // slot is a constant after unrolling
+    if (slot < MAXP_X) {
+      const int p = wave + 4 * slot;
+      if (p < x_pieces) wg_dma16((xcode[slot] & c.cls) ? zero : c.xbase + (unsigned)xrel[slot], raw + p * 1024);
+    } else if (slot < MAXP_X + MAXP_DY) {
+      const int i = slot - MAXP_X, p = wave + 4 * i;
+      if (p < dy_pieces) wg_dma16((dycode[i] & c.cls) ? zero : c.dybase + (unsigned)dyrel[i], raw + (x_pieces + p) * 1024);
+    }
+  };
+
+  const int tr_pix = (lane & 15) >> 2;
+  const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  if (gxi < t.ntiles) {
+    const TileCtx c = tile_ctx(gxi);
+#pragma unroll
+    for (int slot = 0; slot < MAXP_X + MAXP_DY; ++slot) issue_slot(c, slot);
+  }
+  int xo0[NKS], xo1[NKS], ao[NKS];
+  {
+    auto xoff = [&](int m) {
+      int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      if (ti >= t.TI) ti = t.TI - 1;
+      return mul24(mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS), P2) + tr_coff;
+    };
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int m0 = wave * ppw + ks * 16 + 8 * khalf + tr_pix;
+      xo0[ks] = xoff(m0); xo1[ks] = xoff(m0 + 4);
+      ao[ks] = m0 * P2 + tr_coff;
+    }
+  }
+  // conversion: one 32-byte granule (8 floats) of RAW -> 16 bytes of the hi plane + 16 bytes of the lo plane
+  const int ngran_x = t.in_pix * 4, ngran = ngran_x + t.BM * 4;
+
+  for (int tile = gxi; tile < t.ntiles; tile += t.G) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // the tile has landed in RAW; every wave is done with the planes of the previous tile
+    for (int e = tid; e < ngran; e += 256) {
+      const bool isx = e < ngran_x;
+      const int r = isx ? e : e - ngran_x;
+      const char* src = raw + (isx ? 0 : x_pieces * 1024) + r * 32;
+      const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 16);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      uint4 hi, lo;
+      split_bf16x8(x, hi, lo);
+      char* dst = pl + (isx ? 0 : 2 * xpl) + r * 16;
+      *(uint4*)dst = hi;
+      *(uint4*)(dst + (isx ? xpl : dypl)) = lo;
+    }
+    __syncthreads();
+    const bool more = tile + t.G < t.ntiles;
+    TileCtx nx{};
+    if (more) nx = tile_ctx(tile + t.G);
+    const char* lds_x = pl;
+    const char* lds_dy = pl + 2 * xpl;
+    constexpr int D = NT >= 2 ? 2 : NT, TOT = NKS * NT;
+    bf16x8 ah[2], al[2], bh[D + 1], bl[D + 1];
+    auto tr2 = [&](const char* p0, const char* p1) {
+      bf16x4 lo = WG<bf16_t>::tr(p0), hi = WG<bf16_t>::tr(p1);
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_a = [&](int ks, bf16x8& fh, bf16x8& fl) {
+      fh = tr2(lds_dy + ao[ks], lds_dy + ao[ks] + 4 * P2);
+      fl = tr2(lds_dy + dypl + ao[ks], lds_dy + dypl + ao[ks] + 4 * P2);
+    };
+    auto load_b = [&](int q, bf16x8& fh, bf16x8& fl) {
+      const int ks = q / NT, tp = q % NT;   // constants after unrolling
+      fh = tr2(lds_x + xo0[ks] + tapoff[tp], lds_x + xo1[ks] + tapoff[tp]);
+      fl = tr2(lds_x + xpl + xo0[ks] + tapoff[tp], lds_x + xpl + xo1[ks] + tapoff[tp]);
+    };
+    // RAW is free: the next tile's DMA goes out in one burst, so that all of it has the whole MFMA phase to land (pieces issued
+    // between the MFMAs as in the bf16 program: 23.8 instead of 22.8 ms of weight gradients per step - a tile is 54 MFMAs here)
+    if (more) {
+#pragma unroll
+      for (int slot = 0; slot < MAXP_X + MAXP_DY; ++slot) issue_slot(nx, slot);
+    }
+    load_a(0, ah[0], al[0]);
+#pragma unroll
+    for (int q = 0; q < D && q < TOT; ++q) load_b(q, bh[q % (D + 1)], bl[q % (D + 1)]);
+#pragma unroll
+    for (int q = 0; q < TOT; ++q) {
+      const int ks = q / NT, tp = q % NT, r = q % (D + 1);
+      if (tp == 0 && ks + 1 < NKS) load_a(ks + 1, ah[(ks + 1) & 1], al[(ks + 1) & 1]);
+      if (q + D < TOT) load_b(q + D, bh[(q + D) % (D + 1)], bl[(q + D) % (D + 1)]);
+      acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks & 1], bh[r], acc[tp], 0, 0, 0);      // (small terms first)
+      acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1], bl[r], acc[tp], 0, 0, 0);
+      acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1], bh[r], acc[tp], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- combine the 4 waves' partial sums through LDS and write the partial slab (conv_wgrad_body's epilogue) -------------
+  __syncthreads();
+  float* dump = (float*)smem;
+  const int tstride = d.dw_tap_stride > 0 ? d.dw_tap_stride : d.ntaps;
+  float* ws = t.use_ws ? (float*)d.workspace + ((size_t)gxi * npairs + blk) * (NT * 1024) : nullptr;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    float* mine = dump + wave * (NT * 512) + 4 * khalf * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mine[(tp * 16 + (j & 3) + 8 * (j >> 2)) * 32] = acc[tp][8 * h + j];
+    __syncthreads();
+    for (int f = tid; f < NT * 128; f += 256) {
+      float4 v = ((const float4*)dump)[f];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 u = ((const float4*)(dump + w * (NT * 512)))[f];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      const int tp = f >> 7, rem = f & 127;
+      if (ws) {
+        ((float4*)(ws + tp * 1024 + 512 * h))[rem] = v;
+      } else {
+        const int co = co0 + 16 * h + (rem >> 3), cin = ci0 + 4 * (rem & 7);
+        if (co < d.Cout) {
+          float* o = d.dw + ((size_t)co * d.dw_cin + cin) * tstride + d.dw_tap_off + tp;
+          if (cin < d.dw_cin) atomicAdd(o, v.x);
+          if (cin + 1 < d.dw_cin) atomicAdd(o + tstride, v.y);
+          if (cin + 2 < d.dw_cin) atomicAdd(o + 2 * tstride, v.z);
+          if (cin + 3 < d.dw_cin) atomicAdd(o + 3 * tstride, v.w);
+        }
+      }
+    }
+  }
+}
+
 // NB = 32-channel blocks per workgroup in each of the cout / cin dimensions.  NB = 2 (1x1 layers, bf16): a
 // 64 x 64 block of dW per workgroup = 4 MFMAs per 4 fragment reads instead of 1 per 2, and half the re-reads of
 // X and dY across workgroups (the 32 x 32 version of the 1x1 layers ran at 80 TFLOP/s, LDS-read bound).
@@ -127,6 +353,10 @@ __device__ __forceinline__ void wg_dma16(const char* src, char* lds_wave_base) {
 template <typename T, int NT, int NKS, int NB>
 __device__ __forceinline__ void conv_wgrad_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
   static_assert(NB == 1 || (NT == 1 && Elem<T>::SZ == 2), "NB = 2 is built for 1x1 bf16 only");
+  if constexpr (std::is_same<T, f32x3_t>::value) {
+    conv_wgrad_x3_body<NT, (NKS > 0 ? NKS : 1)>(d, t, gxi, blk);
+    return;
+  } else {
   constexpr int SZ = Elem<T>::SZ, VEC = Elem<T>::VEC;
   constexpr int CB = 32 * NB;       // channels per workgroup block (cout and cin)
   constexpr int NTE = NT * NB * NB; // accumulator tiles: [tap][cout block][cin block]
@@ -367,35 +597,6 @@ __device__ __forceinline__ void conv_wgrad_body(const hrp_wgrad_desc& d, const W
         __builtin_amdgcn_sched_barrier(0);
       }
       }   // NB == 1
-    } else if constexpr (std::is_same<T, f32x3_t>::value) {
-      // fp32 tensors, 3 x bf16 products: a lane gathers the 8 pixels of its K half for its channel (8 ds_read_b32 per operand,
-      // the X offsets of the 8 pixels shared by all taps), splits them into hi / lo bf16 and issues lo*hi, hi*lo, hi*hi.
-      if (more) issue(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
-      for (int kb = 0; kb < ppw; kb += 16) {
-        const int m0 = wave * ppw + kb + 8 * khalf;
-        float av[8];
-        int xo[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          av[j] = *(const float*)(lds_dy + (m0 + j) * P + l31 * 4);
-          xo[j] = xtab[m0 + j] + l31 * 4;
-        }
-        uint4 ah, al;
-        split_bf16x8(av, ah, al);
-        const bf16x8 fah = __builtin_bit_cast(bf16x8, ah), fal = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-        for (int tp = 0; tp < NT; ++tp) {
-          float bv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bv[j] = *(const float*)(lds_x + xo[j] + tapoff[tp]);
-          uint4 bh, bl;
-          split_bf16x8(bv, bh, bl);
-          const bf16x8 fbh = __builtin_bit_cast(bf16x8, bh), fbl = __builtin_bit_cast(bf16x8, bl);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fbh, acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fbl, acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fbh, acc[tp], 0, 0, 0);
-        }
-      }
     } else {
       if (more) issue(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
       auto load = [&](int kb, float& a, float (&b)[NT]) {
@@ -463,6 +664,7 @@ __device__ __forceinline__ void conv_wgrad_body(const hrp_wgrad_desc& d, const W
     }
     HRP_STAMP(12 + h);
   }
+  }   // (not fp32x3)
 }
 
 template <typename T, int NT, int NKS, int NB>
@@ -681,6 +883,219 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
   }
 }
 
+// ---- the eight-wave program for HRP_F32X3 (64 x 64 blocks: multiples of 64 channels) ---------------------------------------
+// conv_wgrad_octo_body<4> with the staging of conv_wgrad_x3_body: the fp32 tile (64 channels of x and of dY per pixel) lands in a
+// RAW region, is converted once into bf16 hi / lo planes of 32 channels, and every wave runs the hi / lo wave program on its
+// (cout, cin) pair and pixel slice.  Against the four-wave fp32x3 program a staged byte feeds twice the MFMAs - fp32 tiles are
+// twice the bytes, and the weight gradient is paced by its tile fills.  NKS = 4: 128-pixel tiles; 2: 64-pixel tiles (two 8 x 8
+// images per tile would need 164 KB).
+constexpr int OCTO3_MAXP_X = 7, OCTO3_MAXP_DY = 4;
+
+template <int NKS>
+__device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
+  constexpr int NT = 9, SZ = 4, VEC = 4, P2 = 64, NVEC = 16;   // RAW pixel row: 64 fp32 = 16 vectors of 16 bytes
+  constexpr int BM = 2 * NKS * 16;
+  constexpr int MAXP_X = OCTO3_MAXP_X, MAXP_DY = OCTO3_MAXP_DY;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. 7 = slice * 4 + pair
+  const int pair = wave & 3, ksl = wave >> 2;
+  const int pco = pair >> 1, pci = pair & 1;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int cobw = fdiv(blk, t.fd_cib), cibw = blk - cobw * t.n_cib;
+  const int co0 = cobw * 64, ci0 = cibw * 64;
+  const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const char* xg = (const char*)d.x;
+  const char* dyg = (const char*)d.dy;
+  const char* zero = (const char*)g_wg_zero_page;
+  asm volatile("" : "+v"(zero));
+
+  int tapoff[NT];
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) tapoff[tp] = ((d.dy_t[tp] - t.mindy) * t.IWt + (d.dx_t[tp] - t.mindx)) * P2;
+
+  const int x_pieces = t.x_pieces, dy_pieces = t.dy_pieces;
+  int xrel[MAXP_X], xcode[MAXP_X], dyrel[MAXP_DY], dycode[MAXP_DY];
+  {
+    const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
+    const int iy_last = y_last + t.mindy, ix_last = x_last + t.mindx;
+#pragma unroll
+    for (int i = 0; i < MAXP_X; ++i) {
+      xcode[i] = 32; xrel[i] = 0;
+      const int p = wave + 8 * i;
+      if (p >= x_pieces) continue;
+      const int sl = p * 64 + lane, pix = sl / NVEC, vec = sl - pix * NVEC;
+      const int ti = fdiv16(pix, t.fd_ihw), rem = pix - mul24(ti, ihw);
+      const int iy = fdiv16(rem, t.fd_iwt), ix = rem - mul24(iy, t.IWt);
+      int code = (pix >= t.in_pix) ? 32 : 0;
+      code |= (iy + t.mindy < 0) ? 1 : 0;
+      code |= (iy + iy_last >= d.H) ? 2 : 0;
+      code |= (ix + t.mindx < 0) ? 4 : 0;
+      code |= (ix + ix_last >= d.W) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      xcode[i] = code;
+      xrel[i] = mul24(mul24(mul24(ti, d.H) + iy, d.W) + ix, d.x_pitch * SZ) + (ci0 + vec * VEC) * SZ;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP_DY; ++i) {
+      dycode[i] = 32; dyrel[i] = 0;
+      const int p = wave + 8 * i;
+      if (p >= dy_pieces) continue;
+      const int sl = p * 64 + lane, m = sl / NVEC, vec = sl - m * NVEC;
+      const int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      const int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      int code = (ti >= t.TI) ? 32 : 0;
+      code |= (ty + y_last >= d.Ho) ? 2 : 0;
+      code |= (tx + x_last >= d.Wo) ? 8 : 0;
+      code |= (ti + n_last >= d.N) ? 16 : 0;
+      dycode[i] = code;
+      dyrel[i] = mul24(mul24(mul24(ti, d.Ho) + ty, d.Wo) + tx, d.dy_pitch * SZ) + (co0 + vec * VEC) * SZ;
+    }
+  }
+
+  struct TileCtx { const char* xbase; const char* dybase; int cls; };
+  auto tile_ctx = [&](int tile) {
+    int q = fdiv(tile, t.fd_tx);
+    const int tx_i = tile - q * t.tiles_x;
+    const int tn_i = fdiv(q, t.fd_ty);
+    const int ty_i = q - tn_i * t.tiles_y;
+    const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
+    const int iy0 = oy0 + t.mindy, ix0 = ox0 + t.mindx;
+    TileCtx c;
+    c.cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
+            (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
+    c.xbase = xg + (((long long)n0 * d.H + iy0) * d.W + ix0) * (long long)d.x_pitch * SZ;
+    c.dybase = dyg + (((long long)n0 * d.Ho + oy0) * d.Wo + ox0) * (long long)d.dy_pitch * SZ;
+    return c;
+  };
+  char* const raw = smem;                          // [x_pieces + dy_pieces] KiB, the tile as it lies in HBM
+  char* const pl = smem + t.buf_bytes;             // X: hi cin 0-31 | hi cin 32-63 | lo | lo;  dY: the same for cout
+  const int xps = x_pieces * 256, dps = dy_pieces * 256;       // one plane
+  auto issue_slot = [&](const TileCtx& c, int slot) {   // slot is a constant after unrolling
+    if (slot < MAXP_X) {
+      const int p = wave + 8 * slot;
+      if (p < x_pieces) wg_dma16((xcode[slot] & c.cls) ? zero : c.xbase + (unsigned)xrel[slot], raw + p * 1024);
+    } else if (slot < MAXP_X + MAXP_DY) {
+      const int i = slot - MAXP_X, p = wave + 8 * i;
+      if (p < dy_pieces) wg_dma16((dycode[i] & c.cls) ? zero : c.dybase + (unsigned)dyrel[i], raw + (x_pieces + p) * 1024);
+    }
+  };
+
+  const int tr_pix = (lane & 15) >> 2;
+  const int tr_coff = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  if (gxi < t.ntiles) {
+    const TileCtx c = tile_ctx(gxi);
+#pragma unroll
+    for (int slot = 0; slot < MAXP_X + MAXP_DY; ++slot) issue_slot(c, slot);
+  }
+  int xo0[NKS], xo1[NKS], ao[NKS];
+  {
+    auto xoff = [&](int m) {
+      int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
+      int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
+      if (ti >= t.TI) ti = t.TI - 1;
+      return mul24(mul24(mul24(ti, t.IHt) + ty, t.IWt) + tx, P2) + tr_coff;
+    };
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int m0 = ksl * (NKS * 16) + ks * 16 + 8 * khalf + tr_pix;
+      xo0[ks] = xoff(m0); xo1[ks] = xoff(m0 + 4);
+      ao[ks] = m0 * P2 + tr_coff;
+    }
+  }
+  // conversion: one 32-byte granule (8 floats; 8 per pixel) of RAW -> 16 bytes of a hi plane + 16 bytes of its lo plane
+  const int ngran_x = t.in_pix * 8, ngran = ngran_x + BM * 8;
+
+  for (int tile = gxi; tile < t.ntiles; tile += t.G) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // the tile has landed in RAW; every wave is done with the planes of the previous tile
+    for (int e = tid; e < ngran; e += 512) {
+      const bool isx = e < ngran_x;
+      const int r = isx ? e : e - ngran_x;
+      const int pix = r >> 3, g = r & 7;
+      const char* src = raw + (isx ? 0 : x_pieces * 1024) + r * 32;
+      const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 16);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      uint4 hi, lo;
+      split_bf16x8(x, hi, lo);
+      const int ps = isx ? xps : dps;
+      char* dst = pl + (isx ? 0 : 4 * xps) + (g >> 2) * ps + pix * P2 + (g & 3) * 16;
+      *(uint4*)dst = hi;
+      *(uint4*)(dst + 2 * ps) = lo;
+    }
+    __syncthreads();
+    const bool more = tile + t.G < t.ntiles;
+    if (more) {
+      const TileCtx nx = tile_ctx(tile + t.G);
+#pragma unroll
+      for (int slot = 0; slot < MAXP_X + MAXP_DY; ++slot) issue_slot(nx, slot);
+    }
+    const char* lds_x = pl + pci * xps;
+    const char* lds_dy = pl + 4 * xps + pco * dps;
+    constexpr int D = 2, TOT = NKS * NT;
+    bf16x8 ah[2], al[2], bh[D + 1], bl[D + 1];
+    auto tr2 = [&](const char* p0, const char* p1) {
+      bf16x4 lo = WG<bf16_t>::tr(p0), hi = WG<bf16_t>::tr(p1);
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_a = [&](int ks, bf16x8& fh, bf16x8& fl) {
+      fh = tr2(lds_dy + ao[ks], lds_dy + ao[ks] + 4 * P2);
+      fl = tr2(lds_dy + 2 * dps + ao[ks], lds_dy + 2 * dps + ao[ks] + 4 * P2);
+    };
+    auto load_b = [&](int q, bf16x8& fh, bf16x8& fl) {
+      const int ks = q / NT, tp = q % NT;   // constants after unrolling
+      fh = tr2(lds_x + xo0[ks] + tapoff[tp], lds_x + xo1[ks] + tapoff[tp]);
+      fl = tr2(lds_x + 2 * xps + xo0[ks] + tapoff[tp], lds_x + 2 * xps + xo1[ks] + tapoff[tp]);
+    };
+    load_a(0, ah[0], al[0]);
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_b(q, bh[q % (D + 1)], bl[q % (D + 1)]);
+#pragma unroll
+    for (int q = 0; q < TOT; ++q) {
+      const int ks = q / NT, tp = q % NT, r = q % (D + 1);
+      if (tp == 0 && ks + 1 < NKS) load_a(ks + 1, ah[(ks + 1) & 1], al[(ks + 1) & 1]);
+      if (q + D < TOT) load_b(q + D, bh[(q + D) % (D + 1)], bl[(q + D) % (D + 1)]);
+      acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks & 1], bh[r], acc[tp], 0, 0, 0);      // (small terms first)
+      acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1], bl[r], acc[tp], 0, 0, 0);
+      acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1], bh[r], acc[tp], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- the partial slabs, as conv_wgrad_octo_body<4> writes them
+  __syncthreads();
+  float* dump = (float*)smem;
+  const int ncib32 = t.n_cib * 2, np32 = t.n_cob * 2 * ncib32;
+  float* ws = (float*)d.workspace + (size_t)gxi * np32 * (NT * 1024);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    float* mine = dump + wave * (NT * 512) + 4 * khalf * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mine[(tp * 16 + (j & 3) + 8 * (j >> 2)) * 32] = acc[tp][8 * h + j];
+    __syncthreads();
+    for (int f = tid; f < 4 * NT * 128; f += 512) {
+      const int pr = f / (NT * 128), e = f - pr * (NT * 128);
+      float4 v = ((const float4*)dump)[f];
+      const float4 u = ((const float4*)dump)[f + 4 * (NT * 128)];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      const int cob32 = cobw * 2 + (pr >> 1), cib32 = cibw * 2 + (pr & 1);
+      const int tp = e >> 7, rem = e & 127;
+      ((float4*)(ws + (size_t)(cob32 * ncib32 + cib32) * (NT * 1024) + tp * 1024 + 512 * h))[rem] = v;
+    }
+  }
+}
+
 // dW[co][ci][tp] (+)= sum_g ws[g][blk][tp][row][ci].  bx: which 256 consecutive elements of the pair's NTE * 1024.
 constexpr int FOLD_ELEMS = 256;   // per block: 64 lanes x float4, the 4 waves take every fourth slab
 __device__ __forceinline__ void wgrad_fold_body(const hrp_wgrad_fold_desc& f, const int bx, const int blk) {
@@ -754,7 +1169,8 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
   const int budget = budget_kb * 1024;
   int lds = 0;
   constexpr int BM_MIN = std::is_same<T, float>::value ? 16 : 64;   // bf16 / fp32x3 need 16 pixels per wave and k-step; fp32 tiles are twice the bytes
-  for (int BM = 256; BM >= BM_MIN; BM >>= 1) {
+  constexpr int BM_MAX = std::is_same<T, f32x3_t>::value ? 128 : 256;   // (fp32x3: RAW tile + planes = twice the tile in LDS, k-steps 1 / 2)
+  for (int BM = BM_MAX; BM >= BM_MIN; BM >>= 1) {
     int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
     int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
     int TI = BM / (TW * TH);
@@ -839,16 +1255,17 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
 
 // Eight-wave program (conv_wgrad_octo_body): 0 = not eligible, else PAIRS.  Depends on the layer only, never on the workspace.
 static int octo_pairs(const hrp_wgrad_desc& d) {
-  if (d.dtype != HRP_BF16 || d.ntaps != 9 || d.in_stride != 1) return 0;
+  if (d.dtype == HRP_F32 || d.ntaps != 9 || d.in_stride != 1) return 0;
   if (d.dw_cin != d.Cin || d.Ho != d.H || d.Wo != d.W) return 0;
   for (int i = 0; i < 9; ++i)
     if (d.dy_t[i] < -1 || d.dy_t[i] > 1 || d.dx_t[i] < -1 || d.dx_t[i] > 1) return 0;
-  if (d.Cout == 32 && d.Cin == 32) return 1;
+  if (d.Cout == 32 && d.Cin == 32) return d.dtype == HRP_BF16 ? 1 : 0;      // (fp32x3: the four-wave program)
   return (d.Cout % 64 == 0 && d.Cin % 64 == 0) ? 4 : 0;
 }
 
-static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_w, int wg_budget) {
-  const int npl = pairs_w == 4 ? 2 : 1, BM = 64 * (8 / pairs_w);
+static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_w, int wg_budget, int nks = 4) {
+  const bool x3 = d.dtype == HRP_F32X3;
+  const int npl = pairs_w == 4 ? 2 : 1, BM = nks * 16 * (8 / pairs_w);
   t.mindy = -1; t.mindx = -1;
   int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
   int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
@@ -857,9 +1274,15 @@ static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_
   t.TW = TW; t.TH = TH; t.TI = TI; t.BM = BM;
   t.IHt = TH + 2; t.IWt = TW + 2;
   t.in_pix = TI * t.IHt * t.IWt;
-  const int xpp = cdiv(t.in_pix * 64, 1024);
-  if (npl * xpp > 8 * OCTO_MAXP_X) return HRP_ERR_ARG;          // (tiny maps with many images per tile: the 32 x 32 program)
-  t.x_pieces = npl * xpp; t.dy_pieces = npl * (BM / 16);
+  if (x3) {        // RAW fp32 tile: 64 channels = 256 bytes per pixel; the planes take the same bytes again
+    if (pairs_w != 4) return HRP_ERR_ARG;
+    t.x_pieces = cdiv(t.in_pix * 256, 1024); t.dy_pieces = BM / 4;
+    if (t.x_pieces > 8 * OCTO3_MAXP_X || t.dy_pieces > 8 * OCTO3_MAXP_DY) return HRP_ERR_ARG;
+  } else {
+    const int xpp = cdiv(t.in_pix * 64, 1024);
+    if (npl * xpp > 8 * OCTO_MAXP_X) return HRP_ERR_ARG;          // (tiny maps with many images per tile: the 32 x 32 program)
+    t.x_pieces = npl * xpp; t.dy_pieces = npl * (BM / 16);
+  }
   t.buf_bytes = (t.x_pieces + t.dy_pieces) * 1024;
   t.lds_tab_off = 0; t.lds_red_off = 0;
   const int red_bytes = 8 * 9 * 512 * 4;
@@ -921,9 +1344,10 @@ static int launch_wgrad_nb(const hrp_wgrad_desc& d, hipStream_t s) {
     zero_async(d.dw, sizeof(float) * (size_t)d.Cout * d.dw_cin * d.ntaps, s);
   }
   void (*kern)(const hrp_wgrad_desc, const WgradTiling) = nullptr;
-  if constexpr (Elem<T>::SZ == 2) {
-    // bf16: k-steps of 16 pixels per wave and tile = BM / 64, unrolled at compile time
-    kern = t.BM == 256 ? conv_wgrad_kernel<T, NT, 4, NB> : t.BM == 128 ? conv_wgrad_kernel<T, NT, 2, NB> : conv_wgrad_kernel<T, NT, 1, NB>;
+  if constexpr (Elem<T>::SZ == 2 || std::is_same<T, f32x3_t>::value) {
+    // bf16 / fp32x3: k-steps of 16 pixels per wave and tile = BM / 64, unrolled at compile time
+    if constexpr (std::is_same<T, f32x3_t>::value) kern = t.BM == 128 ? conv_wgrad_kernel<T, NT, 2, NB> : conv_wgrad_kernel<T, NT, 1, NB>;
+    else kern = t.BM == 256 ? conv_wgrad_kernel<T, NT, 4, NB> : t.BM == 128 ? conv_wgrad_kernel<T, NT, 2, NB> : conv_wgrad_kernel<T, NT, 1, NB>;
   } else {
     kern = conv_wgrad_kernel<T, NT, 0, NB>;
   }
@@ -969,9 +1393,9 @@ __global__ __launch_bounds__(256) WGRAD_OCC void wgrad_batch_kernel(const WgradP
   const int local = (int)blockIdx.x - base;
   int gxi, blk;
   wgrad_block_of(P.t, local, gxi, blk);
-  if constexpr (Elem<T>::SZ == 4) {
+  if constexpr (std::is_same<T, float>::value) {
     conv_wgrad_body<T, NT, 0, 1>(P.d, P.t, gxi, blk);
-  } else if constexpr (NT == 1) {
+  } else if constexpr (NT == 1 && Elem<T>::SZ == 2) {
     switch (P.nks * 4 + P.nb) {
       case 4 * 4 + 1: conv_wgrad_body<T, NT, 4, 1>(P.d, P.t, gxi, blk); break;
       case 2 * 4 + 1: conv_wgrad_body<T, NT, 2, 1>(P.d, P.t, gxi, blk); break;
@@ -982,7 +1406,7 @@ __global__ __launch_bounds__(256) WGRAD_OCC void wgrad_batch_kernel(const WgradP
     }
   } else {
     switch (P.nks) {
-      case 4: conv_wgrad_body<T, NT, 4, 1>(P.d, P.t, gxi, blk); break;
+      case 4: if constexpr (Elem<T>::SZ == 2) { conv_wgrad_body<T, NT, 4, 1>(P.d, P.t, gxi, blk); } break;
       case 2: conv_wgrad_body<T, NT, 2, 1>(P.d, P.t, gxi, blk); break;
       default: conv_wgrad_body<T, NT, 1, 1>(P.d, P.t, gxi, blk); break;
     }
@@ -1001,6 +1425,19 @@ __global__ __launch_bounds__(512) void wgrad_octo_batch_kernel(const WgradProble
   wgrad_block_of(P.t, (int)blockIdx.x - base, gxi, blk);
   if (P.nb == 6) conv_wgrad_octo_body<4>(P.d, P.t, gxi, blk);
   else conv_wgrad_octo_body<1>(P.d, P.t, gxi, blk);
+}
+
+__global__ __launch_bounds__(512) void wgrad_octo_x3_batch_kernel(const WgradProblem* __restrict__ tab, const int n) {
+  int g = 0, base = 0;
+  for (int i = 0; i < n; ++i) {
+    const int b0 = tab[i].wblk0;
+    if (tab[i].nb >= 3 && (int)blockIdx.x >= b0) { g = i; base = b0; }
+  }
+  const WgradProblem& P = tab[g];
+  int gxi, blk;
+  wgrad_block_of(P.t, (int)blockIdx.x - base, gxi, blk);
+  if (P.nks == 4) conv_wgrad_octo_x3_body<4>(P.d, P.t, gxi, blk);
+  else conv_wgrad_octo_x3_body<2>(P.d, P.t, gxi, blk);
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProblem* __restrict__ tab, const BatchHdr h) {
@@ -1052,9 +1489,11 @@ static int wgrad_check(const hrp_wgrad_desc* d) {
 template <typename T, int NT>
 static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget, int octo = 0) {
   if (octo) {
-    const int rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256);
+    int rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256);
+    P.nks = 4;
+    if (rc != HRP_OK && d.dtype == HRP_F32X3) { rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256, 2); P.nks = 2; }
     if (rc != HRP_OK) return rc;
-    P.nb = 2 + octo; P.nks = 0; P.nte = NT;
+    P.nb = 2 + octo; P.nte = NT;
     P.pairs = P.t.n_cob * P.t.n_cib;
     P.fold_pairs = (d.Cout / 32) * (d.Cin / 32); P.fold_n_cib = d.Cin / 32; P.fold_nb = 1;
     P.fd_r = make_fastdiv(P.nte * 4);
@@ -1072,7 +1511,7 @@ static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget, 
     rc = wgrad_tiling<T, NT, 1>(d, P.t, budget);
   }
   if (rc != HRP_OK) return rc;
-  P.nks = Elem<T>::SZ == 2 ? P.t.BM / 64 : 0;
+  P.nks = std::is_same<T, float>::value ? 0 : P.t.BM / 64;
   P.nte = NT * P.nb * P.nb;
   P.pairs = P.t.n_cob * P.t.n_cib;
   P.fold_pairs = P.pairs; P.fold_n_cib = P.t.n_cib; P.fold_nb = P.nb;
@@ -1089,7 +1528,7 @@ static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProbl
     memset(&probs[i], 0, sizeof(WgradProblem));
     probs[i].d = descs[i];
     octo[i] = 0;
-    if constexpr (std::is_same<T, bf16_t>::value && NT == 9) {
+    if constexpr (!std::is_same<T, float>::value && NT == 9) {
       octo[i] = octo_pairs(descs[i]);
       if (octo[i] && wgrad_plan_one<T, NT>(descs[i], probs[i], 0, octo[i]) != HRP_OK) octo[i] = 0;
     }
@@ -1176,12 +1615,13 @@ static int wgrad_batch_launch_nt(const WgradProblem* tab, const hrp_batch_info* 
     rc = check_launch("wgrad_batch_kernel");
   }
   if (rc == HRP_OK && info->grid3 > 0) {
+    void (*okern)(const WgradProblem*, const int) = std::is_same<T, f32x3_t>::value ? wgrad_octo_x3_batch_kernel : wgrad_octo_batch_kernel;
     static bool octo_attr = false;
     if (!octo_attr) {
-      (void)hipFuncSetAttribute((const void*)wgrad_octo_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)okern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       octo_attr = true;
     }
-    hipLaunchKernelGGL(wgrad_octo_batch_kernel, dim3(info->grid3), dim3(512), info->lds_bytes3, s, tab, info->n);
+    hipLaunchKernelGGL(okern, dim3(info->grid3), dim3(512), info->lds_bytes3, s, tab, info->n);
     rc = check_launch("wgrad_octo_batch_kernel");
   }
   if (rc != HRP_OK || info->grid2 == 0) return rc;

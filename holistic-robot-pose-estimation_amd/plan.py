@@ -238,9 +238,9 @@ class Launch:
         d = self.desc
         if BATCH_FAMILIES is not None and self.fam not in BATCH_FAMILIES:
             return None
-        esz = 4 if d.dtype == nv.HRP_F32 else 2
+        esz = 2 if d.dtype == nv.HRP_BF16 else 4
         if self.fam == "conv":
-            if d.ntaps not in (1, 2, 4, 9) or (d.Cin * esz) % 32 or (d.dtype == nv.HRP_F32 and d.H == 1 and d.W == 1 and d.Cin >= 512):
+            if d.ntaps not in (1, 2, 4, 9) or (d.Cin * esz) % 32 or (d.dtype != nv.HRP_BF16 and d.H == 1 and d.W == 1 and d.Cin >= 512):
                 return None
             if d.ntaps == 1 and nv.lib().hrp_conv_pointwise(C.byref(d)):
                 return None      # the pointwise kernel (csrc/conv_pw.h) exists as a single launch only
@@ -812,13 +812,14 @@ class Plan:
                 continue
             j, ce = cands[0]
             d = ce.op.desc
-            esz = 4 if d.dtype == nv.HRP_F32 else 2
+            esz = 2 if d.dtype == nv.HRP_BF16 else 4
             vec = 16 // esz
+            ddt = nv.HRP_F32 if d.dtype == nv.HRP_F32X3 else d.dtype      # (fp32x3 convolutions read and write fp32 tensors)
             if j > i or ce.lane != e.lane or ce.path != e.path:
                 continue
             if d.res or d.relu or d.bias or d.scale or d.stats or d.out_stride != 1 or (d.y_H, d.y_W) != (d.Ho, d.Wo) or d.pro_mode or d.bnb_x:
                 continue
-            if (d.N, d.Ho, d.Wo, d.Cout, d.y_pitch, d.dtype) != (b.N, b.H, b.W, b.C, b.dout_pitch, b.dtype) or d.Cout % vec:
+            if (d.N, d.Ho, d.Wo, d.Cout, d.y_pitch, ddt) != (b.N, b.H, b.W, b.C, b.dout_pitch, b.dtype) or d.Cout % vec:
                 continue
             if d.y % 16 or (d.y_pitch * esz) % 16 or b.inp.ptr % 16 or (b.inp.pitch * esz) % 16:
                 continue

@@ -11,12 +11,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _problem(nv, N, H, W, cin, cout, seed):
+def _problem(nv, N, H, W, cin, cout, seed, x3=False):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    x = (torch.randn(N, H, W, cin, generator=g)).to(torch.bfloat16).to(DEV).contiguous()
-    dy = (torch.randn(N, H, W, cout, generator=g) / 8).to(torch.bfloat16).to(DEV).contiguous()
+    dt = torch.float32 if x3 else torch.bfloat16
+    x = (torch.randn(N, H, W, cin, generator=g)).to(dt).to(DEV).contiguous()
+    dy = (torch.randn(N, H, W, cout, generator=g) / 8).to(dt).to(DEV).contiguous()
     d = nv.WgradDesc()
-    d.x, d.dy, d.dtype = x.data_ptr(), dy.data_ptr(), nv.HRP_BF16
+    d.x, d.dy, d.dtype = x.data_ptr(), dy.data_ptr(), nv.HRP_F32X3 if x3 else nv.HRP_BF16
     d.N, d.H, d.W, d.Cin, d.x_pitch = N, H, W, cin, cin
     d.Ho, d.Wo, d.Cout, d.dy_pitch = H, W, cout, cout
     d.in_stride, d.ntaps = 1, 9
@@ -45,11 +46,14 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["bf16", "fp32x3"])
 @pytest.mark.parametrize("phase", [0, 1])
-def test_eight_wave_program_in_a_mixed_batch(phase):
+def test_eight_wave_program_in_a_mixed_batch(phase, x3):
+    """bf16: exact products, fp32 accumulation.  fp32x3 (fp32 tensors, three bf16 products per term; its eight-wave program takes
+    the multiples of 64 channels, 128- or 64-pixel tiles): 2^-16 per product."""
     from hrpe_amd import _native as nv
     L = nv.lib()
-    probs = [_problem(nv, *s, seed=70 + i) for i, s in enumerate(SHAPES)]
+    probs = [_problem(nv, *s, seed=70 + i, x3=x3) for i, s in enumerate(SHAPES)]
     n = len(probs)
     arr = (nv.WgradDesc * n)(*[p[0] for p in probs])
     dws = []

@@ -891,9 +891,9 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
 // images per tile would need 164 KB).
 constexpr int OCTO3_MAXP_X = 7, OCTO3_MAXP_DY = 4;
 
-template <int NKS>
+template <int NT, int NKS>
 __device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
-  constexpr int NT = 9, SZ = 4, VEC = 4, P2 = 64, NVEC = 16;   // RAW pixel row: 64 fp32 = 16 vectors of 16 bytes
+  constexpr int SZ = 4, VEC = 4, P2 = 64, NVEC = 16;   // RAW pixel row: 64 fp32 = 16 vectors of 16 bytes
   constexpr int BM = 2 * NKS * 16;
   constexpr int MAXP_X = OCTO3_MAXP_X, MAXP_DY = OCTO3_MAXP_DY;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d,
     }
     const char* lds_x = pl + pci * xps;
     const char* lds_dy = pl + 4 * xps + pco * dps;
-    constexpr int D = 2, TOT = NKS * NT;
+    constexpr int TOT = NKS * NT, D = TOT >= 2 ? 2 : 1;
     bf16x8 ah[2], al[2], bh[D + 1], bl[D + 1];
     auto tr2 = [&](const char* p0, const char* p1) {
       bf16x4 lo = WG<bf16_t>::tr(p0), hi = WG<bf16_t>::tr(p1);
@@ -1255,9 +1255,10 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
 
 // Eight-wave program (conv_wgrad_octo_body): 0 = not eligible, else PAIRS.  Depends on the layer only, never on the workspace.
 static int octo_pairs(const hrp_wgrad_desc& d) {
-  if (d.dtype == HRP_F32 || d.ntaps != 9 || d.in_stride != 1) return 0;
-  if (d.dw_cin != d.Cin || d.Ho != d.H || d.Wo != d.W) return 0;
-  for (int i = 0; i < 9; ++i)
+  if (d.dtype == HRP_F32 || d.in_stride != 1) return 0;
+  if (d.ntaps != 9 && !(d.ntaps == 1 && d.dtype == HRP_F32X3 && d.dy_t[0] == 0 && d.dx_t[0] == 0)) return 0;   // (bf16 1x1: NB = 2)
+  if (d.dw_cin != d.Cin || d.Ho != d.H || d.Wo != d.W || d.dw_tap_stride != 0) return 0;
+  for (int i = 0; i < d.ntaps; ++i)
     if (d.dy_t[i] < -1 || d.dy_t[i] > 1 || d.dx_t[i] < -1 || d.dx_t[i] > 1) return 0;
   if (d.Cout == 32 && d.Cin == 32) return d.dtype == HRP_BF16 ? 1 : 0;      // (fp32x3: the four-wave program)
   return (d.Cout % 64 == 0 && d.Cin % 64 == 0) ? 4 : 0;
@@ -1266,13 +1267,14 @@ static int octo_pairs(const hrp_wgrad_desc& d) {
 static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_w, int wg_budget, int nks = 4) {
   const bool x3 = d.dtype == HRP_F32X3;
   const int npl = pairs_w == 4 ? 2 : 1, BM = nks * 16 * (8 / pairs_w);
-  t.mindy = -1; t.mindx = -1;
+  const int halo = d.ntaps == 1 ? 0 : 1;
+  t.mindy = -halo; t.mindx = -halo;
   int TW = 1; while (TW < d.Wo && TW < 16) TW <<= 1;
   int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
   int TI = BM / (TW * TH);
   if (TI > d.N) TI = d.N;
   t.TW = TW; t.TH = TH; t.TI = TI; t.BM = BM;
-  t.IHt = TH + 2; t.IWt = TW + 2;
+  t.IHt = TH + 2 * halo; t.IWt = TW + 2 * halo;
   t.in_pix = TI * t.IHt * t.IWt;
   if (x3) {        // RAW fp32 tile: 64 channels = 256 bytes per pixel; the planes take the same bytes again
     if (pairs_w != 4) return HRP_ERR_ARG;
@@ -1285,12 +1287,12 @@ static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_
   }
   t.buf_bytes = (t.x_pieces + t.dy_pieces) * 1024;
   t.lds_tab_off = 0; t.lds_red_off = 0;
-  const int red_bytes = 8 * 9 * 512 * 4;
+  const int red_bytes = 8 * d.ntaps * 512 * 4;
   t.lds_bytes = 2 * t.buf_bytes > red_bytes ? 2 * t.buf_bytes : red_bytes;
   if (t.lds_bytes > 160 * 1024) return HRP_ERR_ARG;
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.ntiles = t.tiles_x * t.tiles_y * t.tiles_n;
-  if ((t.tiles_y >= 2 && (t.tiles_y - 2) * TH - 1 + t.IHt - 1 >= d.H) || (t.tiles_x >= 2 && (t.tiles_x - 2) * TW - 1 + t.IWt - 1 >= d.W))
+  if ((t.tiles_y >= 2 && (t.tiles_y - 2) * TH - halo + t.IHt - 1 >= d.H) || (t.tiles_x >= 2 && (t.tiles_x - 2) * TW - halo + t.IWt - 1 >= d.W))
     return HRP_ERR_ARG;
   t.n_cob = d.Cout / (32 * npl); t.n_cib = d.Cin / (32 * npl);
   const int pairs = t.n_cob * t.n_cib;
@@ -1427,6 +1429,7 @@ __global__ __launch_bounds__(512) void wgrad_octo_batch_kernel(const WgradProble
   else conv_wgrad_octo_body<1>(P.d, P.t, gxi, blk);
 }
 
+template <int NT>
 __global__ __launch_bounds__(512) void wgrad_octo_x3_batch_kernel(const WgradProblem* __restrict__ tab, const int n) {
   int g = 0, base = 0;
   for (int i = 0; i < n; ++i) {
@@ -1436,8 +1439,8 @@ __global__ __launch_bounds__(512) void wgrad_octo_x3_batch_kernel(const WgradPro
   const WgradProblem& P = tab[g];
   int gxi, blk;
   wgrad_block_of(P.t, (int)blockIdx.x - base, gxi, blk);
-  if (P.nks == 4) conv_wgrad_octo_x3_body<4>(P.d, P.t, gxi, blk);
-  else conv_wgrad_octo_x3_body<2>(P.d, P.t, gxi, blk);
+  if (P.nks == 4) conv_wgrad_octo_x3_body<NT, 4>(P.d, P.t, gxi, blk);
+  else conv_wgrad_octo_x3_body<NT, 2>(P.d, P.t, gxi, blk);
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProblem* __restrict__ tab, const BatchHdr h) {
@@ -1528,7 +1531,7 @@ static int wgrad_batch_prepare_nt(const hrp_wgrad_desc* descs, int n, WgradProbl
     memset(&probs[i], 0, sizeof(WgradProblem));
     probs[i].d = descs[i];
     octo[i] = 0;
-    if constexpr (!std::is_same<T, float>::value && NT == 9) {
+    if constexpr (!std::is_same<T, float>::value && (NT == 9 || (NT == 1 && std::is_same<T, f32x3_t>::value))) {
       octo[i] = octo_pairs(descs[i]);
       if (octo[i] && wgrad_plan_one<T, NT>(descs[i], probs[i], 0, octo[i]) != HRP_OK) octo[i] = 0;
     }
@@ -1615,7 +1618,7 @@ static int wgrad_batch_launch_nt(const WgradProblem* tab, const hrp_batch_info* 
     rc = check_launch("wgrad_batch_kernel");
   }
   if (rc == HRP_OK && info->grid3 > 0) {
-    void (*okern)(const WgradProblem*, const int) = std::is_same<T, f32x3_t>::value ? wgrad_octo_x3_batch_kernel : wgrad_octo_batch_kernel;
+    void (*okern)(const WgradProblem*, const int) = std::is_same<T, f32x3_t>::value ? wgrad_octo_x3_batch_kernel<(NT == 1 ? 1 : 9)> : wgrad_octo_batch_kernel;
     static bool octo_attr = false;
     if (!octo_attr) {
       (void)hipFuncSetAttribute((const void*)okern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _problem(nv, N, H, W, cin, cout, seed, x3=False):
+def _problem(nv, N, H, W, cin, cout, seed, x3=False, k=3):
     g = torch.Generator(device="cpu").manual_seed(seed)
     dt = torch.float32 if x3 else torch.bfloat16
     x = (torch.randn(N, H, W, cin, generator=g)).to(dt).to(DEV).contiguous()
@@ -20,17 +20,17 @@ def _problem(nv, N, H, W, cin, cout, seed, x3=False):
     d.x, d.dy, d.dtype = x.data_ptr(), dy.data_ptr(), nv.HRP_F32X3 if x3 else nv.HRP_BF16
     d.N, d.H, d.W, d.Cin, d.x_pitch = N, H, W, cin, cin
     d.Ho, d.Wo, d.Cout, d.dy_pitch = H, W, cout, cout
-    d.in_stride, d.ntaps = 1, 9
-    for i, (a, b) in enumerate([(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]):
+    d.in_stride, d.ntaps = 1, k * k
+    for i, (a, b) in enumerate([(ky - k // 2, kx - k // 2) for ky in range(k) for kx in range(k)]):
         d.dy_t[i], d.dx_t[i] = a, b
     d.dw_cin = cin
     return d, x, dy
 
 
-def _reference(x, dy, cin, cout):
+def _reference(x, dy, cin, cout, k=3):
     xr = x.double().permute(0, 3, 1, 2)
     gr = dy.double().permute(0, 3, 1, 2)
-    return torch.nn.grad.conv2d_weight(xr, (cout, cin, 3, 3), gr, padding=1).reshape(cout, cin, 9)
+    return torch.nn.grad.conv2d_weight(xr, (cout, cin, k, k), gr, padding=k // 2).reshape(cout, cin, k * k)
 
 
 SHAPES = [
@@ -119,3 +119,36 @@ def test_eight_wave_program_alone_accumulates():
         ref = _reference(x, dy, d.Cin, d.Cout).to(DEV) + 0.5
         err = float((dw.view(d.Cout, d.Cin, 9).double() - ref).abs().max() / ref.abs().max())
         assert err < 2e-5, err
+
+
+def test_eight_wave_program_fp32x3_pointwise_layers():
+    """The 1x1 layers of an fp32x3 plan (the Bottleneck convolutions of layer1, 256 <-> 64 channels at 64 x 64: 1 KB of x per
+    pixel) run the eight-wave program without a halo."""
+    from hrpe_amd import _native as nv
+    L = nv.lib()
+    shapes = [(4, 32, 32, 256, 64), (3, 16, 16, 64, 256), (2, 20, 12, 128, 128), (2, 16, 16, 32, 64)]
+    probs = [_problem(nv, *s, seed=120 + i, x3=True, k=1) for i, s in enumerate(shapes)]
+    n = len(probs)
+    arr = (nv.WgradDesc * n)(*[p[0] for p in probs])
+    dws = []
+    for d in arr:
+        d.phase, d.accumulate = 0, 0
+        dws.append(torch.full((d.Cout * d.dw_cin,), 3.0, device=DEV))
+        d.dw = dws[-1].data_ptr()
+    info = nv.BatchInfo()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, None, C.byref(info)), "query")
+    wss = []
+    for i, d in enumerate(arr):
+        ws = torch.zeros(int(info.ws_bytes[i]) // 4 + 4, device=DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(info.ws_bytes[i])
+        wss.append(ws)
+    host = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD, n)))()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, host, C.byref(info)), "prepare")
+    assert info.grid3 > 0 and info.grid > 0
+    tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+    nv.check(L.hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+    torch.cuda.synchronize()
+    for (d, x, dy), dw, s in zip(probs, dws, shapes):
+        ref = _reference(x, dy, s[3], s[4], k=1).to(DEV)
+        err = float((dw.view(s[4], s[3], 1).double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, f"{s}: {err:.2e}"

@@ -43,8 +43,7 @@ int conv_check(const hrp_conv_desc* d) {
 }  // namespace hrp
 
 extern "C" int hrp_conv_rowstrip_channels(const hrp_conv_desc* d) {
-  static const bool off = getenv("HRP_NO_ROWCONV") != nullptr;     // A/B switch: everything on the general tile program
-  return (d && !off) ? hrp::row_channels(*d) : 0;
+  return d ? hrp::row_channels(*d) : 0;
 }
 
 extern "C" int hrp_conv_pointwise(const hrp_conv_desc* d) {

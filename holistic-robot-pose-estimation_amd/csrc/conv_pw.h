@@ -35,10 +35,9 @@ struct PwPlan {
 
 // Host: is this problem one the pointwise kernel takes?  -> 1 and the plan, else 0.
 static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
-  const bool off = getenv("HRP_NO_PWCONV") != nullptr;          // (read per call: tests lower the threshold for small problems)
-  const char* mp = getenv("HRP_PW_MIN_PIXELS");
-  const long min_px = mp ? atol(mp) : PW_MIN_PIXELS;
-  if (off || d.dtype != HRP_BF16 || d.ntaps != 1 || d.in_stride != 1 || d.out_stride != 1) return 0;
+  const char* mp = getenv("HRP_PW_MIN_PIXELS");                 // (read per call: tests lower the threshold for small problems, or raise
+  const long min_px = mp ? atol(mp) : PW_MIN_PIXELS;            // it beyond every problem to compare with the general tile program)
+  if (d.dtype != HRP_BF16 || d.ntaps != 1 || d.in_stride != 1 || d.out_stride != 1) return 0;
   if (d.dy[0] != 0 || d.dx[0] != 0 || d.H != d.Ho || d.W != d.Wo || d.y_H != d.Ho || d.y_W != d.Wo || d.out_off_y || d.out_off_x) return 0;
   if (d.Cin != 32 && d.Cin != 64 && d.Cin != 128 && d.Cin != 256) return 0;
   if (d.Cout % 32 || d.Cout > 1024 || d.w_cout_pad < d.Cout || d.x_pitch != d.Cin || d.y_pitch != d.Cout) return 0;

@@ -117,8 +117,8 @@ static inline void row_plan(const hrp_conv_desc& d, RowPlan& rp) {
   rp.img = 0;
   // persistent workgroups of the 32 / 64-channel kernel: 2 strips each once the problem has more strips than the chip
   // has workgroup slots for it (B = 64: 512 / 256 strips -> 256 / 128 workgroups)
-  static const int spw_env = getenv("HRP_ROWCONV_SPW") ? atoi(getenv("HRP_ROWCONV_SPW")) : 0;
-  rp.spw = spw_env > 0 ? spw_env : (rp.nstrips >= 256 ? 2 : 1);
+  // (one strip per workgroup at B = 64: conv family -0.6 ms one by one, nothing in the step - DESIGN 5, round 5)
+  rp.spw = rp.nstrips >= 256 ? 2 : 1;
   if (rp.spi % rp.spw || d.Cin != 32) rp.spw = 1;       // (the 64-channel kernel keeps its weights in registers: one strip)
   static const bool no_img = false;
   if (!no_img && (d.Cin == 128 || d.Cin == 256) && d.H == d.W) {

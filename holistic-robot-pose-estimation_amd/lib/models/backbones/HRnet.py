@@ -22,7 +22,7 @@ HEAD_FP32 = os.environ.get("HRP_HEAD_FP32", "0") not in ("0", "")
 # measurement switch (DESIGN 4, bf16 key-point 0): from which stage on a FEATURE-ONLY trunk (the DepthNet) computes in fp32 - "" (bf16
 # throughout), "4" or "3": the branch tensors entering that stage are cast and everything behind runs on the fp32 kernels; "1": the
 # whole trunk from its input image on (full_net.py creates that input as an fp32 tensor)
-TRUNK_FP32_FROM = os.environ.get("HRP_DEPTHNET_FP32_FROM", "")
+TRUNK_FP32_FROM = ""      # (a module constant: measurement tools set it before the plan is built)
 logger = logging.getLogger(__name__)
 
 

@@ -92,11 +92,15 @@ def test_pwconv_plain_statistics_and_eval_epilogue(shape):
     # the tile program on the same problem
     y2 = torch.zeros_like(y)
     d.y = y2.data_ptr()
-    os.environ["HRP_NO_PWCONV"] = "1"
+    keep = os.environ.get("HRP_PW_MIN_PIXELS")
+    os.environ["HRP_PW_MIN_PIXELS"] = str(2 ** 31 - 1)       # beyond every problem: the general tile program
     try:
         run(nv, d, expect_pw=False)
     finally:
-        del os.environ["HRP_NO_PWCONV"]
+        if keep is None:
+            del os.environ["HRP_PW_MIN_PIXELS"]
+        else:
+            os.environ["HRP_PW_MIN_PIXELS"] = keep
     assert torch.equal(y, y2)
     # eval epilogue
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3

@@ -54,7 +54,7 @@ if __name__ == "__main__":
         os.environ["HRP_PW_MIN_PIXELS"] = "1"
         assert nv.lib().hrp_conv_pointwise(C.byref(d)) == 1
         t_pw = bk.timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d), None))
-        os.environ["HRP_NO_PWCONV"] = "1"
+        os.environ["HRP_PW_MIN_PIXELS"] = str(2 ** 31 - 1)
         t_tile = bk.timeit(lambda: nv.call("hrp_conv2d_fwd", C.byref(d), None))
-        del os.environ["HRP_NO_PWCONV"]
+        os.environ["HRP_PW_MIN_PIXELS"] = "1"
         print(f"{cin:4d} -> {cout:4d} @ {hw:2d}x{hw:2d} x{B} [{kind:3s}]  pointwise {t_pw:7.1f} us {by / t_pw / 1e3:6.0f} GB/s   tile {t_tile:7.1f} us {by / t_tile / 1e3:6.0f} GB/s")

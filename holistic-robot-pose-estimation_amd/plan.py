@@ -153,7 +153,10 @@ WGRAD_FOLD_EVERY = 32
 # weight gradients feed nothing before the optimizer: the launches of a lane are held back until WGRAD_SINK problems of one
 # tap count are pending (or the lane ends) and then run as ONE batched launch - also the layers that have no lock-step
 # partner (stem, layer1, transitions, the fuse convolutions).  0: every launch stays where the layer's backward put it.
-WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "8"))
+# 16 since round 5: a launch writes one set of partial slabs per workgroup whatever it computes, so half as many launches of
+# twice the problems write (and the folds read) half the slab bytes - 35.17 -> 34.52 ms per step (8 / 12 / 16 / 20 / 24 / 32:
+# 35.9 / 35.9 / 35.4 / 35.3* / 35.5 / 35.6 on one box, * 35.3 against 34.5 for 16 on another)
+WGRAD_SINK = int(os.environ.get("HRP_WGRAD_SINK", "16"))
 # train-mode BasicBlock interiors conv -> BN -> ReLU -> conv on the row-strip kernel (csrc/conv_row.h): the BatchNorm + ReLU
 # runs in the second convolution's staging path, its backward in the staging path of the first convolution's data gradient
 # stride-2 data gradients: parity classes padded to 4 taps (PlanBuilder._conv_bwd)

@@ -169,6 +169,9 @@ BLOCK_FUSE = os.environ.get("HRP_BLOCK_FUSE", "1") not in ("0", "")      # fused
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
 MASKED_RES = True
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
+# lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
+# instead of by position: 646 -> 628 conv launches, 34.12 -> 33.87 ms per step (A/B/A/B on one box)
+GREEDY_MERGE = True
 # development aid (set by tests / tools): batch only these families ({"conv", "wgrad", "ew_fwd", "ew_red", "ew_app"})
 BATCH_FAMILIES = None
 # The switches above without an environment variable are module constants: tests and tools patch them (plan.X = ...) before a
@@ -741,7 +744,41 @@ class Plan:
         def key_of(op):
             return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, BlockLaunch)) else None
 
+        def emit_groups(groups, out):
+            for key, ops in groups.items():
+                if key[0] == "block":
+                    out += _pair_block(self, ops)
+                else:
+                    out += ops if len(ops) == 1 else _merge_ops(self, ops)
+
+        def greedy(kids):
+            """Lanes whose launch sequences differ (the paths of a fuse layer): instead of position k of every lane, take the
+            HEADS of all lanes, send the unbatchable ones out, then the largest group of equal merge key; the other lanes wait
+            for partners.  Any interleaving that keeps each lane's own order is valid."""
+            out, ptr = [], [0] * len(kids)
+            while True:
+                heads = [(i, kids[i][ptr[i]]) for i in range(len(kids)) if ptr[i] < len(kids[i])]
+                if not heads:
+                    return out
+                groups, moved = collections.OrderedDict(), False
+                for i, op in heads:
+                    key = key_of(op)
+                    if key is None:
+                        out.append(op)
+                        ptr[i] += 1
+                        moved = True
+                    else:
+                        groups.setdefault(key, []).append((i, op))
+                if moved:
+                    continue
+                key = max(groups, key=lambda k: len(groups[k]))
+                emit_groups({key: [op for _, op in groups[key]]}, out)
+                for i, _ in groups[key]:
+                    ptr[i] += 1
+
         def lockstep(kids):
+            if GREEDY_MERGE and len({tuple(key_of(op) for op in x) for x in kids}) > 1:
+                return greedy(kids)
             out = []
             for k in range(max(len(x) for x in kids)):
                 groups = collections.OrderedDict()

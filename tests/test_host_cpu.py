@@ -359,9 +359,22 @@ def test_plan_lockstep_merge_into_batched_launches():
     P.PLAN_MODE = "merged"          # every block virtual: one stream
     flat = [e.op for e in pl._flatten(pl.fwd)]
     kinds = [type(op).__name__ if not callable(op) or isinstance(op, (P.Launch, P.BatchLaunch)) else "fn" for op in flat]
-    assert kinds == ["fn", "BatchLaunch", "fn", "fn", "fn", "Launch", "BatchLaunch", "BatchLaunch", "Launch"], kinds
+    # (the lanes' sequences differ - lane 2 has the nested block -, so they merge by their heads: the largest group first)
+    assert kinds == ["fn", "BatchLaunch", "fn", "fn", "fn", "BatchLaunch", "Launch", "BatchLaunch", "Launch"], kinds
     assert [len(op.items) for op in flat if isinstance(op, P.BatchLaunch)] == [3, 2, 2]
-    assert flat[5].desc.ntaps == 9 and {it.desc.ntaps for it in flat[6].items} == {1}
+    assert flat[6].desc.ntaps == 9 and {it.desc.ntaps for it in flat[5].items} == {1}
+    # lanes whose sequences are offset against each other find their partners: [3x3, 1x1] next to [1x1] is two launches
+    # (by position it would be three)
+    pl3 = P.Plan(torch.device("cpu"), torch.bfloat16, True, True)
+    pb3 = P.PlanBuilder(pl3)
+    with pb3.parallel(2, virtual=True) as par:
+        with par.lane(0):
+            pl3.fwd.append(P.Launch("conv", _fake_conv(0x100000)))
+            pl3.fwd.append(P.Launch("conv", _fake_conv(0x200000, ntaps=1)))
+        with par.lane(1):
+            pl3.fwd.append(P.Launch("conv", _fake_conv(0x300000, ntaps=1)))
+    ops3 = [e.op for e in pl3._flatten(pl3.fwd)]
+    assert [type(op).__name__ for op in ops3] == ["Launch", "BatchLaunch"] and ops3[0].desc.ntaps == 9 and len(ops3[1].items) == 2
     # the same output twice at one position: two launches, not one batch
     pl2 = P.Plan(torch.device("cpu"), torch.bfloat16, True, True)
     pb2 = P.PlanBuilder(pl2)

@@ -4,6 +4,7 @@ import collections
 import os
 import sys
 
+os.environ.setdefault("HRP_SERIAL_LANES", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,12 +31,25 @@ if __name__ == "__main__":
     phase = ["fwd"]
     rows = collections.Counter()
 
+    times, nbytes = collections.Counter(), collections.Counter()
+
     def hook(name, args, fn):
         fam, descs = bench.launch_descs(name, args)
-        if fam == "hrp_conv2d_fwd":
-            key = (phase[0], len(descs), tuple(sorted(f"{q.Cin}>{q.Cout} t{q.ntaps} s{q.in_stride}/{q.out_stride} @{q.H}" for q in descs)))
-            rows[key] += 1
+        if fam != "hrp_conv2d_fwd":
+            fn()
+            return
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s = torch.cuda.current_stream()
+        e0.record(s)
         fn()
+        e1.record(s)
+        torch.cuda.synchronize()
+        key = (phase[0], len(descs), tuple(sorted(f"{q.Cin}>{q.Cout} t{q.ntaps} s{q.in_stride}/{q.out_stride} @{q.H}"
+                                                 + (" pro%d" % q.pro_mode if q.pro_mode else "") + (" bnb" if q.bnb_x else "") + (" res" if q.res else "") for q in descs)))
+        rows[key] += 1
+        times[key] += e0.elapsed_time(e1) * 1e3
+        nbytes[key] += bench.conv_bytes(name, args, extended=True)
     nv._profile_hook = hook
     out = model(d["x_reg"], d["x_root"], kv, K)
     loss, _ = full_loss(out, gt, K)
@@ -44,5 +58,7 @@ if __name__ == "__main__":
     nv._profile_hook = None
     tot = sum(rows.values())
     print("conv-family launches per step:", tot)
-    for (ph, n, shapes), c in sorted(rows.items(), key=lambda kv: (-kv[1], kv[0])):
-        print(f"{c:4d} x {ph} [{n} problem(s)] {', '.join(shapes)[:170]}")
+    print(f"one by one (HIP events, serial lanes): {sum(times.values()) / 1e3:.2f} ms, {sum(nbytes.values()) / 1e9:.1f} GB incl. fused operands")
+    for key, c in sorted(rows.items(), key=lambda kv: -times[kv[0]]):
+        ph, n, shapes = key
+        print(f"{c:4d} x {ph} [{n}] {times[key] / c:7.1f} us {nbytes[key] / c / 1e6:7.1f} MB {nbytes[key] / times[key] / 1e6:5.2f} TB/s  {', '.join(shapes)[:150]}")

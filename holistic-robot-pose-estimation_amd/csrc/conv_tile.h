@@ -360,53 +360,101 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
         // fp32 MFMA path spends 8 CT PT instructions of twice the latency on the same products.
         constexpr int SPX = (MAXP_IN + MAXP_W + NT - 1) / NT;
         const int khoff = khalf * t.buf_bytes;
-        struct Raw { uint4 ah[CT], al[CT]; float4 b0[PT], b1[PT]; };
-        auto ldraw = [&](const char* lds_in, int tap, Raw& r) {
-          const char* lds_w = lds_in + t.in_pieces * 1024;
-          const int wr = tap * BN + wrow0;
-#pragma unroll
-          for (int c = 0; c < CT; ++c) { r.ah[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, 0)); r.al[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, 1)); }
+        auto ldpix = [&](const char* lds_in, int tap, float4 (&b0)[PT], float4 (&b1)[PT]) {
 #pragma unroll
           for (int p = 0; p < PT; ++p) {
             const int rr = pixrow[p] + taprow[tap];
-            r.b0[p] = *(const float4*)(lds_in + row_addr(rr, 0));
-            r.b1[p] = *(const float4*)(lds_in + row_addr(rr, 1));
+            b0[p] = *(const float4*)(lds_in + row_addr(rr, 0));
+            b1[p] = *(const float4*)(lds_in + row_addr(rr, 1));
           }
         };
-        for (int g = 0; g < ng; g += 2) {
-          const bool pair = g + 1 < ng;
-          const char* lds_in = sbuf + g * t.buf_bytes + (pair ? khoff : 0);
-          const bool zero_b = !pair && khalf != 0;
-          Raw cur, nxt;
-          ldraw(lds_in, 0, cur);
+        auto issue_next = [&](int gv, int tap, bool both) {      // the pieces of chunk g (and g + 1) of the next stage
+          const int g = __builtin_amdgcn_readfirstlane(gv);      // (uniform; the DMA's LDS base must sit in an SGPR)
+          if (more) {
 #pragma unroll
-          for (int tap = 0; tap < NT; ++tap) {
-            if (tap + 1 < NT) ldraw(lds_in, tap + 1, nxt);
-            uint4 bh[PT], bl[PT];
-#pragma unroll
-            for (int p = 0; p < PT; ++p) {
-              const float x[8] = {cur.b0[p].x, cur.b0[p].y, cur.b0[p].z, cur.b0[p].w, cur.b1[p].x, cur.b1[p].y, cur.b1[p].z, cur.b1[p].w};
-              split_bf16x8(x, bh[p], bl[p]);
-              if (zero_b) bh[p] = bl[p] = make_uint4(0, 0, 0, 0);
+            for (int u = 0; u < SPX; ++u) {
+              if ((st + 1) * G + g < nloc) issue_slot(cbeg + (st + 1) * G + g, nbuf + g * t.buf_bytes, tap * SPX + u);
+              if (both && (st + 1) * G + g + 1 < nloc && g + 1 < G) issue_slot(cbeg + (st + 1) * G + g + 1, nbuf + (g + 1) * t.buf_bytes, tap * SPX + u);
             }
+          }
+        };
+        // (3x3 layers: every chunk on its own - their stages hold one chunk anyway, and the pair form next to the single form in a
+        // nine- or four-tap kernel spills; the 1x1 layers, whose stages hold several chunks, pair them)
+        constexpr bool PAIRS = NT <= 2;
+        for (int g = 0; g < ng; g += PAIRS ? 2 : 1) {
+          if (PAIRS && g + 1 < ng) {
+            // ---- a chunk pair: lane half 0 works on chunk g, half 1 on chunk g + 1; lo*hi, hi*lo, hi*hi per (cout, pixel) tile
+            const char* lds_in = sbuf + g * t.buf_bytes + khoff;
+            const char* lds_w = lds_in + t.in_pieces * 1024;
+            struct Raw { uint4 ah[CT], al[CT]; float4 b0[PT], b1[PT]; };
+            auto ldraw = [&](int tap, Raw& r) {
+              const int wr = tap * BN + wrow0;
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+              for (int c = 0; c < CT; ++c) { r.ah[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, 0)); r.al[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, 1)); }
+              ldpix(lds_in, tap, r.b0, r.b1);
+            };
+            Raw cur, nxt;
+            ldraw(0, cur);
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) {
+              if (tap + 1 < NT) ldraw(tap + 1, nxt);
+              uint4 bh[PT], bl[PT];
 #pragma unroll
               for (int p = 0; p < PT; ++p) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, cur.ah[c]), al = __builtin_bit_cast(bf16x8, cur.al[c]);
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, bh[p]), xl = __builtin_bit_cast(bf16x8, bl[p]);
-                acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[c][p], 0, 0, 0);      // (small terms first)
-                acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[c][p], 0, 0, 0);
-                acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[c][p], 0, 0, 0);
+                const float x[8] = {cur.b0[p].x, cur.b0[p].y, cur.b0[p].z, cur.b0[p].w, cur.b1[p].x, cur.b1[p].y, cur.b1[p].z, cur.b1[p].w};
+                split_bf16x8(x, bh[p], bl[p]);
               }
-            if (more) {
 #pragma unroll
-              for (int u = 0; u < SPX; ++u) {
-                if ((st + 1) * G + g < nloc) issue_slot(cbeg + (st + 1) * G + g, nbuf + g * t.buf_bytes, tap * SPX + u);
-                if ((st + 1) * G + g + 1 < nloc && g + 1 < G) issue_slot(cbeg + (st + 1) * G + g + 1, nbuf + (g + 1) * t.buf_bytes, tap * SPX + u);
-              }
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                  const bf16x8 ah = __builtin_bit_cast(bf16x8, cur.ah[c]), al = __builtin_bit_cast(bf16x8, cur.al[c]);
+                  const bf16x8 xh = __builtin_bit_cast(bf16x8, bh[p]), xl = __builtin_bit_cast(bf16x8, bl[p]);
+                  acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[c][p], 0, 0, 0);      // (small terms first)
+                  acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[c][p], 0, 0, 0);
+                  acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[c][p], 0, 0, 0);
+                }
+              issue_next(g, tap, true);
+              if (tap + 1 < NT) cur = nxt;
             }
-            if (tap + 1 < NT) cur = nxt;
+          } else {
+            // ---- a chunk without a partner (G = 1 - the usual case: fp32 tiles and hi | lo weight rows leave room for one chunk
+            // per stage - or the last of an odd count): the MFMA's K is [w_hi | w_lo] of THIS chunk (one 16-byte read per lane
+            // half), against [x_lo | 0] = w_hi x_lo and against [x_hi | x_hi] = w_hi x_hi + w_lo x_hi: TWO MFMAs per tile (a
+            // zero-padded partner chunk took three, half of each idle)
+            const char* lds_in = sbuf + g * t.buf_bytes;
+            const char* lds_w = lds_in + t.in_pieces * 1024;
+            struct Raw1 { uint4 a[CT]; float4 b0[PT], b1[PT]; };
+            auto ldraw1 = [&](int tap, Raw1& r) {
+              const int wr = tap * BN + wrow0;
+#pragma unroll
+              for (int c = 0; c < CT; ++c) r.a[c] = *(const uint4*)(lds_w + row_addr(wr + c * 32, khalf));
+              ldpix(lds_in, tap, r.b0, r.b1);
+            };
+            Raw1 cur, nxt;
+            ldraw1(0, cur);
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) {
+              if (tap + 1 < NT) ldraw1(tap + 1, nxt);
+              uint4 bh[PT], bl[PT];
+#pragma unroll
+              for (int p = 0; p < PT; ++p) {
+                const float x[8] = {cur.b0[p].x, cur.b0[p].y, cur.b0[p].z, cur.b0[p].w, cur.b1[p].x, cur.b1[p].y, cur.b1[p].z, cur.b1[p].w};
+                split_bf16x8(x, bh[p], bl[p]);
+                if (khalf) bl[p] = make_uint4(0, 0, 0, 0);
+              }
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                  const bf16x8 a = __builtin_bit_cast(bf16x8, cur.a[c]);
+                  const bf16x8 xh = __builtin_bit_cast(bf16x8, bh[p]), xl = __builtin_bit_cast(bf16x8, bl[p]);
+                  acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xl, acc[c][p], 0, 0, 0);
+                  acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xh, acc[c][p], 0, 0, 0);
+                }
+              issue_next(g, tap, PAIRS);
+              if (tap + 1 < NT) cur = nxt;
+            }
           }
         }
       } else {

@@ -223,11 +223,10 @@ class RootNetwithRegInt(PlannedModule):
                 yield
         out["feat"] = pb.avgpool(h)
 
-    def _iter_head(self, pb, xf, init_buf, np_, fc1, fc2, dec, matmul=False):
+    def _iter_head(self, pb, xf, init, np_, fc1, fc2, dec, matmul=False):
         """full_net.py:318-331: p <- p + dec(drop(fc2(drop(fc1([xf; p])))))  x n_iter; matmul (rot_iterative_matmul,
         :346-362): p <- rot6d(R(dec(..)) @ R(p)) instead of the sum."""
-        N = xf.N
-        pred = pb.broadcast_row(init_buf, N, np_)
+        pred = init          # [N, np_] plan input: the module's init buffer expanded, or the caller's per-sample start (full_net.py:245-248)
         for _ in range(self.n_iter):
             xc = pb.cat_cols([xf, pred])
             h = pb.dropout(fc1.emit(pb, xc), self.p_dropout)
@@ -251,7 +250,7 @@ class RootNetwithRegInt(PlannedModule):
             feat = half(pb.conv(f3, self.depth_fc_u1.weight, self.depth_fc_u1.bias, residual=feat))
         return pb.dense(self.depth_layer.emit(pb, feat))
 
-    def _build(self, pb, x_reg, x_root, k_value, K):
+    def _build(self, pb, x_reg, x_root, k_value, K, init_pose, init_rot):
         N = x_reg.shape[0]
         J, root = self.num_joints, self.reference_keypoint_id
         resnet_reg = self.backbone_name in _RESNETS
@@ -265,6 +264,8 @@ class RootNetwithRegInt(PlannedModule):
             xo = (pb.image_input_s2d if resnet_root else pb.image_input)("x_root", N, 3, x_root.shape[2], x_root.shape[3], u8=x_root.dtype == torch.uint8)
         kv = pb.vector_input("k_value", N, 1, dense=True)
         Km = pb.vector_input("K", N, 9, dense=True)
+        ip = None if self.reg_joint_map else pb.vector_input("init_pose", N, self.init_pose.shape[1], dense=True)
+        ir = None if self.direct_reg_rot else pb.vector_input("init_rot", N, self.rotation_dim, dense=True)
         # The trunks share nothing until pose_geometry.  HRNet trunks are emitted in lockstep (emit_trunks: one flat
         # parallel block per step, a lane per branch); a ResNet chain rides along those blocks as one more lane.
         res, rootd = {}, {}
@@ -335,7 +336,7 @@ class RootNetwithRegInt(PlannedModule):
         with (pb.parallel(2) if not self.reg_joint_map else _NoBlock()) as par:
             if not self.reg_joint_map:
                 with par.lane(0):
-                    pose = self._iter_head(pb, xf_pose, self.init_pose, self.init_pose.shape[1], self.fc_pose_1,
+                    pose = self._iter_head(pb, xf_pose, ip, self.init_pose.shape[1], self.fc_pose_1,
                                            self.fc_pose_2, self.decpose)
             with par.lane(1):
                 if self.direct_reg_rot:      # full_net.py:333-345
@@ -345,7 +346,7 @@ class RootNetwithRegInt(PlannedModule):
                         xc = getattr(self, f"fc_rot_{i}").emit(pb, xc)
                     rot = self.decrot.emit(pb, self.fc_rot_6.emit(pb, xc, residual=xc1))
                 else:
-                    rot = self._iter_head(pb, xf_rot, self.init_rot, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
+                    rot = self._iter_head(pb, xf_rot, ir, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
                                           self.decrot, matmul=self.rot_iterative_matmul)
         pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
@@ -354,16 +355,20 @@ class RootNetwithRegInt(PlannedModule):
                 ("dense", xyz_int, (N, J, 3)), ("dense", xyz_fk, (N, J, 3))]
         if depths is not None:      # full_net.py:392-395: the 9-tuple carries pred_depths after pred_depth
             outs.insert(5, ("dense", depths, (N, self.depth_num)))
-        return ["x_reg", "x_root", "k_value", "K"], outs, {"x_reg": xr, "x_root": xo}
+        return ["x_reg", "x_root", "k_value", "K", "init_pose", "init_rot"], outs, {"x_reg": xr, "x_root": xo}
 
     def forward(self, x_reg_input, x_root_input, k_value, K, init_pose=None, init_rot=None, test_fps=False):
-        if init_pose is not None or init_rot is not None:
-            raise NotImplementedError("per-call init_pose / init_rot overrides are not built (no caller uses them)")
         dev = x_reg_input.device
+        B = x_reg_input.shape[0]
+        # full_net.py:245-248: the iterative regressors start from the module's buffers unless the caller brings a start per sample
+        init_pose = (self.init_pose.expand(B, -1) if init_pose is None else init_pose).to(dev).float().reshape(B, -1).contiguous()
+        init_rot = (self.init_rot.expand(B, -1) if init_rot is None else init_rot).to(dev).float().reshape(B, -1).contiguous()
+        if init_pose.shape[1] != self.init_pose.shape[1] or init_rot.shape[1] != self.rotation_dim:
+            raise ValueError(f"init_pose / init_rot must be [B, {self.init_pose.shape[1]}] / [B, {self.rotation_dim}]")
         if test_fps:
             torch.cuda.synchronize(dev)
             t0 = time.time()
-        outs = self._run(x_reg_input, x_root_input, k_value.to(dev).reshape(-1, 1), K.to(dev).reshape(-1, 9))
+        outs = self._run(x_reg_input, x_root_input, k_value.to(dev).reshape(-1, 1), K.to(dev).reshape(-1, 9), init_pose, init_rot)
         if test_fps:
             torch.cuda.synchronize(dev)
             t = time.time() - t0

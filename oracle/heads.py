@@ -108,10 +108,13 @@ def _iter_reg(sd, xf, init, n_iter, fc1, fc2, dec):
 
 def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4, root=3,
                  fix_root=True, image_size=256.0, depth_factor=1.3, reg_backbone="hrnet32", root_backbone="hrnet32",
-                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False, add_fc=False, joint_bounds=None):
+                 direct_reg_rot=False, kps_need_depth=None, rot_iterative_matmul=False, add_fc=False, joint_bounds=None,
+                 init_pose=None, init_rot=None):
     """RootNetwithRegInt.forward with rootnet_backbone_name = 'hrnet32' and backbone_name = 'hrnet32' or a ResNet
     with the deconv head (the shipped full.yaml) (full_net.py:239-397).  Returns the reference's 8-tuple."""
     B = x_reg.shape[0]
+    init_pose = sd["init_pose"].expand(B, -1) if init_pose is None else init_pose     # :245-248
+    init_rot = sd["init_rot"].expand(B, -1) if init_rot is None else init_rot
     if root_backbone.startswith("resnet"):                                            # :262-266
         from .resnet import resnet_forward
         feat_root = resnet_forward(sd, x_root, prefix="rootnet_backbone.",
@@ -157,7 +160,7 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
         jb = torch.as_tensor(joint_bounds, dtype=torch.float32)
         pose = coord * (jb[:, 1] - jb[:, 0]) + jb[:, 0]
     else:
-        pose = _iter_reg(sd, xf, sd["init_pose"].expand(B, -1), n_iter, "fc_pose_1", "fc_pose_2", "decpose")
+        pose = _iter_reg(sd, xf, init_pose, n_iter, "fc_pose_1", "fc_pose_2", "decpose")
     if direct_reg_rot:      # full_net.py:333-345: six stacked Linear layers with one skip, no iteration, no init_rot
         lin = lambda n, v: F.linear(v, sd[n + ".weight"], sd[n + ".bias"])   # noqa: E731
         xc1 = lin("fc_rot_1", xf)
@@ -167,13 +170,13 @@ def full_forward(sd, robot, x_reg, x_root, k_value, K, training=False, n_iter=4,
         rot = lin("decrot", xc + xc1)
     elif rot_iterative_matmul:      # full_net.py:346-362: the decoded 6-vector is composed onto the estimate as a rotation
         from .fk import rot6d_to_rotmat, rotmat_to_rot6d
-        rot = sd["init_rot"].expand(B, -1)
+        rot = init_rot
         for _ in range(n_iter):
             h = F.linear(torch.cat([xf, rot], 1), sd["fc_rot_1.weight"], sd["fc_rot_1.bias"])
             h = F.linear(h, sd["fc_rot_2.weight"], sd["fc_rot_2.bias"])
             rot = rotmat_to_rot6d(rot6d_to_rotmat(F.linear(h, sd["decrot.weight"], sd["decrot.bias"])) @ rot6d_to_rotmat(rot))
     else:
-        rot = _iter_reg(sd, xf, sd["init_rot"].expand(B, -1), n_iter, "fc_rot_1", "fc_rot_2", "decrot")
+        rot = _iter_reg(sd, xf, init_rot, n_iter, "fc_rot_1", "fc_rot_2", "decrot")
     xyz_fk = robot.get_keypoints_root(pose, rot, trans, root=root)                    # :380-383
     if pred_depths is not None:                                                       # :392-393
         return pose, rot, trans, root_uv, pred_depth, pred_depths, uvd, xyz_int, xyz_fk

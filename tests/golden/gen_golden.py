@@ -15,6 +15,7 @@ Fixtures (reference call site that produced each):
   golden_depthnet.npz    RootNet('hrnet32') eval forward, and train-mode L1 loss + grads
                          (lib/models/depth_net.py:92-137, scripts/train_depthnet.py:231-250).
   golden_full_eval.npz   RootNetwithRegInt.forward eval 8-tuple (lib/models/full_net.py:239-397).
+  golden_full_eval_init.npz   the same with per-call init_pose / init_rot (full_net.py:245-248).
   golden_full_eval_fp64.npz   the same call with the reference's arithmetic in float64 (`full_eval_fp64`) + the pixel error of
                          the reference's own fp32 run against it: the noise floor the HIP fp32 path is held to.
   golden_full_eval_baxter.npz   the same for robot_type = "baxter" (15 DoF, 17 key-points), `full_eval_baxter`.
@@ -452,6 +453,24 @@ def gen_full_eval_fp64():
     np.savez_compressed(os.path.join(HERE, "golden_full_eval_fp64.npz"), **out)
     print("full eval fp64 ok: reference fp32 vs fp64 px err per key-point", px.numpy().round(5).tolist())
     print("   rel err of the 8-tuple:", dict(zip(NAMES8, out["ref_fp32_rel_err"].round(9).tolist())))
+
+
+def gen_full_eval_init():
+    """forward(..., init_pose=, init_rot=) (full_net.py:239, 245-248): the iterative regressors start from a per-sample pose /
+    rotation the caller brings instead of the module's buffers."""
+    full, _ = build_full()
+    full.eval()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    g = torch.Generator().manual_seed(77)
+    init_pose = (torch.rand(2, full.init_pose.shape[1], generator=g) - 0.5) * 2.0
+    a = torch.randn(2, 3, 3, generator=g)
+    q, _ = torch.linalg.qr(a)
+    init_rot = torch.cat([q[:, :, 0], q[:, :, 1]], dim=1)           # rot6d: the first two columns
+    with torch.no_grad():
+        o = full(x_reg, x_root, kv, K, init_pose=init_pose, init_rot=init_rot)
+    np.savez_compressed(os.path.join(HERE, "golden_full_eval_init.npz"), init_pose=init_pose.numpy(), init_rot=init_rot.numpy(),
+                        **{n: t.numpy() for n, t in zip(NAMES8, o)})
+    print("full eval (per-call init) ok", o[0][0, :3])
 
 
 def gen_full_eval_direct_rot():

@@ -439,6 +439,27 @@ def test_full_eval_golden():
     assert px < 2e-2, px
 
 
+def test_full_eval_per_call_init_golden():
+    """forward(x_reg, x_root, k_value, K, init_pose=, init_rot=) (reference full_net.py:239, 245-248): the iterative regressors
+    start from the caller's per-sample pose / rotation; the fixture was written by the imported reference.  Passing the module's own
+    buffers, expanded, is the default call bit for bit."""
+    g = load("golden_full_eval_init.npz")
+    m = build_full().eval()
+    x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
+    with torch.no_grad():
+        out = m(x_reg, x_root, kv, K, init_pose=torch.tensor(g["init_pose"]), init_rot=torch.tensor(g["init_rot"]).to(DEV))
+        base = m(x_reg, x_root, kv, K)
+        same = m(x_reg, x_root, kv, K, init_pose=m.init_pose.expand(2, -1), init_rot=m.init_rot.expand(2, -1))
+    for n, t in zip(NAMES8, out):
+        ref = g[n]
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 3e-4, f"{n}: rel err {err}"
+    assert all(torch.equal(a, b) for a, b in zip(base, same))
+    assert (out[0] - base[0]).abs().max().item() > 1e-3
+    with pytest.raises(ValueError):
+        m(x_reg, x_root, kv, K, init_pose=torch.zeros(2, 3))
+
+
 def test_full_eval_baxter_golden():
     """robot_type = 'baxter' (reference full_net.py:48-50): 15 DoF / 17 key-points -> 1088-channel heat-map head,
     17-joint soft-argmax, 2063-wide pose regressor and the tree FK with key-point offsets."""

@@ -291,6 +291,18 @@ def test_full_eval_golden(robot):
         np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
 
 
+def test_full_eval_per_call_init_golden(robot):
+    """forward(..., init_pose=, init_rot=) of the reference (full_net.py:239, 245-248; fixture written by the imported reference)."""
+    g = load("golden_full_eval_init.npz")
+    sd = full_sd()
+    x_reg, x_root, kv, K = synth_inputs(2)
+    with torch.no_grad():
+        out = heads.full_forward(sd, robot, x_reg, x_root, kv, K, init_pose=torch.tensor(g["init_pose"]), init_rot=torch.tensor(g["init_rot"]))
+    for n, t in zip(NAMES8, out):
+        np.testing.assert_allclose(t.numpy(), g[n], atol=1e-5, rtol=1e-5, err_msg=n)
+    assert np.abs(g["pose"] - load("golden_full_eval.npz")["pose"]).max() > 1e-3      # (the start matters)
+
+
 def test_full_eval_direct_rot_golden(robot):
     """direct_reg_rot = True (full_net.py:105-127, 333-345)."""
     g = load("golden_full_eval_direct_rot.npz")

@@ -85,3 +85,38 @@ def test_x3_full_network_meets_the_pixel_bar_on_every_keypoint():
     print("\n", {k: v for k, v in r.items() if "vs_fp64" in k})
     assert r["fp32x3_vs_fp64"] < 0.1, r
     assert r["fp32_vs_fp64"] < 0.01, r
+
+
+def test_x3_training_step_matches_the_reference_at_fp32_tolerances():
+    """The reference's training step at B = 8 (golden_full_train_b8.npz, written by the imported reference) in fp32x3, held to the
+    bounds the fp32 path is held to (tests/test_gpu_parity.py::test_full_train_step_golden_b8): forward 8-tuple 5e-4, loss terms
+    1e-3, loss 5e-4 - and the sampled gradients of every parameter tensor at 4e-2 in l2 (fp32: 1.5e-2; the bf16 path is gated at 0.3
+    on uvd and at a cosine of 0.65 on the trunk's gradients)."""
+    from hrpe_amd.lib.core.function import full_loss
+    from test_gpu_model import NAMES8, build_full, load, summary_check
+    from test_gpu_parity import _sampled_grad_errors, _train_step_inputs
+    g = load("golden_full_train_b8.npz")
+    m = build_full().set_compute_dtype("fp32x3").train()
+    x_reg, x_root, kv, K, gt = _train_step_inputs(g, m, 8)
+    pred = m(x_reg, x_root, kv, K)
+    for n, p in zip(NAMES8, pred):
+        ref = g["fwd:" + n]
+        err = np.abs(p.detach().cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 5e-4, f"train fwd {n}: rel err {err}"
+    loss, terms = full_loss(pred, gt, K)
+    for k, v in terms.items():
+        np.testing.assert_allclose(v.item(), g["term:" + k], rtol=1e-3, atol=1e-8, err_msg=k)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=5e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    errs = _sampled_grad_errors(g, params)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])
+    print("\nB=8 fp32x3 gradient l2 err, worst first:", {k: f"{v:.2e}" for k, v in worst[:6]}, "median", float(np.median(list(errs.values()))))
+    # fp32 is gated at 1.5e-2 (measured 5e-3 .. 9e-3, 1.0e-2 .. 1.6e-2 on the two deepest tensors).  fp32x3 measured: median 2.7e-4,
+    # six tensors between 1.6e-2 and 2.6e-2 (the stems' first convolutions - the end of a 330-layer backward chain -, one BatchNorm
+    # weight of stage 2, three early trunk convolutions): gate 4e-2 on every tensor (the bf16 trunk: cosine >= 0.65)
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":val"):
+            name = key.split(":")[1]
+            tol = 4e-2
+            summary_check(params[name].grad, g, f"grad:{name}:", tol, what="full B=8 fp32x3 ")

@@ -353,11 +353,12 @@ __device__ __forceinline__ void conv_tile_body(const hrp_conv_desc& d, const Con
       // this one, SPP slots per step): issued in one burst a full memory queue stalls the wave for ~2 us.
       const int ng = nloc - st * G < G ? nloc - st * G : G;
       if constexpr (std::is_same<T, f32x3_t>::value) {
-        // ---- fp32 tensors, 3 x bf16 products.  One v_mfma_f32_32x32x16_bf16 takes 16 K values, 8 per lane half: half 0 brings
-        // the 8 channels of chunk g, half 1 those of chunk g + 1 (an odd last chunk: zeros).  Weight rows arrive PRE-SPLIT from
-        // hrp_pack_weights (logical half 0 = 8 hi, half 1 = 8 lo); the pixels' 8 floats are split here (24 VALU per fragment, under
-        // the 3 CT MFMAs it feeds).  Per (chunk pair, tap): CT weight fragment pairs, PT pixel fragments, 3 CT PT MFMAs - the
-        // fp32 MFMA path spends 8 CT PT instructions of twice the latency on the same products.
+        // ---- fp32 tensors, 3 x bf16 products.  One v_mfma_f32_32x32x16_bf16 takes 16 K values, 8 per lane half.  Weight rows
+        // arrive PRE-SPLIT from hrp_pack_weights (logical half 0 = 8 hi, half 1 = 8 lo); the pixels' 8 floats are split here (24
+        // VALU per fragment, under the MFMAs it feeds).  Two forms: a chunk PAIR (1x1 layers, whose stages hold several 8-channel
+        // chunks: lane half 0 works on chunk g, half 1 on chunk g + 1, three MFMAs per 16 channels) and a SINGLE chunk (the 3x3
+        // layers, whose stages hold one chunk: two MFMAs per 8 channels, below).  The fp32 MFMA path spends 8 CT PT instructions of
+        // twice the latency on the products of one chunk.
         constexpr int SPX = (MAXP_IN + MAXP_W + NT - 1) / NT;
         const int khoff = khalf * t.buf_bytes;
         auto ldpix = [&](const char* lds_in, int tap, float4 (&b0)[PT], float4 (&b1)[PT]) {

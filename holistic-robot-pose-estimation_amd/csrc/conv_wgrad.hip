@@ -101,11 +101,6 @@ struct WG<float> {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
 };
-template <>
-struct WG<f32x3_t> {       // HRP_F32X3: fp32 tiles in LDS, 16 pixels per k-step as three bf16 MFMAs on split operands
-  static constexpr int K = 16;
-  using Frag = float;
-};
 
 __device__ uint4 g_wg_zero_page[4];  // 64 zero bytes: DMA source of padding / out-of-range rows
 

@@ -2474,13 +2474,6 @@ class PlanBuilder:
             self.bwd_stack.append(bw)
         return out
 
-    def broadcast_row(self, src_tensor, N, Cc):
-        """[1, C] torch buffer -> [N, C] plan tensor (no gradient)."""
-        p = self.plan
-        out = p.new(N, 1, 1, Cc, torch.float32)
-        p.fwd.append(lambda s: nv.call("hrp_copy_cols", src_tensor.data_ptr(), 0, out.ptr(), out.pitch, N, Cc, 0, s))
-        return out
-
     def dense(self, x):
         """fp32 copy with pitch == C (layout the head kernels expect)."""
         p = self.plan

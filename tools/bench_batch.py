@@ -21,6 +21,7 @@ from hrpe_amd import _native as nv  # noqa: E402
 DEV = bk.DEV
 CLASSES = [(32, 64), (64, 32), (128, 16), (256, 8)]
 KIND = "plain"
+X3 = False
 
 
 def mk_conv(N, hw, c, dtype, stats=True, k=3):
@@ -141,6 +142,10 @@ def wgrad_batch(N, nets, branches, dtype):
             g = nv.WgradDesc()
             dw = torch.zeros(c, c, 9, device=DEV)
             g.x, g.dy, g.dw, g.dtype = d.x, d.y, dw.data_ptr(), d.dtype
+            if X3:      # fp32 tensors, three bf16 products (HRP_F32X3)
+                xf, yf = torch.randn(N * hw * hw * c, device=DEV), torch.randn(N * hw * hw * c, device=DEV)
+                bufs = bufs + (xf, yf)
+                g.x, g.dy, g.dtype = xf.data_ptr(), yf.data_ptr(), nv.HRP_F32X3
             g.N, g.H, g.W, g.Cin, g.x_pitch = N, hw, hw, c, c
             g.Ho, g.Wo, g.Cout, g.dy_pitch = hw, hw, c, c
             g.in_stride, g.ntaps = 1, 9
@@ -194,8 +199,10 @@ if __name__ == "__main__":
     ap.add_argument("--nets", type=int, default=2)
     ap.add_argument("--branches", type=int, default=4)
     ap.add_argument("--kind", default="plain", choices=["plain", "pro1", "g2", "g1", "g2e", "g1e"])
+    ap.add_argument("--x3", action="store_true", help="weight gradients in the fp32x3 mode")
     a = ap.parse_args()
     KIND = a.kind
+    X3 = a.x3
     dt = torch.bfloat16
     if a.what in ("conv", "all"):
         conv_batch(a.batch, a.nets, a.branches, dt)

@@ -25,7 +25,14 @@ if __name__ == "__main__":
         kp3d, kp2d = model.robot.get_keypoints_and_projection(d["q"], rot6, d["t"], K, root=0)
     gt = dict(pose=d["q"], root_rot=model.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3), root_trans=kp3d[:, 3].clone(),
               root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7, device=dev))
+    EVAL = "--eval" in sys.argv
+    if EVAL:
+        model.eval()
     for _ in range(2):
+        if EVAL:
+            with torch.no_grad():
+                model(d["x_reg"], d["x_root"], kv, K)
+            continue
         loss, _ = full_loss(model(d["x_reg"], d["x_root"], kv, K), gt, K)
         loss.backward()
     phase = ["fwd"]
@@ -35,7 +42,7 @@ if __name__ == "__main__":
 
     def hook(name, args, fn):
         fam, descs = bench.launch_descs(name, args)
-        if fam != "hrp_conv2d_fwd":
+        if fam not in ("hrp_conv2d_fwd", "hrp_block_launch"):
             fn()
             return
         torch.cuda.synchronize()
@@ -45,16 +52,23 @@ if __name__ == "__main__":
         fn()
         e1.record(s)
         torch.cuda.synchronize()
-        key = (phase[0], len(descs), tuple(sorted(f"{q.Cin}>{q.Cout} t{q.ntaps} s{q.in_stride}/{q.out_stride} @{q.H}"
-                                                 + (" pro%d" % q.pro_mode if q.pro_mode else "") + (" bnb" if q.bnb_x else "") + (" res" if q.res else "") for q in descs)))
+        if fam == "hrp_block_launch":      # fused inference BasicBlocks (hrp_block_desc: conv1, conv2)
+            key = (phase[0], len(descs), tuple(sorted(f"block {q.conv1.Cin} @{q.conv1.H}" for q in descs)))
+        else:
+            key = (phase[0], len(descs), tuple(sorted(f"{q.Cin}>{q.Cout} t{q.ntaps} s{q.in_stride}/{q.out_stride} @{q.H}"
+                                                     + (" pro%d" % q.pro_mode if q.pro_mode else "") + (" bnb" if q.bnb_x else "") + (" res" if q.res else "") for q in descs)))
         rows[key] += 1
         times[key] += e0.elapsed_time(e1) * 1e3
         nbytes[key] += bench.conv_bytes(name, args, extended=True)
     nv._profile_hook = hook
-    out = model(d["x_reg"], d["x_root"], kv, K)
-    loss, _ = full_loss(out, gt, K)
-    phase[0] = "bwd"
-    loss.backward()
+    if EVAL:
+        with torch.no_grad():
+            model(d["x_reg"], d["x_root"], kv, K)
+    else:
+        out = model(d["x_reg"], d["x_root"], kv, K)
+        loss, _ = full_loss(out, gt, K)
+        phase[0] = "bwd"
+        loss.backward()
     nv._profile_hook = None
     tot = sum(rows.values())
     print("conv-family launches per step:", tot)

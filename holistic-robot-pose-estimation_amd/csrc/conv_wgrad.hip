@@ -676,17 +676,20 @@ __global__ __launch_bounds__(256) WGRAD_OCC void conv_wgrad_kernel(const hrp_wgr
 //   PAIRS = 4:  a 64 x 64 block = 2 x 2 (cout, cin) pairs x 2 pixel slices, 128-pixel tiles: every staged byte feeds twice
 //               the MFMAs (the slices are staged (n_cob + n_cib) / 4 times), slab bytes per wave x 2;
 //   PAIRS = 1:  one 32 x 32 pair x 8 pixel slices, 512-pixel tiles (the 32-channel layers): slab bytes per wave / 2.
+// Stride-2 layers with multiples of 64 channels (fuse-layer down paths, transitions, the cls head's downsamp_modules) run
+// PAIRS = 4 on 64-pixel tiles (NKS = 2: the input halo of a 128-pixel tile does not fit): the four-wave program staged a 22 KB
+// tile per nine MFMAs of a wave there; step 34.65 -> 34.15 ms.
 // LDS: the X halo tile and the dY tile as 32-channel planes laid out exactly like the tiles of conv_wgrad_body (64-byte pixel
 // rows: the transpose reads stay conflict free), double buffered.  The partial sums leave in the 32 x 32 slab layout, so the
 // folding launches do not change.
 constexpr int OCTO_MAXP_X = 5, OCTO_MAXP_DY = 4;
 
-template <int PAIRS>
+template <int PAIRS, int NKS = 4>
 __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, const WgradTiling& t, const int gxi, const int blk) {
   using T = bf16_t;
-  constexpr int NT = 9, SZ = 2, VEC = 8, P = 64, NVEC = 4, NKS = 4;
-  constexpr int KSL = 8 / PAIRS;               // pixel slices of 64 pixels per tile
-  constexpr int BM = 64 * KSL;
+  constexpr int NT = 9, SZ = 2, VEC = 8, P = 64, NVEC = 4;
+  constexpr int KSL = 8 / PAIRS;               // pixel slices of 16 NKS pixels per tile (NKS = 2: the 64-pixel tiles of stride-2 layers)
+  constexpr int BM = 16 * NKS * KSL;
   constexpr int NPL = PAIRS == 4 ? 2 : 1;      // 32-channel planes per operand
   constexpr int DPP = BM / 16;                 // 1 KiB pieces per dY plane
   constexpr int MAXP_X = OCTO_MAXP_X, MAXP_DY = OCTO_MAXP_DY;
@@ -700,6 +703,7 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
   const int cobw = fdiv(blk, t.fd_cib), cibw = blk - cobw * t.n_cib;
   const int co0 = cobw * (32 * NPL), ci0 = cibw * (32 * NPL);
   const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
+  const int IS = d.in_stride;
   const int xpp = NPL == 2 ? t.x_pieces >> 1 : t.x_pieces;      // 1 KiB pieces per X plane
 
   f32x16 acc[NT];
@@ -722,7 +726,7 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
   int xrel[MAXP_X], xcode[MAXP_X], dyrel[MAXP_DY], dycode[MAXP_DY];
   {
     const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
-    const int iy_last = y_last + t.mindy, ix_last = x_last + t.mindx;
+    const int iy_last = y_last * IS + t.mindy, ix_last = x_last * IS + t.mindx;
 #pragma unroll
     for (int i = 0; i < MAXP_X; ++i) {
       xcode[i] = 32; xrel[i] = 0;
@@ -768,7 +772,7 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
     const int tn_i = fdiv(q, t.fd_ty);
     const int ty_i = q - tn_i * t.tiles_y;
     const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
-    const int iy0 = oy0 + t.mindy, ix0 = ox0 + t.mindx;
+    const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
     TileCtx c;
     c.cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
             (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
@@ -803,11 +807,11 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
       int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
       int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
       if (ti >= t.TI) ti = t.TI - 1;       // idle slot (its dY row is zero)
-      return mul24(mul24(mul24(ti, t.IHt) + ty, t.IWt) + tx, P) + tr_coff;
+      return mul24(mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS), P) + tr_coff;
     };
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      const int m0 = ksl * 64 + ks * 16 + 8 * khalf + tr_pix;
+      const int m0 = ksl * (16 * NKS) + ks * 16 + 8 * khalf + tr_pix;
       xo0[ks] = xoff(m0); xo1[ks] = xoff(m0 + 4);
       ao[ks] = m0 * P + tr_coff;
     }
@@ -822,8 +826,8 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
     TileCtx nx{};
     if (more) nx = tile_ctx(tile + t.G, smem + ((it + 1) & 1) * t.buf_bytes);
     // the wave program of conv_wgrad_body (NB = 1): flattened MFMA sequence q = ks * 9 + tap, X fragments D steps ahead, the dY
-    // fragment of the next k-step at the first tap; one DMA piece of the next tile every fourth step
-    constexpr int D = 4, TOT = NKS * NT;
+    // fragment of the next k-step at the first tap; one DMA piece of the next tile every fourth (second) step
+    constexpr int D = 4, TOT = NKS * NT, STRIDE = TOT / (MAXP_X + MAXP_DY);
     bf16x8 a[2], b[D + 1];
     auto load_a = [&](int ks, bf16x8& f) {
       bf16x4 lo = WG<T>::tr(lds_dy + ao[ks]), hi = WG<T>::tr(lds_dy + ao[ks] + 4 * P);
@@ -843,7 +847,7 @@ __device__ __forceinline__ void conv_wgrad_octo_body(const hrp_wgrad_desc& d, co
       if (tp == 0 && ks + 1 < NKS) load_a(ks + 1, a[(ks + 1) & 1]);
       if (q + D < TOT) load_b(q + D, b[(q + D) % (D + 1)]);
       WG<T>::mma(a[ks & 1], b[q % (D + 1)], acc[tp]);
-      if (more && q % 4 == 0) issue_slot(nx, q / 4);
+      if (more && q % STRIDE == 0) issue_slot(nx, q / STRIDE);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1250,12 +1254,12 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
 
 // Eight-wave program (conv_wgrad_octo_body): 0 = not eligible, else PAIRS.  Depends on the layer only, never on the workspace.
 static int octo_pairs(const hrp_wgrad_desc& d) {
-  if (d.dtype == HRP_F32 || d.in_stride != 1) return 0;
+  if (d.dtype == HRP_F32 || (d.in_stride != 1 && !(d.in_stride == 2 && d.dtype == HRP_BF16 && d.ntaps == 9))) return 0;
   if (d.ntaps != 9 && !(d.ntaps == 1 && d.dtype == HRP_F32X3 && d.dy_t[0] == 0 && d.dx_t[0] == 0)) return 0;   // (bf16 1x1: NB = 2)
-  if (d.dw_cin != d.Cin || d.Ho != d.H || d.Wo != d.W || d.dw_tap_stride != 0) return 0;
+  if (d.dw_cin != d.Cin || d.Ho * d.in_stride != d.H || d.Wo * d.in_stride != d.W || d.dw_tap_stride != 0) return 0;
   for (int i = 0; i < d.ntaps; ++i)
     if (d.dy_t[i] < -1 || d.dy_t[i] > 1 || d.dx_t[i] < -1 || d.dx_t[i] > 1) return 0;
-  if (d.Cout == 32 && d.Cin == 32) return d.dtype == HRP_BF16 ? 1 : 0;      // (fp32x3: the four-wave program)
+  if (d.Cout == 32 && d.Cin == 32) return d.dtype == HRP_BF16 && d.in_stride == 1 ? 1 : 0;      // (fp32x3, stride 2: the four-wave program)
   return (d.Cout % 64 == 0 && d.Cin % 64 == 0) ? 4 : 0;
 }
 
@@ -1268,8 +1272,9 @@ static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_
   int TH = 1; while (TH < d.Ho && TH * TW < BM) TH <<= 1;
   int TI = BM / (TW * TH);
   if (TI > d.N) TI = d.N;
+  const int IS = d.in_stride;
   t.TW = TW; t.TH = TH; t.TI = TI; t.BM = BM;
-  t.IHt = TH + 2 * halo; t.IWt = TW + 2 * halo;
+  t.IHt = (TH - 1) * IS + 1 + 2 * halo; t.IWt = (TW - 1) * IS + 1 + 2 * halo;
   t.in_pix = TI * t.IHt * t.IWt;
   if (x3) {        // RAW fp32 tile: 64 channels = 256 bytes per pixel; the planes take the same bytes again
     if (pairs_w != 4) return HRP_ERR_ARG;
@@ -1287,7 +1292,8 @@ static int wgrad_tiling_octo(const hrp_wgrad_desc& d, WgradTiling& t, int pairs_
   if (t.lds_bytes > 160 * 1024) return HRP_ERR_ARG;
   t.tiles_x = cdiv(d.Wo, TW); t.tiles_y = cdiv(d.Ho, TH); t.tiles_n = cdiv(d.N, TI);
   t.ntiles = t.tiles_x * t.tiles_y * t.tiles_n;
-  if ((t.tiles_y >= 2 && (t.tiles_y - 2) * TH - halo + t.IHt - 1 >= d.H) || (t.tiles_x >= 2 && (t.tiles_x - 2) * TW - halo + t.IWt - 1 >= d.W))
+  if ((t.tiles_y >= 2 && (TH * IS - halo < 0 || (t.tiles_y - 2) * TH * IS - halo + t.IHt - 1 >= d.H)) ||
+      (t.tiles_x >= 2 && (TW * IS - halo < 0 || (t.tiles_x - 2) * TW * IS - halo + t.IWt - 1 >= d.W)))
     return HRP_ERR_ARG;
   t.n_cob = d.Cout / (32 * npl); t.n_cib = d.Cin / (32 * npl);
   const int pairs = t.n_cob * t.n_cib;
@@ -1420,7 +1426,8 @@ __global__ __launch_bounds__(512) void wgrad_octo_batch_kernel(const WgradProble
   const WgradProblem& P = tab[g];
   int gxi, blk;
   wgrad_block_of(P.t, (int)blockIdx.x - base, gxi, blk);
-  if (P.nb == 6) conv_wgrad_octo_body<4>(P.d, P.t, gxi, blk);
+  if (P.nb == 6 && P.nks == 2) conv_wgrad_octo_body<4, 2>(P.d, P.t, gxi, blk);
+  else if (P.nb == 6) conv_wgrad_octo_body<4>(P.d, P.t, gxi, blk);
   else conv_wgrad_octo_body<1>(P.d, P.t, gxi, blk);
 }
 
@@ -1489,7 +1496,7 @@ static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget, 
   if (octo) {
     int rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256);
     P.nks = 4;
-    if (rc != HRP_OK && d.dtype == HRP_F32X3) { rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256, 2); P.nks = 2; }
+    if (rc != HRP_OK && (d.dtype == HRP_F32X3 || (d.in_stride == 2 && octo == 4))) { rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256, 2); P.nks = 2; }
     if (rc != HRP_OK) return rc;
     P.nb = 2 + octo; P.nte = NT;
     P.pairs = P.t.n_cob * P.t.n_cib;

@@ -11,26 +11,27 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _problem(nv, N, H, W, cin, cout, seed, x3=False, k=3):
+def _problem(nv, N, H, W, cin, cout, seed, x3=False, k=3, stride=1):
+    """H x W: the OUTPUT map (dY); the input is stride times as large"""
     g = torch.Generator(device="cpu").manual_seed(seed)
     dt = torch.float32 if x3 else torch.bfloat16
-    x = (torch.randn(N, H, W, cin, generator=g)).to(dt).to(DEV).contiguous()
+    x = (torch.randn(N, H * stride, W * stride, cin, generator=g)).to(dt).to(DEV).contiguous()
     dy = (torch.randn(N, H, W, cout, generator=g) / 8).to(dt).to(DEV).contiguous()
     d = nv.WgradDesc()
     d.x, d.dy, d.dtype = x.data_ptr(), dy.data_ptr(), nv.HRP_F32X3 if x3 else nv.HRP_BF16
-    d.N, d.H, d.W, d.Cin, d.x_pitch = N, H, W, cin, cin
+    d.N, d.H, d.W, d.Cin, d.x_pitch = N, H * stride, W * stride, cin, cin
     d.Ho, d.Wo, d.Cout, d.dy_pitch = H, W, cout, cout
-    d.in_stride, d.ntaps = 1, k * k
+    d.in_stride, d.ntaps = stride, k * k
     for i, (a, b) in enumerate([(ky - k // 2, kx - k // 2) for ky in range(k) for kx in range(k)]):
         d.dy_t[i], d.dx_t[i] = a, b
     d.dw_cin = cin
     return d, x, dy
 
 
-def _reference(x, dy, cin, cout, k=3):
+def _reference(x, dy, cin, cout, k=3, stride=1):
     xr = x.double().permute(0, 3, 1, 2)
     gr = dy.double().permute(0, 3, 1, 2)
-    return torch.nn.grad.conv2d_weight(xr, (cout, cin, k, k), gr, padding=k // 2).reshape(cout, cin, k * k)
+    return torch.nn.grad.conv2d_weight(xr, (cout, cin, k, k), gr, stride=stride, padding=k // 2).reshape(cout, cin, k * k)
 
 
 SHAPES = [
@@ -151,4 +152,47 @@ def test_eight_wave_program_fp32x3_pointwise_layers():
     for (d, x, dy), dw, s in zip(probs, dws, shapes):
         ref = _reference(x, dy, s[3], s[4], k=1).to(DEV)
         err = float((dw.view(s[4], s[3], 1).double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, f"{s}: {err:.2e}"
+
+
+@pytest.mark.parametrize("phase", [0, 1])
+def test_eight_wave_program_stride_2_layers(phase):
+    """The stride-2 3x3 layers (fuse-layer down paths, transitions, the cls head's downsamp_modules: reference HRnet.py:195-235,
+    383-405) with multiples of 64 channels run the 64 x 64 arrangement on 64-pixel tiles (the halo of a 128-pixel tile does not fit);
+    32 -> 64 and odd shapes keep the four-wave program."""
+    from hrpe_amd import _native as nv
+    L = nv.lib()
+    shapes = [(3, 16, 16, 128, 256), (4, 8, 8, 256, 512), (2, 32, 32, 64, 64), (3, 12, 20, 64, 128), (2, 16, 16, 32, 64)]
+    probs = [_problem(nv, *s, seed=140 + i, stride=2) for i, s in enumerate(shapes)]
+    n = len(probs)
+    arr = (nv.WgradDesc * n)(*[p[0] for p in probs])
+    dws = []
+    for d in arr:
+        d.phase, d.accumulate = phase, 0
+        dws.append(torch.full((d.Cout * d.dw_cin * 9,), 3.0, device=DEV))
+        d.dw = dws[-1].data_ptr()
+    info = nv.BatchInfo()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, None, C.byref(info)), "query")
+    wss = []
+    for i, d in enumerate(arr):
+        ws = torch.zeros(int(info.ws_bytes[i]) // 4 + 4, device=DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(info.ws_bytes[i])
+        wss.append(ws)
+    host = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD, n)))()
+    nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD, arr, n, host, C.byref(info)), "prepare")
+    assert info.grid3 > 0 and info.grid > 0
+    tab = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(DEV)
+    nv.check(L.hrp_batch_launch(tab.data_ptr(), C.byref(info), None), "launch")
+    if phase == 1:
+        folds = (nv.WgradFoldDesc * n)()
+        nv.check(L.hrp_batch_wgrad_fold_descs(host, C.byref(info), folds), "fold descs")
+        finfo = nv.BatchInfo()
+        fhost = (C.c_char * int(L.hrp_batch_table_bytes(nv.BATCH_WGRAD_FOLD, n)))()
+        nv.check(L.hrp_batch_prepare(nv.BATCH_WGRAD_FOLD, folds, n, fhost, C.byref(finfo)), "fold prepare")
+        ftab = torch.frombuffer(bytearray(bytes(fhost)), dtype=torch.uint8).to(DEV)
+        nv.check(L.hrp_batch_launch(ftab.data_ptr(), C.byref(finfo), None), "fold launch")
+    torch.cuda.synchronize()
+    for (d, x, dy), dw, s in zip(probs, dws, shapes):
+        ref = _reference(x, dy, s[3], s[4], stride=2).to(DEV)
+        err = float((dw.view(s[4], s[3], 9).double() - ref).abs().max() / ref.abs().max())
         assert err < 2e-5, f"{s}: {err:.2e}"

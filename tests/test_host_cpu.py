@@ -580,8 +580,13 @@ def test_batch_prepare_is_host_only():
     # 32-channel problem writes one slab per eight waves, the 128-channel problem four per eight waves
     assert info.grid == 0 and 0 < info.grid3 <= 256 and info.lds_bytes3 <= 160 * 1024 and info.grid2 > 0
     assert 0 < info.ws_bytes[0] <= single[0] and 0 < info.ws_bytes[1] <= 2 * single[1]
-    # a stride-2 layer in the same batch keeps the 32 x 32 program and its launch
+    # a stride-2 layer with multiples of 64 channels runs the eight-wave program too (64-pixel tiles) ...
     gs[1].in_stride, gs[1].H, gs[1].W = 2, 32, 32
+    arr = (nv.WgradDesc * 2)(*gs)
+    assert lib.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, None, C.byref(info)) == 0, lib.hrp_last_error()
+    assert info.grid == 0 and 0 < info.grid3 <= 256
+    # ... one that brings 32 input channels keeps the 32 x 32 program and its launch
+    gs[1].Cin = gs[1].x_pitch = gs[1].dw_cin = 32
     arr = (nv.WgradDesc * 2)(*gs)
     assert lib.hrp_batch_prepare(nv.BATCH_WGRAD, arr, 2, None, C.byref(info)) == 0, lib.hrp_last_error()
     assert 0 < info.grid <= 512 and 0 < info.grid3 <= 256

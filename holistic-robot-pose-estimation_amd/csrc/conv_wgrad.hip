@@ -904,6 +904,7 @@ __device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d,
   const int cobw = fdiv(blk, t.fd_cib), cibw = blk - cobw * t.n_cib;
   const int co0 = cobw * 64, ci0 = cibw * 64;
   const int thw = t.TH * t.TW, ihw = t.IHt * t.IWt;
+  const int IS = d.in_stride;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -924,7 +925,7 @@ __device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d,
   int xrel[MAXP_X], xcode[MAXP_X], dyrel[MAXP_DY], dycode[MAXP_DY];
   {
     const int y_last = (t.tiles_y - 1) * t.TH, x_last = (t.tiles_x - 1) * t.TW, n_last = (t.tiles_n - 1) * t.TI;
-    const int iy_last = y_last + t.mindy, ix_last = x_last + t.mindx;
+    const int iy_last = y_last * IS + t.mindy, ix_last = x_last * IS + t.mindx;
 #pragma unroll
     for (int i = 0; i < MAXP_X; ++i) {
       xcode[i] = 32; xrel[i] = 0;
@@ -966,7 +967,7 @@ __device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d,
     const int tn_i = fdiv(q, t.fd_ty);
     const int ty_i = q - tn_i * t.tiles_y;
     const int n0 = tn_i * t.TI, oy0 = ty_i * t.TH, ox0 = tx_i * t.TW;
-    const int iy0 = oy0 + t.mindy, ix0 = ox0 + t.mindx;
+    const int iy0 = oy0 * IS + t.mindy, ix0 = ox0 * IS + t.mindx;
     TileCtx c;
     c.cls = 32 | (ty_i == 0 ? 1 : 0) | (ty_i == t.tiles_y - 1 ? 2 : 0) | (tx_i == 0 ? 4 : 0) |
             (tx_i == t.tiles_x - 1 ? 8 : 0) | (tn_i == t.tiles_n - 1 ? 16 : 0);
@@ -1001,7 +1002,7 @@ __device__ __forceinline__ void conv_wgrad_octo_x3_body(const hrp_wgrad_desc& d,
       int ti = fdiv16(m, t.fd_thw), rem = m - mul24(ti, thw);
       int ty = fdiv16(rem, t.fd_tw), tx = rem - mul24(ty, t.TW);
       if (ti >= t.TI) ti = t.TI - 1;
-      return mul24(mul24(mul24(ti, t.IHt) + ty, t.IWt) + tx, P2) + tr_coff;
+      return mul24(mul24(mul24(ti, t.IHt) + mul24(ty, IS), t.IWt) + mul24(tx, IS), P2) + tr_coff;
     };
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -1254,7 +1255,7 @@ static int wgrad_tiling(const hrp_wgrad_desc& d, WgradTiling& t, int wg_budget =
 
 // Eight-wave program (conv_wgrad_octo_body): 0 = not eligible, else PAIRS.  Depends on the layer only, never on the workspace.
 static int octo_pairs(const hrp_wgrad_desc& d) {
-  if (d.dtype == HRP_F32 || (d.in_stride != 1 && !(d.in_stride == 2 && d.dtype == HRP_BF16 && d.ntaps == 9))) return 0;
+  if (d.dtype == HRP_F32 || (d.in_stride != 1 && !(d.in_stride == 2 && d.ntaps == 9))) return 0;
   if (d.ntaps != 9 && !(d.ntaps == 1 && d.dtype == HRP_F32X3 && d.dy_t[0] == 0 && d.dx_t[0] == 0)) return 0;   // (bf16 1x1: NB = 2)
   if (d.dw_cin != d.Cin || d.Ho * d.in_stride != d.H || d.Wo * d.in_stride != d.W || d.dw_tap_stride != 0) return 0;
   for (int i = 0; i < d.ntaps; ++i)
@@ -1442,7 +1443,8 @@ __global__ __launch_bounds__(512) void wgrad_octo_x3_batch_kernel(const WgradPro
   int gxi, blk;
   wgrad_block_of(P.t, (int)blockIdx.x - base, gxi, blk);
   if (P.nks == 4) conv_wgrad_octo_x3_body<NT, 4>(P.d, P.t, gxi, blk);
-  else conv_wgrad_octo_x3_body<NT, 2>(P.d, P.t, gxi, blk);
+  else if (P.nks == 2) conv_wgrad_octo_x3_body<NT, 2>(P.d, P.t, gxi, blk);
+  else if constexpr (NT == 9) conv_wgrad_octo_x3_body<NT, 1>(P.d, P.t, gxi, blk);     // (stride-2 layers: 32-pixel tiles)
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradProblem* __restrict__ tab, const BatchHdr h) {
@@ -1497,6 +1499,7 @@ static int wgrad_plan_one(const hrp_wgrad_desc& d, WgradProblem& P, int budget, 
     int rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256);
     P.nks = 4;
     if (rc != HRP_OK && (d.dtype == HRP_F32X3 || (d.in_stride == 2 && octo == 4))) { rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256, 2); P.nks = 2; }
+    if (rc != HRP_OK && d.dtype == HRP_F32X3 && d.in_stride == 2) { rc = wgrad_tiling_octo(d, P.t, octo, budget > 0 ? budget : 256, 1); P.nks = 1; }
     if (rc != HRP_OK) return rc;
     P.nb = 2 + octo; P.nte = NT;
     P.pairs = P.t.n_cob * P.t.n_cib;

@@ -155,15 +155,16 @@ def test_eight_wave_program_fp32x3_pointwise_layers():
         assert err < 2e-5, f"{s}: {err:.2e}"
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["bf16", "fp32x3"])
 @pytest.mark.parametrize("phase", [0, 1])
-def test_eight_wave_program_stride_2_layers(phase):
+def test_eight_wave_program_stride_2_layers(phase, x3):
     """The stride-2 3x3 layers (fuse-layer down paths, transitions, the cls head's downsamp_modules: reference HRnet.py:195-235,
     383-405) with multiples of 64 channels run the 64 x 64 arrangement on 64-pixel tiles (the halo of a 128-pixel tile does not fit);
-    32 -> 64 and odd shapes keep the four-wave program."""
+    32 -> 64 and odd shapes keep the four-wave program.  fp32x3: 32-pixel tiles (RAW tile + planes)."""
     from hrpe_amd import _native as nv
     L = nv.lib()
     shapes = [(3, 16, 16, 128, 256), (4, 8, 8, 256, 512), (2, 32, 32, 64, 64), (3, 12, 20, 64, 128), (2, 16, 16, 32, 64)]
-    probs = [_problem(nv, *s, seed=140 + i, stride=2) for i, s in enumerate(shapes)]
+    probs = [_problem(nv, *s, seed=140 + i, stride=2, x3=x3) for i, s in enumerate(shapes)]
     n = len(probs)
     arr = (nv.WgradDesc * n)(*[p[0] for p in probs])
     dws = []

@@ -157,6 +157,29 @@ class OptChunk(C.Structure):
     _fields_ = [("tensor", C.c_int32), ("offset", C.c_int32)]
 
 
+class RegStepDesc(C.Structure):
+    """hrp_regressor_step_desc (include/hrp.h): one step of one iterative regressor."""
+    _fields_ = [("M", C.c_int32), ("P", C.c_int32), ("K", C.c_int32), ("N", C.c_int32),
+                ("u_prev", C.c_void_p), ("u_bias", C.c_void_p), ("z", C.c_void_p), ("zw", C.c_void_p),
+                ("z_len", C.c_int32), ("z_pitch", C.c_int32), ("zw_sk", C.c_int32), ("zw_sp", C.c_int32),
+                ("u_out", C.c_void_p), ("a", C.c_void_p), ("a_mask", C.c_void_p), ("v", C.c_void_p),
+                ("a_pitch", C.c_int32), ("v_sk", C.c_int32), ("v_sp", C.c_int32), ("a2_pitch", C.c_int32),
+                ("a_out", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out_mask", C.c_void_p),
+                ("a2", C.c_void_p), ("w2", C.c_void_p), ("w_sn", C.c_int64), ("w_sk", C.c_int64),
+                ("out_pitch", C.c_int32), ("out_accumulate", C.c_int32), ("out_sum_accumulate", C.c_int32), ("w2_sk", C.c_int32),
+                ("out", C.c_void_p), ("out_sum", C.c_void_p)]
+
+
+class LinWgradDesc(C.Structure):
+    """hrp_linear_wgrad_desc (include/hrp.h)."""
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
+                ("x_pitch", C.c_int32), ("dy_pitch", C.c_int32), ("dw_ld", C.c_int32), ("M", C.c_int32),
+                ("K", C.c_int32), ("N", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
+REG_MAX_P, REG_MAX_PROBLEMS, LIN_WGRAD_MAX = 16, 4, 8
+
+
 class FkChain(C.Structure):
     _fields_ = [("njoints", C.c_int32), ("parent", C.c_int32 * FK_MAX_JOINTS), ("type", C.c_int32 * FK_MAX_JOINTS),
                 ("cfg", C.c_int32 * FK_MAX_JOINTS), ("mimic_mul", C.c_float * FK_MAX_JOINTS),
@@ -232,6 +255,9 @@ PROTOTYPES = {
     "hrp_linear_bwd_weight": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "hrp_rng_advance": [_P, _P],
     "hrp_dropout_f32": [_P, _I, _P, _I, _P, _I, _I, _F, _P, C.c_uint32, _P],
+    "hrp_dropout_masks": [_P, _L, _F, _P, C.c_uint32, _P],
+    "hrp_regressor_step": [_P, _I, _P],
+    "hrp_linear_wgrad_batch": [_P, _I, _P],
     "hrp_project_fwd": [_P, _P, _I, _I, _P, _P],
     "hrp_project_bwd": [_P, _P, _P, _I, _I, _P, _P],
 }

@@ -23,6 +23,9 @@ from .backbones import HRnet
 from .backbones.HRnet import BatchNorm1d, BatchNorm2d, Conv2d, emit_trunks, get_hrnet
 from .backbones.Resnet import _StemConv, get_resnet
 
+# the two iterative regressors (joint angles, rotation) as ONE chain of fused launches (PlanBuilder.regressors, csrc/regressor.hip);
+# False (tests, A/B measurements): the round-5 form, one launch per nn.Linear / cat / dropout
+FUSED_REGRESSORS = True
 _RESNETS = ["resnet", "resnet34", "resnet50", "resnet101"]
 _HRNETS = ["hrnet", "hrnet32"]
 
@@ -237,6 +240,33 @@ class RootNetwithRegInt(PlannedModule):
                 pred = dec.emit(pb, h, residual=pred)
         return pred
 
+    def _unfused_heads(self, pb, xf, res, ip, ir):
+        """The regressors one launch per layer (round 5; the variants the fused chain does not cover: reg_joint_map,
+        direct_reg_rot, rot_iterative_matmul).  The pose and the rotation regressor are independent chains of 12 small GEMMs
+        each: two lanes; each gets a private copy of the feature so that its gradient accumulates lane-locally."""
+        if self.reg_joint_map:
+            pose, xf_rot = res["pose"], xf
+        else:
+            xf_pose, xf_rot = pb.new_like(xf), pb.new_like(xf)
+            pb.copy_cols(xf, xf_pose)
+            pb.copy_cols(xf, xf_rot)
+        with (pb.parallel(2) if not self.reg_joint_map else _NoBlock()) as par:
+            if not self.reg_joint_map:
+                with par.lane(0):
+                    pose = self._iter_head(pb, xf_pose, ip, self.init_pose.shape[1], self.fc_pose_1,
+                                           self.fc_pose_2, self.decpose)
+            with par.lane(1):
+                if self.direct_reg_rot:      # full_net.py:333-345
+                    xc1 = self.fc_rot_1.emit(pb, xf_rot)
+                    xc = xc1
+                    for i in range(2, 6):
+                        xc = getattr(self, f"fc_rot_{i}").emit(pb, xc)
+                    rot = self.decrot.emit(pb, self.fc_rot_6.emit(pb, xc, residual=xc1))
+                else:
+                    rot = self._iter_head(pb, xf_rot, ir, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
+                                          self.decrot, matmul=self.rot_iterative_matmul)
+        return pose, rot
+
     def _depth_gamma(self, pb, feat):
         """depth_layer on the pooled root feature (full_net.py:271-274); add_fc: the hour-glass MLP of :261-270 first
         (fc_d1 -> fc_d2 -> BatchNorm1d -> LeakyReLU -> fc_u2, 0.5 (. + d1), fc_u1, 0.5 (. + feature))."""
@@ -324,30 +354,15 @@ class RootNetwithRegInt(PlannedModule):
         uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
         depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,
                                                           il.depth_factor)
-        # the pose and the rotation regressor are independent chains of 12 small GEMMs each: two lanes.  Each
-        # gets a private copy of the feature so that its gradient accumulates lane-locally.
-        if self.reg_joint_map:
-            pose, xf_rot = res["pose"], xf
-            par = None
+        fused = (FUSED_REGRESSORS and not self.reg_joint_map and not self.direct_reg_rot and not self.rot_iterative_matmul
+                 and self.fc_pose_2.weight.shape[0] % 16 == 0 and xf.C % 4 == 0)
+        if fused:
+            # both loops of full_net.py:318-331 / :365-378 in one chain: 1 + 1 + n_iter + 1 launches forward, n_iter + 2 backward,
+            # the xf part of fc_*_1 hoisted out of the loop
+            pose, rot = pb.regressors(xf, [(ip, self.fc_pose_1, self.fc_pose_2, self.decpose),
+                                           (ir, self.fc_rot_1, self.fc_rot_2, self.decrot)], self.n_iter, self.p_dropout)
         else:
-            xf_pose, xf_rot = pb.new_like(xf), pb.new_like(xf)
-            pb.copy_cols(xf, xf_pose)
-            pb.copy_cols(xf, xf_rot)
-        with (pb.parallel(2) if not self.reg_joint_map else _NoBlock()) as par:
-            if not self.reg_joint_map:
-                with par.lane(0):
-                    pose = self._iter_head(pb, xf_pose, ip, self.init_pose.shape[1], self.fc_pose_1,
-                                           self.fc_pose_2, self.decpose)
-            with par.lane(1):
-                if self.direct_reg_rot:      # full_net.py:333-345
-                    xc1 = self.fc_rot_1.emit(pb, xf_rot)
-                    xc = xc1
-                    for i in range(2, 6):
-                        xc = getattr(self, f"fc_rot_{i}").emit(pb, xc)
-                    rot = self.decrot.emit(pb, self.fc_rot_6.emit(pb, xc, residual=xc1))
-                else:
-                    rot = self._iter_head(pb, xf_rot, ir, self.rotation_dim, self.fc_rot_1, self.fc_rot_2,
-                                          self.decrot, matmul=self.rot_iterative_matmul)
+            pose, rot = self._unfused_heads(pb, xf, res, ip, ir)
         pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
         outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, rot_d.C)), ("dense", trans, (N, 3)),

@@ -502,6 +502,7 @@ class Plan:
         self._rng, self.n_dropout = None, 0
         self.linear_grad_written = set()
         self.grad_owner = {}       # gradient buffer address -> TensorH root (every producer registers through take_grad_slot)
+        self.reg_chains = []       # PlanBuilder.regressors: mask buffer and saved operands of every fused regressor chain
         self.row_last_writer = {}  # gradient buffer address -> (row-strip conv descriptor that completes it, lane path, producers of the gradient so far)
 
     # ---- build-time helpers -------------------------------------------------------------------
@@ -1977,6 +1978,175 @@ class PlanBuilder:
                                                    M, Kf, Nf, acc, ws.data_ptr(), wsb, s))
             self.bwd_stack.append(bw)
         return y
+
+    def regressors(self, xf, heads, n_iter, prob):
+        """The iterative regressors (reference lib/models/full_net.py:318-331, 365-378) of one feature tensor as ONE chain of
+        launches: p <- p + dec(drop(fc2(drop(fc1(cat(xf, p))))))  n_iter times per head, every head in every launch.
+        heads: [(init [M, P] dense fp32 handle, fc1, fc2, dec modules with .weight / .bias)] -> [prediction handles, dense [M, P]].
+        Forward 1 (masks) + 1 (hoisted xf product, SURVEY K11) + n_iter + 1 launches, backward n_iter + 2 (csrc/regressor.hip);
+        round 5 ran 169 launches for the same arithmetic.  The sum over the iterations of a layer's weight gradient is one
+        product over n_iter * M stacked rows at the end of the chain."""
+        p = self.plan
+        xf.check_readable()
+        assert xf.dtype == torch.float32 and xf.H == 1 and xf.W == 1 and 1 <= len(heads) <= nv.REG_MAX_PROBLEMS
+        M, F = xf.N, xf.C
+        dev = p.device
+        train_drop = p.training and prob > 0.0
+        nh = len(heads)
+        H = heads[0][2].weight.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        masks = None
+        if train_drop:
+            masks = torch.zeros(nh * n_iter * 2 * M * H, **f32)
+            p.keep.append(masks)
+            state = p.rng_state()
+            p.n_dropout += 1
+            salt = p.n_dropout * 0x9E3779B1 & 0xFFFFFFFF
+            p.fwd.append(lambda s: nv.call("hrp_dropout_masks", masks.data_ptr(), masks.numel(), 1.0 - prob, state.data_ptr(), salt, s))
+
+        def mask_ptr(h, i, layer):
+            return masks.data_ptr() + 4 * (((h * n_iter + i) * 2 + layer) * M * H) if masks is not None else None
+
+        hs = []
+        for init, fc1, fc2, dec in heads:
+            init.check_readable()
+            P = init.C
+            assert init.pitch == P and init.dtype == torch.float32 and 1 <= P <= nv.REG_MAX_P
+            assert tuple(fc1.weight.shape) == (H, F + P) and tuple(fc2.weight.shape) == (H, H) and tuple(dec.weight.shape) == (P, H)
+            e = dict(P=P, init=init, fc1=fc1, fc2=fc2, dec=dec, ld1=F + P,
+                     A=torch.zeros(M * H, **f32), preds=torch.zeros(n_iter * M * P, **f32),
+                     d1=torch.zeros(n_iter * M * H, **f32), d2=torch.zeros(n_iter * M * H, **f32))
+            e["out"] = p.new(M, 1, 1, P, torch.float32, pitch=P)
+            e["out"].requires_grad = p.need_grad
+            p.keep += [e["A"], e["preds"], e["d1"], e["d2"]]
+            hs.append(e)
+
+        def launch(descs):
+            arr = (nv.RegStepDesc * len(descs))(*descs)
+            return lambda s: nv.call("hrp_regressor_step", arr, len(descs), s)
+
+        # hoist: A = xf W1[:, :F]^T + b1
+        ds = []
+        for e in hs:
+            d = nv.RegStepDesc()
+            d.M, d.P, d.K, d.N = M, 0, F, H
+            d.a, d.a_pitch = xf.ptr(), xf.pitch
+            d.w, d.w_sn, d.w_sk, d.bias = e["fc1"].weight.data_ptr(), e["ld1"], 1, e["fc1"].bias.data_ptr()
+            d.out, d.out_pitch = e["A"].data_ptr(), H
+            ds.append(d)
+        p.fwd.append(launch(ds))
+        for i in range(n_iter):
+            ds = []
+            for h, e in enumerate(hs):
+                P = e["P"]
+                d = nv.RegStepDesc()
+                d.M, d.P, d.K, d.N = M, P, H, H
+                if i == 0:
+                    d.u_prev = e["init"].ptr()
+                else:
+                    d.u_prev, d.u_bias = e["preds"].data_ptr() + 4 * (i - 1) * M * P, e["dec"].bias.data_ptr()
+                    d.z, d.z_len, d.z_pitch = e["d2"].data_ptr() + 4 * (i - 1) * M * H, H, H
+                    d.zw, d.zw_sk, d.zw_sp = e["dec"].weight.data_ptr(), 1, H
+                d.u_out = e["preds"].data_ptr() + 4 * i * M * P
+                d.a, d.a_pitch, d.a_mask = e["A"].data_ptr(), H, mask_ptr(h, i, 0)
+                d.v, d.v_sk, d.v_sp = e["fc1"].weight.data_ptr() + 4 * F, e["ld1"], 1
+                d.a_out = e["d1"].data_ptr() + 4 * i * M * H if p.need_grad else None
+                d.w, d.w_sn, d.w_sk, d.bias = e["fc2"].weight.data_ptr(), H, 1, e["fc2"].bias.data_ptr()
+                d.out_mask = mask_ptr(h, i, 1)
+                d.out, d.out_pitch = e["d2"].data_ptr() + 4 * i * M * H, H
+                ds.append(d)
+            p.fwd.append(launch(ds))
+        ds = []
+        for e in hs:       # the last state: p_n = p_{n-1} + b3 + d2_{n-1} W3^T
+            P = e["P"]
+            d = nv.RegStepDesc()
+            d.M, d.P, d.K, d.N = M, P, 0, 0
+            d.u_prev, d.u_bias = e["preds"].data_ptr() + 4 * (n_iter - 1) * M * P, e["dec"].bias.data_ptr()
+            d.z, d.z_len, d.z_pitch = e["d2"].data_ptr() + 4 * (n_iter - 1) * M * H, H, H
+            d.zw, d.zw_sk, d.zw_sp = e["dec"].weight.data_ptr(), 1, H
+            d.u_out = e["out"].ptr()
+            ds.append(d)
+        p.fwd.append(launch(ds))
+        p.counters["regressor_chains"] = p.counters.get("regressor_chains", 0) + 1
+        p.reg_chains.append(dict(masks=masks, heads=hs, n_iter=n_iter, xf=xf))      # (tests and tools read the saved operands here)
+
+        if p.need_grad:
+            def bw():
+                for e in hs:
+                    if not e["out"].grad_written:
+                        e["out"].grad_buf()          # (an unused prediction: a zero gradient)
+                    e["gs"] = torch.zeros(n_iter * M * e["P"], **f32)          # g_1 .. g_n (g_{i+1} = the gradient of iteration i's update)
+                    e["gh2"], e["gh1"] = torch.zeros(n_iter * M * H, **f32), torch.zeros(n_iter * M * H, **f32)
+                    e["gA"] = torch.zeros(M * H, **f32)
+                    p.keep += [e["gs"], e["gh2"], e["gh1"], e["gA"]]
+                for i in range(n_iter - 1, -1, -1):
+                    ds = []
+                    for h, e in enumerate(hs):
+                        P = e["P"]
+                        d = nv.RegStepDesc()
+                        d.M, d.P, d.K, d.N = M, P, H, H
+                        if i == n_iter - 1:
+                            d.u_prev = e["out"].gptr()
+                        else:        # g_{i+1} = g_{i+2} + gh1_{i+1} W1[:, F:]
+                            d.u_prev = e["gs"].data_ptr() + 4 * (i + 1) * M * P
+                            d.z, d.z_len, d.z_pitch = e["gh1"].data_ptr() + 4 * (i + 1) * M * H, H, H
+                            d.zw, d.zw_sk, d.zw_sp = e["fc1"].weight.data_ptr() + 4 * F, e["ld1"], 1
+                        d.u_out = e["gs"].data_ptr() + 4 * i * M * P
+                        d.a_mask = mask_ptr(h, i, 1)
+                        d.v, d.v_sk, d.v_sp = e["dec"].weight.data_ptr(), 1, H
+                        d.a_out = e["gh2"].data_ptr() + 4 * i * M * H
+                        d.w, d.w_sn, d.w_sk = e["fc2"].weight.data_ptr(), 1, H
+                        d.out_mask = mask_ptr(h, i, 0)
+                        d.out, d.out_pitch = e["gh1"].data_ptr() + 4 * i * M * H, H
+                        d.out_sum, d.out_sum_accumulate = e["gA"].data_ptr(), 0 if i == n_iter - 1 else 1
+                        ds.append(d)
+                    p.bwd.append(launch(ds))
+                # weight / bias gradients: the n_iter iterations of a layer as one product over n_iter * M stacked rows
+                wd = []
+                for e in hs:
+                    P = e["P"]
+
+                    def prob_(x, xp, dy, dyp, wparam, col0, ld, bparam, rows, K_, N_, acc):
+                        g = nv.LinWgradDesc()
+                        g.x, g.x_pitch, g.dy, g.dy_pitch = x, xp, dy, dyp
+                        g.dw, g.dw_ld = p.grad_of_param(wparam).data_ptr() + 4 * col0, ld
+                        g.dbias = p.grad_of_param(bparam).data_ptr() if (bparam is not None and bparam.requires_grad) else None
+                        g.M, g.K, g.N, g.accumulate = rows, K_, N_, acc
+                        return g
+
+                    def acc_of(t):       # (the arena is zeroed once per backward: every producer accumulates)
+                        first = id(t) not in p.linear_grad_written
+                        p.linear_grad_written.add(id(t))
+                        return 1 if (p.grad_arena is not None or not first) else 0
+                    if e["fc2"].weight.requires_grad:
+                        wd.append(prob_(e["d1"].data_ptr(), H, e["gh2"].data_ptr(), H, e["fc2"].weight, 0, H, e["fc2"].bias, n_iter * M, H, H,
+                                        acc_of(e["fc2"].weight)))
+                    if e["dec"].weight.requires_grad:
+                        wd.append(prob_(e["d2"].data_ptr(), H, e["gs"].data_ptr(), P, e["dec"].weight, 0, H, e["dec"].bias, n_iter * M, H, P,
+                                        acc_of(e["dec"].weight)))
+                    if e["fc1"].weight.requires_grad:
+                        a1 = acc_of(e["fc1"].weight)       # (two column blocks of one parameter: both are its first writers)
+                        wd.append(prob_(xf.ptr(), xf.pitch, e["gA"].data_ptr(), H, e["fc1"].weight, 0, e["ld1"], e["fc1"].bias, M, F, H, a1))
+                        wd.append(prob_(e["preds"].data_ptr(), P, e["gh1"].data_ptr(), H, e["fc1"].weight, F, e["ld1"], None, n_iter * M, P, H, a1))
+                for k in range(0, len(wd), nv.LIN_WGRAD_MAX):
+                    grp = wd[k:k + nv.LIN_WGRAD_MAX]
+                    arr = (nv.LinWgradDesc * len(grp))(*grp)
+                    p.bwd.append(lambda s, arr=arr, n=len(grp): nv.call("hrp_linear_wgrad_batch", arr, n, s))
+                # d xf = sum over the heads of gA W1[:, :F]: one launch, two sources per problem
+                if xf.requires_grad:
+                    acc = xf.take_grad_slot()
+                    for k in range(0, nh, 2):
+                        d = nv.RegStepDesc()
+                        d.M, d.P, d.K, d.N = M, 0, H, F
+                        d.a, d.a_pitch = hs[k]["gA"].data_ptr(), H
+                        d.w, d.w_sn, d.w_sk = hs[k]["fc1"].weight.data_ptr(), 1, hs[k]["ld1"]
+                        if k + 1 < nh:
+                            d.a2, d.a2_pitch = hs[k + 1]["gA"].data_ptr(), H
+                            d.w2, d.w2_sk = hs[k + 1]["fc1"].weight.data_ptr(), hs[k + 1]["ld1"]
+                        d.out, d.out_pitch, d.out_accumulate = xf.gptr(), xf.pitch, 1 if (acc or k > 0) else 0
+                        p.bwd.append(launch([d]))
+            self.bwd_stack.append(bw)
+        return [e["out"] for e in hs]
 
     def _conv_bwd(self, x, w, y, bias, stride, ksize, dtype, residual, relu, dilation=1):
         p = self.plan

@@ -634,6 +634,71 @@ int hrp_sim2real_loss(const hrp_sim2real_loss_desc* d, void* stream);
 int hrp_rng_advance(uint64_t* state_dev, void* stream);
 int hrp_dropout_f32(const float* x, int x_pitch, float* y, int y_pitch, float* mask, int rows, int cols, float keep,
                     const uint64_t* state_dev, uint32_t salt, void* stream);
+/* All dropout masks of one forward in ONE launch: masks[i] = (u_i < keep) / keep, n dense fp32 values (16-byte aligned), the
+ * generator and counter layout of hrp_dropout_f32 (counter = (i / 4, salt, step)).  The fused regressor chain below multiplies by
+ * slices of this buffer in its staging path and its epilogue (full_net.py:98-99, 132-133: drop1 / drop2 inside the loop). */
+int hrp_dropout_masks(float* masks, int64_t n, float keep, const uint64_t* state_dev, uint32_t salt, void* stream);
+
+/* The iterative regressors of the full network (lib/models/full_net.py:318-331 joint angles, :365-378 rotation):
+ *     p_{i+1} = p_i + dec(drop(fc2(drop(fc1(cat(xf, p_i))))))      n_iter times, no non-linearity between the three nn.Linear
+ * as a chain of launches of ONE kernel, several problems (the two heads) per launch.  One step of one problem computes, all fp32,
+ * every sum in a fixed order (bit-reproducible; exact fp32 products on v_mfma_f32_16x16x4_f32):
+ *   1. state    u[m][p]  = u_prev[m][p] + u_bias[p] + sum_{k < z_len} z[m][k] * zw[k * zw_sk + p * zw_sp]
+ *               (z NULL: no sum; P == 0: no state).  Every workgroup computes the u of its rows; u_out (optional) receives it.
+ *   2. operand  a'[m][k] = a_mask[m][k] * (a[m][k] + sum_p u[m][p] * v[k * v_sk + p * v_sp])
+ *               (a NULL: 0; a_mask NULL: 1; v NULL: no update).  a_out (optional, dense [M][K]) receives a'.
+ *   3. product  val[m][n] = out_mask[m][n] * (bias[n] + sum_k a'[m][k] * w[n * w_sn + k * w_sk] + sum_k a2[m][k] * w2[n * w_sn + k * w2_sk])
+ *               out[m][n] (+)= val;  out_sum[m][n] (+)= val (optional).  One of w_sn / w_sk must be 1.  N == 0: step 1 only.
+ * How the plan maps the reference loop onto it (hrpe_amd/plan.py PlanBuilder.regressors; F = feature width, H = 1024):
+ *   hoist      a = xf, w = fc1.weight[:, :F] (w_sn = F + P), bias = fc1.bias -> A                 (full_net.py:319-320 recomputes this
+ *              product in every iteration)
+ *   forward i  u_prev = p_{i-1}, u_bias = dec.bias, z = d2_{i-1}, zw = dec.weight (zw_sk = 1, zw_sp = H) -> p_i;
+ *              a = A, v = fc1.weight[:, F:], a_mask = drop1 mask -> d1_i;  w = fc2.weight, bias = fc2.bias, out_mask = drop2 mask -> d2_i
+ *   backward i u_prev = g_{i+2}, z = gh1_{i+1}, zw = fc1.weight[:, F:] -> g_{i+1};  a = NULL, v = dec.weight^T, a_mask = drop2 mask -> gh2_i;
+ *              w = fc2.weight^T (w_sn = 1, w_sk = H), out_mask = drop1 mask -> gh1_i, out_sum = gA
+ *   d xf       a = gA(pose), w = fc_pose_1.weight^T, a2 = gA(rot), w2 = fc_rot_1.weight^T (w_sn = 1, w_sk = F + P)
+ * Requirements: K % 4 == 0, z_len % 16 == 0, rows of z / a_mask / a_out 16-byte aligned, P <= HRP_REG_MAX_P. */
+#define HRP_REG_MAX_P 16
+#define HRP_REG_MAX_PROBLEMS 4
+typedef struct hrp_regressor_step_desc {
+  int32_t M, P, K, N;             /* rows; state width; reduction length of the product; output columns                            */
+  const float* u_prev;            /* [M][P] dense                                                                                   */
+  const float* u_bias;            /* [P] or NULL                                                                                    */
+  const float* z;                 /* [M][z_pitch] or NULL                                                                           */
+  const float* zw;
+  int32_t z_len, z_pitch, zw_sk, zw_sp;
+  float* u_out;                   /* [M][P] dense or NULL                                                                           */
+  const float* a;                 /* [M][a_pitch] or NULL                                                                           */
+  const float* a_mask;            /* [M][K] dense or NULL                                                                           */
+  const float* v;
+  int32_t a_pitch, v_sk, v_sp, a2_pitch;
+  float* a_out;                   /* [M][K] dense or NULL                                                                           */
+  const float* w;
+  const float* bias;              /* [N] or NULL                                                                                    */
+  const float* out_mask;          /* [M][N] dense or NULL                                                                           */
+  const float* a2;                /* second source [M][a2_pitch] or NULL (no mask, no update)                                       */
+  const float* w2;
+  int64_t w_sn, w_sk;
+  int32_t out_pitch, out_accumulate, out_sum_accumulate;
+  int32_t w2_sk;                  /* k stride of w2 (0: w_sk)                                                                      */
+  float* out;                     /* [M][out_pitch]                                                                                 */
+  float* out_sum;                 /* [M][N] dense or NULL                                                                           */
+} hrp_regressor_step_desc;
+int hrp_regressor_step(const hrp_regressor_step_desc* descs, int n, void* stream);
+
+/* Weight / bias gradients of several nn.Linear layers in one launch (the end of the regressor chain: the n_iter iterations of a
+ * layer are ONE product over n_iter * M stacked rows):  dw[n * dw_ld + k] (+)= sum_m dy[m][n] * x[m][k];  dbias[n] (+)= sum_m dy[m][n]
+ * (dbias optional).  dw_ld: row length of the parameter dw points into (a column block of fc1.weight: dw_ld = F + P). */
+#define HRP_LIN_WGRAD_MAX 8
+typedef struct hrp_linear_wgrad_desc {
+  const float* x;                 /* [M][x_pitch]  */
+  const float* dy;                /* [M][dy_pitch] */
+  float* dw;
+  float* dbias;
+  int32_t x_pitch, dy_pitch, dw_ld, M, K, N, accumulate, reserved;
+} hrp_linear_wgrad_desc;
+int hrp_linear_wgrad_batch(const hrp_linear_wgrad_desc* descs, int n, void* stream);
+
 /* point_projection_from_3d_tensor (lib/utils/transforms.py:17-21): K [B,9], pts [B,P,3] -> uv [B,P,2] */
 int hrp_project_fwd(const float* K, const float* pts, int B, int P, float* uv, void* stream);
 int hrp_project_bwd(const float* K, const float* pts, const float* duv, int B, int P, float* dpts, void* stream);

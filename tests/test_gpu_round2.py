@@ -328,6 +328,8 @@ def test_dropout_mask_on_lane_streams():
     p_dropout = 0.5 the rotation head runs on a side stream: forward y == x * mask, backward dx == dy * mask with the SAME
     mask, masks differ between steps and between the two dropout layers, and the keep rate is ~0.5."""
     from hrpe_amd import plan as P
+    from hrpe_amd.lib.models import full_net as FN
+    FN.FUSED_REGRESSORS = False      # (the per-layer dropout op: what the regressor variants outside the fused chain still run)
     m = build_full(p_dropout=0.5).train()
     x_reg, x_root, kv, K = [t.to(DEV) for t in synth_inputs(2)]
     masks_seen = []
@@ -360,6 +362,7 @@ def test_dropout_mask_on_lane_streams():
             masks_seen.append(allm.clone())
     finally:
         P.PlanBuilder.dropout = orig
+        FN.FUSED_REGRESSORS = True
     assert not torch.equal(masks_seen[0], masks_seen[1]), "a new mask every step"
 
 

@@ -46,10 +46,10 @@ def test_ctypes_struct_sizes_match_c():
 #include <stdio.h>
 #include "hrp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
          sizeof(hrp_ew_input), sizeof(hrp_ew_desc), sizeof(hrp_ew_bwd_desc), sizeof(hrp_bn_entry), sizeof(hrp_fk_chain),
          sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk), sizeof(hrp_batch_info), sizeof(hrp_pose_loss_desc), sizeof(hrp_wgrad_fold_desc),
-         sizeof(hrp_block_desc), sizeof(hrp_block_info));
+         sizeof(hrp_block_desc), sizeof(hrp_block_info), sizeof(hrp_regressor_step_desc), sizeof(hrp_linear_wgrad_desc));
   return 0;
 }'''
     import tempfile
@@ -61,8 +61,27 @@ int main(void) {
     sizes = [int(v) for v in out]
     mirrors = [nv.ConvDesc, nv.WgradDesc, nv.PackEntry, nv.EwInput, nv.EwDesc, nv.EwBwdDesc, nv.BnEntry, nv.FkChain,
                nv.OptTensor, nv.OptChunk, nv.BatchInfo, nv.PoseLossDesc, nv.WgradFoldDesc,
-               nv.BlockDesc, nv.BlockInfo]
+               nv.BlockDesc, nv.BlockInfo, nv.RegStepDesc, nv.LinWgradDesc]
     assert sizes == [C.sizeof(m) for m in mirrors]
+    assert (nv.REG_MAX_P, nv.REG_MAX_PROBLEMS, nv.LIN_WGRAD_MAX) == (16, 4, 8)      # HRP_REG_MAX_P, HRP_REG_MAX_PROBLEMS, HRP_LIN_WGRAD_MAX
+
+
+def test_regressor_entry_points_reject_bad_descriptors_without_a_gpu():
+    """hrp_regressor_step / hrp_linear_wgrad_batch / hrp_dropout_masks validate on the host before they launch."""
+    d = nv.RegStepDesc()
+    arr = (nv.RegStepDesc * 1)(d)
+    assert nv.lib().hrp_regressor_step(arr, 1, None) == -1                       # M == 0
+    assert nv.lib().hrp_regressor_step(arr, 5, None) == -1 and b"problems" in nv.lib().hrp_last_error()
+    d = nv.RegStepDesc()
+    d.M, d.P, d.K, d.N = 4, 17, 8, 8
+    assert nv.lib().hrp_regressor_step((nv.RegStepDesc * 1)(d), 1, None) == -1  # state wider than HRP_REG_MAX_P
+    d.P, d.K = 0, 6
+    d.w = d.out = d.a = 16
+    d.w_sn, d.w_sk, d.out_pitch = 6, 1, 8
+    assert nv.lib().hrp_regressor_step((nv.RegStepDesc * 1)(d), 1, None) == -1 and b"K % 4" in nv.lib().hrp_last_error()
+    g = nv.LinWgradDesc()
+    assert nv.lib().hrp_linear_wgrad_batch((nv.LinWgradDesc * 1)(g), 1, None) == -1
+    assert nv.lib().hrp_dropout_masks(None, 16, 0.5, None, 0, None) == -1
 
 
 def test_bad_descriptor_is_rejected_without_a_gpu():

@@ -13,9 +13,10 @@
 //              is one more launch of this kernel with two sources.
 // Both heads (and any number of problems <= HRP_REG_MAX_PROBLEMS) share every launch (blockIdx.y).
 //
-// Workgroup = 64 rows x 16 output columns x the whole reduction range: wave w owns rows 16 w .. 16 w + 15 (one 16 x 16 accumulator
-// pair, even / odd k-steps), the reduction runs in chunks of 128 through LDS with the next chunk's global loads in flight under the
-// MFMAs.  Every sum has a fixed order (k ascending inside a lane, no atomics, no split across workgroups): bit-reproducible.
+// A step is two kernels behind one entry point: a row-parallel one for the state and the operand (one workgroup per sample: the state
+// is a 1024-long dot product per (sample, p) - inside the product kernel every workgroup repeated it from 256 KB of L2 reads and the
+// launch took 63 us), and the product kernel (32 rows x 16 columns per workgroup, 256 workgroups for the two heads at B = 64).
+// Every sum has a fixed order (no atomics, no split across workgroups): bit-reproducible.
 #include "hrp_common.h"
 
 namespace hrp {
@@ -24,9 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RG_KC = 128;             // reduction indices per chunk
 constexpr int RG_PA = RG_KC + 4;       // LDS row pitch in floats (16-byte aligned rows)
-constexpr int RG_ROWS = 64, RG_COLS = 16;
-constexpr int RG_UP = 16;              // pitch of the state tile U[64][16]
-constexpr int RG_TILE_FLOATS = RG_ROWS * RG_PA + RG_COLS * RG_PA;
+constexpr int RG_ROWS = 32, RG_COLS = 16;
 
 struct RegArgs {
   hrp_regressor_step_desc d[HRP_REG_MAX_PROBLEMS];
@@ -37,118 +36,122 @@ __device__ __forceinline__ float4 ld4(const float* p, bool vec) {
   return make_float4(p[0], p[1], p[2], p[3]);
 }
 
-// PMAX: compile-time bound of the state width P of every problem of the launch (0: no state anywhere)
+// ---- steps 1 + 2 of hrp_regressor_step_desc: one workgroup per row m.  u[p] = u_prev + u_bias + sum_k z[k] zw[k][p] (a thread
+// takes k = tid, tid + 256, ..; wave tree, then the four waves in order: fixed order), then the operand row
+// a'[k] = a_mask[k] (a[k] + sum_p u[p] v[k][p]) into a_out.  PMAX: compile-time bound of P.
 template <int PMAX>
-__global__ __launch_bounds__(256) void regressor_step_kernel(const RegArgs args) {
+__global__ __launch_bounds__(256) void regressor_prep_kernel(const RegArgs args) {
   const hrp_regressor_step_desc& d = args.d[blockIdx.y];
+  const int m = blockIdx.x;
+  if (m >= d.M) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * RG_COLS, m0 = blockIdx.z * RG_ROWS;
-  if (m0 >= d.M) return;
-  if (d.N > 0 ? n0 >= d.N : blockIdx.x > 0) return;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* U = smem;                              // [64][RG_UP] state of the workgroup's rows
-  float* As = smem + RG_ROWS * RG_UP;           // [64][RG_PA] row operand chunk
-  float* Ws = As + RG_ROWS * RG_PA;             // [16][RG_PA] weight chunk
-  float* ZW = As;                               // [P][z_len] during the state update (aliases the tiles)
-  const int P = PMAX ? d.P : 0;
-  const int rows = d.M - m0 < RG_ROWS ? d.M - m0 : RG_ROWS;
-
-  // ---- 1. state: u = u_prev + u_bias + z zw -----------------------------------------------------------------------------
-  if (PMAX && P > 0) {
-    const int m = tid >> 2, pq = tid & 3;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int P = d.P;
+  __shared__ float red[4][PMAX];
+  __shared__ float u_s[PMAX];
+  if (P > 0) {
     if (d.z) {
-      const int zl = d.z_len;
-      if (d.zw_sp == 1) {        // zw[k][p] rows of P contiguous values
-        for (int i = tid; i < P * zl; i += 256) {
-          const int k = i / P, p = i - k * P;
-          ZW[p * zl + k] = d.zw[(size_t)k * d.zw_sk + p];
+      float acc[PMAX];
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) acc[p] = 0.f;
+      const float* zr = d.z + (size_t)m * d.z_pitch;
+      for (int kb = 0; kb < d.z_len; kb += 1024) {          // four k per thread and trip, every load of the trip issued before the first use
+        float zk[4], wv[4][PMAX];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = kb + tid + 256 * j;
+          const bool ok = k < d.z_len;
+          zk[j] = ok ? zr[k] : 0.f;
+          const float* wr = d.zw + (size_t)k * d.zw_sk;
+#pragma unroll
+          for (int p = 0; p < PMAX; ++p) wv[j][p] = (ok && p < P) ? wr[(size_t)p * d.zw_sp] : 0.f;
         }
-      } else {                   // zw[p][k]: contiguous along k
-        for (int i = tid; i < P * zl; i += 256) {
-          const int p = i / zl, k = i - p * zl;
-          ZW[i] = d.zw[(size_t)k * d.zw_sk + (size_t)p * d.zw_sp];
-        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int p = 0; p < PMAX; ++p) acc[p] = fmaf(zk[j], wv[j][p], acc[p]);
+      }
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) {
+        const float t = wave_sum(acc[p]);
+        if (lane == 0) red[wave][p] = t;
       }
       __syncthreads();
-      if (m < rows) {
-        const float* zr = d.z + (size_t)(m0 + m) * d.z_pitch;
-        for (int k4 = 0; k4 < zl; k4 += 16) {
-          float4 zq[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) zq[u] = *(const float4*)(zr + k4 + 4 * u);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int p = pq + 4 * j;
-            if (p < P) {
-              const float* wr = ZW + p * zl + k4;
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float4 w4 = *(const float4*)(wr + 4 * u);
-                acc[j] = fmaf(zq[u].x, w4.x, acc[j]);
-                acc[j] = fmaf(zq[u].y, w4.y, acc[j]);
-                acc[j] = fmaf(zq[u].z, w4.z, acc[j]);
-                acc[j] = fmaf(zq[u].w, w4.w, acc[j]);
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();           // ZW is dead: the tiles may be staged over it
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int p = pq + 4 * j;
-      float v = 0.f;
-      if (p < P && m < rows) {
-        v = d.u_prev[(size_t)(m0 + m) * P + p] + acc[j];
-        if (d.u_bias) v += d.u_bias[p];
-        if (d.u_out && blockIdx.x == 0) d.u_out[(size_t)(m0 + m) * P + p] = v;
-      }
-      U[m * RG_UP + p] = v;
+    if (tid < P) {
+      float v = d.u_prev[(size_t)m * P + tid];
+      if (d.z) v += ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      if (d.u_bias) v += d.u_bias[tid];
+      u_s[tid] = v;
+      if (d.u_out) d.u_out[(size_t)m * P + tid] = v;
     }
     __syncthreads();
   }
-  if (d.N <= 0) return;
+  if (!d.a_out || d.N <= 0) return;
+  float u[PMAX];
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) u[p] = (p < P && d.v) ? u_s[p] : 0.f;
+  const float* ar = d.a ? d.a + (size_t)m * d.a_pitch : nullptr;
+  const float* mr = d.a_mask ? d.a_mask + (size_t)m * d.K : nullptr;
+  float* orow = d.a_out + (size_t)m * d.K;
+  for (int kb = 0; kb < d.K; kb += 1024) {
+    float val[4], mk[4], vv[4][PMAX];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kb + tid + 256 * j;
+      const bool ok = k < d.K;
+      val[j] = (ok && ar) ? ar[k] : 0.f;
+      mk[j] = (ok && mr) ? mr[k] : 1.f;
+      const float* vr = d.v ? d.v + (size_t)k * d.v_sk : nullptr;
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) vv[j][p] = (ok && vr && p < P) ? vr[(size_t)p * d.v_sp] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kb + tid + 256 * j;
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) val[j] = fmaf(u[p], vv[j][p], val[j]);
+      if (k < d.K) orow[k] = val[j] * mk[j];
+    }
+  }
+}
 
-  // ---- 2. / 3. the product, reduction in chunks of RG_KC ------------------------------------------------------------------
-  const int c4 = tid & 31, r0 = tid >> 5;                  // row-operand staging: 4 reduction indices x rows r0, r0 + 8, ..
+// ---- step 3: out = out_mask o (bias + a' w^T (+ a2 w2^T)), a' = a_out when steps 1 / 2 transformed the operand, else a.
+// Workgroup = 32 rows x 16 columns x the whole reduction range in chunks of 128 through LDS (the next chunk's global loads in
+// flight under the MFMAs); wave = (row block w & 1, half w >> 1 of every chunk); the two halves are added through LDS at the end.
+__global__ __launch_bounds__(256) void regressor_gemm_kernel(const RegArgs args) {
+  const hrp_regressor_step_desc& d = args.d[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * RG_COLS, m0 = blockIdx.z * RG_ROWS;
+  if (m0 >= d.M || n0 >= d.N) return;
+  __shared__ __attribute__((aligned(16))) float As[RG_ROWS * RG_PA];
+  __shared__ __attribute__((aligned(16))) float Ws[RG_COLS * RG_PA];
+  const int rows = d.M - m0 < RG_ROWS ? d.M - m0 : RG_ROWS;
+  const int c4 = tid & 31, r0 = tid >> 5;                  // staging: 4 reduction indices x rows r0, r0 + 8, r0 + 16, r0 + 24
   const bool wt = d.w_sn == 1 && d.w_sk != 1;              // weight stored [k][n] (data-gradient direction)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, kq = lane >> 4;
-  const bool wave_on = wave * 16 < rows;
+  const int rb = wave & 1, kh = wave >> 1;
+  const bool wave_on = rb * 16 < rows;
+  const bool transformed = d.a_out && (d.a_mask || (d.v && d.P > 0));
+  const int K = d.K;
 
   for (int src = 0; src < 2; ++src) {
-    const float* a = src ? d.a2 : d.a;
+    const float* a = src ? d.a2 : (transformed ? d.a_out : d.a);
     const float* w = src ? d.w2 : d.w;
     if (src && !a) break;
-    const int a_pitch = src ? d.a2_pitch : d.a_pitch;
-    const float* amask = src ? nullptr : d.a_mask;
-    const float* v = (PMAX && !src && P > 0) ? d.v : nullptr;
-    float* a_out = (!src && blockIdx.x == 0) ? d.a_out : nullptr;
-    const bool a_vec = a && ((uintptr_t)a % 16 == 0) && (a_pitch % 4 == 0);
+    const int a_pitch = src ? d.a2_pitch : (transformed ? K : d.a_pitch);
     const long long w_sk = (src && d.w2_sk) ? (long long)d.w2_sk : d.w_sk;
+    const bool a_vec = ((uintptr_t)a % 16 == 0) && (a_pitch % 4 == 0);
     const bool w_vec = ((uintptr_t)w % 16 == 0) && ((wt ? w_sk : d.w_sn) % 4 == 0);
-    const int K = d.K;
 
-    float4 ra[8], rm[8], rw[2];
-    float rv[4][PMAX ? PMAX : 1];
+    float4 ra[4], rw[2];
     auto load_chunk = [&](int k0) {
       const int k = k0 + 4 * c4;
       const bool kin = k < K;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const int r = r0 + 8 * j;
-        const bool in = kin && r < rows;
-        ra[j] = (in && a) ? ld4(a + (size_t)(m0 + r) * a_pitch + k, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (amask) rm[j] = in ? *(const float4*)(amask + (size_t)(m0 + r) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (PMAX && v) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int p = 0; p < (PMAX ? PMAX : 1); ++p)
-            rv[e][p] = (kin && p < P) ? v[(size_t)(k + e) * d.v_sk + (size_t)p * d.v_sp] : 0.f;
+        ra[j] = (kin && r < rows) ? ld4(a + (size_t)(m0 + r) * a_pitch + k, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (!wt) {             // w[n][k]: rows n0 + (tid >> 5) + 8 j, four consecutive k
 #pragma unroll
@@ -174,31 +177,9 @@ __global__ __launch_bounds__(256) void regressor_step_kernel(const RegArgs args)
         }
       }
     };
-    auto store_chunk = [&](int k0) {
-      const int k = k0 + 4 * c4;
+    auto store_chunk = [&]() {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = r0 + 8 * j;
-        float4 t = ra[j];
-        if (PMAX && v) {
-          float u[PMAX ? PMAX : 1];
-#pragma unroll
-          for (int p = 0; p < (PMAX ? PMAX : 1); p += 4) {
-            const float4 uq = *(const float4*)(U + r * RG_UP + p);
-            u[p] = uq.x; u[p + 1] = uq.y; u[p + 2] = uq.z; u[p + 3] = uq.w;
-          }
-#pragma unroll
-          for (int p = 0; p < (PMAX ? PMAX : 1); ++p) {
-            t.x = fmaf(u[p], rv[0][p], t.x);
-            t.y = fmaf(u[p], rv[1][p], t.y);
-            t.z = fmaf(u[p], rv[2][p], t.z);
-            t.w = fmaf(u[p], rv[3][p], t.w);
-          }
-        }
-        if (amask) { t.x *= rm[j].x; t.y *= rm[j].y; t.z *= rm[j].z; t.w *= rm[j].w; }
-        *(float4*)(As + r * RG_PA + 4 * c4) = t;
-        if (a_out && r < rows && k < K) *(float4*)(a_out + (size_t)(m0 + r) * K + k) = t;
-      }
+      for (int j = 0; j < 4; ++j) *(float4*)(As + (r0 + 8 * j) * RG_PA + 4 * c4) = ra[j];
       if (!wt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) *(float4*)(Ws + (r0 + 8 * j) * RG_PA + 4 * c4) = rw[j];
@@ -216,14 +197,14 @@ __global__ __launch_bounds__(256) void regressor_step_kernel(const RegArgs args)
 
     load_chunk(0);
     for (int k0 = 0; k0 < K; k0 += RG_KC) {
-      store_chunk(k0);
+      store_chunk();
       __syncthreads();
       if (k0 + RG_KC < K) load_chunk(k0 + RG_KC);
       if (wave_on) {
-        const float* ap = As + (wave * 16 + l15) * RG_PA + kq;
-        const float* bp = Ws + l15 * RG_PA + kq;
-#pragma unroll 8
-        for (int ks = 0; ks < RG_KC / 4; ks += 2) {
+        const float* ap = As + (rb * 16 + l15) * RG_PA + kh * (RG_KC / 2) + kq;
+        const float* bp = Ws + l15 * RG_PA + kh * (RG_KC / 2) + kq;
+#pragma unroll
+        for (int ks = 0; ks < RG_KC / 8; ks += 2) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bp[4 * ks], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks + 4], bp[4 * ks + 4], acc1, 0, 0, 0);
         }
@@ -232,17 +213,23 @@ __global__ __launch_bounds__(256) void regressor_step_kernel(const RegArgs args)
     }
   }
 
-  // ---- epilogue: lane = column n0 + (lane & 15), rows 16 wave + 4 (lane >> 4) + i ------------------------------------------
-  if (!wave_on) return;
+  // ---- the second half of every chunk joins the first through LDS, then the epilogue: lane = column n0 + (lane & 15),
+  // rows 16 rb + 4 (lane >> 4) + i
+  f32x4 acc = acc0 + acc1;
+  float* xch = As;                                          // [2 row blocks][64 lanes][4]
+  if (kh == 1) *(f32x4*)(xch + (rb * 64 + lane) * 4) = acc;
+  __syncthreads();
+  if (kh == 1 || !wave_on) return;
+  acc += *(const f32x4*)(xch + (rb * 64 + lane) * 4);
   const int n = n0 + l15;
   if (n >= d.N) return;
   const float bv = d.bias ? d.bias[n] : 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = wave * 16 + 4 * kq + i;
+    const int r = rb * 16 + 4 * kq + i;
     if (r >= rows) continue;
     const size_t m = (size_t)(m0 + r);
-    float val = acc0[i] + acc1[i] + bv;
+    float val = acc[i] + bv;
     if (d.out_mask) val *= d.out_mask[m * d.N + n];
     if (d.out_sum) {
       float* q = d.out_sum + m * d.N + n;
@@ -343,49 +330,40 @@ using namespace hrp;
 extern "C" int hrp_regressor_step(const hrp_regressor_step_desc* descs, int n, void* stream) {
   HRP_REQUIRE(descs && n >= 1 && n <= HRP_REG_MAX_PROBLEMS, "regressor_step: 1 .. %d problems", HRP_REG_MAX_PROBLEMS);
   RegArgs args;
-  int gx = 1, gz = 1, pmax = 0;
-  size_t lds_floats = RG_TILE_FLOATS;
+  int gx = 0, gz = 1, pmax = 0, mmax = 0;
+  bool prep = false;
   for (int i = 0; i < n; ++i) {
     const hrp_regressor_step_desc& d = descs[i];
     HRP_REQUIRE(d.M > 0 && d.N >= 0 && d.P >= 0 && d.P <= HRP_REG_MAX_P, "regressor_step[%d]: M %d, N %d, P %d", i, d.M, d.N, d.P);
     if (d.P > 0) {
       HRP_REQUIRE(d.u_prev, "regressor_step[%d]: a state of width %d needs u_prev", i, d.P);
-      if (d.z) {
-        HRP_REQUIRE(d.zw && d.z_len > 0 && d.z_len % 16 == 0 && d.z_pitch % 4 == 0 && (uintptr_t)d.z % 16 == 0,
-                    "regressor_step[%d]: z needs zw, a length that is a multiple of 16 and 16-byte aligned rows", i);
-        if ((size_t)d.P * d.z_len > lds_floats) lds_floats = (size_t)d.P * d.z_len;
-      }
+      HRP_REQUIRE(!d.z || (d.zw && d.z_len > 0), "regressor_step[%d]: z needs zw and a length", i);
+      prep = true;
     }
     if (d.N > 0) {
       HRP_REQUIRE(d.w && d.out && d.K > 0 && d.K % 4 == 0 && d.out_pitch >= d.N, "regressor_step[%d]: product needs w, out, K %% 4 == 0", i);
       HRP_REQUIRE(d.a || (d.v && d.P > 0), "regressor_step[%d]: no row operand", i);
       HRP_REQUIRE(d.w_sn == 1 || d.w_sk == 1, "regressor_step[%d]: the weight must be contiguous along n or along k", i);
-      HRP_REQUIRE(!d.a_mask || (uintptr_t)d.a_mask % 16 == 0, "regressor_step[%d]: a_mask alignment", i);
-      HRP_REQUIRE(!d.a_out || (uintptr_t)d.a_out % 16 == 0, "regressor_step[%d]: a_out alignment", i);
+      const bool transform = d.a_mask || (d.v && d.P > 0);
+      HRP_REQUIRE(!transform || (d.a_out && (uintptr_t)d.a_out % 16 == 0),
+                  "regressor_step[%d]: a masked / updated operand is staged through a_out (dense [M][K], 16-byte aligned)", i);
+      HRP_REQUIRE(d.a || transform, "regressor_step[%d]: no row operand", i);
       HRP_REQUIRE(!d.a2 || d.w2, "regressor_step[%d]: a2 without w2", i);
+      if (transform || d.a_out) prep = true;
       if ((d.N + RG_COLS - 1) / RG_COLS > gx) gx = (d.N + RG_COLS - 1) / RG_COLS;
     }
     if ((d.M + RG_ROWS - 1) / RG_ROWS > gz) gz = (d.M + RG_ROWS - 1) / RG_ROWS;
     if (d.P > pmax) pmax = d.P;
+    if (d.M > mmax) mmax = d.M;
     args.d[i] = d;
   }
-  const size_t lds = (RG_ROWS * RG_UP + lds_floats) * sizeof(float);
-  HRP_REQUIRE(lds <= 160 * 1024, "regressor_step: state width x z_len does not fit LDS (%zu bytes)", lds);
-  const dim3 grid(gx, n, gz), blk(256);
   hipStream_t s = (hipStream_t)stream;
-#define HRP_REG_CASE(PM)                                                                                                          \
-  {                                                                                                                               \
-    static bool raised = false;                                                                                                   \
-    if (!raised) {                                                                                                                \
-      (void)hipFuncSetAttribute((const void*)regressor_step_kernel<PM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-      raised = true;                                                                                                              \
-    }                                                                                                                             \
-    hipLaunchKernelGGL((regressor_step_kernel<PM>), grid, blk, lds, s, args);                                                     \
+  if (prep) {
+    const dim3 grid(mmax, n), blk(256);
+    if (pmax <= 8) hipLaunchKernelGGL((regressor_prep_kernel<8>), grid, blk, 0, s, args);
+    else hipLaunchKernelGGL((regressor_prep_kernel<16>), grid, blk, 0, s, args);
   }
-  if (pmax == 0) HRP_REG_CASE(0)
-  else if (pmax <= 8) HRP_REG_CASE(8)
-  else HRP_REG_CASE(16)
-#undef HRP_REG_CASE
+  if (gx > 0) hipLaunchKernelGGL(regressor_gemm_kernel, dim3(gx, n, gz), dim3(256), 0, s, args);
   return check_launch("regressor_step");
 }
 

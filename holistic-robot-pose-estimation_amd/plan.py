@@ -2050,7 +2050,7 @@ class PlanBuilder:
                 d.u_out = e["preds"].data_ptr() + 4 * i * M * P
                 d.a, d.a_pitch, d.a_mask = e["A"].data_ptr(), H, mask_ptr(h, i, 0)
                 d.v, d.v_sk, d.v_sp = e["fc1"].weight.data_ptr() + 4 * F, e["ld1"], 1
-                d.a_out = e["d1"].data_ptr() + 4 * i * M * H if p.need_grad else None
+                d.a_out = e["d1"].data_ptr() + 4 * i * M * H        # (the operand is staged through it; the backward reads it again)
                 d.w, d.w_sn, d.w_sk, d.bias = e["fc2"].weight.data_ptr(), H, 1, e["fc2"].bias.data_ptr()
                 d.out_mask = mask_ptr(h, i, 1)
                 d.out, d.out_pitch = e["d2"].data_ptr() + 4 * i * M * H, H

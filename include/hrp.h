@@ -646,7 +646,8 @@ int hrp_dropout_masks(float* masks, int64_t n, float keep, const uint64_t* state
  *   1. state    u[m][p]  = u_prev[m][p] + u_bias[p] + sum_{k < z_len} z[m][k] * zw[k * zw_sk + p * zw_sp]
  *               (z NULL: no sum; P == 0: no state).  Every workgroup computes the u of its rows; u_out (optional) receives it.
  *   2. operand  a'[m][k] = a_mask[m][k] * (a[m][k] + sum_p u[m][p] * v[k * v_sk + p * v_sp])
- *               (a NULL: 0; a_mask NULL: 1; v NULL: no update).  a_out (optional, dense [M][K]) receives a'.
+ *               (a NULL: 0; a_mask NULL: 1; v NULL: no update).  a_out (dense [M][K]; required when there is a mask or an update: the
+ *               product reads a' from it) receives a'.
  *   3. product  val[m][n] = out_mask[m][n] * (bias[n] + sum_k a'[m][k] * w[n * w_sn + k * w_sk] + sum_k a2[m][k] * w2[n * w_sn + k * w2_sk])
  *               out[m][n] (+)= val;  out_sum[m][n] (+)= val (optional).  One of w_sn / w_sk must be 1.  N == 0: step 1 only.
  * How the plan maps the reference loop onto it (hrpe_amd/plan.py PlanBuilder.regressors; F = feature width, H = 1024):
@@ -657,7 +658,8 @@ int hrp_dropout_masks(float* masks, int64_t n, float keep, const uint64_t* state
  *   backward i u_prev = g_{i+2}, z = gh1_{i+1}, zw = fc1.weight[:, F:] -> g_{i+1};  a = NULL, v = dec.weight^T, a_mask = drop2 mask -> gh2_i;
  *              w = fc2.weight^T (w_sn = 1, w_sk = H), out_mask = drop1 mask -> gh1_i, out_sum = gA
  *   d xf       a = gA(pose), w = fc_pose_1.weight^T, a2 = gA(rot), w2 = fc_rot_1.weight^T (w_sn = 1, w_sk = F + P)
- * Requirements: K % 4 == 0, z_len % 16 == 0, rows of z / a_mask / a_out 16-byte aligned, P <= HRP_REG_MAX_P. */
+ * Two kernels per call: steps 1 + 2 with one workgroup per row, step 3 with a workgroup per 32 rows x 16 columns.
+ * Requirements: K % 4 == 0, a_out 16-byte aligned, P <= HRP_REG_MAX_P. */
 #define HRP_REG_MAX_P 16
 #define HRP_REG_MAX_PROBLEMS 4
 typedef struct hrp_regressor_step_desc {

@@ -209,12 +209,18 @@ def test_fused_chain_equals_the_layerwise_path():
         _close(a, b, 2e-5)
     ga, gb = res[True][2], res[False][2]
     assert set(ga) == set(gb)
-    worst = 0.0
+    # (a conv bias in front of a BatchNorm has an analytically zero gradient: pure rounding noise, left out by the floor)
+    floor = 1e-4 * max(float(v.abs().max()) for v in gb.values())
+    worst, where = 0.0, None
     for k in ga:
         if k.startswith(("fc_", "dec")) or "final_feat_layer" in k or "stage4.2.fuse_layers.0" in k:
-            scale = float(gb[k].abs().max()) + 1e-30
-            worst = max(worst, float((ga[k] - gb[k]).abs().max()) / scale)
-    assert worst < 2e-4, worst
+            scale = float(gb[k].abs().max())
+            if scale < floor:
+                continue
+            e = float((ga[k] - gb[k]).abs().max()) / scale
+            if e > worst:
+                worst, where = e, k
+    assert worst < 2e-4, (worst, where)
 
 
 def test_fused_chain_with_dropout_against_torch_autograd():

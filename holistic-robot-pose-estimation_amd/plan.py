@@ -59,6 +59,7 @@ class TensorH:
         self.producer = None
         self.lane_path = plan.lane_path   # where it is produced; consumers in a concurrent lane are an error
         self._grad_paths = []
+        self.n_readers = self.n_bn_readers = 0   # forward consumers / those of them that are batch-statistics BatchNorm terms
 
     @property
     def esz(self):
@@ -98,6 +99,7 @@ class TensorH:
         """Forward consumers must be ordered after the producer (same lane, or outside its parallel block)."""
         if lanes_concurrent(self.plan.lane_path, self.lane_path):
             raise RuntimeError("plan: a tensor is consumed in a lane concurrent with its producer")
+        self.n_readers += 1
 
     def view4(self):
         return self.buf.view(self.N, self.H, self.W, self.pitch)[..., :self.C]
@@ -2162,8 +2164,14 @@ class PlanBuilder:
             acc = residual.take_grad_slot()
             p.bwd.append(lambda s: nv.call("hrp_copy_cols", y.gptr(), y.pitch, residual.gptr(), residual.pitch,
                                            y.N * y.H * y.W, y.C, acc, s))
-        # bias gradient
-        if bias is not None and bias.requires_grad:
+        # bias gradient.  A bias in front of a BatchNorm that normalises with batch statistics (the cls head's downsamp_modules and
+        # final_feat_layer, HRnet.py:364-383) has the gradient sum_pixels dy = 0 identically - the BatchNorm backward subtracts the
+        # mean of its output gradient; the reference's autograd computes that zero with fp32 rounding noise (~1e-9 of the weight
+        # gradients' scale).  No launch: the gradient keeps the zero of the arena (8 column-sum launches per step, 0.3 ms one by one).
+        if bias is not None and bias.requires_grad and y.n_bn_readers > 0 and y.n_readers == y.n_bn_readers:
+            p.grad_of_param(bias)
+            p.counters["bias_grad_zero_by_bn"] = p.counters.get("bias_grad_zero_by_bn", 0) + 1
+        elif bias is not None and bias.requires_grad:
             gb = p.grad_of_param(bias)
             cwb = int(nv.lib().hrp_colsum_workspace_bytes(y.N * y.H * y.W, y.C))      # deterministic: partial sums folded in order
             cws = torch.empty(cwb // 4 + 4, dtype=torch.float32, device=p.device)
@@ -2316,6 +2324,7 @@ class PlanBuilder:
             elif self.bn_batch_stats(tm.bn):
                 assert tm.t.stats is not None, "train-mode BN needs conv statistics"
                 e.mode = nv.EW_BN_TRAIN
+                tm.t.n_bn_readers += 1           # (read by nothing else, its producer's bias has an identically zero gradient: _conv_bwd)
                 e.a, e.b = tm.bn.weight.data_ptr(), tm.bn.bias.data_ptr()
                 e.count, e.eps = float(tm.t.N * tm.t.H * tm.t.W), tm.bn.eps
                 p.bn_train.append((tm.bn, tm.t.stats, tm.t.N * tm.t.H * tm.t.W))
@@ -2393,6 +2402,7 @@ class PlanBuilder:
     def avgpool(self, x, out=None):
         """Global average pool -> fp32 [N, C] (optionally into a column slice of `out`)."""
         p = self.plan
+        x.n_readers += 1
         y = out if out is not None else p.new(x.N, 1, 1, x.C, torch.float32)
         y.requires_grad = p.need_grad and x.requires_grad
         p.fwd.append(lambda s: nv.call("hrp_avgpool_fwd", x.ptr(), _dt(x.dtype), x.N, x.H * x.W, x.C, x.pitch,
@@ -2438,6 +2448,7 @@ class PlanBuilder:
     def copy_cols(self, src, dst):
         """dst[:, :src.C] = src (fp32), gradient flows back additively."""
         p = self.plan
+        src.n_readers += 1
         rows = src.N * src.H * src.W
         dst.requires_grad = dst.requires_grad or src.requires_grad
         p.fwd.append(lambda s: nv.call("hrp_copy_cols", src.ptr(), src.pitch, dst.ptr(), dst.pitch, rows, src.C, 0, s))
@@ -2501,6 +2512,7 @@ class PlanBuilder:
     def softargmax(self, heat, J, D, root, fix_root):
         """3-D soft-argmax of NHWC logits [N,H,W,J*D] -> uvd fp32 [N, J*3] (dense)."""
         p = self.plan
+        heat.n_readers += 1
         N, H, W = heat.N, heat.H, heat.W
         uvd = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
         ms = p.new(N, 1, 1, J * 2, torch.float32, pitch=J * 2)
@@ -2658,6 +2670,7 @@ class PlanBuilder:
         """HeatmapIntegralJoint's core (integral.py:206-224): per channel softmax over the H*W positions of NHWC logits
         [N, H, W, J] -> E[flat index] / (H*W), fp32 [N, J] dense."""
         p = self.plan
+        heat.n_readers += 1
         N, HW = heat.N, heat.H * heat.W
         coord = p.new(N, 1, 1, J, torch.float32, pitch=J)
         ms = p.new(N, 1, 1, J * 2, torch.float32, pitch=J * 2)

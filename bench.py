@@ -213,7 +213,9 @@ def conv_flops(name, args):
     """Algorithmic FLOP of one launch from its descriptor(s) (real channel counts)."""
     fam, descs = launch_descs(name, args)
     if fam == "hrp_conv2d_fwd":
-        return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps for d in descs)
+        # (the Bottleneck-tail launches - hrp_conv_desc.tail_mode - multiply again what the reference multiplies once: only the launch
+        # that writes the layer's output, mode 2, counts as the layer's algorithmic FLOP)
+        return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps for d in descs if getattr(d, "tail_mode", 0) in (0, 2))
     if fam == "hrp_conv2d_bwd_weight":
         return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps for d in descs)
     if fam == "hrp_block_launch":       # both convolutions of the block
@@ -235,6 +237,16 @@ def conv_bytes(name, args, extended=False):
         esz = 2 if d.dtype == nv.HRP_BF16 else 4
         if fam == "hrp_conv2d_fwd":
             b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
+            tm = getattr(d, "tail_mode", 0)
+            if tm in (1, 3, 4):
+                # recompute passes of a Bottleneck tail (statistics / BatchNorm backward): BatchNorm work in the reference, no
+                # convolution of SURVEY 8(d) - zero strict bytes (their TIME stays in the family); extended: what they move
+                b = 0.0
+                if extended:
+                    yb = d.N * d.Ho * d.Wo * d.Cout * esz
+                    b = d.N * d.H * d.W * d.Cin * esz + {1: 0, 3: yb, 4: 2 * yb + (yb * (2 if d.tail_side_acc else 1) if d.tail_side else 0)}[tm]
+                tot += b
+                continue
             if extended:
                 if d.res:
                     b += d.N * d.Ho * d.Wo * d.Cout * esz

@@ -42,7 +42,10 @@ class ConvDesc(C.Structure):
                 ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p),
                 ("pro_count", C.c_float), ("pro_eps", C.c_float), ("pro_side", C.c_void_p),
                 ("pro_mask", C.c_void_p), ("pro_side2", C.c_void_p), ("pro_side2_acc", C.c_int32), ("pro_reserved2", C.c_int32),
-                ("res_mask", C.c_void_p)]
+                ("res_mask", C.c_void_p),
+                ("tail_mode", C.c_int32), ("tail_side_acc", C.c_int32), ("tail_stats", C.c_void_p), ("tail_bsums", C.c_void_p),
+                ("tail_gamma", C.c_void_p), ("tail_beta", C.c_void_p), ("tail_count", C.c_float), ("tail_eps", C.c_float),
+                ("tail_mask", C.c_void_p), ("tail_g", C.c_void_p), ("tail_side", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

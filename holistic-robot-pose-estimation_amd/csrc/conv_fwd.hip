@@ -35,6 +35,7 @@ int conv_check(const hrp_conv_desc* d) {
   // input transforms / the mask-less epilogue reduce exist in the row-strip kernel only (conv_row.h)
   if (d->pro_mode != 0 || d->pro_side || d->pro_side2 || d->pro_mask || d->res_mask)
     HRP_REQUIRE(hrp_conv_rowstrip_channels(d) != 0, "conv: pro_mode / pro_side / pro_mask / res_mask need a row-strip problem (hrp_conv_rowstrip_channels)");
+  if (d->tail_mode) HRP_REQUIRE(pw_plan(*d, pwp) != 0, "conv: tail_mode needs a pointwise problem with Cin 32 / 64 and Cout %% 64 == 0 (hrp_conv_pointwise)");
   if (d->bnb_x && (!d->bnb_mask || d->res))
     HRP_REQUIRE(lean_kernel, "conv: a mask-less bnb_x / bnb_x with res needs a row-strip or pointwise problem (hrp_conv_rowstrip_channels, hrp_conv_pointwise)");
   return HRP_OK;

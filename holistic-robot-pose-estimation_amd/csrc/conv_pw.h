@@ -53,6 +53,15 @@ static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
     if (!d.bnb_mask && !d.bnb_stats) return 0;       // a recomputed mask needs scale / shift: the bnb_stats form only
   }
   if (d.bnb_x && d.Cin == 256) return 0;           // 16 k-steps leave no registers for the prefetch next to the butterfly: the tile program is 10 % faster
+  if (d.tail_mode) {         // the tail of a train-mode Bottleneck (conv_pw_tail_kernel): 32 / 64 -> a multiple of 64 channels
+    if (d.tail_mode < 1 || d.tail_mode > 4 || (d.Cin != 32 && d.Cin != 64) || d.Cout % 64) return 0;
+    if (d.bnb_x || d.scale || d.relu || d.stats == nullptr && (d.tail_mode == 1 || d.tail_mode == 3)) return 0;
+    if (d.tail_mode != 1 && (!d.tail_stats || !d.tail_gamma || !d.tail_beta || !d.tail_mask || (uintptr_t)d.tail_mask % 2)) return 0;
+    if (d.tail_mode == 2 && !d.res) return 0;
+    if (d.tail_mode != 2 && d.res) return 0;
+    if (d.tail_mode >= 3 && (!d.tail_g || (uintptr_t)d.tail_g % 16)) return 0;
+    if (d.tail_mode == 4 && (!d.tail_bsums || (uintptr_t)d.tail_side % 16)) return 0;
+  }
   p.ks = d.Cin / 16;
   p.mw = (p.ks <= 8 && d.Cout % 64 == 0) ? 2 : 1;
   const int nb = d.Cout / (32 * p.mw);
@@ -242,6 +251,238 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const hrp_conv_desc d, 
   conv_pw_body<KS, MW>(d, p, blockIdx.x, blockIdx.x & (HRP_STAT_SLOTS - 1));
 }
 
+// ---- the tail of a train-mode Bottleneck: out = relu(bn3(conv3(h)) + shortcut) (reference HRnet.py:88-96) and its backward without
+// the raw product in HBM (hrp_conv_desc.tail_mode, include/hrp.h).  The product of a 64 -> 256 layer costs 33 MB of reads; its
+// output, stored and read back, 2 x 134 MB - so every pass that needs it multiplies again:
+//   MODE 1  statistics (sum, sum of squares of the unrounded product) from the TRANSPOSED product alone - lane = one channel x 16 pixels
+//   MODE 2  y = relu(acc * sc + sh + res), ReLU bits to tail_mask                                (replaces the store of y3 + hrp_ew_fwd)
+//   MODE 3  s1 += g, s2 += g * acc with g = tail_g under the bits; one butterfly per workgroup   (replaces hrp_ew_bwd_reduce)
+//   MODE 4  y = sc * g + (c1 * acc + c0), tail_side (+)= g                                       (replaces hrp_ew_bwd_apply)
+// A lane's 16 channels are the same in every tile: the per-channel constants live in registers.
+template <int KS, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_desc d, const PwPlan p) {
+  constexpr int MW = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stat_lds = (float*)smem;
+  const int bid = blockIdx.x, stat_slot = blockIdx.x & (HRP_STAT_SLOTS - 1);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int Cin = KS * 16, Cout = d.Cout;
+  const int grp = bid % p.groups, wg = bid / p.groups;
+  const int wci = wave % p.wc, wpi = wave / p.wc;
+  const int cbase = (grp * p.wc + wci) * (32 * MW);
+  const int co_lane = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+
+  bf16x8 wf[MW][KS];
+  {
+    const char* wl = (const char*)d.w + (size_t)(d.wtap[0] * d.w_cout_pad + cbase + co_lane) * ROW + half * 16;
+    const size_t kstride = (size_t)d.w_ntaps * d.w_cout_pad * ROW;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) wf[mi][kk] = *(const bf16x8*)(wl + kk * kstride + mi * 32 * ROW);
+  }
+
+  // per-channel constants: a table in LDS (one thread per channel derives them from the statistic slots), then the lane's
+  // channels cl(mi) .. + 15 into registers - a lane's channels are the same in every tile
+  float* ctab = (float*)(smem + PW_STAT_BYTES);          // [3][Cout]: sc, sh | sc, c0, c1
+  float k_sc[MODE == 2 || MODE == 4 ? MW : 1][16], k_sh[MODE == 2 || MODE == 4 ? MW : 1][16], k_c1[MODE == 4 ? MW : 1][16];
+  if constexpr (MODE == 2 || MODE == 4) {
+    for (int c = tid; c < Cout; c += 256) {
+      float mean, inv, sc, sh;
+      row_bn_consts(d.tail_stats, d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps, c, Cout, mean, inv, sc, sh);
+      ctab[c] = sc;
+      if constexpr (MODE == 2) ctab[Cout + c] = sh;
+      else {         // sc * (g - k0 - xhat * k1), xhat = inv * y - mean * inv  ==  sc * g + (c1 * y + c0)
+        const float k0 = slot_sum(d.tail_bsums, c, 2 * Cout) / d.tail_count, k1 = slot_sum(d.tail_bsums, Cout + c, 2 * Cout) / d.tail_count;
+        ctab[Cout + c] = -sc * fmaf(k1, -mean * inv, k0);
+        ctab[2 * Cout + c] = -sc * k1 * inv;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      const int cl = cbase + mi * 32 + 16 * half;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const float4 a4 = *(const float4*)(ctab + cl + i), b4 = *(const float4*)(ctab + Cout + cl + i);
+        k_sc[mi][i] = a4.x; k_sc[mi][i + 1] = a4.y; k_sc[mi][i + 2] = a4.z; k_sc[mi][i + 3] = a4.w;
+        k_sh[mi][i] = b4.x; k_sh[mi][i + 1] = b4.y; k_sh[mi][i + 2] = b4.z; k_sh[mi][i + 3] = b4.w;
+        if constexpr (MODE == 4) {
+          const float4 c4 = *(const float4*)(ctab + 2 * Cout + cl + i);
+          k_c1[mi][i] = c4.x; k_c1[mi][i + 1] = c4.y; k_c1[mi][i + 2] = c4.z; k_c1[mi][i + 3] = c4.w;
+        }
+      }
+    }
+  }
+
+  const long M = (long)d.N * d.Ho * d.Wo;
+  const int tile0 = wg * (p.tpw * p.wp) + wpi, tstep = p.wp;
+  const char* xg = (const char*)d.x + half * 16;
+  auto load_tile = [&](int t, bf16x8 (&xb)[KS]) {
+    const long pix = (long)t * 32 + l31;
+    if (t < p.ntiles && pix < M) {
+      const char* q = xg + (size_t)pix * (Cin * 2);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) xb[kk] = *(const bf16x8*)(q + kk * 32);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xb[kk][i] = (__bf16)0.f;
+    }
+  };
+
+  float vt[MW], vq[MW];                      // MODE 1: per lane (channel co_lane) sum / sum of squares
+  float s1[MODE == 3 ? MW : 1][16], s2[MODE == 3 ? MW : 1][16];
+#pragma unroll
+  for (int mi = 0; mi < MW; ++mi) vt[mi] = vq[mi] = 0.f;
+  if constexpr (MODE == 3) {
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s1[mi][i] = s2[mi][i] = 0.f;
+  }
+
+  auto compute = [&](int t, const bf16x8 (&xb)[KS]) {
+    const long pix = (long)t * 32 + l31;
+    const bool ok = t < p.ntiles && pix < M;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      if constexpr (MODE == 1) {
+        f32x16 tr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tr[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[kk], wf[mi][kk], tr, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { vt[mi] += tr[i]; vq[mi] = fmaf(tr[i], tr[i], vq[mi]); }      // (pixels outside the tensor: zero rows)
+      } else {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mi][kk], xb[kk], acc, 0, 0, 0);
+        const int cl = cbase + mi * 32 + 16 * half;
+        const unsigned off = (unsigned)(pix * Cout + cl) * 2u;
+        if constexpr (MODE == 2) {
+          uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+          if (ok) { rr[0] = *(const uint4*)((const char*)d.res + off); rr[1] = *(const uint4*)((const char*)d.res + off + 16); }
+          unsigned bits = 0;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float v[8], r[8];
+            Elem<bf16_t>::unpack(rr[hh], r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              v[i] = fmaxf(fmaf(acc[8 * hh + i], k_sc[mi][8 * hh + i], k_sh[mi][8 * hh + i]) + r[i], 0.f);
+              bits |= (v[i] > 0.f ? 1u : 0u) << (8 * hh + i);
+            }
+            if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
+          }
+          if (ok) *(unsigned short*)(d.tail_mask + (off >> 4)) = (unsigned short)bits;
+        } else {
+          uint4 gr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+          int bits = 0;
+          if (ok) {
+            gr[0] = *(const uint4*)((const char*)d.tail_g + off); gr[1] = *(const uint4*)((const char*)d.tail_g + off + 16);
+            bits = *(const unsigned short*)(d.tail_mask + (off >> 4));
+          }
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float g[8];
+            Elem<bf16_t>::unpack(gr[hh], g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = row_keep_if_bit(g[i], bits, 8 * hh + i);
+            if constexpr (MODE == 3) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { s1[mi][8 * hh + i] += g[i]; s2[mi][8 * hh + i] = fmaf(g[i], acc[8 * hh + i], s2[mi][8 * hh + i]); }
+            } else {
+              if (d.tail_side && ok) {
+                char* q = (char*)d.tail_side + off + 16 * hh;
+                if (d.tail_side_acc) {
+                  float o[8];
+                  Elem<bf16_t>::unpack(*(const uint4*)q, o);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) o[i] += g[i];
+                  *(uint4*)q = Elem<bf16_t>::pack(o);
+                } else {
+                  *(uint4*)q = Elem<bf16_t>::pack(g);
+                }
+              }
+              float v[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = fmaf(k_sc[mi][8 * hh + i], g[i], fmaf(k_c1[mi][8 * hh + i], acc[8 * hh + i], k_sh[mi][8 * hh + i]));
+              if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  {
+    bf16x8 xa[KS], xb[KS];
+    load_tile(tile0, xa);
+    for (int it = 0; it < p.tpw; it += 2) {
+      load_tile(tile0 + (it + 1) * tstep, xb);
+      compute(tile0 + it * tstep, xa);
+      if (it + 2 < p.tpw) load_tile(tile0 + (it + 2) * tstep, xa);
+      if (it + 1 < p.tpw) compute(tile0 + (it + 1) * tstep, xb);
+    }
+  }
+
+  if constexpr (MODE == 1 || MODE == 3) {
+    // one value per lane and channel block.  MODE 1: half 0 = sum, half 1 = sum of squares of channel co_lane.  MODE 3 (after the
+    // reduce-scatter butterfly): l31 < 16 the sum of g, l31 >= 16 the sum of g * y of channel cl + (l31 & 15).
+    float v[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      if constexpr (MODE == 1) {
+        const float a = vt[mi] + __shfl_xor(vt[mi], 32, 64), b = vq[mi] + __shfl_xor(vq[mi], 32, 64);
+        v[mi] = half ? b : a;
+      } else {
+        v[mi] = row_reduce32(s1[mi], s2[mi], l31);
+      }
+    }
+    if (p.wp > 1) {
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi) stat_lds[(wave * 2 + mi) * 64 + lane] = v[mi];
+      __syncthreads();
+      if (wpi != 0) return;
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi)
+        for (int q = 1; q < p.wp; ++q) v[mi] += stat_lds[((wci + q * p.wc) * 2 + mi) * 64 + lane];
+    }
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      if constexpr (MODE == 1) {
+        atomicAdd(d.stats + stat_slot * 2 * Cout + half * Cout + cbase + mi * 32 + co_lane, (double)v[mi]);
+      } else {
+        const int which = l31 >> 4, c = cbase + mi * 32 + 16 * half + (l31 & 15);
+        const float other = __shfl_xor(v[mi], 16, 64);          // sum g of the same channel, for the lanes holding sum g * y
+        float tot = v[mi];
+        if (which == 1) {                                       // sum g * xhat = inv * sum g y - mean * inv * sum g
+          float mean, inv, sc, sh;
+          row_bn_consts(d.tail_stats, d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps, c, Cout, mean, inv, sc, sh);
+          tot = fmaf(inv, v[mi], -mean * inv * other);
+        }
+        atomicAdd(d.stats + stat_slot * 2 * Cout + which * Cout + c, (double)tot);
+      }
+    }
+  }
+}
+
+template <int KS, int MODE>
+static inline int pw_tail_occupancy() {
+  static int occ = 0;
+  if (!occ) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail_kernel<KS, MODE>, 256, PW_STAT_BYTES + 3 * 256 * 4) != hipSuccess || nb < 1) nb = 1;
+    occ = nb;
+  }
+  return occ;
+}
+
 // ONE round of workgroups: as many as are resident at once (all of them run side by side and finish together - a second,
 // partly filled round would idle most of the chip), each walking ntiles / (that many) tiles
 static inline void pw_fill_grid(PwPlan& p, int occupancy) {
@@ -269,6 +510,13 @@ static inline int launch_conv_pw(const hrp_conv_desc& d, const PwPlan& p0, hipSt
   PwPlan p = p0;
   const dim3 blk(256);
   const int lds = pw_lds_bytes(d);
+  if (d.tail_mode) {
+#define HRP_PWT_CASE(K, MD) if (p.ks == K && d.tail_mode == MD) { pw_fill_grid(p, pw_tail_occupancy<K, MD>()); hipLaunchKernelGGL((conv_pw_tail_kernel<K, MD>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p); return check_launch("conv_pw_tail_kernel"); }
+    HRP_PWT_CASE(2, 1) HRP_PWT_CASE(2, 2) HRP_PWT_CASE(2, 3) HRP_PWT_CASE(2, 4) HRP_PWT_CASE(4, 1) HRP_PWT_CASE(4, 2) HRP_PWT_CASE(4, 3) HRP_PWT_CASE(4, 4)
+#undef HRP_PWT_CASE
+    set_error("conv: no Bottleneck-tail instantiation for Cin=%d mode %d", d.Cin, d.tail_mode);
+    return HRP_ERR_ARG;
+  }
 #define HRP_PW_CASE(K, M_) if (p.ks == K && p.mw == M_) { pw_fill_grid(p, pw_occupancy<K, M_>()); hipLaunchKernelGGL((conv_pw_kernel<K, M_>), dim3(p.wgs * p.groups), blk, lds, s, d, p); return check_launch("conv_pw_kernel"); }
   HRP_PW_CASE(2, 1) HRP_PW_CASE(2, 2) HRP_PW_CASE(4, 1) HRP_PW_CASE(4, 2) HRP_PW_CASE(8, 1) HRP_PW_CASE(8, 2) HRP_PW_CASE(16, 1)
 #undef HRP_PW_CASE

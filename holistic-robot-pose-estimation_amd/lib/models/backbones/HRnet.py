@@ -136,6 +136,12 @@ class Bottleneck(SingleTensorModule):
     def emit(self, pb, x):
         h = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
         h = pb.act([conv_bn(pb, h, self.conv2, self.bn2)], relu=True)
+        if self.downsample is None:
+            # training plans, the wide high-resolution blocks (layer1 blocks 1-3): conv3's 134 MB output is never stored, its
+            # BatchNorm + shortcut + ReLU and their backward run inside pointwise launches that multiply again (PlanBuilder.bottleneck_tail)
+            out = pb.bottleneck_tail(h, self.conv3.weight, self.bn3, x)
+            if out is not None:
+                return out
         skip = Term(x) if self.downsample is None else conv_bn(pb, x, self.downsample[0], self.downsample[1])
         return pb.act([conv_bn(pb, h, self.conv3, self.bn3), skip], relu=True)
 

@@ -170,6 +170,9 @@ BLOCK_END_REDUCE_FUSE = True
 BLOCK_FUSE = os.environ.get("HRP_BLOCK_FUSE", "1") not in ("0", "")      # fused inference BasicBlock (csrc/conv_block.h)
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
 MASKED_RES = True
+# train-mode Bottlenecks with an identity shortcut at >= 131 072 pixels (layer1 blocks 1-3): conv3 + BatchNorm + shortcut + ReLU as
+# two pointwise launches that never store conv3's raw output, the BatchNorm backward likewise (PlanBuilder.bottleneck_tail)
+BNECK_TAIL_FUSE = True
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
 # lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
 # instead of by position: 646 -> 628 conv launches, 34.12 -> 33.87 ms per step (A/B/A/B on one box)
@@ -1928,6 +1931,89 @@ class PlanBuilder:
             if bn2 is not None and fd is None:
                 list.append(self.bwd_stack, act_bw)
         return out if bn2 is not None else y2
+
+    def bottleneck_tail(self, h, conv3_w, bn3, x):
+        """out = relu(bn3(conv3(h)) + x): the tail of a train-mode Bottleneck with an identity shortcut (reference HRnet.py:88-96)
+        WITHOUT conv3's raw output in HBM.  At 64 x 64 the output of the 64 -> 256 layer is 134 MB per batch of 64, its input 33 MB:
+        the product is recomputed wherever it is needed instead of stored and read back (hrp_conv_desc.tail_mode, csrc/conv_pw.h):
+          forward   mode 1 (batch statistics of the product, nothing stored) + mode 2 (normalise, add the shortcut, ReLU, bit mask)
+                    replace conv3 + hrp_ew_fwd: x and out once, h twice - 343 MB instead of 577 per block
+          backward  mode 3 (sum g, sum g xhat) + mode 4 (gradient of the product, shortcut gradient as a rider) replace
+                    hrp_ew_bwd_reduce + hrp_ew_bwd_apply: they read h (33 MB) instead of y3 (134 MB) each
+        The data and weight gradient of conv3 are the ordinary launches on mode 4's output.
+        -> out, or None when the problem is not the pointwise kernel's (caller: the general path)."""
+        p = self.plan
+        if not (BNECK_TAIL_FUSE and p.training and h.dtype == torch.bfloat16 and self.bn_batch_stats(bn3)):
+            return None
+        cout, cin = conv3_w.shape[0], conv3_w.shape[1]
+        if (conv3_w.dim() == 4 and conv3_w.shape[2] != 1) or (x.N, x.H, x.W, x.C) != (h.N, h.H, h.W, cout):
+            return None
+        if x.pitch != cout or x.offset or h.pitch != cin or h.offset or h.C != cin or x.dtype != h.dtype:
+            return None
+        if p.need_grad and not (x.requires_grad and h.requires_grad and conv3_w.requires_grad):
+            return None
+        h.check_readable()
+        x.check_readable()
+        dtype = h.dtype
+        w3 = p.weight(conv3_w, cout, cin, 1)
+        y3 = p.new(h.N, h.H, h.W, cout, dtype)          # (never written by the forward; its gradient buffer is mode 4's output)
+        out = p.new(h.N, h.H, h.W, cout, dtype)
+        cnt = float(h.N * h.H * h.W)
+        mask = torch.zeros(h.N * h.H * h.W * (cout // 8), dtype=torch.uint8, device=p.device)
+        p.keep.append(mask)
+
+        def desc(mode):
+            d = self._conv_desc(h, w3, y3, 1, 1, dtype)
+            d.tail_mode = mode
+            d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps = bn3.weight.data_ptr(), bn3.bias.data_ptr(), cnt, bn3.eps
+            d.tail_mask = mask.data_ptr()
+            return d
+        dA, dB = desc(1), desc(2)
+        dB.y, dB.res, dB.res_pitch = out.ptr(), x.ptr(), x.pitch
+        # eligibility of all four forms (dummy aligned pointers where the arenas are not allocated yet)
+        for mode in (1, 2, 3, 4):
+            q = desc(mode)
+            q.w = q.stats = q.tail_stats = q.tail_bsums = q.tail_g = q.x
+            if mode == 2:
+                q.res = q.x
+            if not nv.lib().hrp_conv_pointwise(C.byref(q)):
+                return None
+        w3.dtype, w3.cin_used = dtype, cin
+        w3.need_t = getattr(w3, "need_t", False) or p.need_grad
+        y3.requires_grad = out.requires_grad = p.need_grad
+        y3.stats = p.alloc_stats(cout)
+        p.bn_train.append((bn3, y3.stats, h.N * h.H * h.W))
+
+        def late():
+            dA.w = dB.w = w3.arena.data_ptr() + w3.fwd_off * 2
+            dA.stats = dB.tail_stats = p.stats.data_ptr() + 8 * y3.stats
+        p.late(late)
+        p.fwd.append(Launch("conv", dA))
+        p.fwd.append(Launch("conv", dB))
+        out.producer = None
+        p.counters["bottleneck_tails"] = p.counters.get("bottleneck_tails", 0) + 1
+        if p.need_grad:
+            def bw():
+                if not out.grad_written:
+                    return
+                y3.take_grad_slot()
+                boff = p.alloc_bsums(cout)
+                p.bn_bwd.append((bn3, boff))
+                dC, dD = desc(3), desc(4)
+                dC.tail_g = dD.tail_g = out.gptr()
+                dD.y = y3.gptr()
+                dD.tail_side, dD.tail_side_acc = x.gptr(), x.take_grad_slot()
+
+                def late_b():
+                    dC.w = dD.w = w3.arena.data_ptr() + w3.fwd_off * 2
+                    dC.tail_stats = dD.tail_stats = p.stats.data_ptr() + 8 * y3.stats
+                    dC.stats = dD.tail_bsums = p.bsums.data_ptr() + 8 * boff
+                p.late(late_b)
+                p.bwd.append(Launch("conv", dC))
+                p.bwd.append(Launch("conv", dD))
+                self._conv_bwd(h, w3, y3, None, 1, 1, dtype, None, False)
+            self.bwd_stack.append(bw)
+        return out
 
     def linear(self, x, weight, bias=None, residual=None):
         """y = x W^T + b (+ residual) on fp32 [N, C] tensors: nn.Linear of the regression heads as a skinny GEMM that reads

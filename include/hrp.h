@@ -153,6 +153,27 @@ typedef struct hrp_conv_desc {
    * block input in one write - conv1's data gradient plus the gradient of the identity shortcut, which is the block output's
    * gradient masked by the block-end ReLU (HRnet.py:52-56) - instead of accumulating onto a tensor another launch wrote. */
   const uint8_t* res_mask;
+  /* ---- pointwise kernel only (hrp_conv_pointwise(d) != 0, Cin 32 / 64, Cout a multiple of 64): the tail of a train-mode Bottleneck,
+   * out = relu(bn3(conv3(h)) + shortcut) (HRnet.py:88-96), WITHOUT storing conv3's raw output - a 64 -> 256 product is cheaper to
+   * recompute from its 33 MB input than its 134 MB output is to write and read back (B = 64).  tail_mode:
+   *   1  statistics only: stats += sum / sum of squares of the (unrounded) product over the pixels; nothing is stored (y unused)
+   *   2  y = relu(bn(product) + res): batch statistics from tail_stats (the slots a mode-1 launch filled), tail_gamma / _beta / _count /
+   *      _eps; res = the shortcut (geometry of y, required); the ReLU bits of y go to tail_mask ([pixels][Cout / 8] bytes, the
+   *      layout of hrp_ew_desc.mask)
+   *   3  backward reduce of that BatchNorm: the product is recomputed, g = tail_g masked by tail_mask;
+   *      stats += sum g, sum g * xhat (the slots hrp_bn_param_grad and mode 4 read); nothing is stored
+   *   4  backward apply: y = gamma invstd (g - k0 - xhat k1), k0 / k1 = slot sums of tail_bsums / tail_count - the gradient of the
+   *      product, which the ordinary data- and weight-gradient launches of the layer then read; tail_side (optional, geometry of y)
+   *      = or += (tail_side_acc) g: the gradient of the identity shortcut. */
+  int32_t tail_mode, tail_side_acc;
+  const double* tail_stats;
+  const double* tail_bsums;
+  const float* tail_gamma;
+  const float* tail_beta;
+  float tail_count, tail_eps;
+  uint8_t* tail_mask;
+  const void* tail_g;
+  void* tail_side;
 } hrp_conv_desc;
 
 /* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],

@@ -215,7 +215,8 @@ def conv_flops(name, args):
     if fam == "hrp_conv2d_fwd":
         # (the Bottleneck-tail launches - hrp_conv_desc.tail_mode - multiply again what the reference multiplies once: only the launch
         # that writes the layer's output, mode 2, counts as the layer's algorithmic FLOP)
-        return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps for d in descs if getattr(d, "tail_mode", 0) in (0, 2))
+        return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps * (2 if getattr(d, "tail_mode", 0) == 5 else 1)
+                   for d in descs if getattr(d, "tail_mode", 0) in (0, 2, 5))
     if fam == "hrp_conv2d_bwd_weight":
         return sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.dw_cin * d.ntaps for d in descs)
     if fam == "hrp_block_launch":       # both convolutions of the block
@@ -247,6 +248,8 @@ def conv_bytes(name, args, extended=False):
                     b = d.N * d.H * d.W * d.Cin * esz + {1: 0, 3: yb, 4: 2 * yb + (yb * (2 if d.tail_side_acc else 1) if d.tail_side else 0)}[tm]
                 tot += b
                 continue
+            if tm == 5:       # two layers in one launch (conv3 and the projection): both inputs, both weights, one output
+                b += (d.N * d.H * d.W * d.Cin + d.ntaps * d.Cin * d.Cout) * esz
             if extended:
                 if d.res:
                     b += d.N * d.Ho * d.Wo * d.Cout * esz

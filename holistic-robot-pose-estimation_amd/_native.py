@@ -45,7 +45,9 @@ class ConvDesc(C.Structure):
                 ("res_mask", C.c_void_p),
                 ("tail_mode", C.c_int32), ("tail_side_acc", C.c_int32), ("tail_stats", C.c_void_p), ("tail_bsums", C.c_void_p),
                 ("tail_gamma", C.c_void_p), ("tail_beta", C.c_void_p), ("tail_count", C.c_float), ("tail_eps", C.c_float),
-                ("tail_mask", C.c_void_p), ("tail_g", C.c_void_p), ("tail_side", C.c_void_p)]
+                ("tail_mask", C.c_void_p), ("tail_g", C.c_void_p), ("tail_side", C.c_void_p),
+                ("tail_x2", C.c_void_p), ("tail_w2", C.c_void_p), ("tail_stats2", C.c_void_p), ("tail_gamma2", C.c_void_p),
+                ("tail_beta2", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

@@ -54,7 +54,9 @@ static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
   }
   if (d.bnb_x && d.Cin == 256) return 0;           // 16 k-steps leave no registers for the prefetch next to the butterfly: the tile program is 10 % faster
   if (d.tail_mode) {         // the tail of a train-mode Bottleneck (conv_pw_tail_kernel): 32 / 64 -> a multiple of 64 channels
-    if (d.tail_mode < 1 || d.tail_mode > 4 || (d.Cin != 32 && d.Cin != 64) || d.Cout % 64) return 0;
+    if (d.tail_mode < 1 || d.tail_mode > 5 || (d.Cin != 32 && d.Cin != 64) || d.Cout % 64) return 0;
+    if (d.tail_mode == 5 && (!d.tail_x2 || !d.tail_w2 || !d.tail_stats2 || !d.tail_gamma2 || !d.tail_beta2 || d.res ||
+                             ((uintptr_t)d.tail_x2 | (uintptr_t)d.tail_w2) % 16)) return 0;
     if (d.bnb_x || d.scale || d.relu || d.stats == nullptr && (d.tail_mode == 1 || d.tail_mode == 3)) return 0;
     if (d.tail_mode != 1 && (!d.tail_stats || !d.tail_gamma || !d.tail_beta || !d.tail_mask || (uintptr_t)d.tail_mask % 2)) return 0;
     if (d.tail_mode == 2 && !d.res) return 0;
@@ -472,6 +474,100 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
   }
 }
 
+// MODE 5: the projection form, out = relu(bn(w h) + bn2(w2 x2)): two products per tile, the constants of both BatchNorms read
+// from the LDS table per tile (two weight sets and two operand prefetches leave no registers for 128 constants).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_pw_tail2_kernel(const hrp_conv_desc d, const PwPlan p) {
+  constexpr int MW = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ctab = (float*)(smem + PW_STAT_BYTES);          // [4][Cout]: sc, sh, sc2, sh2 (sh holds sh + sh2, row 3 unused)
+  const int bid = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int Cin = KS * 16, Cout = d.Cout;
+  const int grp = bid % p.groups, wg = bid / p.groups;
+  const int wci = wave % p.wc, wpi = wave / p.wc;
+  const int cbase = (grp * p.wc + wci) * (32 * MW);
+  const int co_lane = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  for (int c = tid; c < Cout; c += 256) {
+    float mean, inv, sc, sh, sc2, sh2;
+    row_bn_consts(d.tail_stats, d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps, c, Cout, mean, inv, sc, sh);
+    row_bn_consts(d.tail_stats2, d.tail_gamma2, d.tail_beta2, d.tail_count, d.tail_eps, c, Cout, mean, inv, sc2, sh2);
+    ctab[c] = sc; ctab[Cout + c] = sh + sh2; ctab[2 * Cout + c] = sc2;
+  }
+  bf16x8 wf[MW][KS], wg2[MW][KS];
+  {
+    const size_t lane_off = (size_t)(d.wtap[0] * d.w_cout_pad + cbase + co_lane) * ROW + half * 16;
+    const size_t kstride = (size_t)d.w_ntaps * d.w_cout_pad * ROW;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        wf[mi][kk] = *(const bf16x8*)((const char*)d.w + lane_off + kk * kstride + mi * 32 * ROW);
+        wg2[mi][kk] = *(const bf16x8*)((const char*)d.tail_w2 + lane_off + kk * kstride + mi * 32 * ROW);
+      }
+  }
+  __syncthreads();
+  const long M = (long)d.N * d.Ho * d.Wo;
+  const int tile0 = wg * (p.tpw * p.wp) + wpi, tstep = p.wp;
+  auto load_tile = [&](int t, bf16x8 (&xb)[KS], bf16x8 (&xc)[KS]) {
+    const long pix = (long)t * 32 + l31;
+    if (t < p.ntiles && pix < M) {
+      const char* q = (const char*)d.x + half * 16 + (size_t)pix * (Cin * 2);
+      const char* q2 = (const char*)d.tail_x2 + half * 16 + (size_t)pix * (Cin * 2);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) { xb[kk] = *(const bf16x8*)(q + kk * 32); xc[kk] = *(const bf16x8*)(q2 + kk * 32); }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xb[kk][i] = (__bf16)0.f; xc[kk][i] = (__bf16)0.f; }
+    }
+  };
+  auto compute = [&](int t, const bf16x8 (&xb)[KS], const bf16x8 (&xc)[KS]) {
+    const long pix = (long)t * 32 + l31;
+    const bool ok = t < p.ntiles && pix < M;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+      f32x16 acc, acc2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mi][kk], xb[kk], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg2[mi][kk], xc[kk], acc2, 0, 0, 0);
+      }
+      const int cl = cbase + mi * 32 + 16 * half;
+      const unsigned off = (unsigned)(pix * Cout + cl) * 2u;
+      unsigned bits = 0;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 4) {
+          const float4 a4 = *(const float4*)(ctab + cl + 8 * hh + i), b4 = *(const float4*)(ctab + Cout + cl + 8 * hh + i);
+          const float4 c4 = *(const float4*)(ctab + 2 * Cout + cl + 8 * hh + i);
+          const float sa[4] = {a4.x, a4.y, a4.z, a4.w}, sb[4] = {b4.x, b4.y, b4.z, b4.w}, sc2[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[i + e] = fmaxf(fmaf(acc[8 * hh + i + e], sa[e], fmaf(acc2[8 * hh + i + e], sc2[e], sb[e])), 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bits |= (v[i] > 0.f ? 1u : 0u) << (8 * hh + i);
+        if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
+      }
+      if (ok) *(unsigned short*)(d.tail_mask + (off >> 4)) = (unsigned short)bits;
+    }
+  };
+  bf16x8 xa[KS], xa2[KS], xb[KS], xb2[KS];
+  load_tile(tile0, xa, xa2);
+  for (int it = 0; it < p.tpw; it += 2) {
+    load_tile(tile0 + (it + 1) * tstep, xb, xb2);
+    compute(tile0 + it * tstep, xa, xa2);
+    if (it + 2 < p.tpw) load_tile(tile0 + (it + 2) * tstep, xa, xa2);
+    if (it + 1 < p.tpw) compute(tile0 + (it + 1) * tstep, xb, xb2);
+  }
+}
+
 template <int KS, int MODE>
 static inline int pw_tail_occupancy() {
   static int occ = 0;
@@ -514,6 +610,20 @@ static inline int launch_conv_pw(const hrp_conv_desc& d, const PwPlan& p0, hipSt
 #define HRP_PWT_CASE(K, MD) if (p.ks == K && d.tail_mode == MD) { pw_fill_grid(p, pw_tail_occupancy<K, MD>()); hipLaunchKernelGGL((conv_pw_tail_kernel<K, MD>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p); return check_launch("conv_pw_tail_kernel"); }
     HRP_PWT_CASE(2, 1) HRP_PWT_CASE(2, 2) HRP_PWT_CASE(2, 3) HRP_PWT_CASE(2, 4) HRP_PWT_CASE(4, 1) HRP_PWT_CASE(4, 2) HRP_PWT_CASE(4, 3) HRP_PWT_CASE(4, 4)
 #undef HRP_PWT_CASE
+    if (d.tail_mode == 5) {
+      static int occ2[2] = {0, 0};
+      const int which = p.ks == 2 ? 0 : 1;
+      if (!occ2[which]) {
+        int nb = 0;
+        const hipError_t e = p.ks == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail2_kernel<2>, 256, PW_STAT_BYTES + 3 * 256 * 4)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail2_kernel<4>, 256, PW_STAT_BYTES + 3 * 256 * 4);
+        occ2[which] = (e != hipSuccess || nb < 1) ? 1 : nb;
+      }
+      pw_fill_grid(p, occ2[which]);
+      if (p.ks == 2) hipLaunchKernelGGL((conv_pw_tail2_kernel<2>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p);
+      else hipLaunchKernelGGL((conv_pw_tail2_kernel<4>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p);
+      return check_launch("conv_pw_tail2_kernel");
+    }
     set_error("conv: no Bottleneck-tail instantiation for Cin=%d mode %d", d.Cin, d.tail_mode);
     return HRP_ERR_ARG;
   }

@@ -136,10 +136,12 @@ class Bottleneck(SingleTensorModule):
     def emit(self, pb, x):
         h = pb.act([conv_bn(pb, x, self.conv1, self.bn1)], relu=True)
         h = pb.act([conv_bn(pb, h, self.conv2, self.bn2)], relu=True)
-        if self.downsample is None:
-            # training plans, the wide high-resolution blocks (layer1 blocks 1-3): conv3's 134 MB output is never stored, its
-            # BatchNorm + shortcut + ReLU and their backward run inside pointwise launches that multiply again (PlanBuilder.bottleneck_tail)
-            out = pb.bottleneck_tail(h, self.conv3.weight, self.bn3, x)
+        if self.stride == 1:
+            # training plans, the wide high-resolution blocks (layer1, the first incre-module): conv3's 134 MB output - and the raw output
+            # of a 1x1 projection shortcut - are never stored, the BatchNorm + shortcut + ReLU and their backward run inside pointwise
+            # launches that multiply again (PlanBuilder.bottleneck_tail)
+            proj = None if self.downsample is None else (self.downsample[0].weight, self.downsample[1])
+            out = pb.bottleneck_tail(h, self.conv3.weight, self.bn3, x, proj=proj)
             if out is not None:
                 return out
         skip = Term(x) if self.downsample is None else conv_bn(pb, x, self.downsample[0], self.downsample[1])

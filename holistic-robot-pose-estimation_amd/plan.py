@@ -170,8 +170,9 @@ BLOCK_END_REDUCE_FUSE = True
 BLOCK_FUSE = os.environ.get("HRP_BLOCK_FUSE", "1") not in ("0", "")      # fused inference BasicBlock (csrc/conv_block.h)
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
 MASKED_RES = True
-# train-mode Bottlenecks with an identity shortcut at >= 131 072 pixels (layer1 blocks 1-3): conv3 + BatchNorm + shortcut + ReLU as
-# two pointwise launches that never store conv3's raw output, the BatchNorm backward likewise (PlanBuilder.bottleneck_tail)
+# train-mode Bottlenecks at >= 131 072 pixels (layer1, the first incre-module of the cls head): conv3 (+ the 1x1 projection of the
+# shortcut) + BatchNorm + shortcut + ReLU as pointwise launches that never store a raw 1x1 output, the BatchNorm backward likewise
+# (PlanBuilder.bottleneck_tail)
 BNECK_TAIL_FUSE = True
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
 # lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
@@ -1932,63 +1933,94 @@ class PlanBuilder:
                 list.append(self.bwd_stack, act_bw)
         return out if bn2 is not None else y2
 
-    def bottleneck_tail(self, h, conv3_w, bn3, x):
-        """out = relu(bn3(conv3(h)) + x): the tail of a train-mode Bottleneck with an identity shortcut (reference HRnet.py:88-96)
-        WITHOUT conv3's raw output in HBM.  At 64 x 64 the output of the 64 -> 256 layer is 134 MB per batch of 64, its input 33 MB:
-        the product is recomputed wherever it is needed instead of stored and read back (hrp_conv_desc.tail_mode, csrc/conv_pw.h):
-          forward   mode 1 (batch statistics of the product, nothing stored) + mode 2 (normalise, add the shortcut, ReLU, bit mask)
-                    replace conv3 + hrp_ew_fwd: x and out once, h twice - 343 MB instead of 577 per block
-          backward  mode 3 (sum g, sum g xhat) + mode 4 (gradient of the product, shortcut gradient as a rider) replace
-                    hrp_ew_bwd_reduce + hrp_ew_bwd_apply: they read h (33 MB) instead of y3 (134 MB) each
-        The data and weight gradient of conv3 are the ordinary launches on mode 4's output.
+    def bottleneck_tail(self, h, conv3_w, bn3, x, proj=None):
+        """out = relu(bn3(conv3(h)) + shortcut): the tail of a train-mode Bottleneck (reference HRnet.py:88-96) WITHOUT conv3's raw
+        output in HBM; shortcut = x (identity) or, proj = (1x1 weight, BatchNorm), bn_d(conv_d(x)) - the projection of the first block of
+        a stack (HRnet.py:139-150), whose raw output is not stored either.  At 64 x 64 the output of the 64 -> 256 layer is 134 MB per
+        batch of 64, its input 33 MB: the product is recomputed wherever it is needed instead of stored and read back
+        (hrp_conv_desc.tail_mode, csrc/conv_pw.h):
+          forward   mode 1 (batch statistics of a product, nothing stored; one launch per product) + mode 2 / 5 (normalise, add the
+                    shortcut, ReLU, bit mask) replace conv3 (+ the projection) + hrp_ew_fwd: 343 MB instead of 577 per identity block,
+                    276 instead of 745 per projection block
+          backward  per product mode 3 (sum g, sum g xhat) + mode 4 (gradient of the product; identity: the shortcut gradient as a
+                    rider) replace hrp_ew_bwd_reduce + hrp_ew_bwd_apply: they read the 33 MB input instead of the 134 MB output
+        The data and weight gradients of the 1x1 layers are the ordinary launches on mode 4's output.
         -> out, or None when the problem is not the pointwise kernel's (caller: the general path)."""
         p = self.plan
         if not (BNECK_TAIL_FUSE and p.training and h.dtype == torch.bfloat16 and self.bn_batch_stats(bn3)):
             return None
         cout, cin = conv3_w.shape[0], conv3_w.shape[1]
-        if (conv3_w.dim() == 4 and conv3_w.shape[2] != 1) or (x.N, x.H, x.W, x.C) != (h.N, h.H, h.W, cout):
+        if (conv3_w.dim() == 4 and conv3_w.shape[2] != 1) or (x.N, x.H, x.W) != (h.N, h.H, h.W) or x.dtype != h.dtype:
             return None
-        if x.pitch != cout or x.offset or h.pitch != cin or h.offset or h.C != cin or x.dtype != h.dtype:
+        if h.pitch != cin or h.offset or h.C != cin or x.offset or x.pitch != x.C:
             return None
-        if p.need_grad and not (x.requires_grad and h.requires_grad and conv3_w.requires_grad):
+        if proj is None:
+            if x.C != cout:
+                return None
+        else:
+            wd_param, bnd = proj
+            if tuple(wd_param.shape[:2]) != (cout, cin) or x.C != cin or (wd_param.dim() == 4 and wd_param.shape[2] != 1) or not self.bn_batch_stats(bnd):
+                return None
+        if p.need_grad and not (x.requires_grad and h.requires_grad and conv3_w.requires_grad and (proj is None or proj[0].requires_grad)):
             return None
         h.check_readable()
         x.check_readable()
         dtype = h.dtype
         w3 = p.weight(conv3_w, cout, cin, 1)
+        wd = p.weight(proj[0], cout, cin, 1) if proj is not None else None
         y3 = p.new(h.N, h.H, h.W, cout, dtype)          # (never written by the forward; its gradient buffer is mode 4's output)
+        yd = p.new(h.N, h.H, h.W, cout, dtype) if proj is not None else None
         out = p.new(h.N, h.H, h.W, cout, dtype)
         cnt = float(h.N * h.H * h.W)
         mask = torch.zeros(h.N * h.H * h.W * (cout // 8), dtype=torch.uint8, device=p.device)
         p.keep.append(mask)
 
-        def desc(mode):
-            d = self._conv_desc(h, w3, y3, 1, 1, dtype)
+        def desc(mode, second=False):
+            src, w, y, bn = (x, wd, yd, proj[1]) if second else (h, w3, y3, bn3)
+            d = self._conv_desc(src, w, y, 1, 1, dtype)
             d.tail_mode = mode
-            d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps = bn3.weight.data_ptr(), bn3.bias.data_ptr(), cnt, bn3.eps
+            d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps = bn.weight.data_ptr(), bn.bias.data_ptr(), cnt, bn.eps
             d.tail_mask = mask.data_ptr()
             return d
-        dA, dB = desc(1), desc(2)
-        dB.y, dB.res, dB.res_pitch = out.ptr(), x.ptr(), x.pitch
-        # eligibility of all four forms (dummy aligned pointers where the arenas are not allocated yet)
-        for mode in (1, 2, 3, 4):
+        dA, dB = desc(1), desc(5 if proj is not None else 2)
+        dA2 = desc(1, True) if proj is not None else None
+        dB.y = out.ptr()
+        if proj is None:
+            dB.res, dB.res_pitch = x.ptr(), x.pitch
+        else:
+            dB.tail_x2, dB.tail_gamma2, dB.tail_beta2 = x.ptr(), proj[1].weight.data_ptr(), proj[1].bias.data_ptr()
+        # eligibility of all forms (dummy aligned pointers where the arenas are not allocated yet)
+        for mode in (1, 5 if proj is not None else 2, 3, 4):
             q = desc(mode)
             q.w = q.stats = q.tail_stats = q.tail_bsums = q.tail_g = q.x
             if mode == 2:
                 q.res = q.x
+            if mode == 5:
+                q.tail_x2 = q.tail_w2 = q.tail_stats2 = q.tail_gamma2 = q.tail_beta2 = q.x
             if not nv.lib().hrp_conv_pointwise(C.byref(q)):
                 return None
-        w3.dtype, w3.cin_used = dtype, cin
-        w3.need_t = getattr(w3, "need_t", False) or p.need_grad
+        for w in (w3, wd):
+            if w is not None:
+                w.dtype, w.cin_used = dtype, cin
+                w.need_t = getattr(w, "need_t", False) or p.need_grad
         y3.requires_grad = out.requires_grad = p.need_grad
         y3.stats = p.alloc_stats(cout)
         p.bn_train.append((bn3, y3.stats, h.N * h.H * h.W))
+        if proj is not None:
+            yd.requires_grad = p.need_grad
+            yd.stats = p.alloc_stats(cout)
+            p.bn_train.append((proj[1], yd.stats, h.N * h.H * h.W))
 
         def late():
             dA.w = dB.w = w3.arena.data_ptr() + w3.fwd_off * 2
             dA.stats = dB.tail_stats = p.stats.data_ptr() + 8 * y3.stats
+            if proj is not None:
+                dA2.w = dB.tail_w2 = wd.arena.data_ptr() + wd.fwd_off * 2
+                dA2.stats = dB.tail_stats2 = p.stats.data_ptr() + 8 * yd.stats
         p.late(late)
         p.fwd.append(Launch("conv", dA))
+        if proj is not None:
+            p.fwd.append(Launch("conv", dA2))
         p.fwd.append(Launch("conv", dB))
         out.producer = None
         p.counters["bottleneck_tails"] = p.counters.get("bottleneck_tails", 0) + 1
@@ -1996,22 +2028,27 @@ class PlanBuilder:
             def bw():
                 if not out.grad_written:
                     return
-                y3.take_grad_slot()
-                boff = p.alloc_bsums(cout)
-                p.bn_bwd.append((bn3, boff))
-                dC, dD = desc(3), desc(4)
-                dC.tail_g = dD.tail_g = out.gptr()
-                dD.y = y3.gptr()
-                dD.tail_side, dD.tail_side_acc = x.gptr(), x.take_grad_slot()
+                for second in ((False, True) if proj is not None else (False,)):
+                    src, w, y, bn = (x, wd, yd, proj[1]) if second else (h, w3, y3, bn3)
+                    y.take_grad_slot()
+                    boff = p.alloc_bsums(cout)
+                    p.bn_bwd.append((bn, boff))
+                    dC, dD = desc(3, second), desc(4, second)
+                    dC.tail_g = dD.tail_g = out.gptr()
+                    dD.y = y.gptr()
+                    if proj is None:
+                        dD.tail_side, dD.tail_side_acc = x.gptr(), x.take_grad_slot()
 
-                def late_b():
-                    dC.w = dD.w = w3.arena.data_ptr() + w3.fwd_off * 2
-                    dC.tail_stats = dD.tail_stats = p.stats.data_ptr() + 8 * y3.stats
-                    dC.stats = dD.tail_bsums = p.bsums.data_ptr() + 8 * boff
-                p.late(late_b)
-                p.bwd.append(Launch("conv", dC))
-                p.bwd.append(Launch("conv", dD))
+                    def late_b(dC=dC, dD=dD, w=w, y=y, boff=boff):
+                        dC.w = dD.w = w.arena.data_ptr() + w.fwd_off * 2
+                        dC.tail_stats = dD.tail_stats = p.stats.data_ptr() + 8 * y.stats
+                        dC.stats = dD.tail_bsums = p.bsums.data_ptr() + 8 * boff
+                    p.late(late_b)
+                    p.bwd.append(Launch("conv", dC))
+                    p.bwd.append(Launch("conv", dD))
                 self._conv_bwd(h, w3, y3, None, 1, 1, dtype, None, False)
+                if proj is not None:
+                    self._conv_bwd(x, wd, yd, None, 1, 1, dtype, None, False)
             self.bwd_stack.append(bw)
         return out
 

@@ -165,6 +165,10 @@ typedef struct hrp_conv_desc {
    *   4  backward apply: y = gamma invstd (g - k0 - xhat k1), k0 / k1 = slot sums of tail_bsums / tail_count - the gradient of the
    *      product, which the ordinary data- and weight-gradient launches of the layer then read; tail_side (optional, geometry of y)
    *      = or += (tail_side_acc) g: the gradient of the identity shortcut. */
+  /*   5  mode 2 with a PROJECTION shortcut (the first block of a stack, HRnet.py:139-150: downsample = conv1x1 + BatchNorm):
+   *      y = relu(bn(product) + bn2(product2)), product2 = tail_x2 (geometry and channels of x) times tail_w2 (packed like w, same
+   *      Cout), batch statistics tail_stats2 / tail_gamma2 / tail_beta2 (count and eps as the first).  Its statistics and its backward
+   *      are mode 1 / 3 / 4 launches of their own on (tail_x2, tail_w2): neither raw product is ever stored. */
   int32_t tail_mode, tail_side_acc;
   const double* tail_stats;
   const double* tail_bsums;
@@ -174,6 +178,11 @@ typedef struct hrp_conv_desc {
   uint8_t* tail_mask;
   const void* tail_g;
   void* tail_side;
+  const void* tail_x2;
+  const void* tail_w2;
+  const double* tail_stats2;
+  const float* tail_gamma2;
+  const float* tail_beta2;
 } hrp_conv_desc;
 
 /* Weight gradient: dW[co][ci][t] (+)= sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*IS+dy[t], ox*IS+dx[t], ci],

@@ -76,6 +76,22 @@ def test_tail_modes_against_float64(cin, cout, npix, small_pointwise):
     first = out.clone()
     run(2, y=out.data_ptr(), res=xs.data_ptr(), tail_stats=stats.data_ptr())
     assert torch.equal(out, first)
+    # mode 5: the shortcut is a second product under its own BatchNorm (the projection of a stack's first block)
+    h2 = torch.randn(npix, cin, generator=g).to(DEV).to(torch.bfloat16)
+    w2 = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
+    wp2, _ = bk.pack(w2, torch.bfloat16)
+    gamma2, beta2 = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.3).to(DEV)
+    stats2 = torch.zeros(8 * 2 * cout, dtype=torch.float64, device=DEV)
+    run(1, x=h2.data_ptr(), w=wp2.data_ptr(), stats=stats2.data_ptr())
+    y2 = h2.double() @ w2.view(cout, cin).to(torch.bfloat16).double().t()
+    m2, i2 = y2.mean(0), (y2.var(0, unbiased=False) + 1e-5).rsqrt()
+    want5 = torch.relu((y - mean) * inv * gamma.double() + beta.double() + (y2 - m2) * i2 * gamma2.double() + beta2.double())
+    out5, mask5 = torch.zeros_like(out), torch.zeros_like(mask)
+    run(5, y=out5.data_ptr(), tail_stats=stats.data_ptr(), tail_mask=mask5.data_ptr(), tail_x2=h2.data_ptr(), tail_w2=wp2.data_ptr(),
+        tail_stats2=stats2.data_ptr(), tail_gamma2=gamma2.data_ptr(), tail_beta2=beta2.data_ptr())
+    assert rel_err(out5, want5) < 1e-2, rel_err(out5, want5)
+    pos5 = torch.stack([(mask5.view(npix, cout // 8) >> i) & 1 for i in range(8)], -1).view(npix, cout).bool()
+    assert torch.equal(pos5, out5 > 0)
     # backward: the gradient of out
     dout = torch.randn(npix, cout, generator=g).to(DEV).to(torch.bfloat16)
     gm = dout.double() * got_pos
@@ -131,6 +147,10 @@ def _run(kind, fuse, x, sd, gy):
             m = H.Bottleneck(128, 32)
         elif kind == "wide":
             m = H.Bottleneck(256, 64)
+        elif kind == "proj":          # layer1's first block (HRnet.py:291, 448-465): 64 -> 256 with a 1x1 projection shortcut
+            m = H.Bottleneck(64, 64, downsample=H._Downsample(64, 256, 1))
+        elif kind == "proj_narrow":   # incre_modules[0] of the cls head (HRnet.py:343-362): 32 -> 128
+            m = H.Bottleneck(32, 32, downsample=H._Downsample(32, 128, 1))
         else:
             class Stack(H.SingleTensorModule):          # layer1 of the trunk (HRnet.py:291): a projection block and three identity blocks
                 def __init__(self):
@@ -152,14 +172,14 @@ def _run(kind, fuse, x, sd, gy):
         P.BNECK_TAIL_FUSE = True
 
 
-@pytest.mark.parametrize("kind", ["narrow", "wide"])
+@pytest.mark.parametrize("kind", ["narrow", "wide", "proj", "proj_narrow"])
 def test_bottleneck_with_fused_tail_matches_oracle(kind):
     """One Bottleneck with an identity shortcut at [32, C, 64, 64] (131 072 pixels: the pointwise kernel's threshold) in train mode,
     bf16: forward, input gradient, every parameter gradient and the running statistics against the CPU oracle in fp32 (bf16
     tolerances of test_gpu_kernels: 4e-2 forward, L2 on gradients), with the fusion on (counter checked) and - same bounds - off;
     the two plans agree with each other more closely than either with fp32."""
     from oracle import hrnet as O
-    cin = 128 if kind == "narrow" else 256
+    cin, cout = {"narrow": (128, 128), "wide": (256, 256), "proj": (64, 256), "proj_narrow": (32, 128)}[kind]
     x = torch.randn(32, cin, 64, 64, generator=torch.Generator().manual_seed(5))
     cache = {}
 
@@ -167,7 +187,7 @@ def test_bottleneck_with_fused_tail_matches_oracle(kind):
         if "sd" not in cache:
             cache["sd"] = _rand_sd(m, 3)
         return cache["sd"]
-    gy = torch.randn(32, cin, 64, 64, generator=torch.Generator().manual_seed(6))
+    gy = torch.randn(32, cout, 64, 64, generator=torch.Generator().manual_seed(6))
     mf, yf, dxf, gf, nf = _run(kind, True, x, sd, gy)
     mu, yu, dxu, gu, nu = _run(kind, False, x, sd, gy)
     assert nf == 1 and nu == 0
@@ -201,8 +221,8 @@ def test_bottleneck_with_fused_tail_matches_oracle(kind):
 
 
 def test_layer1_stack_with_fused_tails():
-    """layer1 of the trunk (a projection block + three identity blocks, HRnet.py:291) at B = 32: three tails fuse, the block with
-    the 1x1 projection keeps the element-wise path; outputs and gradients against the same plan with the fusion off."""
+    """layer1 of the trunk (a projection block + three identity blocks, HRnet.py:291) at B = 32: all four tails fuse (the first in
+    the projection form); outputs and gradients against the same plan with the fusion off."""
     x = torch.randn(32, 64, 64, 64, generator=torch.Generator().manual_seed(7))
     cache = {}
 
@@ -213,7 +233,7 @@ def test_layer1_stack_with_fused_tails():
     gy = torch.randn(32, 256, 64, 64, generator=torch.Generator().manual_seed(8))
     _, yf, dxf, gf, nf = _run("stack", True, x, sd, gy)
     _, yu, dxu, gu, nu = _run("stack", False, x, sd, gy)
-    assert nf == 3 and nu == 0
+    assert nf == 4 and nu == 0
     assert l2_err(yf, yu) < 1.5e-2, l2_err(yf, yu)
     assert l2_err(dxf, dxu) < 6e-2, l2_err(dxf, dxu)
     # two bf16 plans that round at different places, through four blocks: weight gradients within 8 %, the BatchNorm vectors

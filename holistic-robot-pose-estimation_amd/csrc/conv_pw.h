@@ -61,7 +61,7 @@ static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
     if (d.tail_mode != 1 && (!d.tail_stats || !d.tail_gamma || !d.tail_beta || !d.tail_mask || (uintptr_t)d.tail_mask % 2)) return 0;
     if (d.tail_mode == 2 && !d.res) return 0;
     if (d.tail_mode != 2 && d.res) return 0;
-    if (d.tail_mode >= 3 && (!d.tail_g || (uintptr_t)d.tail_g % 16)) return 0;
+    if ((d.tail_mode == 3 || d.tail_mode == 4) && (!d.tail_g || (uintptr_t)d.tail_g % 16)) return 0;
     if (d.tail_mode == 4 && (!d.tail_bsums || (uintptr_t)d.tail_side % 16)) return 0;
   }
   p.ks = d.Cin / 16;

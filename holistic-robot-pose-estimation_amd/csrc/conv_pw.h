@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
   // per-channel constants: a table in LDS (one thread per channel derives them from the statistic slots), then the lane's
   // channels cl(mi) .. + 15 into registers - a lane's channels are the same in every tile
   float* ctab = (float*)(smem + PW_STAT_BYTES);          // [3][Cout]: sc, sh | sc, c0, c1
-  float k_sc[MODE == 2 || MODE == 4 ? MW : 1][16], k_sh[MODE == 2 || MODE == 4 ? MW : 1][16], k_c1[MODE == 4 ? MW : 1][16];
+  float k_sc[MODE == 2 || MODE == 4 ? MW : 1][16], k_sh[MODE == 2 ? MW : 1][16];
   if constexpr (MODE == 2 || MODE == 4) {
     for (int c = tid; c < Cout; c += 256) {
       float mean, inv, sc, sh;
@@ -308,11 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
       for (int i = 0; i < 16; i += 4) {
         const float4 a4 = *(const float4*)(ctab + cl + i), b4 = *(const float4*)(ctab + Cout + cl + i);
         k_sc[mi][i] = a4.x; k_sc[mi][i + 1] = a4.y; k_sc[mi][i + 2] = a4.z; k_sc[mi][i + 3] = a4.w;
-        k_sh[mi][i] = b4.x; k_sh[mi][i + 1] = b4.y; k_sh[mi][i + 2] = b4.z; k_sh[mi][i + 3] = b4.w;
-        if constexpr (MODE == 4) {
-          const float4 c4 = *(const float4*)(ctab + 2 * Cout + cl + i);
-          k_c1[mi][i] = c4.x; k_c1[mi][i + 1] = c4.y; k_c1[mi][i + 2] = c4.z; k_c1[mi][i + 3] = c4.w;
-        }
+        if constexpr (MODE == 2) { k_sh[mi][i] = b4.x; k_sh[mi][i + 1] = b4.y; k_sh[mi][i + 2] = b4.z; k_sh[mi][i + 3] = b4.w; }
       }
     }
   }
@@ -345,7 +341,38 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
       for (int i = 0; i < 16; ++i) s1[mi][i] = s2[mi][i] = 0.f;
   }
 
-  auto compute = [&](int t, const bf16x8 (&xb)[KS]) {
+  // operands of the epilogue at the lane's 2 x 16 channels of one pixel: MODE 2 the shortcut, MODE 3 / 4 the gradient of the block
+  // output and its ReLU bits (+ the rider's old value when it accumulates).  Loaded one tile AHEAD, with x: issued inside the tile
+  // that uses them they were one exposed HBM latency per tile (mode 2: 99 us for 310 MB; the element-wise pass it replaces streams
+  // the same tensors at 4.6 TB/s)
+  struct Epi {
+    uint4 v[MW][2];
+    uint4 sd[MODE == 4 ? MW : 1][2];
+    int bits[MW];
+  };
+  const bool side_acc = MODE == 4 && d.tail_side && d.tail_side_acc;
+  auto load_epi = [&](int t, Epi& e) {
+    if constexpr (MODE != 1) {
+      const long pix = (long)t * 32 + l31;
+      const bool ok = t < p.ntiles && pix < M;
+      const char* src = (const char*)(MODE == 2 ? d.res : d.tail_g);
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi) {
+        const unsigned off = (unsigned)(pix * Cout + cbase + mi * 32 + 16 * half) * 2u;
+        e.v[mi][0] = e.v[mi][1] = make_uint4(0, 0, 0, 0);
+        e.bits[mi] = 0;
+        if (ok) {
+          e.v[mi][0] = *(const uint4*)(src + off); e.v[mi][1] = *(const uint4*)(src + off + 16);
+          if constexpr (MODE >= 3) e.bits[mi] = *(const unsigned short*)(d.tail_mask + (off >> 4));
+          if constexpr (MODE == 4) {
+            if (side_acc) { e.sd[mi][0] = *(const uint4*)((const char*)d.tail_side + off); e.sd[mi][1] = *(const uint4*)((const char*)d.tail_side + off + 16); }
+          }
+        }
+      }
+    }
+  };
+
+  auto compute = [&](int t, const bf16x8 (&xb)[KS], const Epi& e) {
     const long pix = (long)t * 32 + l31;
     const bool ok = t < p.ntiles && pix < M;
 #pragma unroll
@@ -367,13 +394,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
         const int cl = cbase + mi * 32 + 16 * half;
         const unsigned off = (unsigned)(pix * Cout + cl) * 2u;
         if constexpr (MODE == 2) {
-          uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-          if (ok) { rr[0] = *(const uint4*)((const char*)d.res + off); rr[1] = *(const uint4*)((const char*)d.res + off + 16); }
           unsigned bits = 0;
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             float v[8], r[8];
-            Elem<bf16_t>::unpack(rr[hh], r);
+            Elem<bf16_t>::unpack(e.v[mi][hh], r);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               v[i] = fmaxf(fmaf(acc[8 * hh + i], k_sc[mi][8 * hh + i], k_sh[mi][8 * hh + i]) + r[i], 0.f);
@@ -383,16 +408,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
           }
           if (ok) *(unsigned short*)(d.tail_mask + (off >> 4)) = (unsigned short)bits;
         } else {
-          uint4 gr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-          int bits = 0;
-          if (ok) {
-            gr[0] = *(const uint4*)((const char*)d.tail_g + off); gr[1] = *(const uint4*)((const char*)d.tail_g + off + 16);
-            bits = *(const unsigned short*)(d.tail_mask + (off >> 4));
-          }
+          const int bits = e.bits[mi];
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             float g[8];
-            Elem<bf16_t>::unpack(gr[hh], g);
+            Elem<bf16_t>::unpack(e.v[mi][hh], g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = row_keep_if_bit(g[i], bits, 8 * hh + i);
             if constexpr (MODE == 3) {
@@ -401,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
             } else {
               if (d.tail_side && ok) {
                 char* q = (char*)d.tail_side + off + 16 * hh;
-                if (d.tail_side_acc) {
+                if (side_acc) {
                   float o[8];
-                  Elem<bf16_t>::unpack(*(const uint4*)q, o);
+                  Elem<bf16_t>::unpack(e.sd[mi][hh], o);
 #pragma unroll
                   for (int i = 0; i < 8; ++i) o[i] += g[i];
                   *(uint4*)q = Elem<bf16_t>::pack(o);
@@ -413,7 +433,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
               }
               float v[8];
 #pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] = fmaf(k_sc[mi][8 * hh + i], g[i], fmaf(k_c1[mi][8 * hh + i], acc[8 * hh + i], k_sh[mi][8 * hh + i]));
+              for (int i = 0; i < 8; i += 4) {          // c0 / c1 from the LDS table per tile (as registers they spill next to the prefetched operands)
+                const float4 c0 = *(const float4*)(ctab + Cout + cl + 8 * hh + i), c1 = *(const float4*)(ctab + 2 * Cout + cl + 8 * hh + i);
+                v[i] = fmaf(k_sc[mi][8 * hh + i], g[i], fmaf(c1.x, acc[8 * hh + i], c0.x));
+                v[i + 1] = fmaf(k_sc[mi][8 * hh + i + 1], g[i + 1], fmaf(c1.y, acc[8 * hh + i + 1], c0.y));
+                v[i + 2] = fmaf(k_sc[mi][8 * hh + i + 2], g[i + 2], fmaf(c1.z, acc[8 * hh + i + 2], c0.z));
+                v[i + 3] = fmaf(k_sc[mi][8 * hh + i + 3], g[i + 3], fmaf(c1.w, acc[8 * hh + i + 3], c0.w));
+              }
               if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
             }
           }
@@ -424,12 +450,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
 
   {
     bf16x8 xa[KS], xb[KS];
+    Epi ea, eb;
     load_tile(tile0, xa);
+    load_epi(tile0, ea);
     for (int it = 0; it < p.tpw; it += 2) {
       load_tile(tile0 + (it + 1) * tstep, xb);
-      compute(tile0 + it * tstep, xa);
-      if (it + 2 < p.tpw) load_tile(tile0 + (it + 2) * tstep, xa);
-      if (it + 1 < p.tpw) compute(tile0 + (it + 1) * tstep, xb);
+      load_epi(tile0 + (it + 1) * tstep, eb);
+      compute(tile0 + it * tstep, xa, ea);
+      if (it + 2 < p.tpw) { load_tile(tile0 + (it + 2) * tstep, xa); load_epi(tile0 + (it + 2) * tstep, ea); }
+      if (it + 1 < p.tpw) compute(tile0 + (it + 1) * tstep, xb, eb);
     }
   }
 

@@ -222,7 +222,10 @@ def test_bottleneck_with_fused_tail_matches_oracle(kind):
 
 def test_layer1_stack_with_fused_tails():
     """layer1 of the trunk (a projection block + three identity blocks, HRnet.py:291) at B = 32: all four tails fuse (the first in
-    the projection form); outputs and gradients against the same plan with the fusion off."""
+    the projection form).  Output, input gradient and every parameter gradient of both plans - fusion on / off - against the CPU oracle
+    in fp32: the fused plan is held to the plain plan's distance from fp32 (two bf16 plans that round at different places differ from
+    EACH OTHER by up to 9 % in L2 on the input gradient after four blocks; what matters is that neither is further from fp32)."""
+    from oracle import hrnet as O
     x = torch.randn(32, 64, 64, 64, generator=torch.Generator().manual_seed(7))
     cache = {}
 
@@ -234,10 +237,20 @@ def test_layer1_stack_with_fused_tails():
     _, yf, dxf, gf, nf = _run("stack", True, x, sd, gy)
     _, yu, dxu, gu, nu = _run("stack", False, x, sd, gy)
     assert nf == 4 and nu == 0
-    assert l2_err(yf, yu) < 1.5e-2, l2_err(yf, yu)
-    assert l2_err(dxf, dxu) < 6e-2, l2_err(dxf, dxu)
-    # two bf16 plans that round at different places, through four blocks: weight gradients within 8 %, the BatchNorm vectors
-    # (sums of cancelling terms: measured up to 10 %) within 15 % in L2
-    worst_w = max((l2_err(gf[k], gu[k]), k) for k in gf if gu[k].dim() > 1)
-    worst_v = max((l2_err(gf[k], gu[k]), k) for k in gf if gu[k].dim() <= 1 and gu[k].abs().max() > 0)
-    assert worst_w[0] < 8e-2 and worst_v[0] < 0.15, (worst_w, worst_v)
+    osd = {k: v.clone() for k, v in cache["sd"].items()}
+    for k, v in osd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ctx = O._Ctx(osd, "", True)
+    t = xr
+    for i in range(4):
+        t = O._bottleneck(ctx, f"layer1.{i}", t)
+    (t * gy).sum().backward()
+    assert rel_err(yf, t) < 6e-2 and l2_err(yf, t) <= 1.1 * l2_err(yu, t) + 1e-4, (l2_err(yf, t), l2_err(yu, t))
+    ef, eu = l2_err(dxf, xr.grad), l2_err(dxu, xr.grad)
+    assert ef < 0.15 and ef <= 1.25 * eu + 5e-3, (ef, eu)
+    for k, v in osd.items():
+        if v.grad is not None and float(v.grad.abs().max()) > 0:
+            ef, eu = l2_err(gf[k], v.grad), l2_err(gu[k], v.grad)
+            assert ef < 0.2 and ef <= 1.3 * eu + 1e-2, (k, ef, eu)

@@ -753,7 +753,11 @@ static int plan_cfg(const hrp_conv_desc& d, ConvTiling& t, int& lds_out, bool al
     // (out_stride == 1: the launch covers all of y, which it zeroes first)
     // (not onto an existing value - res == y, a gradient that accumulates: (y + a) + b and (y + b) + a differ in the last bit)
     if (allow_ksplit && SZ == 4 && !d.relu && !d.scale && !d.stats && d.out_stride == 1 && d.y_H == d.Ho && d.y_W == d.Wo && t.nblocks <= 64 &&
-        (const void*)d.res != (const void*)d.y) {
+        (const void*)d.res != (const void*)d.y &&
+        // y must own its whole pitch: the zero fill below runs over N * y_H * y_W * y_pitch elements from d.y - a channel SLICE of a
+        // wider buffer (ASPP's branches into the 1280-channel concatenation, PlanBuilder.channel_slice) would have its neighbours'
+        // columns wiped and the fill run past the end of the allocation
+        d.y_pitch <= ((d.Cout + 7) / 8) * 8) {
       int ks = 1;
       // at most TWO slices: two fp32 partials added atomically onto a zeroed output give the same bits in either order
       // (a + b == b + a); four or more do not - the fp32 inference forward differed in the last bit from run to run

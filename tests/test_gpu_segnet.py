@@ -100,6 +100,45 @@ def test_large_dilation_conv_as_shifted_taps(rate, dtype):
     assert ((y.cpu() - yr).abs().max() / yr.abs().max()).item() < tol
 
 
+def test_small_map_conv_into_a_channel_slice_keeps_its_neighbours():
+    """an fp32 convolution with few output tiles (<= 64 workgroups: a 15 x 20 map at B <= 2) takes the split-K
+    path, whose zero fill ran over the WHOLE pitch of y - for a channel slice of the ASPP concatenation it wiped the slices written
+    before it and ran past the end of the buffer.  Two 1x1 branches into one 96-channel buffer, the second one small enough to
+    split: both slices hold their convolution, the guard columns behind the buffer keep their value."""
+    from hrpe_amd.lib.models.backbones.HRnet import Conv2d
+    from hrpe_amd.runtime import PlannedModule
+
+    class TwoSlices(PlannedModule):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = Conv2d(512, 32, 1, bias=False), Conv2d(512, 64, 1, bias=False)
+
+        def _build(self, pb, x):
+            N, Cc, H, W = x.shape
+            t = pb.image_input("x", N, Cc, H, W)
+            cat = pb.plan.new(N, H, W, 96)
+            cat.buf.fill_(7.0)
+            pb.conv(t, self.a.weight, out=pb.channel_slice(cat, 0, 32))
+            pb.conv(t, self.b.weight, out=pb.channel_slice(cat, 32, 64))
+            holder = pb.nchw_output(cat)
+            holder["handle"] = cat
+            return ["x"], [("nchw", holder, None)], {"x": t}
+
+        def forward(self, x):
+            return self._run(x)[0]
+    g = torch.Generator().manual_seed(3)
+    m = TwoSlices()
+    with torch.no_grad():
+        for c in (m.a, m.b):
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) / 512 ** 0.5)
+    x = torch.randn(2, 512, 15, 20, generator=g)
+    want = torch.cat([F.conv2d(x, m.a.weight), F.conv2d(x, m.b.weight)], 1)
+    m = m.to(DEV).set_compute_dtype(torch.float32).eval()
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    assert ((y.cpu() - want).abs().max() / want.abs().max()).item() < 2e-4
+
+
 def test_large_dilation_is_refused_with_gradients():
     """Round 4 refused every dilation beyond the tile halo; round 5 runs them in inference plans.  A TRAINING plan still refuses
     loudly (no data / weight gradient for the shifted-tap form: the reference never trains the mask network)."""

@@ -694,10 +694,12 @@ def main():
     # passes over tools/one_step.py, the same network and batch) summarised in profiles/r02_traffic.json; a family = its
     # single-problem and its batched kernels together
     traffic, traffic_source = None, None
-    tpath = next((pp for pp in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(pp)), None)
-    fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel", "conv_row_kernel", "conv_deep_kernel", "conv_img_kernel", "conv_pw_kernel"),
+    tpath = next((pp for pp in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(pp)), None)
+    fam_kernels = {"hrp_conv2d_fwd": ("conv_tile_kernel", "conv_batch_kernel", "conv_row_kernel", "conv_deep_kernel", "conv_img_kernel", "conv_pw_kernel",
+                                      "conv_pw_tail_kernel", "conv_pw_tail2_kernel"),
                    "hrp_block_launch": ("block_kernel",),
-                   "hrp_conv2d_bwd_weight": ("conv_wgrad_kernel", "wgrad_batch_kernel", "wgrad_reduce_kernel", "wgrad_reduce_batch_kernel"),
+                   "hrp_conv2d_bwd_weight": ("conv_wgrad_kernel", "wgrad_batch_kernel", "wgrad_octo_batch_kernel", "wgrad_octo_x3_batch_kernel",
+                                             "wgrad_reduce_kernel", "wgrad_reduce_batch_kernel", "wgrad_fold_batch_kernel"),
                    "hrp_ew_fwd": ("ew_fwd_kernel", "ew_fwd_batch_kernel"),
                    "hrp_ew_bwd_reduce": ("ew_bwd_reduce_kernel",), "hrp_ew_bwd_apply": ("ew_bwd_apply_kernel",)}.get(dom[0])
     if tpath and fam_kernels and B == 64 and a.dtype == "bf16" and not hrnet and not fwd_only:

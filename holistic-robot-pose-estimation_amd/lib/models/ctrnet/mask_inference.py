@@ -17,9 +17,12 @@ MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # transforms.N
 
 
 class seg_mask_inference(PlannedModule):
-    def __init__(self, intrinsics, dataset, image_hw=(480, 640), scale=0.5):
+    def __init__(self, intrinsics, dataset, image_hw=(480, 640), scale=0.5, allow_random_init=False):
+        """allow_random_init: keep the random initialisation when the checkpoint of `dataset` does not exist (tests and benchmarks on
+        synthetic weights); by default a missing file raises FileNotFoundError as the reference's torch.load does (CtRNet.py:35)."""
         super().__init__()
         self.args = self.set_args(intrinsics, dataset, image_hw, scale)
+        self.args.allow_random_seg_init = bool(allow_random_init)
         self.net = CtRNet(self.args)
         for p in self.parameters():          # never trained (train_sim2real.py:412 detaches the output; the optimizer holds the
             p.requires_grad_(False)          # pose network's parameters only): plans of this module are inference plans

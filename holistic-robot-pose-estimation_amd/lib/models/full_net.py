@@ -378,6 +378,10 @@ class RootNetwithRegInt(PlannedModule):
         # full_net.py:245-248: the iterative regressors start from the module's buffers unless the caller brings a start per sample
         init_pose = (self.init_pose.expand(B, -1) if init_pose is None else init_pose).to(dev).float().reshape(B, -1).contiguous()
         init_rot = (self.init_rot.expand(B, -1) if init_rot is None else init_rot).to(dev).float().reshape(B, -1).contiguous()
+        if torch.is_grad_enabled() and (init_pose.requires_grad or init_rot.requires_grad):
+            # the reference backpropagates through the regressors to a caller-supplied start (full_net.py:245-248, 318-331); the plan treats
+            # the starts as inputs without gradient - say so instead of silently returning None for them
+            raise NotImplementedError("RootNetwithRegInt: init_pose / init_rot that require grad are not differentiated; pass them detached")
         if init_pose.shape[1] != self.init_pose.shape[1] or init_rot.shape[1] != self.rotation_dim:
             raise ValueError(f"init_pose / init_rot must be [B, {self.init_pose.shape[1]}] / [B, {self.rotation_dim}]")
         if test_fps:

@@ -1561,6 +1561,9 @@ class PlanBuilder:
         over PIL images).  One launch; bit-exact with PIL.Image.resize on the bytes."""
         p = self.plan
         Ho, Wo = int(H * scale), int(W * scale)
+        if Ho % 2 or Wo % 2:
+            raise nv.HrpError(f"pil_resize_input: the resized image {Ho} x {Wo} (image {H} x {W}, scale {scale}) must have even sides: "
+                              "it is written straight into the ResNet stem's 2 x 2 space-to-depth layout")
         t = p.new(N, Ho // 2, Wo // 2, 12, pitch=16)
         tabs = []
         for n_in, n_out in ((W, Wo), (H, Ho)):

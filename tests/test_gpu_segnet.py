@@ -151,7 +151,7 @@ def test_large_dilation_is_refused_with_gradients():
 
 def _mask_net():
     from hrpe_amd.lib.models.ctrnet.mask_inference import seg_mask_inference
-    m = seg_mask_inference((600.0, 600.0, 320.0, 240.0), "azure")
+    m = seg_mask_inference((600.0, 600.0, 320.0, 240.0), "azure", allow_random_init=True)
     sd = synth_state_dict(m.state_dict())
     # synthesised weights give logits of ~0.15 +- 0.05: spread them so that the sigmoid output uses its range (test sensitivity)
     k = "net.keypoint_seg_predictor.module.classifer.0.4."

@@ -773,3 +773,13 @@ def test_plan_cache_key_tells_frozen_batchnorm_subsets_apart():
     assert m._frozen_bn_signature() not in (0, sig_a, sig_b)
     m.eval()
     assert m._frozen_bn_signature() == 0                           # an eval-mode module: the inference plan, whatever the children say
+
+
+def test_mask_network_refuses_a_missing_checkpoint():
+    """the reference fails in torch.load when keypoint_seg_model_path does not exist (CtRNet.py:35); a silent random
+    initialisation would let train_sim2real self-train against random masks.  Random weights are an explicit opt-in."""
+    from hrpe_amd.lib.models.ctrnet.mask_inference import seg_mask_inference
+    with pytest.raises(FileNotFoundError, match="keypoint_seg_model_path"):
+        seg_mask_inference((600.0, 600.0, 320.0, 240.0), "azure")
+    m = seg_mask_inference((600.0, 600.0, 320.0, 240.0), "azure", allow_random_init=True)
+    assert any(k.startswith("net.keypoint_seg_predictor.module.") for k in m.state_dict())

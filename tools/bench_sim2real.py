@@ -91,7 +91,7 @@ def main():
     seg_net = None
     if not a.no_mask_net:
         from hrpe_amd.lib.models.ctrnet.mask_inference import seg_mask_inference
-        seg_net = seg_mask_inference((640.0, 640.0, 320.0, 240.0), "azure")
+        seg_net = seg_mask_inference((640.0, 640.0, 320.0, 240.0), "azure", allow_random_init=True)
         seg_net.load_state_dict(synth_state_dict(seg_net.state_dict()))
         seg_net = seg_net.to(DEV).set_compute_dtype(torch.bfloat16)
         images_original_255 = torch.randint(0, 256, (B, 3, 480, 640), device=DEV).float()      # train_sim2real.py:412

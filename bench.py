@@ -449,7 +449,10 @@ def main():
             step_eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        if fwd_only or (world == 1 and not os.environ.get("HRP_BENCH_TWO_GRAPHS")):   # (the flag exercises the N > 1 structure on one GPU)
+        from hrpe_amd.parallel import force_world1
+        # (HRP_BENCH_TWO_GRAPHS exercises the N > 1 graph structure on one GPU; HRP_DIST_WORLD1=1 also creates the RCCL group of one
+        # rank and issues every collective of the k-cut step)
+        if fwd_only or (world == 1 and not os.environ.get("HRP_BENCH_TWO_GRAPHS") and not force_world1()):
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 fwd_bwd()
@@ -599,7 +602,7 @@ def main():
 
     # the same step without clip + Adam (SURVEY 8d C3 "Adam excluded and included: report both"), one GPU only
     ms_no_opt = None
-    if world == 1 and use_graph and not fwd_only and not h2d and not os.environ.get("HRP_BENCH_TWO_GRAPHS"):
+    if world == 1 and use_graph and not fwd_only and not h2d and not os.environ.get("HRP_BENCH_TWO_GRAPHS") and not force_world1():
         gno = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gno):
             fwd_bwd()

@@ -13,12 +13,22 @@ import torch
 import torch.distributed as dist
 
 
+def force_world1():
+    """HRP_DIST_WORLD1=1: create the process group and issue every collective even with ONE rank - the only execution of the
+    RCCL path (stream ordering of graph replays against RCCL's stream in the k-cut step) a one-GPU box can produce."""
+    return os.environ.get("HRP_DIST_WORLD1", "") not in ("", "0")
+
+
+def collectives_active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_world1())
+
+
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_world1()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -32,7 +42,7 @@ def init_distributed(backend=None):
 
 def broadcast_module(module, src=0):
     """Start-up: every replica takes rank `src`'s parameters and buffers."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not collectives_active():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
@@ -57,7 +67,7 @@ class GradAllReducer:
     def start(self, flat, ranges):
         """Asynchronous all-reduce (sum) of the (offset, numel) ranges of one flat buffer, in buckets; -> work handles.
         The collective is ordered after the work already enqueued on the current stream."""
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not collectives_active():
             return []
         works = []
         for off, n in ranges:
@@ -77,7 +87,7 @@ class GradAllReducer:
         for b, c in self._pending:
             b.copy_(c)
         self._pending = []
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collectives_active():
             for flat in flats:
                 flat.div_(dist.get_world_size())
 
@@ -94,7 +104,7 @@ class GradAllReducer:
         return out
 
     def __call__(self, flats):
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not collectives_active():
             return
         works = []
         for flat in flats:

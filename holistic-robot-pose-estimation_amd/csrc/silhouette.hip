@@ -93,24 +93,49 @@ __device__ __forceinline__ bool pixel_face(const Face2D& F, float cx, float cy, 
   return true;
 }
 
+// A face whose (blurred) bounding box holds more than S2R_BIG pixel centres is not walked by its own lane: the wave takes such faces
+// one after the other, all 64 lanes sharing the box (a robot close to the camera projects single triangles onto thousands of pixels;
+// one lane walking them serialises the wave behind it - ADVICE r4 / VERDICT r5 item 7).
+constexpr int S2R_BIG = 64;
+
+__device__ __forceinline__ Face2D face_from_lane(const Face2D& F, int src) {
+  Face2D G;
+  G.x0 = __shfl(F.x0, src, 64); G.y0 = __shfl(F.y0, src, 64); G.x1 = __shfl(F.x1, src, 64); G.y1 = __shfl(F.y1, src, 64);
+  G.x2 = __shfl(F.x2, src, 64); G.y2 = __shfl(F.y2, src, 64); G.area = __shfl(F.area, src, 64);
+  G.v0 = __shfl(F.v0, src, 64); G.v1 = __shfl(F.v1, src, 64); G.v2 = __shfl(F.v2, src, 64);
+  G.px0 = __shfl(F.px0, src, 64); G.px1 = __shfl(F.px1, src, 64); G.py0 = __shfl(F.py0, src, 64); G.py1 = __shfl(F.py1, src, 64);
+  return G;
+}
+
+__device__ __forceinline__ void fwd_pixel(const hrp_silhouette_desc& d, const Face2D& F, int b, int x, int y, float k2, long long* lp) {
+  float s, tt; int e;
+  if (!pixel_face(F, x + 0.5f, y + 0.5f, k2, d.blur_radius, s, e, tt)) return;
+  // log(1 - sigmoid(-s / sigma)) = -softplus(-s / sigma)
+  const float a = -s / d.sigma;
+  float l = a > 30.f ? -a : -log1pf(expf(a));
+  l = fmaxf(l, S2R_LOG_FLOOR);
+  atomicAdd((unsigned long long*)(lp + y * d.W + x), (unsigned long long)(long long)llrint((double)l * S2R_FIX));
+  if (d.count) atomicAdd(d.count + (size_t)b * d.H * d.W + y * d.W + x, 1);
+}
+
 __global__ __launch_bounds__(256) void silhouette_fwd_kernel(const hrp_silhouette_desc d) {
-  const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (f >= d.F) return;
+  const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
   const float sc = 2.f / (float)min(d.H, d.W), k2 = sc * sc;
-  Face2D F;
-  if (!load_face(d, b, f, k2, F)) return;
+  Face2D F = {};
+  const bool have = f < d.F && load_face(d, b, f, k2, F);
+  const int npx = have ? (F.px1 - F.px0 + 1) * (F.py1 - F.py0 + 1) : 0;
   long long* lp = (long long*)d.logp + (size_t)b * d.H * d.W;
-  for (int y = F.py0; y <= F.py1; ++y)
-    for (int x = F.px0; x <= F.px1; ++x) {
-      float s, tt; int e;
-      if (!pixel_face(F, x + 0.5f, y + 0.5f, k2, d.blur_radius, s, e, tt)) continue;
-      // log(1 - sigmoid(-s / sigma)) = -softplus(-s / sigma)
-      const float a = -s / d.sigma;
-      float l = a > 30.f ? -a : -log1pf(expf(a));
-      l = fmaxf(l, S2R_LOG_FLOOR);
-      atomicAdd((unsigned long long*)(lp + y * d.W + x), (unsigned long long)(long long)llrint((double)l * S2R_FIX));
-      if (d.count) atomicAdd(d.count + (size_t)b * d.H * d.W + y * d.W + x, 1);
-    }
+  if (have && npx <= S2R_BIG)
+    for (int y = F.py0; y <= F.py1; ++y)
+      for (int x = F.px0; x <= F.px1; ++x) fwd_pixel(d, F, b, x, y, k2, lp);
+  unsigned long long big = __ballot(npx > S2R_BIG);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const Face2D G = face_from_lane(F, src);
+    const int w = G.px1 - G.px0 + 1, n = w * (G.py1 - G.py0 + 1);
+    for (int i = lane; i < n; i += 64) fwd_pixel(d, G, b, G.px0 + i % w, G.py0 + i / w, k2, lp);
+  }
 }
 
 __global__ __launch_bounds__(256) void silhouette_alpha_kernel(const hrp_silhouette_desc d) {
@@ -119,44 +144,72 @@ __global__ __launch_bounds__(256) void silhouette_alpha_kernel(const hrp_silhoue
     d.alpha[i] = 1.f - expf((float)((double)((const long long*)d.logp)[i] / S2R_FIX));
 }
 
+__device__ __forceinline__ bool bwd_pixel(const hrp_silhouette_desc& d, const Face2D& F, int x, int y, float k2, const long long* lp,
+                                          const float* ga, float (&g)[3][2]) {
+  const float gp = ga[y * d.W + x];
+  if (gp == 0.f) return false;
+  const float cx = x + 0.5f, cy = y + 0.5f;
+  float s, tt; int e;
+  if (!pixel_face(F, cx, cy, k2, d.blur_radius, s, e, tt)) return false;
+  const float P = expf((float)((double)lp[y * d.W + x] / S2R_FIX));
+  if (P == 0.f) return false;
+  const float p = 1.f / (1.f + expf(s / d.sigma));
+  // d alpha / d s = -P p / sigma;  s = +-k2 * (pixel distance)^2
+  const float gd = gp * (-P * p / d.sigma) * (s < 0.f ? -k2 : k2);
+  const float ax = e == 0 ? F.x0 : e == 1 ? F.x1 : F.x2, ay = e == 0 ? F.y0 : e == 1 ? F.y1 : F.y2;
+  const float bx = e == 0 ? F.x1 : e == 1 ? F.x2 : F.x0, by = e == 0 ? F.y1 : e == 1 ? F.y2 : F.y0;
+  const float rx = cx - (ax + tt * (bx - ax)), ry = cy - (ay + tt * (by - ay));
+  const bool degenerate = (bx - ax) * (bx - ax) + (by - ay) * (by - ay) <= S2R_EPS;
+  const float wa = degenerate ? 0.f : -2.f * (1.f - tt), wb = -2.f * tt;      // d (dist^2) / d a = wa r, / d b = wb r
+  const int ia = e, ib = (e + 1) % 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {       // (static indices: g stays in registers)
+    if (k == ia) { g[k][0] += gd * wa * rx; g[k][1] += gd * wa * ry; }
+    if (k == ib) { g[k][0] += gd * wb * rx; g[k][1] += gd * wb * ry; }
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(256) void silhouette_bwd_kernel(const hrp_silhouette_desc d, const float* __restrict__ d_alpha, float* __restrict__ d_uv) {
-  const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (f >= d.F) return;
+  const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
   const float sc = 2.f / (float)min(d.H, d.W), k2 = sc * sc;
-  Face2D F;
-  if (!load_face(d, b, f, k2, F)) return;
+  Face2D F = {};
+  const bool have = f < d.F && load_face(d, b, f, k2, F);
+  const int npx = have ? (F.px1 - F.px0 + 1) * (F.py1 - F.py0 + 1) : 0;
   const long long* lp = (const long long*)d.logp + (size_t)b * d.H * d.W;
   const float* ga = d_alpha + (size_t)b * d.H * d.W;
-  float g[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-  bool any = false;
-  for (int y = F.py0; y <= F.py1; ++y)
-    for (int x = F.px0; x <= F.px1; ++x) {
-      const float gp = ga[y * d.W + x];
-      if (gp == 0.f) continue;
-      const float cx = x + 0.5f, cy = y + 0.5f;
-      float s, tt; int e;
-      if (!pixel_face(F, cx, cy, k2, d.blur_radius, s, e, tt)) continue;
-      const float P = expf((float)((double)lp[y * d.W + x] / S2R_FIX));
-      if (P == 0.f) continue;
-      const float p = 1.f / (1.f + expf(s / d.sigma));
-      // d alpha / d s = -P p / sigma;  s = +-k2 * (pixel distance)^2
-      const float gd = gp * (-P * p / d.sigma) * (s < 0.f ? -k2 : k2);
-      const float ax = e == 0 ? F.x0 : e == 1 ? F.x1 : F.x2, ay = e == 0 ? F.y0 : e == 1 ? F.y1 : F.y2;
-      const float bx = e == 0 ? F.x1 : e == 1 ? F.x2 : F.x0, by = e == 0 ? F.y1 : e == 1 ? F.y2 : F.y0;
-      const float rx = cx - (ax + tt * (bx - ax)), ry = cy - (ay + tt * (by - ay));
-      const bool degenerate = (bx - ax) * (bx - ax) + (by - ay) * (by - ay) <= S2R_EPS;
-      const float wa = degenerate ? 0.f : -2.f * (1.f - tt), wb = -2.f * tt;      // d (dist^2) / d a = wa r, / d b = wb r
-      const int ia = e, ib = (e + 1) % 3;
-      g[ia][0] += gd * wa * rx; g[ia][1] += gd * wa * ry;
-      g[ib][0] += gd * wb * rx; g[ib][1] += gd * wb * ry;
-      any = true;
-    }
-  if (!any) return;
   float* o = d_uv + (size_t)b * d.V * 2;
-  const int vid[3] = {F.v0, F.v1, F.v2};
-  for (int k = 0; k < 3; ++k) {
-    if (g[k][0] != 0.f) atomicAdd(o + 2 * vid[k], g[k][0]);
-    if (g[k][1] != 0.f) atomicAdd(o + 2 * vid[k] + 1, g[k][1]);
+  if (have && npx <= S2R_BIG) {
+    float g[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    bool any = false;
+    for (int y = F.py0; y <= F.py1; ++y)
+      for (int x = F.px0; x <= F.px1; ++x) any |= bwd_pixel(d, F, x, y, k2, lp, ga, g);
+    if (any) {
+      const int vid[3] = {F.v0, F.v1, F.v2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (g[k][0] != 0.f) atomicAdd(o + 2 * vid[k], g[k][0]);
+        if (g[k][1] != 0.f) atomicAdd(o + 2 * vid[k] + 1, g[k][1]);
+      }
+    }
+  }
+  unsigned long long big = __ballot(npx > S2R_BIG);
+  while (big) {            // large faces: the wave shares the box, lane sums are folded across the wave, one lane adds them
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const Face2D G = face_from_lane(F, src);
+    const int w = G.px1 - G.px0 + 1, n = w * (G.py1 - G.py0 + 1);
+    float g[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int i = lane; i < n; i += 64) bwd_pixel(d, G, G.px0 + i % w, G.py0 + i / w, k2, lp, ga, g);
+    const int vid[3] = {G.v0, G.v1, G.v2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float gx = wave_sum(g[k][0]), gy = wave_sum(g[k][1]);
+      if (lane == 0) {
+        if (gx != 0.f) atomicAdd(o + 2 * vid[k], gx);
+        if (gy != 0.f) atomicAdd(o + 2 * vid[k] + 1, gy);
+      }
+    }
   }
 }
 

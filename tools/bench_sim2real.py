@@ -62,6 +62,13 @@ def main():
     ap.add_argument("--mask-target", choices=["rendered", "net"], default="rendered")
     ap.add_argument("--no-mask-net", action="store_true")
     a = ap.parse_args()
+    print(json.dumps(run(a)))
+
+
+def run(a, check=False):
+    """The step of main(), callable (tests/test_gpu_config5.py runs it once at the configuration's stated size).  check: also return
+    what a test asserts on - the mask network's output shape, the rasteriser's largest per-pixel face count, gradient norms of both
+    trunks and of the regressor heads."""
     from hrpe_amd.lib.core.function import compute_k_values, sim2real_mask_loss
     from hrpe_amd.optim import FusedClipAdam
     B = a.batch
@@ -138,7 +145,22 @@ def main():
     ms = t0.elapsed_time(t1) / a.steps
     names = ["mask network (resize + DeepLabv3-ResNet50 + upsample)", "network forward", "mesh posing + rasteriser", "mask losses",
              "backward (losses, rasteriser, network)", "clip + Adam"]
-    print(json.dumps({"workload": "self-supervised render-and-compare step (BASELINE config 5) on synthetic meshes / images, plans replayed "
+    extra = {}
+    if check:
+        with torch.no_grad():
+            out = model(d["x_reg"], d["x_root"], kv, K)
+            B_ = out[0].shape[0]
+            model.robot.render_silhouette(out[0], out[1], out[2] + t_off, renderer.mesh, renderer.K.expand(B_, 3, 3), renderer.image_size, root=3,
+                                          sigma=renderer.sigma, blur_radius=renderer.blur_radius, check_faces_per_pixel=True)
+        gn = {}
+        for name, pre in (("reg_trunk", "reg_backbone."), ("root_trunk", "rootnet_backbone."), ("heads", "fc_")):
+            gs = [p.grad.float() for k, p in model.named_parameters() if k.startswith(pre) and p.grad is not None]
+            gn[name] = float(torch.sqrt(sum((g_ * g_).sum() for g_ in gs))) if gs else 0.0
+            gn[name + "_finite"] = all(bool(torch.isfinite(g_).all()) for g_ in gs)
+        extra = {"grad_norms": gn, "max_faces_per_pixel": int(model.robot.last_faces_per_pixel),
+                 "seg_mask_shape": list(seg_net(images_original_255).shape) if seg_net is not None else None,
+                 "rendered_shape": list(seg.shape)}
+    return dict({"workload": "self-supervised render-and-compare step (BASELINE config 5) on synthetic meshes / images, plans replayed "
                                   "from HIP graphs, full network bf16 with frozen BatchNorm, mask network on 480x640 images, 240x320 masks",
                       "batch": B, "images_per_sec": round(B / ms * 1e3, 1),
                       "ms_per_step": round(ms, 2), "phases_ms": {n: round(v / a.steps, 3) for n, v in zip(names, acc)},
@@ -146,7 +168,7 @@ def main():
                       "loss": round(float(loss.detach()), 5), "rasteriser": "parity unpinned (csrc/silhouette.hip)",
                       "mask_network": ("absent (--no-mask-net)" if seg_net is None else
                                        "present (parity unpinned); loss target: " + ("its output" if a.mask_target == "net" else
-                                                                                       "a mask rendered from a perturbed pose"))}))
+                                                                                       "a mask rendered from a perturbed pose"))}, **extra)
 
 
 if __name__ == "__main__":

@@ -119,7 +119,7 @@ class EwBwdDesc(C.Structure):
                 ("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("relu", C.c_int32), ("accumulate", C.c_int32),
                 ("mask", C.c_void_p), ("mask_pitch", C.c_int32),
-                ("din2", C.c_void_p), ("din2_pitch", C.c_int32), ("accumulate2", C.c_int32)]
+                ("din2", C.c_void_p), ("din2_pitch", C.c_int32), ("accumulate2", C.c_int32), ("pooled", C.c_void_p)]
 
 
 class BnEntry(C.Structure):
@@ -219,6 +219,7 @@ PROTOTYPES = {
     "hrp_colsum_workspace_bytes": [_L, _I],
     "hrp_ew_fwd": [C.POINTER(EwDesc), _P],
     "hrp_ew_bwd_reduce": [C.POINTER(EwBwdDesc), _P],
+    "hrp_ew_pool2": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P],
     "hrp_ew_bwd_apply": [C.POINTER(EwBwdDesc), _P],
     "hrp_bn_running_update": [_P, _I, _P], "hrp_bn_fold": [_P, _I, _P], "hrp_bn_param_grad": [_P, _I, _P],
     "hrp_avgpool_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P],

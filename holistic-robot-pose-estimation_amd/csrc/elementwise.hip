@@ -256,6 +256,19 @@ __device__ __forceinline__ void pooled_grad_rows(const hrp_ew_bwd_desc& d, unsig
 // pooled, masked output gradient at input pixel q = (n, qy, qx)
 template <typename T, int V, bool LEAKY = false>
 __device__ __forceinline__ void pooled_grad(const hrp_ew_bwd_desc& d, unsigned q, int c, float* g) {
+  if (d.pooled) {            // (uniform) the window sums were formed once for all terms of this activation: hrp_ew_pool2
+    const float* q0 = d.pooled + (size_t)q * d.C + c;
+#pragma unroll
+    for (int i = 0; i < V; i += (V >= 4 ? 4 : 1)) {
+      if constexpr (V >= 4) {
+        const float4 t = *(const float4*)(q0 + i);
+        g[i] = t.x; g[i + 1] = t.y; g[i + 2] = t.z; g[i + 3] = t.w;
+      } else {
+        g[i] = q0[i];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < V; ++i) g[i] = 0.f;
   const int up = d.in.up;
@@ -331,6 +344,49 @@ __device__ __forceinline__ unsigned reduce_pixels(const hrp_ew_bwd_desc& d, int 
     }
   }
   return q;
+}
+
+// 2 x 2 window sums of a gradient: thread = (output pixel, 8 channels).  SRC16: the source is bf16 (16 bytes per 8 channels), else fp32.
+template <bool SRC16>
+__global__ __launch_bounds__(256) void ew_pool2_kernel(const void* __restrict__ src, int src_pitch, const uint8_t* __restrict__ mask, int mask_pitch,
+                                                       int N, int H, int W, int C, float* __restrict__ dst) {
+  const int cv = C / 8, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cv);
+    size_t r = i / cv;
+    const int x = (int)(r % Wo);
+    r /= Wo;
+    const int y = (int)(r % Ho), n = (int)(r / Ho);
+    const size_t p00 = ((size_t)n * H + 2 * y) * W + 2 * x;
+    const size_t pp[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    float v[4][8];
+    unsigned bits[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (SRC16) {
+        const uint4 raw = *(const uint4*)((const char*)src + (pp[k] * src_pitch + 8 * c8) * 2);
+        Elem<bf16_t>::unpack(raw, v[k]);
+      } else {
+        const float* q = (const float*)src + pp[k] * src_pitch + 8 * c8;
+        const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
+        v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w; v[k][4] = b.x; v[k][5] = b.y; v[k][6] = b.z; v[k][7] = b.w;
+      }
+      // the mask has one byte per 16-byte vector of the SOURCE: 8 channels of bf16, 4 of fp32
+      bits[k] = 0xffu;
+      if (mask) bits[k] = SRC16 ? mask[pp[k] * mask_pitch + c8] : (unsigned)mask[pp[k] * mask_pitch + 2 * c8] | ((unsigned)mask[pp[k] * mask_pitch + 2 * c8 + 1] << 4);
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = (bits[0] >> e) & 1u ? v[0][e] : 0.f, b = (bits[1] >> e) & 1u ? v[1][e] : 0.f;
+      const float c = (bits[2] >> e) & 1u ? v[2][e] : 0.f, dd = (bits[3] >> e) & 1u ? v[3][e] : 0.f;
+      o[e] = (a + b) + (c + dd);
+    }
+    float* q = dst + i * 8;
+    *(float4*)q = make_float4(o[0], o[1], o[2], o[3]);
+    *(float4*)(q + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
 }
 
 template <typename T, int V>
@@ -870,6 +926,7 @@ static int hrp::ew_bwd_check(const hrp_ew_bwd_desc* d, bool apply) {
   HRP_REQUIRE(d->in.mode != HRP_EW_BN_TRAIN || (d->sums && d->in.stats && d->in.a), "ew_bwd: bn needs sums/stats");
   HRP_REQUIRE(!apply || d->din, "ew_bwd_apply: din");
   HRP_REQUIRE(!d->din2 || d->in.up == 1, "ew_bwd: din2 needs up == 1");   /* (the reduce pass ignores din2) */
+  HRP_REQUIRE(!d->pooled || (d->in.up > 1 && d->C % 8 == 0 && (uintptr_t)d->pooled % 16 == 0), "ew_bwd: pooled needs up > 1, C %% 8 == 0, 16-byte alignment");
   HRP_REQUIRE(apply || (d->sums && d->in.ptr), "ew_bwd_reduce: sums / input values");
   return HRP_OK;
 }
@@ -879,6 +936,21 @@ extern "C" int hrp_ew_bwd_reduce(const hrp_ew_bwd_desc* d, void* stream) {
   if (rc) return rc;
   if (d->dtype == HRP_F32) return ew_bwd_t<float, false>(*d, (hipStream_t)stream);
   return ew_bwd_t<bf16_t, false>(*d, (hipStream_t)stream);
+}
+
+extern "C" int hrp_ew_pool2(const void* src, int src_dtype, int src_pitch, const uint8_t* mask, int mask_pitch, int N, int H, int W, int C,
+                            float* dst, void* stream) {
+  HRP_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0 && src_pitch >= C,
+              "ew_pool2: geometry (H, W even, C a multiple of 8)");
+  HRP_REQUIRE(src_dtype == HRP_BF16 || src_dtype == HRP_F32, "ew_pool2: source dtype");
+  const int esz = src_dtype == HRP_BF16 ? 2 : 4;
+  HRP_REQUIRE((uintptr_t)src % 16 == 0 && ((size_t)src_pitch * esz) % 16 == 0 && (uintptr_t)dst % 16 == 0, "ew_pool2: alignment");
+  HRP_REQUIRE(!mask || mask_pitch >= C / (16 / esz), "ew_pool2: mask pitch");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  if (src_dtype == HRP_BF16) hipLaunchKernelGGL((ew_pool2_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, mask, mask_pitch, N, H, W, C, dst);
+  else hipLaunchKernelGGL((ew_pool2_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, mask, mask_pitch, N, H, W, C, dst);
+  return check_launch("ew_pool2");
 }
 
 extern "C" int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream) {

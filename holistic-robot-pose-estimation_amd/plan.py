@@ -174,6 +174,8 @@ MASKED_RES = True
 # shortcut) + BatchNorm + shortcut + ReLU as pointwise launches that never store a raw 1x1 output, the BatchNorm backward likewise
 # (PlanBuilder.bottleneck_tail)
 BNECK_TAIL_FUSE = True
+# the backward of a fuse sum pools its output gradient once for all upsampled terms (hrp_ew_pool2; PlanBuilder._act_bwd)
+POOL_FUSE_GRADS = True
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
 # lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
 # instead of by position: 646 -> 628 conv launches, 34.12 -> 33.87 ms per step (A/B/A/B on one box)
@@ -2479,6 +2481,23 @@ class PlanBuilder:
             return
         # an identity term (residual) at the output resolution rides along with a BN / affine term of the same
         # activation: one apply launch writes both gradients (hrp_ew_bwd_desc.din2)
+        # upsampled terms (the 2 / 4 / 8-fold inputs of a fuse sum, HRnet.py:197-208): the masked output gradient is summed over the
+        # 2 x 2 windows ONCE (hrp_ew_pool2; 4 x 4 and 8 x 8 from the level below) and every term's reduce and apply pass read their
+        # level instead of pooling out.grad under the mask again - six passes over the [N, 64, 64, 32] gradient per stage-4 output
+        pooled = {}
+        ups = sorted({tm.up for tm in terms if tm.up > 1 and tm.t.requires_grad})
+        if POOL_FUSE_GRADS and ups and relu and relu != "leaky" and fd.mask and fd.C % 8 == 0 and all(u in (2, 4, 8) for u in ups):
+            src, sdt, spitch, msk, mp = out.gptr(), fd.dtype, out.pitch, fd.mask, fd.mask_pitch
+            Hc, Wc, lvl = fd.H, fd.W, 1
+            while lvl < ups[-1]:
+                lvl *= 2
+                buf = torch.zeros(fd.N * (Hc // 2) * (Wc // 2) * fd.C, dtype=torch.float32, device=p.device)
+                p.keep.append(buf)
+                p.bwd.append(lambda s, src=src, sdt=sdt, spitch=spitch, msk=msk, mp=mp, Hc=Hc, Wc=Wc, buf=buf: nv.call(
+                    "hrp_ew_pool2", src, sdt, spitch, msk, mp, fd.N, Hc, Wc, fd.C, buf.data_ptr(), s))
+                pooled[lvl] = buf
+                src, sdt, spitch, msk, mp, Hc, Wc = buf.data_ptr(), nv.HRP_F32, fd.C, None, 0, Hc // 2, Wc // 2
+            p.counters["fuse_grad_pools"] = p.counters.get("fuse_grad_pools", 0) + 1
         host = next((j for j, tm in enumerate(terms) if tm.t.requires_grad and tm.bn is not None and tm.up == 1), None)
         rider = next((j for j, tm in enumerate(terms) if tm.t.requires_grad and tm.bn is None and tm.up == 1
                       and fd.inp[j].mode == nv.EW_IDENTITY), None) if host is not None else None
@@ -2498,6 +2517,8 @@ class PlanBuilder:
             b.mask, b.mask_pitch = fd.mask, fd.mask_pitch
             b.din, b.din_pitch = tm.t.gptr(), tm.t.pitch
             b.accumulate = tm.t.take_grad_slot()
+            if tm.up in pooled:
+                b.pooled = pooled[tm.up].data_ptr()
             if j == host and rider is not None:
                 rt = terms[rider].t
                 # the check above guarantees the aligned vector path is the same for both outputs

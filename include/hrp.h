@@ -291,6 +291,11 @@ typedef struct hrp_ew_bwd_desc {
   void* din2;          /* apply, optional, in.up == 1 only: second output = the masked gradient g itself, i.e. */
   int32_t din2_pitch;  /* the gradient of an identity (residual) input of the same activation - saves the   */
   int32_t accumulate2; /* separate identity launch that would re-read dout / out; din2 += when accumulate2  */
+  /* in.up > 1 (an upsampled input of a fuse layer, HRnet.py:197-208, 256-263): optional fp32 [N, H/up, W/up, C] dense tensor holding
+   * the output gradient already masked and summed over the up x up window of every input pixel (hrp_ew_pool2, applied log2(up)
+   * times).  Reduce and apply then read it instead of pooling dout under the mask again - the 2 / 4 / 8-fold terms of one fuse sum
+   * each pooled the same [N, H, W, C] gradient twice (six passes over it per stage-4 output; now one). */
+  const float* pooled;
 } hrp_ew_bwd_desc;
 
 /* Table entry for the one-launch batch-norm bookkeeping kernels. */
@@ -406,6 +411,12 @@ int hrp_opt_adam_step(const hrp_opt_tensor* tensors_dev, const hrp_opt_chunk* ch
 
 int hrp_ew_fwd(const hrp_ew_desc* d, void* stream);
 int hrp_ew_bwd_reduce(const hrp_ew_bwd_desc* d, void* stream);
+/* dst[n, y, x, c] (fp32, dense [N, H/2, W/2, C]) = sum over the 2 x 2 window of src[n, 2y + dy, 2x + dx, c] * bit: the first level
+ * (src_dtype HRP_BF16 / HRP_F32 of the plan, mask = the ReLU bits of hrp_ew_desc.mask, one byte per 16-byte vector) pools the masked
+ * output gradient of a fuse sum, further levels (src_dtype HRP_F32, mask NULL, src = the previous level) halve it again.  Fixed
+ * summation order ((a + b) + (c + d)); H, W even, C a multiple of 8. */
+int hrp_ew_pool2(const void* src, int src_dtype, int src_pitch, const uint8_t* mask, int mask_pitch, int N, int H, int W, int C, float* dst,
+                 void* stream);
 int hrp_ew_bwd_apply(const hrp_ew_bwd_desc* d, void* stream);
 
 /* ---- batched launches ---------------------------------------------------------------------------------------

@@ -142,7 +142,7 @@ def test_bf16_keypoint_0_documents_known_bf16_defect():
     assert by_kp2[0] < 1.3 and max(by_kp2[1:]) < 0.5, by_kp2
 
 
-def _train_curve(dtype, steps, B=8, nbatches=4):
+def _train_curve(dtype, steps, B=8, nbatches=4, lr=1e-4):
     """`steps` training steps of the full network (synthetic batches of bench.py, the loss of lib/core/function.py:191-322, clip 5 +
     Adam 1e-4, no dropout) over `nbatches` DIFFERENT batches visited in turn -> losses.  Same seeded weights and batches for every call."""
     import sys
@@ -163,7 +163,7 @@ def _train_curve(dtype, steps, B=8, nbatches=4):
             gt = dict(pose=d["q"], root_rot=m.robot.get_rotation_at_specific_root(d["q"], rot6, d["t"], root=3),
                       root_trans=kp3d[:, 3].clone(), root_uv=kp2d[:, 3].clone(), kp3d=kp3d, kp2d=kp2d, mask=torch.ones(B, 7, device=DEV))
         batches.append((d, kv, K, gt))
-    opt = FusedClipAdam([p for p in m.parameters() if p.requires_grad], lr=1e-4, max_norm=5.0)
+    opt = FusedClipAdam([p for p in m.parameters() if p.requires_grad], lr=lr, max_norm=5.0)
     losses = []
     for it in range(steps):
         d, kv, K, gt = batches[it % nbatches]
@@ -176,32 +176,34 @@ def _train_curve(dtype, steps, B=8, nbatches=4):
 
 
 def test_bf16_training_follows_the_fp32_loss_curve():
-    """80 optimizer steps in fp32 and in bf16 from the same weights over the same FOUR batches visited in turn (one
-    memorised batch with a 20 % band was evidence of "not broken", not of parity).  At B = 8 single steps spike (a visit at 2-4 x the
-    neighbouring losses, at different steps in the two runs), so the curves are compared through MEDIANS: per batch, the median loss of
-    each window of five visits (20 steps); the bf16 / fp32 ratio of those medians, averaged over the four batches, must be within 10 % of
-    1 in the LAST window and within 30 % in every window, and the medians must have fallen (last / first window, mean over the
-    batches, below 0.95) in both precisions.  Measured: the ratio runs 0.96 -> 1.22 -> 1.02 -> 1.02: bf16 trails fp32 by about a fifth
-    between steps 20 and 40 (one batch by 40 %) and ends within 2 %; the falls are 0.84 (fp32) and 0.88 (bf16) - one of the four
-    synthetic batches carries a loss of ~430 that hardly moves in 80 steps.  The 10 % band the verdict asked for holds at the end,
-    not throughout."""
+    """80 optimizer steps in fp32 and in bf16 from the same weights over the same FOUR batches visited in turn, compared through the
+    per-batch median loss of each window of five visits (20 steps).
+
+    Learning rate 2e-5, not the trainers' 1e-4 (scripts/train_full.py:42): at 1e-4 this synthetic problem (random weights, B = 8,
+    train-mode BatchNorm) is CHAOTIC - round 6 measured four runs of the SAME fp32 arithmetic that differ only in summation order
+    (fused / unfused regressors, pooled / re-pooled fuse gradients: tools/curve_ab.py) ending between 0.77 and 0.95 of their first
+    window, with first-window medians 10 % apart; the 10 % / 30 % bands of round 5 were inside that spread and the test could fail
+    for either precision.  At 2e-5 the curves are smooth, two runs repeat bit for bit, and bf16 can be held to fp32 for real:
+    measured window ratios (mean over the batches) 1.00, 0.97, 0.99, 0.99, worst single batch 0.86, falls 0.82 (fp32) / 0.81 (bf16).
+    Gates: every window within 8 %, every batch of every window within 20 %, both falls below 0.9."""
     n, nb, vis = 80, 4, 5
-    f32 = _train_curve(torch.float32, n, nbatches=nb)
-    b16 = _train_curve(torch.bfloat16, n, nbatches=nb)
+    f32 = _train_curve(torch.float32, n, nbatches=nb, lr=2e-5)
+    b16 = _train_curve(torch.bfloat16, n, nbatches=nb, lr=2e-5)
     nwin = n // (nb * vis)
     med = lambda v, k, w: float(np.median(v[k::nb][w * vis:(w + 1) * vis]))      # noqa: E731
     print("\nwindow   bf16 / fp32 median ratio per batch          mean")
-    ratios = []
+    ratios, single = [], []
     for w in range(nwin):
         r = [med(b16, k, w) / med(f32, k, w) for k in range(nb)]
+        single += r
         ratios.append(float(np.mean(r)))
         print(f"{w:4d}     " + " ".join(f"{x:8.3f}" for x in r) + f"   {ratios[-1]:8.3f}")
     for v, name in ((f32, "fp32"), (b16, "bf16")):
         fall = float(np.mean([med(v, k, nwin - 1) / med(v, k, 0) for k in range(nb)]))
         print(f"{name}: last / first window median, mean over the batches: {fall:.3f}")
-        assert fall < 0.95, (name, fall)
-    assert all(abs(r - 1.0) < 0.30 for r in ratios), ratios
-    assert abs(ratios[-1] - 1.0) < 0.10, ratios
+        assert fall < 0.9, (name, fall)
+    assert all(abs(r - 1.0) < 0.08 for r in ratios), ratios
+    assert all(abs(r - 1.0) < 0.20 for r in single), single
 
 
 def test_full_train_step_with_frozen_batchnorm_golden():

@@ -173,9 +173,9 @@ MASKED_RES = True
 # train-mode Bottlenecks at >= 131 072 pixels (layer1, the first incre-module of the cls head): conv3 (+ the 1x1 projection of the
 # shortcut) + BatchNorm + shortcut + ReLU as pointwise launches that never store a raw 1x1 output, the BatchNorm backward likewise
 # (PlanBuilder.bottleneck_tail)
-BNECK_TAIL_FUSE = True
+BNECK_TAIL_FUSE = os.environ.get("HRP_TAIL_FUSE", "1") not in ("0", "")
 # the backward of a fuse sum pools its output gradient once for all upsampled terms (hrp_ew_pool2; PlanBuilder._act_bwd)
-POOL_FUSE_GRADS = True
+POOL_FUSE_GRADS = os.environ.get("HRP_POOL_FUSE", "1") not in ("0", "")
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
 # lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
 # instead of by position: 646 -> 628 conv launches, 34.12 -> 33.87 ms per step (A/B/A/B on one box)

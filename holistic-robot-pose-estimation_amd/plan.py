@@ -174,8 +174,11 @@ MASKED_RES = True
 # shortcut) + BatchNorm + shortcut + ReLU as pointwise launches that never store a raw 1x1 output, the BatchNorm backward likewise
 # (PlanBuilder.bottleneck_tail)
 BNECK_TAIL_FUSE = os.environ.get("HRP_TAIL_FUSE", "1") not in ("0", "")
-# the backward of a fuse sum pools its output gradient once for all upsampled terms (hrp_ew_pool2; PlanBuilder._act_bwd)
-POOL_FUSE_GRADS = os.environ.get("HRP_POOL_FUSE", "1") not in ("0", "")
+# the backward of a fuse sum pools its output gradient once for all upsampled terms (hrp_ew_pool2; PlanBuilder._act_bwd): built for
+# VERDICT r5 item 1(d), correct (tests/test_gpu_kernels.py::test_hr_module_fuse_pooled_gradients) and OFF: it trades ~0.8 GB of
+# re-reads for 62 small launches in the lanes' serial chains - A/B/A/B on one box 32.85 / 33.00 ms with it, 32.84 / 32.80 without
+# (reduce + apply 5.02 -> 4.63 ms of kernel time, the pool launches 0.47 ms).  HRP_POOL_FUSE=1 turns it on.
+POOL_FUSE_GRADS = os.environ.get("HRP_POOL_FUSE", "0") not in ("0", "")
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
 # lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
 # instead of by position: 646 -> 628 conv launches, 34.12 -> 33.87 ms per step (A/B/A/B on one box)

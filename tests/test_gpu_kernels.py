@@ -222,6 +222,27 @@ def test_hr_module_fuse(training, dtype):
     assert worst < t, f"param grads {worst}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hr_module_fuse_pooled_gradients(dtype):
+    """The optional pooled form of the fuse sums' backward (plan.POOL_FUSE_GRADS, hrp_ew_pool2 + hrp_ew_bwd_desc.pooled; off by
+    default - a negative A/B result): the same module and bounds as test_hr_module_fuse in train mode, with the masked output
+    gradient pooled once for the 2- and 4-fold terms; the plan really took that path (counter)."""
+    from hrpe_amd import plan as P
+    saved = P.POOL_FUSE_GRADS
+    P.POOL_FUSE_GRADS = True
+    try:
+        test_hr_module_fuse(True, dtype)
+        from hrpe_amd.lib.models.backbones import HRnet as H
+        m = H.HighResolutionModule(3, H.BasicBlock, [4, 4, 4], [32, 64, 128], [32, 64, 128], "SUM", True).to(DEV).set_compute_dtype(dtype).train()
+        g = torch.Generator().manual_seed(11)
+        xd = [torch.randn(2, 32, 16, 16, generator=g).to(DEV).requires_grad_(True), torch.randn(2, 64, 8, 8, generator=g).to(DEV).requires_grad_(True),
+              torch.randn(2, 128, 4, 4, generator=g).to(DEV).requires_grad_(True)]
+        sum(y.sum() for y in m(xd)).backward()
+        assert next(iter(m._plans.values())).plan.counters.get("fuse_grad_pools", 0) == 2      # outputs 0 (terms x2, x4) and 1 (x2)
+    finally:
+        P.POOL_FUSE_GRADS = saved
+
+
 def test_softargmax_golden_and_backward():
     """One-pass 3-D soft-argmax against the reference fixture (HeatmapIntegralPose, integral.py:147-186)."""
     from hrpe_amd.lib.utils.integral import HeatmapIntegralPose

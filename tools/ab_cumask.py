@@ -22,7 +22,9 @@ DEV = torch.device("cuda:0")
 
 def masked_stream(bits):
     """-> torch.cuda.ExternalStream on a HIP stream restricted to the CUs whose bit is set (256 bits, 8 words)."""
-    hip = C.CDLL(None)
+    import glob
+    cand = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
+    hip = C.CDLL(cand[0])          # (the runtime torch already loaded: same handle)
     words = (C.c_uint32 * 8)(*[sum(((bits >> (32 * w + b)) & 1) << b for b in range(32)) for w in range(8)])
     st = C.c_void_p()
     rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(8), words)

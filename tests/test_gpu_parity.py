@@ -36,14 +36,36 @@ BF16_B64_TOL = {"pose": 6e-3, "rot": 1.1e-2, "trans": 9e-2, "root_uv": 0.19, "de
 HEADS = ("fc_pose", "fc_rot", "decpose", "decrot", "depth_layer")
 
 
+# bf16 gradients against fp32, PER TENSOR (a global cosine gate of 0.65 said "not broken", not "parity").  The step is
+# bit-reproducible, so every sampled tensor has ONE value; measured on MI355X in round 6 (tests run with -s print them):
+#   (l2 error, cosine) at B = 8 against the reference's fixture / at B = 64 against the fp32 HIP step of the same batch.
+# Gates: l2 <= 1.5 x the measurement, 1 - cosine <= 1.5 x the measurement (+ 0.002).  What the numbers say is unchanged: the heads'
+# gradients are within 2-4 % (15 % at B = 64, where the loss is dominated by one term), the trunk keeps the direction (0.75-0.99) and
+# loses length - gradients stored in bf16 lose the cancelling terms of the BatchNorm backward on this randomly weighted network.
+BF16_GRAD_MEASURED = {
+    "bf16 B=8": {
+        "reg_backbone.conv1.weight": (0.628, 0.816), "reg_backbone.final_layer.weight": (0.192, 0.989),
+        "reg_backbone.final_layer.bias": (0.0795, 0.998), "reg_backbone.stage3.0.branches.0.1.conv1.weight": (0.565, 0.836),
+        "reg_backbone.stage4.1.fuse_layers.2.0.0.0.weight": (0.423, 0.907), "reg_backbone.stage4.2.fuse_layers.0.1.0.weight": (0.153, 0.988),
+        "reg_backbone.incre_modules.0.0.conv1.weight": (0.482, 0.878), "rootnet_backbone.conv1.weight": (0.669, 0.774),
+        "rootnet_backbone.stage2.0.branches.1.3.bn2.weight": (0.756, 0.746), "rootnet_backbone.final_feat_layer.0.weight": (0.267, 0.966),
+        "fc_pose_1.weight": (0.0352, 1.0), "fc_pose_2.bias": (0.0269, 1.0), "decpose.weight": (0.034, 1.0), "fc_rot_1.weight": (0.0338, 1.0),
+        "decrot.bias": (0.0257, 1.0), "depth_layer.weight": (0.0185, 1.0), "depth_layer.bias": (0.0141, 1.0)},
+    "bf16 B=64": {
+        "reg_backbone.conv1.weight": (0.684, 0.809), "reg_backbone.stage3.0.branches.0.1.conv1.weight": (0.601, 0.842),
+        "reg_backbone.stage4.2.branches.3.3.conv2.weight": (0.488, 0.910), "reg_backbone.stage4.1.fuse_layers.2.0.0.0.weight": (0.534, 0.883),
+        "reg_backbone.final_layer.weight": (0.152, 0.989), "rootnet_backbone.stage2.0.branches.1.3.bn2.weight": (0.780, 0.769),
+        "rootnet_backbone.final_feat_layer.0.weight": (0.375, 0.951), "fc_pose_1.weight": (0.144, 1.0), "decrot.bias": (0.146, 1.0),
+        "depth_layer.weight": (0.0606, 1.0)}}
+
+
 def _check_bf16_grads(l2, cos, what):
+    table = BF16_GRAD_MEASURED[what]
+    assert set(l2) <= set(table), f"{what}: no measurement recorded for {sorted(set(l2) - set(table))}"
     for n, e in l2.items():
-        if n.startswith(HEADS):
-            assert e < 0.25, f"{what} {n}: l2 err {e}"
-        elif "final_layer" in n:
-            assert cos[n] > 0.95, f"{what} {n}: cosine {cos[n]}"
-        else:
-            assert cos[n] > 0.65, f"{what} {n}: cosine {cos[n]}"      # (measured minimum 0.70: a BatchNorm weight of the depth trunk at B = 64)
+        m_l2, m_cos = table[n]
+        assert e <= 1.5 * m_l2, f"{what} {n}: l2 err {e} (measured {m_l2})"
+        assert 1.0 - cos[n] <= 1.5 * (1.0 - m_cos) + 2e-3, f"{what} {n}: cosine {cos[n]} (measured {m_cos})"
 
 
 def _train_step_inputs(g, m, B):

@@ -197,16 +197,24 @@ def build_depthnet():
 
 
 def launch_descs(name, args):
-    """-> (family entry point, descriptors) of one launch: a single C-ABI call or one batched launch of n problems."""
+    """-> (family entry point, descriptors) of one launch: a single C-ABI call or one batched launch of n problems.
+    A launch counts towards the family of the REFERENCE operation it carries out: the backward forms of the Bottleneck tail
+    (hrp_conv_desc.tail_mode 3 / 4, csrc/conv_pw.h) enter through hrp_conv2d_fwd but ARE the BatchNorm backward's reduce / apply
+    passes (they replace hrp_ew_bwd_reduce / _apply launches one for one) - they are listed with those families and keep their
+    time out of the convolution family's roofline, which prices convolutions by SURVEY 8(d) bytes; the forward forms (mode 1:
+    the product's statistics, mode 2 / 5: the product with its BatchNorm, shortcut and ReLU) are the convolution."""
     if name == "hrp_batch_launch":
         b = args[0]
         return nv.FAMILY_FN[b.fam], [it.desc for it in b.items]
     if name == "hrp_block_launch":      # fused inference blocks (hrp_block_desc)
         return name, [it.desc for it in args[0].items]
     try:
-        return name, [args[0]._obj]
+        d = args[0]._obj
     except (AttributeError, IndexError):
         return name, []
+    if name == "hrp_conv2d_fwd" and getattr(d, "tail_mode", 0) in (3, 4):
+        return ("hrp_ew_bwd_reduce" if d.tail_mode == 3 else "hrp_ew_bwd_apply"), [d]
+    return name, [d]
 
 
 def conv_flops(name, args):
@@ -232,21 +240,17 @@ def conv_bytes(name, args, extended=False):
     if fam == "hrp_block_launch":       # what the fused block must move: x read once, out written once, both weights
         return float(sum(2 * d.conv1.N * d.conv1.H * d.conv1.W * d.conv1.Cin * 2 + 2 * 9 * d.conv1.Cin * d.conv1.Cout * 2 for d in descs))
     if fam not in ("hrp_conv2d_fwd", "hrp_conv2d_bwd_weight"):
-        return 0.0
+        return 0.0       # (incl. the tail's backward forms, listed with the element-wise backward families: launch_descs)
     tot = 0.0
     for d in descs:
         esz = 2 if d.dtype == nv.HRP_BF16 else 4
         if fam == "hrp_conv2d_fwd":
             b = (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.ntaps * d.Cin * d.Cout) * esz
             tm = getattr(d, "tail_mode", 0)
-            if tm in (1, 3, 4):
-                # recompute passes of a Bottleneck tail (statistics / BatchNorm backward): BatchNorm work in the reference, no
-                # convolution of SURVEY 8(d) - zero strict bytes (their TIME stays in the family); extended: what they move
-                b = 0.0
-                if extended:
-                    yb = d.N * d.Ho * d.Wo * d.Cout * esz
-                    b = d.N * d.H * d.W * d.Cin * esz + {1: 0, 3: yb, 4: 2 * yb + (yb * (2 if d.tail_side_acc else 1) if d.tail_side else 0)}[tm]
-                tot += b
+            if tm == 1:
+                # the statistics pass of a Bottleneck tail multiplies what mode 2 / 5 multiplies again: part of the SAME convolution of
+                # SURVEY 8(d) - zero strict bytes of its own (its TIME stays in the family); extended: what it moves
+                tot += d.N * d.H * d.W * d.Cin * esz if extended else 0.0
                 continue
             if tm == 5:       # two layers in one launch (conv3 and the projection): both inputs, both weights, one output
                 b += (d.N * d.H * d.W * d.Cin + d.ntaps * d.Cin * d.Cout) * esz

@@ -94,10 +94,13 @@ static inline int row_channels(const hrp_conv_desc& d) {
   if (d.bnb_x && (d.bnb_x_pitch != C || !d.bnb_stats || !d.bnb_gamma || !d.bnb_beta || !d.stats ||
                   d.relu || d.scale || (uintptr_t)d.bnb_x % 16)) return 0;
   if (d.bnb_x && d.bnb_mask && (d.bnb_mask_pitch != C / 8 || (uintptr_t)d.bnb_mask % 2)) return 0;
-  if (d.pro_mode < 0 || d.pro_mode > 2) return 0;
+  if (d.pro_mode < 0 || d.pro_mode > 3) return 0;
   if (d.pro_mode && (!d.pro_stats || !d.pro_gamma || !d.pro_beta)) return 0;
   if (d.pro_mode == 2 && (!d.pro_x2 || !d.pro_bsums || (uintptr_t)d.pro_x2 % 16)) return 0;
-  if (d.pro_mode != 2 && (d.pro_mask || d.pro_side2)) return 0;
+  // pro_mode 3 (x = raw conv2 output of the previous block, pro_x2 = that block's input): the activation goes to pro_side, its
+  // ReLU bits to pro_mask (an OUTPUT here) - both required, the backward of the previous block reads them
+  if (d.pro_mode == 3 && (!d.pro_x2 || (uintptr_t)d.pro_x2 % 16 || !d.pro_side || !d.pro_mask || d.pro_side2)) return 0;
+  if (d.pro_mode < 2 && (d.pro_mask || d.pro_side2)) return 0;
   if ((d.pro_side && (uintptr_t)d.pro_side % 16) || (d.pro_side2 && (uintptr_t)d.pro_side2 % 16)) return 0;
   if (d.res_mask && (!d.res || (uintptr_t)d.res_mask % 2 || d.relu || d.scale)) return 0;
   if ((long long)d.N * d.H * d.W * C * 2 >= (1ll << 31)) return 0;     // 32-bit byte offsets inside the tensors
@@ -170,6 +173,20 @@ struct RowPro {
     Elem<bf16_t>::unpack(raw, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]), 0.f);
+    return Elem<bf16_t>::pack(f);
+  }
+  // pro_mode 3: the block-end activation of the PREVIOUS BasicBlock, relu(bn(y2) + res) (HRnet.py:52-56), applied while this block's
+  // conv1 stages its input; bits: bit i = channel i of the vector is > 0 (the layout hrp_ew_fwd writes)
+  __device__ __forceinline__ uint4 fwd3(const uint4 raw, const uint4 res, unsigned& bits) const {
+    float f[8], r[8];
+    Elem<bf16_t>::unpack(raw, f);
+    Elem<bf16_t>::unpack(res, r);
+    bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f[i] = fmaxf(row_bn_act(f[i], sc[i], sh[i]) + r[i], 0.f);
+      bits |= (f[i] > 0.f ? 1u : 0u) << i;
+    }
     return Elem<bf16_t>::pack(f);
   }
   // pro_mode 2: BatchNorm + ReLU backward of (gradient of the activation, BatchNorm input).  The ReLU mask: recomputed from
@@ -570,7 +587,8 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
           if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + lane_off + y * (W * P)) = o;
         }
       } else {
-        pc.load2(ctab, C, cb);
+        const bool f3 = EXT && pro == 3;                          // (uniform) block-end forward of the previous block
+        if (!f3) pc.load2(ctab, C, cb);
         // second operand: the same bytes of the BatchNorm input (and the mask byte of the vector), through registers,
         // five rows at a time
         const char* x2g = (const char*)d.pro_x2 + img_off + lane_off;
@@ -587,7 +605,7 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
             if (y >= 0 && y < H) {
               x2[j] = *(const uint4*)(x2g + y * (W * P));
               if constexpr (EXT) {
-                if (mg) bits[j] = mg[y * (W * P / 16)];
+                if (mg && !f3) bits[j] = mg[y * (W * P / 16)];
               }
             }
           }
@@ -596,6 +614,18 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
             const int rs = r0 + j, y = y0 - 1 + rs;
             if (y < 0 || y >= H) continue;
             char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+            if constexpr (EXT) {
+              if (f3) {
+                unsigned ob;
+                const uint4 o3 = pc.fwd3(*(const uint4*)p, x2[j], ob);
+                *(uint4*)p = o3;
+                if (rs >= 1 && rs <= TH) {
+                  *(uint4*)(side + img_off + lane_off + y * (W * P)) = o3;
+                  const_cast<uint8_t*>(mg)[y * (W * P / 16)] = (uint8_t)ob;
+                }
+                continue;
+              }
+            }
             uint4 gm;
             const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm, ub, wgm);
             *(uint4*)p = o;
@@ -824,7 +854,8 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
           if (side && rs >= 1 && rs <= TH) *(uint4*)(side + img_off + y * (W * P) + lane_off_of(y)) = o;
         }
       } else {
-        pc.load2(ctab, C, cb);
+        const bool f3 = EXT && pro == 3;                          // (uniform) block-end forward of the previous block
+        if (!f3) pc.load2(ctab, C, cb);
         // the BatchNorm inputs (and mask bytes) of this parity's rows: same lane-constant addressing, through registers
         uint4 x2[NROWS];
         int bits[NROWS];
@@ -837,7 +868,7 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
             const unsigned off = img_off + y * (W * P) + lane_off_of(y);
             x2[rs] = *(const uint4*)((const char*)d.pro_x2 + off);
             if constexpr (EXT) {
-              if (d.pro_mask) bits[rs] = d.pro_mask[off >> 4];
+              if (d.pro_mask && !f3) bits[rs] = d.pro_mask[off >> 4];
             }
           }
         }
@@ -846,6 +877,19 @@ __device__ __forceinline__ void conv_deep_body_t(const hrp_conv_desc& d, const R
           const int y = y0 - 1 + rs;
           if (y < 0 || y >= H || (NPAR == 2 && ((y & 1) != par))) continue;
           char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
+          if constexpr (EXT) {
+            if (f3) {
+              unsigned ob;
+              const uint4 o3 = pc.fwd3(*(const uint4*)p, x2[rs], ob);
+              *(uint4*)p = o3;
+              if (rs >= 1 && rs <= TH) {
+                const unsigned off = img_off + y * (W * P) + lane_off_of(y);
+                *(uint4*)(side + off) = o3;
+                const_cast<uint8_t*>(d.pro_mask)[off >> 4] = (uint8_t)ob;
+              }
+              continue;
+            }
+          }
           uint4 gm;
           const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[rs], bits[rs], gm, ub, wgm);
           *(uint4*)p = o;
@@ -1083,7 +1127,8 @@ __device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const Ro
           if (side) *(uint4*)(side + grp_off + piece_off(i)) = o;
         }
       } else {
-        pc.load2(ctab, C, cb);
+        const bool f3 = EXT && pro == 3;                          // (uniform) block-end forward of the previous block
+        if (!f3) pc.load2(ctab, C, cb);
         uint4 x2[8];
         int bits[8];
 #pragma unroll
@@ -1095,7 +1140,7 @@ __device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const Ro
             const unsigned off = grp_off + piece_off(i);
             x2[j] = *(const uint4*)((const char*)d.pro_x2 + off);
             if constexpr (EXT) {
-              if (d.pro_mask) bits[j] = d.pro_mask[off >> 4];
+              if (d.pro_mask && !f3) bits[j] = d.pro_mask[off >> 4];
             }
           }
         }
@@ -1104,6 +1149,17 @@ __device__ __forceinline__ void conv_img_body_t(const hrp_conv_desc& d, const Ro
           const int i = piece_i(j), q = wave + 4 * i, tq = q / PPT;
           if (tq >= nvalid * TPI) continue;
           char* p = smem + tq * T + (q % PPT) * 1024 + lane * 16;
+          if constexpr (EXT) {
+            if (f3) {
+              unsigned ob;
+              const uint4 o3 = pc.fwd3(*(const uint4*)p, x2[j], ob);
+              *(uint4*)p = o3;
+              const unsigned off = grp_off + piece_off(i);
+              *(uint4*)(side + off) = o3;
+              const_cast<uint8_t*>(d.pro_mask)[off >> 4] = (uint8_t)ob;
+              continue;
+            }
+          }
           uint4 gm;
           const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm, ub, wgm);
           *(uint4*)p = o;

@@ -99,7 +99,19 @@ class TensorH:
         """Forward consumers must be ordered after the producer (same lane, or outside its parallel block)."""
         if lanes_concurrent(self.plan.lane_path, self.lane_path):
             raise RuntimeError("plan: a tensor is consumed in a lane concurrent with its producer")
+        self.materialize()
         self.n_readers += 1
+
+    def materialize(self):
+        """A block output whose forward pass (hrp_ew_fwd: relu(bn2(y2) + x)) was held back for the next block's conv1 prologue
+        (PlanBuilder.conv_bn_relu_conv, pro_mode 3) and is read by something else after all: the pass runs here, in the reader's lane,
+        right in front of the reader."""
+        pend = getattr(self, "pending_block_end", None)
+        if pend is not None:
+            self.pending_block_end = None
+            self.plan.fwd.append(pend["launch"])
+            if self in self.plan.pending_block_ends:
+                self.plan.pending_block_ends.remove(self)
 
     def view4(self):
         return self.buf.view(self.N, self.H, self.W, self.pitch)[..., :self.C]
@@ -170,6 +182,10 @@ BLOCK_END_REDUCE_FUSE = True
 BLOCK_FUSE = os.environ.get("HRP_BLOCK_FUSE", "1") not in ("0", "")      # fused inference BasicBlock (csrc/conv_block.h)
 # ... with the shortcut's gradient added by conv1's data gradient as a masked residual (one write of the block input's gradient)
 MASKED_RES = True
+# ... and the block-end FORWARD pass, out = relu(bn2(y2) + x), inside the NEXT block's conv1 (row-strip pro_mode 3: the raw y2 rows are
+# staged, bn + shortcut + ReLU applied in place, `out` and its ReLU bits leave as side outputs): three of the four block ends of a
+# branch stack lose their hrp_ew_fwd launch and conv1 no longer reads `out` back
+BLOCK_END_FWD_FUSE = os.environ.get("HRP_BLOCK_END_FWD", "1") not in ("0", "")
 # train-mode Bottlenecks at >= 131 072 pixels (layer1, the first incre-module of the cls head): conv3 (+ the 1x1 projection of the
 # shortcut) + BatchNorm + shortcut + ReLU as pointwise launches that never store a raw 1x1 output, the BatchNorm backward likewise
 # (PlanBuilder.bottleneck_tail)
@@ -514,6 +530,7 @@ class Plan:
         self.linear_grad_written = set()
         self.grad_owner = {}       # gradient buffer address -> TensorH root (every producer registers through take_grad_slot)
         self.reg_chains = []       # PlanBuilder.regressors: mask buffer and saved operands of every fused regressor chain
+        self.pending_block_ends = []   # block outputs whose forward pass waits for a consumer (TensorH.materialize)
         self.row_last_writer = {}  # gradient buffer address -> (row-strip conv descriptor that completes it, lane path, producers of the gradient so far)
 
     # ---- build-time helpers -------------------------------------------------------------------
@@ -1552,6 +1569,7 @@ class PlanBuilder:
         dt = _dt(t.dtype)
         holder = {}
         p = self.plan
+        t.materialize()
 
         def op(s):
             out = torch.empty(t.N, t.C, t.H, t.W, dtype=torch.float32, device=p.device)
@@ -1798,6 +1816,13 @@ class PlanBuilder:
             return None
         if p.need_grad and not x.requires_grad:
             return None
+        # x = the previous block's output whose forward pass is still held back: this block's conv1 applies it while staging
+        pend = getattr(x, "pending_block_end", None)
+        if pend is not None and not (BLOCK_END_FWD_FUSE and x.lane_path == p.lane_path):
+            pend = None
+        if pend is not None:
+            x.pending_block_end = None
+            p.pending_block_ends.remove(x)
         x.check_readable()
         dtype = x.dtype
         w1 = p.weight(conv1_w, Cc, Cc, 9)
@@ -1805,6 +1830,10 @@ class PlanBuilder:
         probe.w = probe.x
         probe.pro_mode, probe.pro_stats, probe.pro_gamma, probe.pro_beta = 1, probe.x, probe.x, probe.x
         if nv.lib().hrp_conv_rowstrip_channels(C.byref(probe)) != Cc:
+            if pend is not None:          # (not reachable: the previous block had this shape; keep the plan correct anyway)
+                x.pending_block_end = pend
+                p.pending_block_ends.append(x)
+                x.materialize()
             return None
         w2 = p.weight(conv2_w, Cc, Cc, 9)
         for w in (w1, w2):
@@ -1821,11 +1850,21 @@ class PlanBuilder:
         d1 = self._conv_desc(x, w1, y1, 1, 3, dtype)
         d2 = self._conv_desc(y1, w2, y2, 1, 3, dtype)
         d2.pro_mode, d2.pro_gamma, d2.pro_beta, d2.pro_count, d2.pro_eps, d2.pro_side = 1, gam, bet, cnt, bn1.eps, h.ptr()
+        if pend is not None:
+            # conv1 stages the previous block's raw conv2 output and turns it into x = relu(bn2'(y2') + x') in place; x and its
+            # ReLU bits (what the previous block's backward reads) leave as side outputs
+            py2, px, pbn = pend["y2"], pend["x"], pend["bn"]
+            d1.x, d1.pro_mode, d1.pro_x2 = py2.ptr(), 3, px.ptr()
+            d1.pro_gamma, d1.pro_beta, d1.pro_count, d1.pro_eps = pbn.weight.data_ptr(), pbn.bias.data_ptr(), cnt, pbn.eps
+            d1.pro_side, d1.pro_mask = x.ptr(), pend["mask"]
+            p.counters["block_end_forward_fused"] = p.counters.get("block_end_forward_fused", 0) + 1
 
         def late():
             d1.w, d2.w = w1.arena.data_ptr() + w1.fwd_off * esz, w2.arena.data_ptr() + w2.fwd_off * esz
             d1.stats, d2.stats = p.stats.data_ptr() + 8 * y1.stats, p.stats.data_ptr() + 8 * y2.stats
             d2.pro_stats = d1.stats
+            if pend is not None:
+                d1.pro_stats = p.stats.data_ptr() + 8 * pend["y2"].stats
         p.late(late)
         p.fwd.append(Launch("conv", d1))
         p.fwd.append(Launch("conv", d2))
@@ -1836,6 +1875,13 @@ class PlanBuilder:
             out = self.act([Term(y2, bn2), Term(x)], relu=True)
             fd = out.ew_desc
             act_bw = list.pop(self.bwd_stack) if p.need_grad else None      # the activation's own backward
+            if BLOCK_END_FWD_FUSE and p.need_grad and fd.mask:
+                # hold the forward pass back: the next block of the stack runs it inside its conv1 (pro_mode 3); any other reader
+                # (a fuse layer, the head, a plan output) makes it run in front of itself (TensorH.materialize)
+                ent = list.pop(p.fwd)
+                assert isinstance(ent.op, Launch) and ent.op.desc is fd
+                out.pending_block_end = dict(launch=ent.op, y2=y2, x=x, bn=bn2, mask=fd.mask)
+                p.pending_block_ends.append(out)
             if not (p.need_grad and fd.mask and BLOCK_END_FUSE):
                 fd = None                         # ... stays (hrp_ew_bwd_reduce + hrp_ew_bwd_apply), re-pushed behind bw below
         if p.need_grad:
@@ -2615,6 +2661,8 @@ class PlanBuilder:
         """Emit the backward list (reverse forward order) and resolve pointers."""
         p = self.plan
         assert p.cur_lane == 0 and p.lane_path == ()
+        for t in list(p.pending_block_ends):      # block outputs nobody read in the forward (plan outputs are handled in output())
+            t.materialize()
         for lane, path, emit in reversed(self.bwd_stack):
             if lane is None:
                 list.append(p.bwd, Entry(None, (), emit))    # lane fork / join marker (already mirrored)

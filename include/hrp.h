@@ -131,6 +131,10 @@ typedef struct hrp_conv_desc {
    *   pro_mode 2: x' = gamma * invstd * (g - k0 - xhat * k1),  g = x * [bn(pro_x2) > 0],  xhat = (pro_x2 - mean) * invstd,
    *               k0 / k1 = slot sums of pro_bsums / count: x is the gradient of relu(bn(pro_x2)), x' the gradient of
    *               pro_x2 - what hrp_ew_bwd_apply computes in a pass of its own;
+   *   pro_mode 3: x' = relu(gamma * (x - mean) * invstd + beta + pro_x2) - the block-end activation of the PREVIOUS BasicBlock
+   *               (HRnet.py:52-56: x = that block's raw conv2 output, pro_x2 = its input, pro_stats the statistics of x) applied while
+   *               this block's first convolution stages its rows; pro_side (required) receives x', pro_mask (required, an OUTPUT in
+   *               this mode) its ReLU bits in the layout of hrp_ew_desc.mask - replaces that block's hrp_ew_fwd pass;
    *   pro_side  (optional, geometry of x): x' is also written there, every pixel once - the operand the weight gradient
    *               of the neighbouring layer reads (forward: the activation; backward: the BatchNorm input gradient). */
   int32_t pro_mode, pro_reserved;

@@ -172,6 +172,52 @@ def test_rowconv_bn_relu_prologue(shape):
 
 
 @pytest.mark.parametrize("shape", SHAPES)
+def test_rowconv_block_end_prologue(shape):
+    """pro_mode 3 (round 6): conv(relu(bn(y2) + res)) - the previous BasicBlock's block-end activation (HRnet.py:52-56) applied while
+    the rows are staged, the activation as side output and its ReLU bits as a second one == hrp_ew_fwd followed by the conv."""
+    nv = nvmod()
+    Cc, N, H = shape
+    W = 2048 // Cc
+    g = torch.Generator().manual_seed(Cc * 19 + N)
+    y2 = bf(torch.randn(N, Cc, H, W, generator=g) * 1.5 + 0.3)
+    res = bf(torch.randn(N, Cc, H, W, generator=g))
+    w = bf(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc))
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    m, inv, sc, sh, tot, cnt = bn_consts(y2, gamma, beta)
+    a = bf(torch.relu(y2 * sc[None, :, None, None] + sh[None, :, None, None] + res))
+    ref = F.conv2d(a.double(), w.double(), padding=1).float()
+    wp, _ = pack(nv, w)
+    y2d, resd = nhwc(y2), nhwc(res)
+    y = torch.zeros(N * H * W * Cc, dtype=torch.bfloat16, device=DEV)
+    side = torch.full((N * H * W * Cc,), 7.0, dtype=torch.bfloat16, device=DEV)
+    mask = torch.full((N * H * W * Cc // 8,), 0xAA, dtype=torch.uint8, device=DEV)
+    st_in, st = slots_of(tot, g), torch.zeros(SLOTS * 2 * Cc, dtype=torch.float64, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    d = desc(nv, y2d, wp, y, N, H, W, Cc)
+    d.stats = st.data_ptr()
+    d.pro_mode, d.pro_stats, d.pro_gamma, d.pro_beta = 3, st_in.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    d.pro_count, d.pro_eps, d.pro_x2 = float(cnt), EPS, resd.data_ptr()
+    assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == 0          # the side output and the mask are required
+    d.pro_side, d.pro_mask = side.data_ptr(), mask.data_ptr()
+    assert nv.lib().hrp_conv_rowstrip_channels(C.byref(d)) == Cc
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    got, gside = from_nhwc(y, N, H, W, Cc), from_nhwc(side, N, H, W, Cc)
+    assert rel(gside, a) < 1e-2, rel(gside, a)
+    assert rel(got, ref) < 2e-2, rel(got, ref)
+    bits = mask.view(N, H, W, Cc // 8).cpu()
+    pos = torch.stack([(bits >> i) & 1 for i in range(8)], -1).view(N, H, W, Cc).permute(0, 3, 1, 2).bool()
+    assert torch.equal(pos, gside > 0), "bit i of byte j = channel 8 j + i of the stored activation is positive"
+    s = st.view(SLOTS, 2 * Cc).sum(0).float().cpu()
+    own = torch.cat([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
+    assert rel(s, own) < 2e-3, rel(s, own)
+    y_first = y.clone()
+    nv.call("hrp_conv2d_fwd", C.byref(d), None)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_first)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
 def test_rowconv_bn_backward_reduce_epilogue(shape):
     """Data gradient whose epilogue accumulates sum g, sum g * xhat of the stored gradient (mask recomputed from the
     BatchNorm input) == the conv followed by hrp_ew_bwd_reduce."""
@@ -546,6 +592,82 @@ def test_block_stack_with_fused_block_end_backward_equals_elementwise_backward(C
     assert counters[True].get("block_end_apply_fused") == NB and counters[True].get("block_end_reduce_fused") == NB - 1, counters[True]
     assert counters[True].get("block_end_masked_residual") == NB, counters[True]
     assert not counters[False].get("block_end_apply_fused")
+
+    def err(a, b):
+        return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-12)).item()
+
+    for k in want:
+        ef, eu, ab = err(res[True][k], want[k]), err(res[False][k], want[k]), err(res[True][k], res[False][k])
+        assert ef <= 1.15 * eu + 2e-3, (k, ef, eu)
+        assert ab < 4e-2, (k, ab)
+
+
+@pytest.mark.parametrize("Cc", [32, 64, 128, 256])
+def test_block_stack_with_block_end_forward_in_the_next_conv1(Cc):
+    """Round 6: the block-end FORWARD pass of three of the four blocks of a branch stack runs inside the next
+    block's conv1 (row-strip pro_mode 3; plan.BLOCK_END_FWD_FUSE) - the last block's output is read by something else (here: the plan
+    output) and keeps its hrp_ew_fwd launch.  Same stack, same bounds as the test above: every output and gradient as close to torch
+    fp32 as the plan without the fusion (<= 1.15 x + 2e-3), the two plans within 4e-2 of each other; the launches really went."""
+    from hrpe_amd import _native as nv
+    from hrpe_amd import plan as P
+    from hrpe_amd.runtime import SingleTensorModule
+    from hrpe_amd.lib.models.backbones import HRnet as Hn
+    NB = 4
+
+    class Stack(SingleTensorModule):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([Hn.BasicBlock(Cc, Cc) for _ in range(NB)])
+
+        def emit(self, pb, x):
+            for b in self.blocks:
+                x = b.emit(pb, x)
+            return x
+
+    W = 2048 // Cc
+    N, H = 4, W
+    g = torch.Generator().manual_seed(Cc + 2)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    gy = torch.randn(N, Cc, H, W, generator=g)
+    ref = Stack()
+    with torch.no_grad():
+        for n, prm in ref.named_parameters():
+            if prm.dim() == 1:
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5 if n.endswith("weight") else torch.randn(prm.shape, generator=g) * 0.2)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    rm = torch.nn.Module()
+    rm.blocks = torch.nn.ModuleList([_RefBlock(Cc) for _ in range(NB)])
+    rm.load_state_dict(sd)
+    rm.train()
+    xr = x.clone().requires_grad_(True)
+    yr = xr
+    for b in rm.blocks:
+        yr = b(yr)
+    (yr * gy).sum().backward()
+    want = dict(y=yr.detach(), dx=xr.grad, **{n: p.grad for n, p in rm.named_parameters()},
+                **{n: b for n, b in rm.named_buffers() if "running" in n})
+    res, counters, ew_launches = {}, {}, {}
+    saved = P.BLOCK_END_FWD_FUSE
+    for fused in (True, False):
+        P.BLOCK_END_FWD_FUSE = fused
+        try:
+            m = Stack()
+            m.load_state_dict({k: v.clone() for k, v in sd.items()})
+            m = m.to(DEV).set_compute_dtype(torch.bfloat16).train()
+            xd = x.to(DEV).requires_grad_(True)
+            y = m(xd)
+            (y * gy.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            res[fused] = dict(y=y.detach().float().cpu(), dx=xd.grad.float().cpu(),
+                              **{n: p.grad.float().cpu() for n, p in m.named_parameters()},
+                              **{n: b.float().cpu() for n, b in m.named_buffers() if "running" in n})
+            plan = next(iter(m._plans.values())).plan
+            counters[fused] = dict(plan.counters)
+            ew_launches[fused] = sum(1 for e in plan.fwd if isinstance(e.op, P.Launch) and e.op.fam == "ew_fwd")
+        finally:
+            P.BLOCK_END_FWD_FUSE = saved
+    assert counters[True].get("block_end_forward_fused") == NB - 1 and not counters[False].get("block_end_forward_fused")
+    assert ew_launches[True] == 1 and ew_launches[False] == NB, ew_launches
 
     def err(a, b):
         return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-12)).item()

@@ -568,32 +568,7 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
     int n, y0;
     strip_of(s, n, y0);
     const unsigned img_off = (unsigned)n * (unsigned)(H * W * P);
-    // the second operand of prologues 2 / 3 (BatchNorm input resp. the shortcut: the same bytes of another tensor, through
-    // registers) and the mask bytes of prologue 2: the FIRST five rows are requested before the wait for the DMA (issued behind
-    // it, every workgroup paid one more exposed HBM latency per batch of five rows - round 6: the block-end forward in this
-    // prologue cost conv1 as much as the element-wise launch it replaced); all ten at once spill (the 144 weight registers)
-    constexpr int NB0 = 5;
-    uint4 x2[NROWS];
-    int x2bits[NROWS];
-    const char* x2g = pro >= 2 ? (const char*)d.pro_x2 + img_off + lane_off : nullptr;
-    const uint8_t* x2m = (EXT && d.pro_mask && pro == 2) ? d.pro_mask + ((img_off + lane_off) >> 4) : nullptr;
-    auto load_x2 = [&](int r_lo, int r_hi) {
-#pragma unroll
-      for (int rs = 0; rs < NROWS; ++rs) {
-        if (rs < r_lo || rs >= r_hi) continue;
-        const int y = y0 - 1 + rs;
-        x2[rs] = make_uint4(0, 0, 0, 0);
-        x2bits[rs] = -1;
-        if (y >= 0 && y < H) {
-          x2[rs] = *(const uint4*)(x2g + y * (W * P));
-          if constexpr (EXT) {
-            if (x2m) x2bits[rs] = x2m[y * (W * P / 16)];
-          }
-        }
-      }
-    };
-    if (pro >= 2) load_x2(0, NB0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this lane's DMA pieces of strip s (and the rows above) have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this lane's DMA pieces of strip s have landed
     // ---- prologue: transform the bytes this lane staged, in place
     if (pro != 0) {
       RowPro pc;
@@ -614,29 +589,45 @@ __device__ __forceinline__ void conv_row_body_t(const hrp_conv_desc& d, const Ro
       } else {
         const bool f3 = EXT && pro == 3;                          // (uniform) block-end forward of the previous block
         if (!f3) pc.load2(ctab, C, cb);
-        // second operand: the same bytes of the BatchNorm input resp. the shortcut (rows 0-4 requested above, 5-9 here)
-        uint8_t* mout = (EXT && f3) ? const_cast<uint8_t*>(d.pro_mask) + ((img_off + lane_off) >> 4) : nullptr;
-        load_x2(NB0, NROWS);
-        {
+        // second operand: the same bytes of the BatchNorm input (and the mask byte of the vector), through registers,
+        // five rows at a time
+        const char* x2g = (const char*)d.pro_x2 + img_off + lane_off;
+        const uint8_t* mg = (EXT && d.pro_mask) ? d.pro_mask + ((img_off + lane_off) >> 4) : nullptr;
 #pragma unroll
-          for (int rs = 0; rs < NROWS; ++rs) {
-            const int y = y0 - 1 + rs;
+        for (int r0 = 0; r0 < NROWS; r0 += 5) {
+          uint4 x2[5];
+          int bits[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int y = y0 - 1 + r0 + j;
+            x2[j] = make_uint4(0, 0, 0, 0);
+            bits[j] = -1;
+            if (y >= 0 && y < H) {
+              x2[j] = *(const uint4*)(x2g + y * (W * P));
+              if constexpr (EXT) {
+                if (mg && !f3) bits[j] = mg[y * (W * P / 16)];
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int rs = r0 + j, y = y0 - 1 + rs;
             if (y < 0 || y >= H) continue;
             char* p = lds_rows + rs * ROWB + wave * 1024 + lane * 16;
             if constexpr (EXT) {
               if (f3) {
                 unsigned ob;
-                const uint4 o3 = pc.fwd3(*(const uint4*)p, x2[rs], ob);
+                const uint4 o3 = pc.fwd3(*(const uint4*)p, x2[j], ob);
                 *(uint4*)p = o3;
                 if (rs >= 1 && rs <= TH) {
                   *(uint4*)(side + img_off + lane_off + y * (W * P)) = o3;
-                  mout[y * (W * P / 16)] = (uint8_t)ob;
+                  const_cast<uint8_t*>(mg)[y * (W * P / 16)] = (uint8_t)ob;
                 }
                 continue;
               }
             }
             uint4 gm;
-            const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[rs], x2bits[rs], gm, ub, wgm);
+            const uint4 o = pc.template bwd<EXT>(*(const uint4*)p, x2[j], bits[j], gm, ub, wgm);
             *(uint4*)p = o;
             if (rs >= 1 && rs <= TH) {
               const unsigned off = img_off + lane_off + y * (W * P);

@@ -745,250 +745,27 @@ class Plan:
                         f" launches, {nb} of them batched, streams {sorted({e.lane for e in self.fwd_run if e.lane is not None})}")
             print(msg, file=sys.stderr)
 
+
+    # ---- passes over the launch lists (plan_passes.py) -------------------------------------------------------------------
     def _flatten(self, entries):
-        """Launch list of the merged / hybrid modes.  The lanes of every VIRTUAL parallel block (all blocks in merged mode)
-        are walked in lock step - position k of every lane before position k + 1 of any - and launches of equal merge
-        key at one position are folded into batched launches.  Lanes of one block are independent by construction
-        (TensorH.check_readable / take_grad_slot), so any interleaving that keeps each lane's own order is a valid
-        serial order.  Blocks that asked for streams (hybrid mode) keep their fork / join markers; the merge happens
-        inside each of their lanes.  -> list of Entry (path unused)."""
-        root = _Seq()
-        for e in entries:
-            if e.lane is None and not isinstance(e.op, _PackJoin):
-                continue        # fork / join markers are re-created below
-            seq = root
-            for blk, idx in (e.path or ()):
-                node = seq.blocks.get(blk)
-                if node is None:
-                    node = _Par()
-                    node.blk = blk
-                    seq.blocks[blk] = node
-                    seq.items.append(node)
-                # a block's launches must be contiguous in its parent's sequence: anything emitted after the block
-                # started and before it ended would otherwise be moved behind it
-                assert seq.items[-1] is node, "plan: launches of a parallel block are interleaved with its parent's"
-                seq = node.lanes.setdefault(idx, _Seq())
-            seq.items.append(e.op)
-
-        def key_of(op):
-            return op.merge_key() if BATCHING and isinstance(op, (Launch, BatchLaunch, BlockLaunch)) else None
-
-        def emit_groups(groups, out):
-            for key, ops in groups.items():
-                if key[0] == "block":
-                    out += _pair_block(self, ops)
-                else:
-                    out += ops if len(ops) == 1 else _merge_ops(self, ops)
-
-        def greedy(kids):
-            """Lanes whose launch sequences differ (the paths of a fuse layer): instead of position k of every lane, take the
-            HEADS of all lanes, send the unbatchable ones out, then the largest group of equal merge key; the other lanes wait
-            for partners.  Any interleaving that keeps each lane's own order is valid."""
-            out, ptr = [], [0] * len(kids)
-            while True:
-                heads = [(i, kids[i][ptr[i]]) for i in range(len(kids)) if ptr[i] < len(kids[i])]
-                if not heads:
-                    return out
-                groups, moved = collections.OrderedDict(), False
-                for i, op in heads:
-                    key = key_of(op)
-                    if key is None:
-                        out.append(op)
-                        ptr[i] += 1
-                        moved = True
-                    else:
-                        groups.setdefault(key, []).append((i, op))
-                if moved:
-                    continue
-                key = max(groups, key=lambda k: len(groups[k]))
-                emit_groups({key: [op for _, op in groups[key]]}, out)
-                for i, _ in groups[key]:
-                    ptr[i] += 1
-
-        def lockstep(kids):
-            if GREEDY_MERGE and len({tuple(key_of(op) for op in x) for x in kids}) > 1:
-                return greedy(kids)
-            out = []
-            for k in range(max(len(x) for x in kids)):
-                groups = collections.OrderedDict()
-                for x in kids:
-                    if k < len(x):
-                        key = key_of(x[k])
-                        if key is None:
-                            out.append(x[k])
-                        else:
-                            groups.setdefault(key, []).append(x[k])
-                for key, ops in groups.items():
-                    if key[0] == "block":
-                        out += _pair_block(self, ops)
-                    else:
-                        out += ops if len(ops) == 1 else _merge_ops(self, ops)
-            return out
-
-        def walk(seq, lane):
-            """-> entries of this sequence, running on stream `lane`."""
-            out = []
-            for it in seq.items:
-                if isinstance(it, _PackJoin):
-                    out.append(Entry(None, (), it))
-                elif not isinstance(it, _Par):
-                    out.append(Entry(lane, (), it))
-                else:
-                    real = PLAN_MODE == "hybrid" and self._block_lanes.get(it.blk) is not None
-                    if real:
-                        ids = self._block_lanes[it.blk]
-                        kids = [(ids[idx], walk(sub, ids[idx])) for idx, sub in sorted(it.lanes.items())]
-                        children = [l for l, _ in kids if l != lane]
-                        out.append(Entry(None, (), _LaneSync("fork", lane, children)))
-                        for _, ents in kids:
-                            out += ents
-                        out.append(Entry(None, (), _LaneSync("join", lane, children)))
-                    else:
-                        kids = [walk(sub, lane) for _, sub in sorted(it.lanes.items())]
-                        assert all(e.lane == lane for x in kids for e in x), "a virtual block cannot contain a block with streams"
-                        out += [Entry(lane, (), op) for op in lockstep([[e.op for e in x] for x in kids])]
-            return out
-        return walk(root, 0)
+        from . import plan_passes
+        return plan_passes.flatten(self, entries)
 
     def _fuse_bn_reduce(self):
-        """conv -> BN -> ReLU -> conv (the interior of BasicBlock / Bottleneck, HRnet.py:41-57): the gradient of the
-        activation comes from exactly one data-gradient launch; its epilogue then also accumulates the two BatchNorm
-        backward sums (sum g, sum g * xhat) and the separate hrp_ew_bwd_reduce launch over the same tensors goes away."""
-        is_l = lambda e, fam: isinstance(e.op, Launch) and e.op.fam == fam   # noqa: E731
-        convs, other = {}, set()
-        for i, e in enumerate(self.bwd):
-            if is_l(e, "conv"):
-                convs.setdefault(e.op.desc.y, []).append((i, e))
-            elif is_l(e, "ew_app"):
-                other.update(x for x in (e.op.desc.din, e.op.desc.din2) if x)
-        fwd_by_mask = {e.op.desc.mask: e.op for e in self.fwd if is_l(e, "ew_fwd") and e.op.desc.mask}
-        drop = set()
-        for i, e in enumerate(self.bwd):
-            if not is_l(e, "ew_red"):
-                continue
-            b = e.op.desc
-            if b.inp.mode != nv.EW_BN_TRAIN or b.inp.up != 1 or b.relu != 1 or not b.mask or b.dout in other:
-                continue
-            cands = convs.get(b.dout, [])
-            fw = fwd_by_mask.get(b.mask)
-            if len(cands) != 1 or fw is None or fw.desc.nin != 1:
-                continue
-            # every producer of a gradient registers through take_grad_slot - also the ones that are plain closures in the
-            # launch list (copy_cols, pooling, linear layers, soft-argmax ..), which the scan above cannot see: exactly ONE
-            # producer (the candidate conv) or the epilogue would reduce a partial gradient
-            owner = self.grad_owner.get(b.dout)
-            if owner is None or len(owner._grad_paths) != 1:
-                continue
-            j, ce = cands[0]
-            d = ce.op.desc
-            esz = 2 if d.dtype == nv.HRP_BF16 else 4
-            vec = 16 // esz
-            ddt = nv.HRP_F32 if d.dtype == nv.HRP_F32X3 else d.dtype      # (fp32x3 convolutions read and write fp32 tensors)
-            if j > i or ce.lane != e.lane or ce.path != e.path:
-                continue
-            if d.res or d.relu or d.bias or d.scale or d.stats or d.out_stride != 1 or (d.y_H, d.y_W) != (d.Ho, d.Wo) or d.pro_mode or d.bnb_x:
-                continue
-            if (d.N, d.Ho, d.Wo, d.Cout, d.y_pitch, ddt) != (b.N, b.H, b.W, b.C, b.dout_pitch, b.dtype) or d.Cout % vec:
-                continue
-            if d.y % 16 or (d.y_pitch * esz) % 16 or b.inp.ptr % 16 or (b.inp.pitch * esz) % 16:
-                continue
-            consts = torch.zeros(2 * b.C, dtype=torch.float32, device=self.device)
-            self.keep.append(consts)
-            fw.desc.consts_out = consts.data_ptr()
-            d.bnb_x, d.bnb_x_pitch = b.inp.ptr, b.inp.pitch
-            d.bnb_mask, d.bnb_mask_pitch = b.mask, b.mask_pitch
-            d.bnb_consts, d.stats = consts.data_ptr(), b.sums
-            drop.add(i)
-        if drop:
-            kept = [e for i, e in enumerate(self.bwd) if i not in drop]
-            del self.bwd[:]
-            list.extend(self.bwd, kept)
-        self.counters["bn_reduce_fused"] = len(drop)
+        from . import plan_passes
+        return plan_passes.fuse_bn_reduce(self)
 
     def _sink_wgrads(self, entries):
-        """Regroup the weight-gradient launches of every lane into batches of WGRAD_SINK problems of one tap count (their
-        inputs - the layer's forward input and its output gradient - stay untouched for the rest of the step)."""
-        out, pend = [], {}
-
-        def emit(lane, key, path, force):
-            items = pend[lane][key]
-            while items and (force or len(items) >= WGRAD_SINK):
-                grp, rest, seen = [], [], set()
-                for it in items:
-                    w = it.written()
-                    if len(grp) < WGRAD_SINK and not any(a in seen for a in w):
-                        grp.append(it)
-                        seen.update(w)
-                    else:
-                        rest.append(it)
-                out.append(Entry(lane, path, grp[0] if len(grp) == 1 else BatchLaunch(self, grp)))
-                items = rest
-            pend[lane][key] = items
-
-        def flush(lane, path):
-            for key in list(pend.get(lane, {})):
-                emit(lane, key, path, True)
-
-        for e in entries:
-            if e.lane is None:
-                if getattr(e.op, "kind", None) == "join":
-                    for c in e.op.children:
-                        flush(c, e.path)
-                out.append(e)
-                continue
-            op = e.op
-            if isinstance(op, (Launch, BatchLaunch)) and op.fam == "wgrad" and not any(it.desc.reserved for it in op.launches()):
-                for it in op.launches():
-                    key = it.merge_key()
-                    if key is None:
-                        out.append(Entry(e.lane, e.path, it))
-                        continue
-                    pend.setdefault(e.lane, {}).setdefault(key, []).append(it)
-                    if len(pend[e.lane][key]) >= WGRAD_SINK:
-                        emit(e.lane, key, e.path, False)
-            else:
-                out.append(e)
-        for lane in sorted(pend):
-            flush(lane, ())
-        return out
+        from . import plan_passes
+        return plan_passes.sink_wgrads(self, entries)
 
     def _insert_folds(self, entries):
-        """Deferred weight-gradient folds: after every WGRAD_FOLD_EVERY phase-1 problems of a lane, before the lane
-        joins its parent and at the end of the list, one HRP_BATCH_WGRAD_FOLD launch folds the lane's pending slabs."""
-        out, pending = [], {}
+        from . import plan_passes
+        return plan_passes.insert_folds(self, entries)
 
-        def flush(lane, path, everything=True):
-            descs = pending.pop(lane, [])
-            while descs and (everything or len(descs) >= nv.BATCH_MAX):
-                # one launch folds problems with pairwise DISTINCT outputs only (the fold is a plain read-modify-write of dW:
-                # a weight applied twice - or a tap group launched twice - must fold in consecutive launches, not race in one)
-                grp, rest, seen = [], [], set()
-                for f in descs:
-                    key = f.dw + 4 * f.dw_tap_off
-                    if len(grp) < nv.BATCH_MAX and key not in seen:
-                        grp.append(f)
-                        seen.add(key)
-                    else:
-                        rest.append(f)
-                b = BatchLaunch(self, [Launch("wgrad_fold", f) for f in grp])
-                b.prepare()
-                out.append(Entry(lane, path, b))
-                descs = rest
-            if descs:
-                pending[lane] = descs
-
-        for e in entries:
-            if e.lane is None and getattr(e.op, "kind", None) == "join":
-                for c in e.op.children:
-                    flush(c, e.path)
-            out.append(e)
-            if e.lane is not None and isinstance(e.op, (Launch, BatchLaunch)) and e.op.fam == "wgrad" and e.op.launches()[0].desc.phase == 1:
-                pending.setdefault(e.lane, []).extend(f for f in e.op.fold_descs() if f.G > 0)
-                if len(pending[e.lane]) >= min(max(WGRAD_FOLD_EVERY, 1), nv.BATCH_MAX):
-                    flush(e.lane, e.path, everything=WGRAD_FOLD_EVERY < nv.BATCH_MAX)
-        for lane in sorted(pending):
-            flush(lane, ())
-        return out
+    def analyze_backward_split(self, min_frac=0.55, fracs=None):
+        from . import plan_passes
+        return plan_passes.analyze_backward_split(self, min_frac, fracs)
 
     def _late_pack_cut(self):
         """Index in self.fwd right after the first parallel block (the join back into the main lane), or None when the
@@ -1162,109 +939,6 @@ class Plan:
         if (j is None or j == len(cuts)) and self._pgrad_tab:
             nv.call("hrp_bn_param_grad", self._pgrad_tab[0].data_ptr(), self._pgrad_tab[1], s)
 
-    def analyze_backward_split(self, min_frac=0.55, fracs=None):
-        """-> (split index, [(offset, numel)] arena ranges that no launch at or after the split touches) or None.
-        fracs (e.g. (0.25, 0.6, 0.9)): k cuts instead -> [(split index, ranges that became final since the previous cut)], so
-        that the collective left behind the last launch is a small tail (buckets in reverse registration order).
-
-        Every backward launch is replayed against a recording stand-in for the C ABI (nothing runs); any pointer
-        argument or descriptor field that points into the gradient arena marks that parameter as touched by that
-        launch.  The split is the first top-level position (outside every parallel block) after which at least
-        `min_frac` of the gradient bytes are final."""
-        import bisect
-        if self.grad_arena is None or not self._grad_layout:
-            return None
-        base, nbytes = self.grad_arena.data_ptr(), self.grad_arena.numel() * 4
-        starts = [o * 4 for o, _ in self._grad_layout]
-        last = [-1] * len(starts)
-        hits = []
-
-        def walk(v):
-            if isinstance(v, bool) or v is None:
-                return
-            if isinstance(v, int):
-                if base <= v < base + nbytes:
-                    hits.append(v - base)
-            elif isinstance(v, C.Structure):
-                for name, _t in v._fields_:
-                    walk(getattr(v, name))
-            elif isinstance(v, C.Array):
-                if issubclass(v._type_, (C.Structure, C.Array, C.c_void_p)):
-                    for e in v:
-                        walk(e)
-            elif hasattr(v, "_obj"):          # ctypes.byref(struct)
-                walk(v._obj)
-            elif isinstance(v, C.c_void_p):
-                walk(v.value)
-
-        real = nv.call
-        try:
-            nv.call = lambda name, *args: [walk(a) for a in args] and 0
-            depth, tops = 0, []
-            for i, e in enumerate(self.bwd_ops()):
-                lane, op = e.lane, e.op
-                if lane is None:
-                    if getattr(op, "kind", None) == "fork":
-                        if depth == 0:
-                            tops.append(i)
-                        depth += 1
-                    elif getattr(op, "kind", None) == "join":
-                        depth -= 1
-                    continue
-                if depth == 0:
-                    tops.append(i)
-                del hits[:]
-                if isinstance(op, (Launch, BatchLaunch, BlockLaunch, BlockBatch)):
-                    for it in op.launches():     # the descriptors say what a launch touches
-                        walk(it.desc)
-                else:
-                    op(0)
-                for h in hits:
-                    last[bisect.bisect_right(starts, h) - 1] = i
-        finally:
-            nv.call = real
-        if self._pgrad_tab:   # hrp_bn_param_grad after the list writes the BatchNorm weight / bias gradients
-            bn_ptrs = set()
-            for bn, _off in self.bn_bwd:
-                for t in (bn.weight, bn.bias):
-                    g = self._grad_views.get(id(t))
-                    if g is not None:
-                        bn_ptrs.add(g.data_ptr() - base)
-            for k, st in enumerate(starts):
-                if st in bn_ptrs:
-                    last[k] = len(self.bwd_ops())
-        total = sum(n for _, n in self._grad_layout)
-
-        def ranges_final_before(c, lo=-1):
-            """arena ranges whose last toucher lies in [lo, c)"""
-            ranges = []
-            for (off, n), l in zip(self._grad_layout, last):
-                if not (lo <= l < c):
-                    continue
-                n4 = _rup(n, 4)
-                if ranges and ranges[-1][0] + ranges[-1][1] == off:
-                    ranges[-1][1] += n4
-                else:
-                    ranges.append([off, n4])
-            return [tuple(r) for r in ranges]
-
-        if fracs is not None:
-            # k cut positions: the first top-level position at which at least f of the gradient bytes are final, for every f
-            cuts, prev = [], -1
-            for f in sorted(fracs):
-                c = next((c for c in tops if c > 0 and sum(n for (_, n), l in zip(self._grad_layout, last) if l < c) >= f * total), None)
-                if c is None or (cuts and c <= cuts[-1][0]):
-                    continue
-                cuts.append((c, ranges_final_before(c, prev)))
-                prev = c
-            return cuts or None
-        for c in tops:
-            if c == 0:
-                continue
-            final = sum(n for (_, n), l in zip(self._grad_layout, last) if l < c)
-            if final >= min_frac * total:
-                return c, ranges_final_before(c)
-        return None
 
     def publish_param_grads(self):
         """Hand the plan-owned gradient buffers to the parameters (torch semantics: .grad holds this
@@ -1310,7 +984,11 @@ class _Parallel:
             p.cur_lane, p.lane_path = saved
 
 
-class PlanBuilder:
+from .plan_blocks import BlockOps    # noqa: E402  (the mixins read this module's names at call time)
+from .plan_heads import HeadOps      # noqa: E402
+
+
+class PlanBuilder(BlockOps, HeadOps):
     def __init__(self, plan):
         self.plan = plan
         self.bwd_stack = _BwdStack(plan)   # emitters of backward ops, in forward order (run reversed at the end)
@@ -1755,577 +1433,6 @@ class PlanBuilder:
         p.late(lambda g=g, lane=lane: p.patch_wgrad_ws(g, lane))
         p.bwd.append(Launch("wgrad", g))
 
-    def basic_block_eval(self, x, conv1_w, bn1, conv2_w, bn2):
-        """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), a whole BasicBlock without downsample (reference HRnet.py:41-57) of an
-        INFERENCE plan as ONE launch (csrc/conv_block.h): BatchNorm folded to scale / shift, the intermediate stays in LDS.
-        -> out, or None when the shapes are not the fused kernel's (32 / 64 channels at 64 / 32 pixels per row, bf16; caller:
-        the general path - two convolutions with folded epilogues)."""
-        p = self.plan
-        if not (BLOCK_FUSE and self.fuse_inference and not p.training and not p.need_grad and x.dtype == torch.bfloat16):
-            return None
-        Cc = x.C
-        if Cc not in (32, 64) or tuple(conv1_w.shape) != (Cc, Cc, 3, 3) or tuple(conv2_w.shape) != (Cc, Cc, 3, 3) or x.pitch != Cc or x.offset:
-            return None
-        x.check_readable()
-        dtype = x.dtype
-        w1, w2 = p.weight(conv1_w, Cc, Cc, 9), p.weight(conv2_w, Cc, Cc, 9)
-        out = p.new(x.N, x.H, x.W, Cc, dtype)
-        b = nv.BlockDesc()
-        d1 = self._conv_desc(x, w1, out, 1, 3, dtype, into=b.conv1)
-        d2 = self._conv_desc(x, w2, out, 1, 3, dtype, into=b.conv2)
-        (sc1, sh1), (sc2, sh2) = self._fold(bn1), self._fold(bn2)
-        d1.scale, d1.shift, d1.relu, d1.y = sc1.data_ptr(), sh1.data_ptr(), 1, None
-        d2.scale, d2.shift, d2.relu, d2.x = sc2.data_ptr(), sh2.data_ptr(), 1, None
-        d2.res, d2.res_pitch = x.ptr(), x.pitch
-        d1.w = d2.w = x.ptr()                      # (placeholders for the host-side shape query; final in late())
-        if nv.lib().hrp_block_channels(C.byref(b)) != Cc:
-            return None
-        for w in (w1, w2):
-            w.dtype, w.cin_used = dtype, Cc
-            w.need_t = getattr(w, "need_t", False)
-
-        def late():
-            d1.w, d2.w = w1.arena.data_ptr() + w1.fwd_off * 2, w2.arena.data_ptr() + w2.fwd_off * 2
-        p.late(late)
-        p.fwd.append(BlockLaunch(b))
-        out.producer = None
-        p.counters["block_fused"] = p.counters.get("block_fused", 0) + 1
-        return out
-
-    def conv_bn_relu_conv(self, x, conv1_w, bn1, conv2_w, bn2=None):
-        """y2 = conv2(relu(bn1(conv1(x)))), the interior of a BasicBlock (reference HRnet.py:41-50), in a TRAINING plan on the
-        row-strip kernel: conv1 as usual (statistics in its epilogue), conv2 with the BatchNorm + ReLU applied while its
-        input rows are staged (the activation leaves as a side output, the operand of conv2's weight gradient) - no
-        hrp_ew_fwd pass.  Backward: conv2's data gradient accumulates the BatchNorm-backward sums in its epilogue, conv1's
-        data gradient applies the BatchNorm + ReLU backward while IT stages (side output: the gradient of conv1's output,
-        the operand of conv1's weight gradient) - no hrp_ew_bwd_reduce / hrp_ew_bwd_apply passes.
-        bn2 given: the whole BasicBlock, out = relu(bn2(y2) + x) (HRnet.py:52-56).  The block-end activation keeps its forward
-        pass (hrp_ew_fwd, with the ReLU bit mask); its BACKWARD apply pass moves into conv2's data gradient (pro_mode 2 with the
-        bit mask: side output = y2.grad for conv2's weight gradient, second side output = the masked gradient for the
-        residual), and its reduce pass into the epilogue of the NEXT block's conv1 data gradient when that launch is the
-        last producer of out.grad (the blocks of a branch stack) - no hrp_ew_bwd_apply and mostly no hrp_ew_bwd_reduce.
-        -> y2 (raw, with statistics) or, with bn2, out; None when the shapes / mode are not the row-strip kernel's (caller:
-        general path)."""
-        p = self.plan
-        if not (ROWCONV_FUSE and p.training and x.dtype == torch.bfloat16):
-            return None
-        if not (self.bn_batch_stats(bn1) and (bn2 is None or self.bn_batch_stats(bn2))):
-            return None              # (a BatchNorm in eval mode inside a training plan: general path)
-        Cc = x.C
-        if tuple(conv1_w.shape) != (Cc, Cc, 3, 3) or tuple(conv2_w.shape) != (Cc, Cc, 3, 3) or x.pitch != Cc or x.offset:
-            return None
-        if p.need_grad and not x.requires_grad:
-            return None
-        # x = the previous block's output whose forward pass is still held back: this block's conv1 applies it while staging
-        pend = getattr(x, "pending_block_end", None)
-        if pend is not None and not (BLOCK_END_FWD_FUSE and x.lane_path == p.lane_path):
-            pend = None
-        if pend is not None:
-            x.pending_block_end = None
-            p.pending_block_ends.remove(x)
-        x.check_readable()
-        dtype = x.dtype
-        w1 = p.weight(conv1_w, Cc, Cc, 9)
-        probe = self._conv_desc(x, w1, x, 1, 3, dtype)       # geometry only; dummy aligned pointers
-        probe.w = probe.x
-        probe.pro_mode, probe.pro_stats, probe.pro_gamma, probe.pro_beta = 1, probe.x, probe.x, probe.x
-        if nv.lib().hrp_conv_rowstrip_channels(C.byref(probe)) != Cc:
-            if pend is not None:          # (not reachable: the previous block had this shape; keep the plan correct anyway)
-                x.pending_block_end = pend
-                p.pending_block_ends.append(x)
-                x.materialize()
-            return None
-        w2 = p.weight(conv2_w, Cc, Cc, 9)
-        for w in (w1, w2):
-            w.dtype, w.cin_used = dtype, Cc
-            w.need_t = getattr(w, "need_t", False) or p.need_grad
-        esz = 2
-        cnt = float(x.N * x.H * x.W)
-        y1, h, y2 = p.new(x.N, x.H, x.W, Cc, dtype), p.new(x.N, x.H, x.W, Cc, dtype), p.new(x.N, x.H, x.W, Cc, dtype)
-        for t in (y1, h, y2):
-            t.requires_grad = p.need_grad
-        y1.stats, y2.stats = p.alloc_stats(Cc), p.alloc_stats(Cc)
-        p.bn_train.append((bn1, y1.stats, x.N * x.H * x.W))
-        gam, bet = bn1.weight.data_ptr(), bn1.bias.data_ptr()
-        d1 = self._conv_desc(x, w1, y1, 1, 3, dtype)
-        d2 = self._conv_desc(y1, w2, y2, 1, 3, dtype)
-        d2.pro_mode, d2.pro_gamma, d2.pro_beta, d2.pro_count, d2.pro_eps, d2.pro_side = 1, gam, bet, cnt, bn1.eps, h.ptr()
-        if pend is not None:
-            # conv1 stages the previous block's raw conv2 output and turns it into x = relu(bn2'(y2') + x') in place; x and its
-            # ReLU bits (what the previous block's backward reads) leave as side outputs
-            py2, px, pbn = pend["y2"], pend["x"], pend["bn"]
-            d1.x, d1.pro_mode, d1.pro_x2 = py2.ptr(), 3, px.ptr()
-            d1.pro_gamma, d1.pro_beta, d1.pro_count, d1.pro_eps = pbn.weight.data_ptr(), pbn.bias.data_ptr(), cnt, pbn.eps
-            d1.pro_side, d1.pro_mask = x.ptr(), pend["mask"]
-            p.counters["block_end_forward_fused"] = p.counters.get("block_end_forward_fused", 0) + 1
-
-        def late():
-            d1.w, d2.w = w1.arena.data_ptr() + w1.fwd_off * esz, w2.arena.data_ptr() + w2.fwd_off * esz
-            d1.stats, d2.stats = p.stats.data_ptr() + 8 * y1.stats, p.stats.data_ptr() + 8 * y2.stats
-            d2.pro_stats = d1.stats
-            if pend is not None:
-                d1.pro_stats = p.stats.data_ptr() + 8 * pend["y2"].stats
-        p.late(late)
-        p.fwd.append(Launch("conv", d1))
-        p.fwd.append(Launch("conv", d2))
-        y1.producer, y2.producer = None, ("conv", d2)
-        p.counters["rowconv_fused_blocks"] = p.counters.get("rowconv_fused_blocks", 0) + 1
-        out, fd = None, None
-        if bn2 is not None:
-            out = self.act([Term(y2, bn2), Term(x)], relu=True)
-            fd = out.ew_desc
-            act_bw = list.pop(self.bwd_stack) if p.need_grad else None      # the activation's own backward
-            if BLOCK_END_FWD_FUSE and p.need_grad and fd.mask:
-                # hold the forward pass back: the next block of the stack runs it inside its conv1 (pro_mode 3); any other reader
-                # (a fuse layer, the head, a plan output) makes it run in front of itself (TensorH.materialize)
-                ent = list.pop(p.fwd)
-                assert isinstance(ent.op, Launch) and ent.op.desc is fd
-                out.pending_block_end = dict(launch=ent.op, y2=y2, x=x, bn=bn2, mask=fd.mask)
-                p.pending_block_ends.append(out)
-            if not (p.need_grad and fd.mask and BLOCK_END_FUSE):
-                fd = None                         # ... stays (hrp_ew_bwd_reduce + hrp_ew_bwd_apply), re-pushed behind bw below
-        if p.need_grad:
-            def bw():
-                if fd is not None:
-                    if not out.grad_written:
-                        return
-                elif not y2.grad_written:
-                    return
-                # the identity shortcut's gradient (out.grad under the block-end mask): nobody has written x.grad yet -> conv1's data
-                # gradient below adds it as a MASKED residual and writes x.grad once; else conv2's data gradient accumulates it as
-                # a second side output
-                masked_res = fd is not None and MASKED_RES and not x.grad_written
-                if fd is not None:
-                    y2.take_grad_slot()
-                wg2_first = fd is None
-                if wg2_first and conv2_w.requires_grad:
-                    self._wgrad_launch(h, w2, y2)
-                # data gradient of conv2 -> gradient of the activation h (raw), BatchNorm-backward sums in the epilogue
-                h.take_grad_slot()
-                boff = p.alloc_bsums(Cc)
-                p.bn_bwd.append((bn1, boff))
-                g2 = nv.ConvDesc()
-                self._conv_desc(y2, w2, h, 1, 3, dtype, into=g2)
-                g2.x, g2.y = y2.gptr() if (fd is None) else 0, h.gptr()
-                red = None
-                if fd is not None:
-                    # the block-end BatchNorm + ReLU backward (bn2, mask bits): staged operand of this launch
-                    boff2 = p.alloc_bsums(Cc)
-                    p.bn_bwd.append((bn2, boff2))
-                    g2.x = out.gptr()
-                    g2.pro_mode, g2.pro_x2, g2.pro_gamma, g2.pro_beta = 2, y2.ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
-                    g2.pro_count, g2.pro_eps, g2.pro_mask = cnt, bn2.eps, fd.mask
-                    g2.pro_side = y2.gptr()
-                    if not masked_res:
-                        g2.pro_side2, g2.pro_side2_acc = x.gptr(), x.take_grad_slot()
-                    # its reduce: in the epilogue of the launch that completes out.grad when that is a row-strip data gradient
-                    # of this lane accumulating onto ONE earlier producer (the next block of the stack), else a pass of its own
-                    nxt = p.row_last_writer.get(out.gptr())
-                    if (BLOCK_END_REDUCE_FUSE and nxt is not None and not nxt[0].bnb_x and nxt[2] == len(out._grad_paths)
-                            and all(q == p.lane_path for q in out._grad_paths)):
-                        gn = nxt[0]
-                        gn.bnb_x, gn.bnb_x_pitch, gn.bnb_mask, gn.bnb_mask_pitch = y2.ptr(), y2.pitch, fd.mask, fd.mask_pitch
-                        gn.bnb_gamma, gn.bnb_beta, gn.bnb_count, gn.bnb_eps = bn2.weight.data_ptr(), bn2.bias.data_ptr(), cnt, bn2.eps
-                        red = gn
-                        p.counters["block_end_reduce_fused"] = p.counters.get("block_end_reduce_fused", 0) + 1
-                    else:
-                        b = nv.EwBwdDesc()
-                        b.dout, b.out, b.dout_pitch, b.out_pitch = out.gptr(), out.ptr(), out.pitch, out.pitch
-                        for f, _ in nv.EwInput._fields_:
-                            setattr(b.inp, f, getattr(fd.inp[0], f))
-                        b.dtype, b.N, b.H, b.W, b.C, b.relu = fd.dtype, fd.N, fd.H, fd.W, fd.C, fd.relu
-                        b.mask, b.mask_pitch = fd.mask, fd.mask_pitch
-                        red = b
-                        p.bwd.append(Launch("ew_red", b))
-                    p.counters["block_end_apply_fused"] = p.counters.get("block_end_apply_fused", 0) + 1
-                for i, (a, b) in enumerate(_TAPS3):
-                    g2.dy[i], g2.dx[i], g2.wtap[i] = -a, -b, i
-                g2.bnb_x, g2.bnb_x_pitch = y1.ptr(), y1.pitch
-                g2.bnb_gamma, g2.bnb_beta, g2.bnb_count, g2.bnb_eps = gam, bet, cnt, bn1.eps
-                # data gradient of conv1 -> x.grad; its staged operand is the BatchNorm + ReLU backward of (h.grad, y1)
-                y1.take_grad_slot()
-                acc = x.take_grad_slot()
-                g1 = nv.ConvDesc()
-                self._conv_desc(h, w1, x, 1, 3, dtype, into=g1)
-                g1.x, g1.y = h.gptr(), x.gptr()
-                for i, (a, b) in enumerate(_TAPS3):
-                    g1.dy[i], g1.dx[i], g1.wtap[i] = -a, -b, i
-                if fd is not None and masked_res:
-                    assert not acc
-                    g1.res, g1.res_pitch, g1.res_mask = out.gptr(), out.pitch, fd.mask
-                    p.counters["block_end_masked_residual"] = p.counters.get("block_end_masked_residual", 0) + 1
-                elif acc:
-                    g1.res, g1.res_pitch = x.gptr(), x.pitch
-                g1.pro_mode, g1.pro_x2, g1.pro_gamma, g1.pro_beta, g1.pro_count, g1.pro_eps = 2, y1.ptr(), gam, bet, cnt, bn1.eps
-                g1.pro_side = y1.gptr()
-
-                def late_b():
-                    g2.w, g1.w = w2.arena.data_ptr() + w2.bwd_off * esz, w1.arena.data_ptr() + w1.bwd_off * esz
-                    g2.stats = p.bsums.data_ptr() + 8 * boff
-                    g2.bnb_stats = g1.pro_stats = p.stats.data_ptr() + 8 * y1.stats
-                    g1.pro_bsums = g2.stats
-                    if fd is not None:
-                        sums2 = p.bsums.data_ptr() + 8 * boff2
-                        g2.pro_stats, g2.pro_bsums = p.stats.data_ptr() + 8 * y2.stats, sums2
-                        if isinstance(red, nv.ConvDesc):
-                            red.stats, red.bnb_stats = sums2, g2.pro_stats
-                        else:
-                            red.sums, red.inp.stats = sums2, fd.inp[0].stats
-                p.late(late_b)
-                p.bwd.append(Launch("conv", g2))
-                if conv2_w.requires_grad and not wg2_first:
-                    self._wgrad_launch(h, w2, y2)
-                p.bwd.append(Launch("conv", g1))
-                # (so far) the last producer of x.grad: the block in front of this one may put its BatchNorm reduce here if
-                # that is still so when its own backward is emitted
-                if acc or (fd is not None and masked_res):
-                    p.row_last_writer[x.gptr()] = (g1, p.lane_path, len((x.base if x.base is not None else x)._grad_paths))
-                if conv1_w.requires_grad:
-                    self._wgrad_launch(x, w1, y1)
-            self.bwd_stack.append(bw)
-            if bn2 is not None and fd is None:
-                list.append(self.bwd_stack, act_bw)
-        return out if bn2 is not None else y2
-
-    def bottleneck_tail(self, h, conv3_w, bn3, x, proj=None):
-        """out = relu(bn3(conv3(h)) + shortcut): the tail of a train-mode Bottleneck (reference HRnet.py:88-96) WITHOUT conv3's raw
-        output in HBM; shortcut = x (identity) or, proj = (1x1 weight, BatchNorm), bn_d(conv_d(x)) - the projection of the first block of
-        a stack (HRnet.py:139-150), whose raw output is not stored either.  At 64 x 64 the output of the 64 -> 256 layer is 134 MB per
-        batch of 64, its input 33 MB: the product is recomputed wherever it is needed instead of stored and read back
-        (hrp_conv_desc.tail_mode, csrc/conv_pw.h):
-          forward   mode 1 (batch statistics of a product, nothing stored; one launch per product) + mode 2 / 5 (normalise, add the
-                    shortcut, ReLU, bit mask) replace conv3 (+ the projection) + hrp_ew_fwd: 343 MB instead of 577 per identity block,
-                    276 instead of 745 per projection block
-          backward  per product mode 3 (sum g, sum g xhat) + mode 4 (gradient of the product; identity: the shortcut gradient as a
-                    rider) replace hrp_ew_bwd_reduce + hrp_ew_bwd_apply: they read the 33 MB input instead of the 134 MB output
-        The data and weight gradients of the 1x1 layers are the ordinary launches on mode 4's output.
-        -> out, or None when the problem is not the pointwise kernel's (caller: the general path)."""
-        p = self.plan
-        if not (BNECK_TAIL_FUSE and p.training and h.dtype == torch.bfloat16 and self.bn_batch_stats(bn3)):
-            return None
-        cout, cin = conv3_w.shape[0], conv3_w.shape[1]
-        if (conv3_w.dim() == 4 and conv3_w.shape[2] != 1) or (x.N, x.H, x.W) != (h.N, h.H, h.W) or x.dtype != h.dtype:
-            return None
-        if h.pitch != cin or h.offset or h.C != cin or x.offset or x.pitch != x.C:
-            return None
-        if proj is None:
-            if x.C != cout:
-                return None
-        else:
-            wd_param, bnd = proj
-            if tuple(wd_param.shape[:2]) != (cout, cin) or x.C != cin or (wd_param.dim() == 4 and wd_param.shape[2] != 1) or not self.bn_batch_stats(bnd):
-                return None
-        if p.need_grad and not (x.requires_grad and h.requires_grad and conv3_w.requires_grad and (proj is None or proj[0].requires_grad)):
-            return None
-        h.check_readable()
-        x.check_readable()
-        dtype = h.dtype
-        w3 = p.weight(conv3_w, cout, cin, 1)
-        wd = p.weight(proj[0], cout, cin, 1) if proj is not None else None
-        y3 = p.new(h.N, h.H, h.W, cout, dtype)          # (never written by the forward; its gradient buffer is mode 4's output)
-        yd = p.new(h.N, h.H, h.W, cout, dtype) if proj is not None else None
-        out = p.new(h.N, h.H, h.W, cout, dtype)
-        cnt = float(h.N * h.H * h.W)
-        mask = torch.zeros(h.N * h.H * h.W * (cout // 8), dtype=torch.uint8, device=p.device)
-        p.keep.append(mask)
-
-        def desc(mode, second=False):
-            src, w, y, bn = (x, wd, yd, proj[1]) if second else (h, w3, y3, bn3)
-            d = self._conv_desc(src, w, y, 1, 1, dtype)
-            d.tail_mode = mode
-            d.tail_gamma, d.tail_beta, d.tail_count, d.tail_eps = bn.weight.data_ptr(), bn.bias.data_ptr(), cnt, bn.eps
-            d.tail_mask = mask.data_ptr()
-            return d
-        dA, dB = desc(1), desc(5 if proj is not None else 2)
-        dA2 = desc(1, True) if proj is not None else None
-        dB.y = out.ptr()
-        if proj is None:
-            dB.res, dB.res_pitch = x.ptr(), x.pitch
-        else:
-            dB.tail_x2, dB.tail_gamma2, dB.tail_beta2 = x.ptr(), proj[1].weight.data_ptr(), proj[1].bias.data_ptr()
-        # eligibility of all forms (dummy aligned pointers where the arenas are not allocated yet)
-        for mode in (1, 5 if proj is not None else 2, 3, 4):
-            q = desc(mode)
-            q.w = q.stats = q.tail_stats = q.tail_bsums = q.tail_g = q.x
-            if mode == 2:
-                q.res = q.x
-            if mode == 5:
-                q.tail_x2 = q.tail_w2 = q.tail_stats2 = q.tail_gamma2 = q.tail_beta2 = q.x
-            if not nv.lib().hrp_conv_pointwise(C.byref(q)):
-                return None
-        for w in (w3, wd):
-            if w is not None:
-                w.dtype, w.cin_used = dtype, cin
-                w.need_t = getattr(w, "need_t", False) or p.need_grad
-        y3.requires_grad = out.requires_grad = p.need_grad
-        y3.stats = p.alloc_stats(cout)
-        p.bn_train.append((bn3, y3.stats, h.N * h.H * h.W))
-        if proj is not None:
-            yd.requires_grad = p.need_grad
-            yd.stats = p.alloc_stats(cout)
-            p.bn_train.append((proj[1], yd.stats, h.N * h.H * h.W))
-
-        def late():
-            dA.w = dB.w = w3.arena.data_ptr() + w3.fwd_off * 2
-            dA.stats = dB.tail_stats = p.stats.data_ptr() + 8 * y3.stats
-            if proj is not None:
-                dA2.w = dB.tail_w2 = wd.arena.data_ptr() + wd.fwd_off * 2
-                dA2.stats = dB.tail_stats2 = p.stats.data_ptr() + 8 * yd.stats
-        p.late(late)
-        p.fwd.append(Launch("conv", dA))
-        if proj is not None:
-            p.fwd.append(Launch("conv", dA2))
-        p.fwd.append(Launch("conv", dB))
-        out.producer = None
-        p.counters["bottleneck_tails"] = p.counters.get("bottleneck_tails", 0) + 1
-        if p.need_grad:
-            def bw():
-                if not out.grad_written:
-                    return
-                for second in ((False, True) if proj is not None else (False,)):
-                    src, w, y, bn = (x, wd, yd, proj[1]) if second else (h, w3, y3, bn3)
-                    y.take_grad_slot()
-                    boff = p.alloc_bsums(cout)
-                    p.bn_bwd.append((bn, boff))
-                    dC, dD = desc(3, second), desc(4, second)
-                    dC.tail_g = dD.tail_g = out.gptr()
-                    dD.y = y.gptr()
-                    if proj is None:
-                        dD.tail_side, dD.tail_side_acc = x.gptr(), x.take_grad_slot()
-
-                    def late_b(dC=dC, dD=dD, w=w, y=y, boff=boff):
-                        dC.w = dD.w = w.arena.data_ptr() + w.fwd_off * 2
-                        dC.tail_stats = dD.tail_stats = p.stats.data_ptr() + 8 * y.stats
-                        dC.stats = dD.tail_bsums = p.bsums.data_ptr() + 8 * boff
-                    p.late(late_b)
-                    p.bwd.append(Launch("conv", dC))
-                    p.bwd.append(Launch("conv", dD))
-                self._conv_bwd(h, w3, y3, None, 1, 1, dtype, None, False)
-                if proj is not None:
-                    self._conv_bwd(x, wd, yd, None, 1, 1, dtype, None, False)
-            self.bwd_stack.append(bw)
-        return out
-
-    def linear(self, x, weight, bias=None, residual=None):
-        """y = x W^T + b (+ residual) on fp32 [N, C] tensors: nn.Linear of the regression heads as a skinny GEMM that reads
-        the PyTorch-shaped weight directly (hrp_linear_*; no packed copy, no split-K memset + conv launch)."""
-        p = self.plan
-        x.check_readable()
-        assert x.dtype == torch.float32 and x.H == 1 and x.W == 1 and weight.shape[1] == x.C
-        assert weight.dim() == 2 or (weight.dim() == 4 and weight.shape[2] == weight.shape[3] == 1)     # (a 1x1 conv on pooled features)
-        M, Kf, Nf = x.N, weight.shape[1], weight.shape[0]
-        y = p.new(M, 1, 1, Nf, torch.float32)
-        y.requires_grad = p.need_grad
-        if residual is not None:
-            residual.check_readable()
-        bp = bias.data_ptr() if bias is not None else None
-        # workspace of the deterministic split reduction; forward and data gradient of one layer never overlap
-        wsb = int(nv.lib().hrp_linear_workspace_bytes(M, Kf, Nf))
-        ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=p.device)      # (needs no initialisation, include/hrp.h)
-        p.keep.append(ws)
-        p.fwd.append(lambda s: nv.call("hrp_linear_fwd", x.ptr(), x.pitch, weight.data_ptr(), bp,
-                                       residual.ptr() if residual is not None else None, residual.pitch if residual is not None else 0,
-                                       y.ptr(), y.pitch, M, Kf, Nf, ws.data_ptr(), wsb, s))
-        if p.need_grad:
-            def bw():
-                if not y.grad_written:
-                    return
-                if residual is not None and residual.requires_grad:
-                    acc = residual.take_grad_slot()
-                    p.bwd.append(lambda s: nv.call("hrp_copy_cols", y.gptr(), y.pitch, residual.gptr(), residual.pitch, M, Nf, acc, s))
-                want_b = bias is not None and bias.requires_grad
-                if weight.requires_grad:
-                    gw = p.grad_of_param(weight)
-                    gb = p.grad_of_param(bias) if want_b else None
-                    first = id(weight) not in p.linear_grad_written
-                    p.linear_grad_written.add(id(weight))
-                    accw = 1 if (p.grad_arena is not None or not first) else 0
-                    p.bwd.append(lambda s: nv.call("hrp_linear_bwd_weight", x.ptr(), x.pitch, y.gptr(), y.pitch, gw.data_ptr(),
-                                                   gb.data_ptr() if gb is not None else None, M, Kf, Nf, accw, s))
-                elif want_b:     # a frozen weight with a trainable bias: the bias gradient is a column sum of its own
-                    gb = p.grad_of_param(bias)
-                    first = id(bias) not in p.linear_grad_written
-                    p.linear_grad_written.add(id(bias))
-                    cwb = int(nv.lib().hrp_colsum_workspace_bytes(M, Nf))
-                    cws = torch.empty(cwb // 4 + 4, dtype=torch.float32, device=p.device)
-                    p.keep.append(cws)
-                    accb = 1 if (p.grad_arena is not None or not first) else 0
-                    p.bwd.append(lambda s: nv.call("hrp_colsum", y.gptr(), nv.HRP_F32, M, Nf, y.pitch, gb.data_ptr(), accb, cws.data_ptr(), cwb, s))
-                if x.requires_grad:
-                    acc = x.take_grad_slot()
-                    p.bwd.append(lambda s: nv.call("hrp_linear_bwd_data", y.gptr(), y.pitch, weight.data_ptr(), x.gptr(), x.pitch,
-                                                   M, Kf, Nf, acc, ws.data_ptr(), wsb, s))
-            self.bwd_stack.append(bw)
-        return y
-
-    def regressors(self, xf, heads, n_iter, prob):
-        """The iterative regressors (reference lib/models/full_net.py:318-331, 365-378) of one feature tensor as ONE chain of
-        launches: p <- p + dec(drop(fc2(drop(fc1(cat(xf, p))))))  n_iter times per head, every head in every launch.
-        heads: [(init [M, P] dense fp32 handle, fc1, fc2, dec modules with .weight / .bias)] -> [prediction handles, dense [M, P]].
-        Forward 1 (masks) + 1 (hoisted xf product, SURVEY K11) + n_iter + 1 launches, backward n_iter + 2 (csrc/regressor.hip);
-        round 5 ran 169 launches for the same arithmetic.  The sum over the iterations of a layer's weight gradient is one
-        product over n_iter * M stacked rows at the end of the chain."""
-        p = self.plan
-        xf.check_readable()
-        assert xf.dtype == torch.float32 and xf.H == 1 and xf.W == 1 and 1 <= len(heads) <= nv.REG_MAX_PROBLEMS
-        M, F = xf.N, xf.C
-        dev = p.device
-        train_drop = p.training and prob > 0.0
-        nh = len(heads)
-        H = heads[0][2].weight.shape[0]
-        f32 = dict(dtype=torch.float32, device=dev)
-        masks = None
-        if train_drop:
-            masks = torch.zeros(nh * n_iter * 2 * M * H, **f32)
-            p.keep.append(masks)
-            state = p.rng_state()
-            p.n_dropout += 1
-            salt = p.n_dropout * 0x9E3779B1 & 0xFFFFFFFF
-            p.fwd.append(lambda s: nv.call("hrp_dropout_masks", masks.data_ptr(), masks.numel(), 1.0 - prob, state.data_ptr(), salt, s))
-
-        def mask_ptr(h, i, layer):
-            return masks.data_ptr() + 4 * (((h * n_iter + i) * 2 + layer) * M * H) if masks is not None else None
-
-        hs = []
-        for init, fc1, fc2, dec in heads:
-            init.check_readable()
-            P = init.C
-            assert init.pitch == P and init.dtype == torch.float32 and 1 <= P <= nv.REG_MAX_P
-            assert tuple(fc1.weight.shape) == (H, F + P) and tuple(fc2.weight.shape) == (H, H) and tuple(dec.weight.shape) == (P, H)
-            e = dict(P=P, init=init, fc1=fc1, fc2=fc2, dec=dec, ld1=F + P,
-                     A=torch.zeros(M * H, **f32), preds=torch.zeros(n_iter * M * P, **f32),
-                     d1=torch.zeros(n_iter * M * H, **f32), d2=torch.zeros(n_iter * M * H, **f32))
-            e["out"] = p.new(M, 1, 1, P, torch.float32, pitch=P)
-            e["out"].requires_grad = p.need_grad
-            p.keep += [e["A"], e["preds"], e["d1"], e["d2"]]
-            hs.append(e)
-
-        def launch(descs):
-            arr = (nv.RegStepDesc * len(descs))(*descs)
-            return lambda s: nv.call("hrp_regressor_step", arr, len(descs), s)
-
-        # hoist: A = xf W1[:, :F]^T + b1
-        ds = []
-        for e in hs:
-            d = nv.RegStepDesc()
-            d.M, d.P, d.K, d.N = M, 0, F, H
-            d.a, d.a_pitch = xf.ptr(), xf.pitch
-            d.w, d.w_sn, d.w_sk, d.bias = e["fc1"].weight.data_ptr(), e["ld1"], 1, e["fc1"].bias.data_ptr()
-            d.out, d.out_pitch = e["A"].data_ptr(), H
-            ds.append(d)
-        p.fwd.append(launch(ds))
-        for i in range(n_iter):
-            ds = []
-            for h, e in enumerate(hs):
-                P = e["P"]
-                d = nv.RegStepDesc()
-                d.M, d.P, d.K, d.N = M, P, H, H
-                if i == 0:
-                    d.u_prev = e["init"].ptr()
-                else:
-                    d.u_prev, d.u_bias = e["preds"].data_ptr() + 4 * (i - 1) * M * P, e["dec"].bias.data_ptr()
-                    d.z, d.z_len, d.z_pitch = e["d2"].data_ptr() + 4 * (i - 1) * M * H, H, H
-                    d.zw, d.zw_sk, d.zw_sp = e["dec"].weight.data_ptr(), 1, H
-                d.u_out = e["preds"].data_ptr() + 4 * i * M * P
-                d.a, d.a_pitch, d.a_mask = e["A"].data_ptr(), H, mask_ptr(h, i, 0)
-                d.v, d.v_sk, d.v_sp = e["fc1"].weight.data_ptr() + 4 * F, e["ld1"], 1
-                d.a_out = e["d1"].data_ptr() + 4 * i * M * H        # (the operand is staged through it; the backward reads it again)
-                d.w, d.w_sn, d.w_sk, d.bias = e["fc2"].weight.data_ptr(), H, 1, e["fc2"].bias.data_ptr()
-                d.out_mask = mask_ptr(h, i, 1)
-                d.out, d.out_pitch = e["d2"].data_ptr() + 4 * i * M * H, H
-                ds.append(d)
-            p.fwd.append(launch(ds))
-        ds = []
-        for e in hs:       # the last state: p_n = p_{n-1} + b3 + d2_{n-1} W3^T
-            P = e["P"]
-            d = nv.RegStepDesc()
-            d.M, d.P, d.K, d.N = M, P, 0, 0
-            d.u_prev, d.u_bias = e["preds"].data_ptr() + 4 * (n_iter - 1) * M * P, e["dec"].bias.data_ptr()
-            d.z, d.z_len, d.z_pitch = e["d2"].data_ptr() + 4 * (n_iter - 1) * M * H, H, H
-            d.zw, d.zw_sk, d.zw_sp = e["dec"].weight.data_ptr(), 1, H
-            d.u_out = e["out"].ptr()
-            ds.append(d)
-        p.fwd.append(launch(ds))
-        p.counters["regressor_chains"] = p.counters.get("regressor_chains", 0) + 1
-        p.reg_chains.append(dict(masks=masks, heads=hs, n_iter=n_iter, xf=xf))      # (tests and tools read the saved operands here)
-
-        if p.need_grad:
-            def bw():
-                for e in hs:
-                    if not e["out"].grad_written:
-                        e["out"].grad_buf()          # (an unused prediction: a zero gradient)
-                    e["gs"] = torch.zeros(n_iter * M * e["P"], **f32)          # g_1 .. g_n (g_{i+1} = the gradient of iteration i's update)
-                    e["gh2"], e["gh1"] = torch.zeros(n_iter * M * H, **f32), torch.zeros(n_iter * M * H, **f32)
-                    e["gA"] = torch.zeros(M * H, **f32)
-                    p.keep += [e["gs"], e["gh2"], e["gh1"], e["gA"]]
-                for i in range(n_iter - 1, -1, -1):
-                    ds = []
-                    for h, e in enumerate(hs):
-                        P = e["P"]
-                        d = nv.RegStepDesc()
-                        d.M, d.P, d.K, d.N = M, P, H, H
-                        if i == n_iter - 1:
-                            d.u_prev = e["out"].gptr()
-                        else:        # g_{i+1} = g_{i+2} + gh1_{i+1} W1[:, F:]
-                            d.u_prev = e["gs"].data_ptr() + 4 * (i + 1) * M * P
-                            d.z, d.z_len, d.z_pitch = e["gh1"].data_ptr() + 4 * (i + 1) * M * H, H, H
-                            d.zw, d.zw_sk, d.zw_sp = e["fc1"].weight.data_ptr() + 4 * F, e["ld1"], 1
-                        d.u_out = e["gs"].data_ptr() + 4 * i * M * P
-                        d.a_mask = mask_ptr(h, i, 1)
-                        d.v, d.v_sk, d.v_sp = e["dec"].weight.data_ptr(), 1, H
-                        d.a_out = e["gh2"].data_ptr() + 4 * i * M * H
-                        d.w, d.w_sn, d.w_sk = e["fc2"].weight.data_ptr(), 1, H
-                        d.out_mask = mask_ptr(h, i, 0)
-                        d.out, d.out_pitch = e["gh1"].data_ptr() + 4 * i * M * H, H
-                        d.out_sum, d.out_sum_accumulate = e["gA"].data_ptr(), 0 if i == n_iter - 1 else 1
-                        ds.append(d)
-                    p.bwd.append(launch(ds))
-                # weight / bias gradients: the n_iter iterations of a layer as one product over n_iter * M stacked rows
-                wd = []
-                for e in hs:
-                    P = e["P"]
-
-                    def prob_(x, xp, dy, dyp, wparam, col0, ld, bparam, rows, K_, N_, acc):
-                        g = nv.LinWgradDesc()
-                        g.x, g.x_pitch, g.dy, g.dy_pitch = x, xp, dy, dyp
-                        g.dw, g.dw_ld = p.grad_of_param(wparam).data_ptr() + 4 * col0, ld
-                        g.dbias = p.grad_of_param(bparam).data_ptr() if (bparam is not None and bparam.requires_grad) else None
-                        g.M, g.K, g.N, g.accumulate = rows, K_, N_, acc
-                        return g
-
-                    def acc_of(t):       # (the arena is zeroed once per backward: every producer accumulates)
-                        first = id(t) not in p.linear_grad_written
-                        p.linear_grad_written.add(id(t))
-                        return 1 if (p.grad_arena is not None or not first) else 0
-                    if e["fc2"].weight.requires_grad:
-                        wd.append(prob_(e["d1"].data_ptr(), H, e["gh2"].data_ptr(), H, e["fc2"].weight, 0, H, e["fc2"].bias, n_iter * M, H, H,
-                                        acc_of(e["fc2"].weight)))
-                    if e["dec"].weight.requires_grad:
-                        wd.append(prob_(e["d2"].data_ptr(), H, e["gs"].data_ptr(), P, e["dec"].weight, 0, H, e["dec"].bias, n_iter * M, H, P,
-                                        acc_of(e["dec"].weight)))
-                    if e["fc1"].weight.requires_grad:
-                        a1 = acc_of(e["fc1"].weight)       # (two column blocks of one parameter: both are its first writers)
-                        wd.append(prob_(xf.ptr(), xf.pitch, e["gA"].data_ptr(), H, e["fc1"].weight, 0, e["ld1"], e["fc1"].bias, M, F, H, a1))
-                        wd.append(prob_(e["preds"].data_ptr(), P, e["gh1"].data_ptr(), H, e["fc1"].weight, F, e["ld1"], None, n_iter * M, P, H, a1))
-                for k in range(0, len(wd), nv.LIN_WGRAD_MAX):
-                    grp = wd[k:k + nv.LIN_WGRAD_MAX]
-                    arr = (nv.LinWgradDesc * len(grp))(*grp)
-                    p.bwd.append(lambda s, arr=arr, n=len(grp): nv.call("hrp_linear_wgrad_batch", arr, n, s))
-                # d xf = sum over the heads of gA W1[:, :F]: one launch, two sources per problem
-                if xf.requires_grad:
-                    acc = xf.take_grad_slot()
-                    for k in range(0, nh, 2):
-                        d = nv.RegStepDesc()
-                        d.M, d.P, d.K, d.N = M, 0, H, F
-                        d.a, d.a_pitch = hs[k]["gA"].data_ptr(), H
-                        d.w, d.w_sn, d.w_sk = hs[k]["fc1"].weight.data_ptr(), 1, hs[k]["ld1"]
-                        if k + 1 < nh:
-                            d.a2, d.a2_pitch = hs[k + 1]["gA"].data_ptr(), H
-                            d.w2, d.w2_sk = hs[k + 1]["fc1"].weight.data_ptr(), hs[k + 1]["ld1"]
-                        d.out, d.out_pitch, d.out_accumulate = xf.gptr(), xf.pitch, 1 if (acc or k > 0) else 0
-                        p.bwd.append(launch([d]))
-            self.bwd_stack.append(bw)
-        return [e["out"] for e in hs]
 
     def _conv_bwd(self, x, w, y, bias, stride, ksize, dtype, residual, relu, dilation=1):
         p = self.plan
@@ -2706,222 +1813,4 @@ class PlanBuilder:
         p.out_handles.append(t)
         return t
 
-    # ---- heads ------------------------------------------------------------------------------------------
-    def softargmax(self, heat, J, D, root, fix_root):
-        """3-D soft-argmax of NHWC logits [N,H,W,J*D] -> uvd fp32 [N, J*3] (dense)."""
-        p = self.plan
-        heat.n_readers += 1
-        N, H, W = heat.N, heat.H, heat.W
-        uvd = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
-        ms = p.new(N, 1, 1, J * 2, torch.float32, pitch=J * 2)
-        uvd.requires_grad = p.need_grad and heat.requires_grad
-        dt = _dt(heat.dtype)
-        p.fwd.append(lambda s: nv.call("hrp_softargmax3d_fwd", heat.ptr(), dt, N, J, D, H, W, heat.pitch, root,
-                                       1 if fix_root else 0, uvd.ptr(), ms.ptr(), s))
-        if p.need_grad:
-            def bw():
-                if not uvd.grad_written or not heat.requires_grad:
-                    return
-                assert not heat.grad_written, "heat-map gradient has a single producer"
-                heat.take_grad_slot()
-                p.bwd.append(lambda s: nv.call("hrp_softargmax3d_bwd", heat.ptr(), dt, N, J, D, H, W, heat.pitch, root,
-                                               1 if fix_root else 0, uvd.ptr(), ms.ptr(), uvd.gptr(), heat.gptr(),
-                                               heat.pitch, s))
-            self.bwd_stack.append(bw)
-        return uvd
 
-    def pose_geometry(self, gamma, kval, uvd, Kmat, J, root, image_size, depth_factor):
-        """depth = gamma*k/1000; xyz_int = uvd_to_xyz; root_uv; trans = uvz2xyz (all fp32, dense)."""
-        p = self.plan
-        N = gamma.N
-        depth = p.new(N, 1, 1, 1, torch.float32, pitch=1)
-        xyz = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
-        ruv = p.new(N, 1, 1, 2, torch.float32, pitch=2)
-        trans = p.new(N, 1, 1, 3, torch.float32, pitch=3)
-        rg = p.need_grad and (gamma.requires_grad or uvd.requires_grad)
-        for t in (depth, xyz, ruv, trans):
-            t.requires_grad = rg
-        assert gamma.pitch == 1 and kval.pitch == 1 and Kmat.pitch == 9
-        p.fwd.append(lambda s: nv.call("hrp_pose_geometry_fwd", gamma.ptr(), kval.ptr(), uvd.ptr(), Kmat.ptr(), N, J, root,
-                                       float(image_size), float(depth_factor), depth.ptr(), xyz.ptr(), ruv.ptr(),
-                                       trans.ptr(), s))
-        if p.need_grad:
-            def bw():
-                if not rg:
-                    return
-                gp = [t.gptr() if t.grad_written else None for t in (depth, xyz, ruv, trans)]
-                if not any(gp):
-                    return
-                dg = p.new(N, 1, 1, 1, torch.float32, pitch=1)
-                du = p.new(N, 1, 1, J * 3, torch.float32, pitch=J * 3)
-                p.bwd.append(lambda s: nv.call("hrp_pose_geometry_bwd", gamma.ptr(), kval.ptr(), uvd.ptr(), Kmat.ptr(), N, J,
-                                               root, float(image_size), float(depth_factor), gp[0], gp[1], gp[2], gp[3],
-                                               dg.ptr(), du.ptr(), s))
-                for src, dst in ((dg, gamma), (du, uvd)):
-                    if dst.requires_grad:
-                        acc = dst.take_grad_slot()
-                        p.bwd.append(lambda s, src=src, dst=dst, acc=acc: nv.call(
-                            "hrp_copy_cols", src.ptr(), src.pitch, dst.gptr(), dst.pitch, N, src.C, acc, s))
-            self.bwd_stack.append(bw)
-        return depth, xyz, ruv, trans
-
-    def fk(self, chain_dev, dof, nkp, q, rot, trans, root, Kmat=None, want_uv=False, want_root_rot=False):
-        """Forward kinematics (+projection): q [N,dof], rot [N,6] (two matrix rows) or [N,4] (quaternion), trans [N,3] dense fp32."""
-        p = self.plan
-        N = q.N
-        rd = rot.C
-        assert q.pitch == dof and rd in (6, 4) and rot.pitch == rd and trans.pitch == 3
-        xyz = p.new(N, 1, 1, nkp * 3, torch.float32, pitch=nkp * 3)
-        uv = p.new(N, 1, 1, nkp * 2, torch.float32, pitch=nkp * 2) if want_uv else None
-        rr = p.new(N, 1, 1, rd, torch.float32, pitch=rd) if want_root_rot else None
-        rg = p.need_grad and (q.requires_grad or rot.requires_grad or trans.requires_grad)
-        xyz.requires_grad = rg
-        if uv is not None:
-            uv.requires_grad = rg
-        kp = Kmat.ptr() if Kmat is not None else None
-        p.fwd.append(lambda s: nv.call("hrp_fk_project_rot_fwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), rd, trans.ptr(), kp, N, root,
-                                       xyz.ptr(), uv.ptr() if uv is not None else None,
-                                       rr.ptr() if rr is not None else None, s))
-        if p.need_grad:
-            def bw():
-                gx = xyz.gptr() if xyz.grad_written else None
-                gu = uv.gptr() if (uv is not None and uv.grad_written) else None
-                if not rg or (gx is None and gu is None):
-                    return
-                dq = p.new(N, 1, 1, dof, torch.float32, pitch=dof)
-                dr = p.new(N, 1, 1, rd, torch.float32, pitch=rd)
-                dtv = p.new(N, 1, 1, 3, torch.float32, pitch=3)
-                p.bwd.append(lambda s: nv.call("hrp_fk_project_rot_bwd", chain_dev.data_ptr(), q.ptr(), rot.ptr(), rd, trans.ptr(), kp, N,
-                                               root, gx, gu, dq.ptr(), dr.ptr(), dtv.ptr(), s))
-                for src, dst in ((dq, q), (dr, rot), (dtv, trans)):
-                    if dst.requires_grad:
-                        acc = dst.take_grad_slot()
-                        p.bwd.append(lambda s, src=src, dst=dst, acc=acc: nv.call(
-                            "hrp_copy_cols", src.ptr(), src.pitch, dst.gptr(), dst.pitch, N, src.C, acc, s))
-            self.bwd_stack.append(bw)
-        return xyz, uv, rr
-
-    def dropout(self, x, prob):
-        """Inverted dropout on an fp32 [N, C] tensor: one launch draws the Philox mask (plan seed, per-op salt, a step
-        counter the forward advances) and applies it, on the lane's own stream (hrp_dropout_f32)."""
-        p = self.plan
-        if not p.training or prob <= 0.0:
-            return x
-        rows, cols = x.N, x.C
-        mask = torch.zeros(rows, cols, dtype=torch.float32, device=p.device)
-        p.keep.append(mask)
-        y = p.new(x.N, 1, 1, x.C, torch.float32, pitch=x.pitch)
-        y.requires_grad = x.requires_grad
-        keep = 1.0 - prob
-        state = p.rng_state()
-        p.n_dropout += 1
-        salt = p.n_dropout * 0x9E3779B1 & 0xFFFFFFFF
-        p.fwd.append(lambda s: nv.call("hrp_dropout_f32", x.ptr(), x.pitch, y.ptr(), y.pitch, mask.data_ptr(), rows, cols, keep,
-                                       state.data_ptr(), salt, s))
-        if p.need_grad:
-            def bw():
-                if not y.grad_written or not x.requires_grad:
-                    return
-                acc = x.take_grad_slot()
-                p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), y.pitch, mask.data_ptr(), cols, x.gptr(), x.pitch,
-                                               rows, cols, acc, s))
-            self.bwd_stack.append(bw)
-        y.dropout_mask = mask
-        return y
-
-    def cat_cols(self, parts, width=None):
-        """fp32 [N, sum C_i] = concatenation of [N, C_i] tensors; gradient splits back additively."""
-        p = self.plan
-        N = parts[0].N
-        total = sum(t.C for t in parts)
-        out = p.new(N, 1, 1, width or total, torch.float32)
-        out.requires_grad = p.need_grad and any(t.requires_grad for t in parts)
-        offs, c = [], 0
-        for t in parts:
-            offs.append(c)
-            c += t.C
-        for t, o in zip(parts, offs):
-            p.fwd.append(lambda s, t=t, o=o: nv.call("hrp_copy_cols", t.ptr(), t.pitch, out.ptr() + 4 * o, out.pitch, N, t.C, 0, s))
-        if p.need_grad:
-            def bw():
-                if not out.grad_written:
-                    return
-                for t, o in zip(parts, offs):
-                    if t.requires_grad:
-                        acc = t.take_grad_slot()
-                        p.bwd.append(lambda s, t=t, o=o, acc=acc: nv.call(
-                            "hrp_copy_cols", out.gptr() + 4 * o, out.pitch, t.gptr(), t.pitch, N, t.C, acc, s))
-            self.bwd_stack.append(bw)
-        return out
-
-    def dense(self, x):
-        """fp32 copy with pitch == C (layout the head kernels expect)."""
-        p = self.plan
-        if x.pitch == x.C:
-            return x
-        out = p.new(x.N, 1, 1, x.C, torch.float32, pitch=x.C)
-        out.requires_grad = x.requires_grad
-        self.copy_cols(x, out)
-        return out
-
-    def softargmax_flat(self, heat, J):
-        """HeatmapIntegralJoint's core (integral.py:206-224): per channel softmax over the H*W positions of NHWC logits
-        [N, H, W, J] -> E[flat index] / (H*W), fp32 [N, J] dense."""
-        p = self.plan
-        heat.n_readers += 1
-        N, HW = heat.N, heat.H * heat.W
-        coord = p.new(N, 1, 1, J, torch.float32, pitch=J)
-        ms = p.new(N, 1, 1, J * 2, torch.float32, pitch=J * 2)
-        coord.requires_grad = p.need_grad and heat.requires_grad
-        dt = _dt(heat.dtype)
-        p.fwd.append(lambda s: nv.call("hrp_softargmax_flat_fwd", heat.ptr(), dt, N, J, HW, heat.pitch, coord.ptr(), ms.ptr(), s))
-        if p.need_grad:
-            def bw():
-                if not coord.grad_written or not heat.requires_grad:
-                    return
-                assert not heat.grad_written, "joint-map gradient has a single producer"
-                heat.take_grad_slot()
-                p.bwd.append(lambda s: nv.call("hrp_softargmax_flat_bwd", heat.ptr(), dt, N, J, HW, heat.pitch, coord.ptr(), ms.ptr(),
-                                               coord.gptr(), heat.gptr(), heat.pitch, s))
-            self.bwd_stack.append(bw)
-        return coord
-
-    def rot6d_compose(self, a, b):
-        """out = rotmat_to_rot6d(R(a) @ R(b)) on dense fp32 [N, 6] tensors (full_net.py:362)."""
-        p = self.plan
-        assert a.C == 6 and b.C == 6 and a.pitch == 6 and b.pitch == 6
-        N = a.N
-        out = p.new(N, 1, 1, 6, torch.float32, pitch=6)
-        out.requires_grad = p.need_grad and (a.requires_grad or b.requires_grad)
-        p.fwd.append(lambda s: nv.call("hrp_rot6d_compose_fwd", a.ptr(), b.ptr(), out.ptr(), N, s))
-        if p.need_grad:
-            def bw():
-                if not out.grad_written or not out.requires_grad:
-                    return
-                acc_a = a.take_grad_slot() if a.requires_grad else 0
-                acc_b = b.take_grad_slot() if b.requires_grad else 0
-                p.bwd.append(lambda s: nv.call("hrp_rot6d_compose_bwd", a.ptr(), b.ptr(), out.gptr(),
-                                               a.gptr() if a.requires_grad else None, b.gptr() if b.requires_grad else None,
-                                               N, acc_a, acc_b, s))
-            self.bwd_stack.append(bw)
-        return out
-
-    def row_scale(self, x, kvec, into=None):
-        """y[n, c] = x[n, c] * k[n, c]  (fp32; C == 1: depth = gamma * k_value, C > 1: the multi_kp depths); into: y += x * k
-        on an existing row_scale result (depth += 1000 * offset, depth_net.py:127-131)."""
-        p = self.plan
-        Cc = x.C
-        assert kvec.C == Cc
-        y = into if into is not None else p.new(x.N, 1, 1, Cc, torch.float32, pitch=Cc)
-        facc = 1 if into is not None else 0
-        y.requires_grad = x.requires_grad or (into is not None and into.requires_grad)
-        p.fwd.append(lambda s: nv.call("hrp_mul_f32", x.ptr(), x.pitch, kvec.ptr(), kvec.pitch, y.ptr(), y.pitch, x.N, Cc, facc, s))
-        if p.need_grad:
-            def bw():
-                if not y.grad_written or not x.requires_grad:
-                    return
-                acc = x.take_grad_slot()
-                p.bwd.append(lambda s: nv.call("hrp_mul_f32", y.gptr(), y.pitch, kvec.ptr(), kvec.pitch, x.gptr(), x.pitch, x.N, Cc,
-                                               acc, s))
-            self.bwd_stack.append(bw)
-        return y

@@ -18,6 +18,9 @@ EW = ("hrp_ew_fwd", "hrp_ew_bwd_reduce", "hrp_ew_bwd_apply")
 
 def shape_of(fam, q):
     esz = 2 if q.dtype == nv.HRP_BF16 else 4
+    if isinstance(q, nv.ConvDesc):      # a Bottleneck tail's backward pass carried out by a pointwise launch (tail_mode 3 / 4)
+        px = q.N * q.Ho * q.Wo * esz
+        return f"tail mode {q.tail_mode} C{q.Cin}>{q.Cout} @{q.Ho}", px * (q.Cin + q.Cout * (1 if q.tail_mode == 3 else 2 + bool(q.tail_side)))
     if fam == "hrp_ew_fwd":
         ins = "+".join(("bn" if q.inp[j].mode else "id") + (f"^{q.inp[j].up}" if q.inp[j].up != 1 else "") for j in range(q.nin))
         nbytes = q.N * q.H * q.W * q.C * esz * (1 + sum(1.0 / (q.inp[j].up ** 2) for j in range(q.nin)))

@@ -39,3 +39,22 @@ gaps.sort(reverse=True)
 print(f"idle total {sum(g[0] for g in gaps) / 1e6:.3f} ms in {len(gaps)} gaps; > 5 us: {sum(g[0] for g in gaps if g[0] > 5000) / 1e6:.3f} ms")
 for g in gaps[:25]:
     print(f"  {g[0] / 1e3:7.1f} us at {g[3]:7.3f} ms  after {g[1]:45s} before {g[2]}")
+# the serial section between the trunks (everything from the first soft-argmax launch to the first backward element-wise launch
+# behind it): what runs there, in order
+if len(sys.argv) > 2 and sys.argv[2] == "heads":
+    i0 = next(i for i, r in enumerate(step) if "softargmax_fwd" in r[2]) - 30
+    i1 = next(i for i, r in enumerate(step) if "softargmax_bwd" in r[2]) + 30
+    prev_end = step[i0][0]
+    for s, e, n in step[i0:i1]:
+        print(f"  {(s - t0) / 1e6:8.3f} ms  +{(s - prev_end) / 1e3:6.1f} us gap  {(e - s) / 1e3:7.1f} us  {n}")
+        prev_end = max(prev_end, e)
+    import collections
+    c = collections.Counter(n for _, _, n in step)
+    print({k: v for k, v in c.items() if "rocclr" in k or "at::" in k})
+if len(sys.argv) > 2 and sys.argv[2] == "edges":
+    for part in (step[:45], step[-40:]):
+        prev_end = part[0][0]
+        for s, e, n in part:
+            print(f"  {(s - t0) / 1e6:8.3f} ms  +{(s - prev_end) / 1e3:6.1f} us gap  {(e - s) / 1e3:7.1f} us  {n}")
+            prev_end = max(prev_end, e)
+        print("  ...")

@@ -183,6 +183,23 @@ class LinWgradDesc(C.Structure):
 
 
 REG_MAX_P, REG_MAX_PROBLEMS, LIN_WGRAD_MAX = 16, 4, 8
+COPY_MAX = 16
+
+
+class CopyDesc(C.Structure):      # hrp_copy_desc
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_pitch", C.c_int), ("dst_pitch", C.c_int), ("rows", C.c_int),
+                ("cols", C.c_int), ("accumulate", C.c_int), ("reserved", C.c_int)]
+
+
+def copy_cols_batch(items, stream):
+    """items: [(src pointer or None, src_pitch, dst pointer, dst_pitch, rows, cols, accumulate)] -> hrp_copy_cols_batch launches of
+    at most COPY_MAX problems each."""
+    for i0 in range(0, len(items), COPY_MAX):
+        grp = items[i0:i0 + COPY_MAX]
+        arr = (CopyDesc * len(grp))()
+        for d, (src, sp, dst, dp, rows, cols, acc) in zip(arr, grp):
+            d.src, d.src_pitch, d.dst, d.dst_pitch, d.rows, d.cols, d.accumulate = src, sp, dst, dp, rows, cols, acc
+        call("hrp_copy_cols_batch", arr, len(grp), stream)
 
 
 class FkChain(C.Structure):
@@ -201,6 +218,8 @@ PROTOTYPES = {
     "hrp_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_nchw_grad_from_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_pack_weights": [_P, _I, _I, _I, _P],
+    "hrp_pack_blocks": [_I, _I, _I, _I, _I, _I],
+    "hrp_pack_weights_compact": [_P, _P, _I, _I, _I, _P],
     "hrp_nchw_to_nhwc_s2d": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hrp_u8_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "hrp_gather_f32": [_P, _P, _P, _I, _I, _P],
@@ -233,6 +252,7 @@ PROTOTYPES = {
     "hrp_fk_project_rot_fwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P],
     "hrp_fk_project_rot_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "hrp_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "hrp_copy_cols_batch": [_P, _I, _P],
     "hrp_scale_rows": [_P, _I, _I, _I, _P, _F, _P],
     "hrp_mul_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hrp_opt_grad_sumsq": [_P, _P, _I, _P, _P, _P],

@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
 // of one (chunk, tap, channel)); the tap is the fastest thread index so that a wave reads whole contiguous spans of the
 // PyTorch-shaped source ([Cout][Cin][taps]) between its CK loads.  32-bit index arithmetic, one vector store per row (the
 // element-per-thread version with 64-bit divisions took 0.46 ms for the 29 M parameters of an HRNet-W32: 2.5 % of a step).
+// (blk, nblk): this workgroup's index among the nblk workgroups that share entry e
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry* __restrict__ table) {
-  const hrp_pack_entry e = table[blockIdx.y];
+__device__ __forceinline__ void pack_entry(const hrp_pack_entry& e, const unsigned blk, const unsigned nblk) {
   constexpr int CK = 32 / Elem<T>::SZ;  // one 32-byte K chunk of the conv kernels (csrc/conv_fwd.hip ROW)
   const unsigned Cout = e.Cout, Cin = e.Cin, nt = e.ntaps;
   const unsigned cout_pad = (Cout + 31) / 32 * 32, cin_pad = (Cin + 31) / 32 * 32;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
   };
   if (e.dst) {
     const unsigned nch = (Cin + CK - 1) / CK, rows = nch * nt * cout_pad;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    for (unsigned i = blk * 256 + threadIdx.x; i < rows; i += nblk * 256) {
       const unsigned tap = i % nt, q = i / nt, co = q % cout_pad, ch = q / cout_pad;
       float v[CK];
 #pragma unroll
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
   }
   if (e.dst_t) {
     const unsigned nch = (Cout + CK - 1) / CK, rows = nch * nt * cin_pad;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    for (unsigned i = blk * 256 + threadIdx.x; i < rows; i += nblk * 256) {
       const unsigned tap = i % nt, q = i / nt, ci = q % cin_pad, ch = q / cin_pad;
       float v[CK];
 #pragma unroll
@@ -242,6 +242,29 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
       store_row(e.dst_t, (size_t)(ch * (nt + e.pad_t) + tap) * cin_pad + ci, v);
     }
   }
+}
+
+// one entry per blockIdx.y, the same number of workgroups for every entry (single tensors: tests, tools)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry* __restrict__ table) {
+  const hrp_pack_entry e = table[blockIdx.y];
+  pack_entry<T>(e, blockIdx.x, gridDim.x);
+}
+
+// A network's table: entry i owns the workgroups first[i] .. first[i + 1] - 1 (hrp_pack_blocks each).  The rectangular grid above
+// launched 256 x 650 workgroups for the benchmark network, nearly all of them empty: 0.4 ms of workgroup dispatch that the trunks'
+// first kernels on the other streams queued behind (the step lost 0.8 ms to a 0.9 GB side-stream copy).
+constexpr int PACK_ROWS_PER_BLOCK = 256 * 4;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_compact_kernel(const hrp_pack_entry* __restrict__ table, const int32_t* __restrict__ first,
+                                                                   const int count) {
+  int lo = 0, hi = count;                   // largest lo with first[lo] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const hrp_pack_entry e = table[lo];
+  pack_entry<T>(e, blockIdx.x - first[lo], first[lo + 1] - first[lo]);
 }
 
 // ---- column sums -----------------------------------------------------------------------------------
@@ -343,6 +366,19 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int sp, float* _
   float v = src[(size_t)r * sp + c];
   float* d = dst + (size_t)r * dp + c;
   *d = acc ? *d + v : v;
+}
+
+// up to HRP_COPY_MAX column-block copies (or zero fills: src == NULL) in one launch: blockIdx.y = problem
+struct CopyBatchArgs { hrp_copy_desc d[HRP_COPY_MAX]; };
+__global__ void copy_cols_batch_kernel(const CopyBatchArgs a) {
+  const hrp_copy_desc& d = a.d[blockIdx.y];
+  const size_t total = (size_t)d.rows * d.cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / d.cols), c = (int)(i - (size_t)r * d.cols);
+    const float v = d.src ? d.src[(size_t)r * d.src_pitch + c] : 0.f;
+    float* q = d.dst + (size_t)r * d.dst_pitch + c;
+    *q = d.accumulate ? *q + v : v;
+  }
 }
 
 __global__ void scale_rows_kernel(float* __restrict__ x, int pitch, int rows, int cols, const float* __restrict__ rs, float s) {
@@ -547,6 +583,26 @@ extern "C" int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int 
   return check_launch("pack_weights");
 }
 
+extern "C" int hrp_pack_blocks(int Cout, int Cin, int ntaps, int dtype, int has_dst, int has_dst_t) {
+  if (Cout <= 0 || Cin <= 0 || ntaps <= 0) return 0;
+  const int CK = dtype == HRP_BF16 ? 16 : 8;
+  const long cout_pad = (Cout + 31) / 32 * 32, cin_pad = (Cin + 31) / 32 * 32;
+  const long rf = has_dst ? (long)cdiv(Cin, CK) * ntaps * cout_pad : 0, rt = has_dst_t ? (long)cdiv(Cout, CK) * ntaps * cin_pad : 0;
+  const long rows = rf > rt ? rf : rt;      // (a workgroup walks its share of the forward rows, then of the transposed rows)
+  const long b = (rows + PACK_ROWS_PER_BLOCK - 1) / PACK_ROWS_PER_BLOCK;
+  return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int hrp_pack_weights_compact(const hrp_pack_entry* table_dev, const int32_t* first_block_dev, int count, int total_blocks,
+                                        int dtype, void* stream) {
+  HRP_REQUIRE(table_dev && first_block_dev && count > 0 && total_blocks >= count, "pack_weights_compact: empty table / fewer workgroups than entries");
+  const dim3 grid(total_blocks);
+  if (dtype == HRP_F32) hipLaunchKernelGGL(pack_weights_compact_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, first_block_dev, count);
+  else if (dtype == HRP_F32X3) hipLaunchKernelGGL(pack_weights_compact_kernel<f32x3_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, first_block_dev, count);
+  else hipLaunchKernelGGL(pack_weights_compact_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, first_block_dev, count);
+  return check_launch("pack_weights_compact");
+}
+
 static inline int colsum_groups(int64_t rows) {
   int gx = (int)((rows + 63) / 64);
   if (gx > 512) gx = 512;
@@ -710,6 +766,23 @@ extern "C" int hrp_copy_cols(const float* src, int src_pitch, float* dst, int ds
   HRP_REQUIRE(src && dst && rows > 0 && cols > 0, "copy_cols: bad args");
   hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, rows, cols, accumulate);
   return check_launch("copy_cols");
+}
+extern "C" int hrp_copy_cols_batch(const hrp_copy_desc* descs, int n, void* stream) {
+  HRP_REQUIRE(descs && n > 0 && n <= HRP_COPY_MAX, "copy_cols_batch: 1 .. %d problems (n=%d)", HRP_COPY_MAX, n);
+  CopyBatchArgs a;
+  size_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const hrp_copy_desc& d = descs[i];
+    HRP_REQUIRE(d.dst && d.rows > 0 && d.cols > 0 && d.dst_pitch >= d.cols && (!d.src || d.src_pitch >= d.cols),
+                "copy_cols_batch: problem %d: bad pointers / shape (rows=%d cols=%d pitches %d -> %d)", i, d.rows, d.cols, d.src_pitch, d.dst_pitch);
+    HRP_REQUIRE(d.src || !d.accumulate, "copy_cols_batch: problem %d accumulates nothing (src == NULL)", i);
+    a.d[i] = d;
+    const size_t t = (size_t)d.rows * d.cols;
+    most = t > most ? t : most;
+  }
+  const int gx = (int)(most >= 64 * 256 ? 64 : cdiv((int)most, 256));
+  hipLaunchKernelGGL(copy_cols_batch_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("copy_cols_batch");
 }
 extern "C" int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_scale, float s, void* stream) {
   HRP_REQUIRE(x && rows > 0 && cols > 0, "scale_rows: bad args");

@@ -88,7 +88,12 @@ class _FusedPoseLoss(torch.autograd.Function):
         from hrpe_amd import _native as nv
         preds = [t.contiguous().float() for t in (pose, rot, trans, root_uv, depth, xyz_int, xyz_fk)]
         need = any(t.requires_grad for t in (pose, rot, trans, root_uv, depth, xyz_int, xyz_fk))
-        grads = [torch.empty_like(t) for t in preds] if need else [None] * 7
+        # the seven gradients are views of ONE buffer: the backward scales it by the incoming gradient in one launch
+        flat = torch.empty(sum(t.numel() for t in preds), dtype=torch.float32, device=pose.device) if need else None
+        grads, off = [], 0
+        for t in preds:
+            grads.append(flat[off:off + t.numel()].view(t.shape) if need else None)
+            off += t.numel()
         out = torch.empty(11, dtype=torch.float32, device=pose.device)
         d = nv.PoseLossDesc()
         for name, t in zip(("pose", "rot", "trans", "root_uv", "depth", "xyz_int", "xyz_fk"), preds):
@@ -105,13 +110,18 @@ class _FusedPoseLoss(torch.autograd.Function):
         d.B, d.P, d.J, d.root, d.image_size = pose.shape[0], pose.shape[1], xyz_fk.shape[1], root, image_size
         d.rot_dim = rot.shape[1]
         nv.call("hrp_pose_loss", C.byref(d), torch.cuda.current_stream(pose.device).cuda_stream)
-        ctx.grads = grads
+        ctx.flat, ctx.shapes = flat, [t.shape for t in preds]
         ctx.mark_non_differentiable(out)
         return out[10], out
 
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
-        gs = [None if g is None else g * g_loss for g in ctx.grads]
+        if ctx.flat is None:
+            return (None,) * 12
+        fs, gs, off = ctx.flat * g_loss, [], 0
+        for shape in ctx.shapes:
+            gs.append(fs[off:off + shape.numel()].view(shape))
+            off += shape.numel()
         return (None, None, None, None, None) + tuple(gs)
 
 

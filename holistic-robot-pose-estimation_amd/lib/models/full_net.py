@@ -26,6 +26,8 @@ from .backbones.Resnet import _StemConv, get_resnet
 # the two iterative regressors (joint angles, rotation) as ONE chain of fused launches (PlanBuilder.regressors, csrc/regressor.hip);
 # False (tests, A/B measurements): the round-5 form, one launch per nn.Linear / cat / dropout
 FUSED_REGRESSORS = True
+# soft-argmax + camera geometry and the regressors as two lanes of a parallel block of their own (_build)
+HEADS_IN_LANES = os.environ.get("HRP_HEADS_IN_LANES", "1") not in ("0", "")
 _RESNETS = ["resnet", "resnet34", "resnet50", "resnet101"]
 _HRNETS = ["hrnet", "hrnet32"]
 
@@ -351,19 +353,25 @@ class RootNetwithRegInt(PlannedModule):
             gamma = pb.plan.new(N, 1, 1, 1, torch.float32, pitch=1)
             pb.copy_cols(col, gamma)
         il = self.integral_layer
-        uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
-        depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,
-                                                          il.depth_factor)
         fused = (FUSED_REGRESSORS and not self.reg_joint_map and not self.direct_reg_rot and not self.rot_iterative_matmul
                  and self.fc_pose_2.weight.shape[0] % 16 == 0 and xf.C % 4 == 0)
-        if fused:
-            # both loops of full_net.py:318-331 / :365-378 in one chain: 1 + 1 + n_iter + 1 launches forward, n_iter + 2 backward,
-            # the xf part of fc_*_1 hoisted out of the loop
-            pose, rot = pb.regressors(xf, [(ip, self.fc_pose_1, self.fc_pose_2, self.decpose),
-                                           (ir, self.fc_rot_1, self.fc_rot_2, self.decrot)], self.n_iter, self.p_dropout)
-        else:
-            pose, rot = self._unfused_heads(pb, xf, res, ip, ir)
-        pose_d, rot_d = pb.dense(pose), pb.dense(rot)
+        # Between the trunks and the forward kinematics two chains share nothing: heat-map -> soft-argmax -> camera geometry, and
+        # feature -> regressors.  Both sit where the trunks have joined and nothing else can overlap them, so they get a lane each
+        # (HEADS_IN_LANES; forward 0.12 + 0.15 ms one after the other, backward 0.11 + 0.24).
+        with (pb.parallel(2) if HEADS_IN_LANES else _NoBlock()) as par:
+            with par.lane(0):
+                uvd = pb.softargmax(heat, J, il.depth_dim, root, il.fixroot)
+                depth, xyz_int, root_uv, trans = pb.pose_geometry(gamma, kv, uvd, Km, J, root, self.image_size,
+                                                                  il.depth_factor)
+            with par.lane(1):
+                if fused:
+                    # both loops of full_net.py:318-331 / :365-378 in one chain: 1 + 1 + n_iter + 1 launches forward, n_iter + 2
+                    # backward, the xf part of fc_*_1 hoisted out of the loop
+                    pose, rot = pb.regressors(xf, [(ip, self.fc_pose_1, self.fc_pose_2, self.decpose),
+                                                   (ir, self.fc_rot_1, self.fc_rot_2, self.decrot)], self.n_iter, self.p_dropout)
+                else:
+                    pose, rot = self._unfused_heads(pb, xf, res, ip, ir)
+                pose_d, rot_d = pb.dense(pose), pb.dense(rot)
         xyz_fk, _, _ = pb.fk(self.robot.chain_on(pb.plan.device), self.robot.dof, self.robot.nkp, pose_d, rot_d, trans, root)
         outs = [("dense", pose_d, (N, pose_d.C)), ("dense", rot_d, (N, rot_d.C)), ("dense", trans, (N, 3)),
                 ("dense", root_uv, (N, 2)), ("dense", depth, (N, 1)), ("dense", uvd, (N, J, 3)),

@@ -106,6 +106,13 @@ class TensorH:
         """A block output whose forward pass (hrp_ew_fwd: relu(bn2(y2) + x)) was held back for the next block's conv1 prologue
         (PlanBuilder.conv_bn_relu_conv, pro_mode 3) and is read by something else after all: the pass runs here, in the reader's lane,
         right in front of the reader."""
+        op = getattr(self, "pending_input", None)
+        if op is not None:
+            # an external image whose layout conversion waited for its reader (PlanBuilder.image_input): it runs in the reader's lane
+            self.pending_input = None
+            self.plan.pending_inputs.remove(self)
+            self.lane_path = self.plan.lane_path
+            self.plan.fwd.append(op)
         pend = getattr(self, "pending_block_end", None)
         if pend is not None:
             self.pending_block_end = None
@@ -195,6 +202,9 @@ BNECK_TAIL_FUSE = os.environ.get("HRP_TAIL_FUSE", "1") not in ("0", "")
 # re-reads for 62 small launches in the lanes' serial chains - A/B/A/B on one box 32.85 / 33.00 ms with it, 32.84 / 32.80 without
 # (reduce + apply 5.02 -> 4.63 ms of kernel time, the pool launches 0.47 ms).  HRP_POOL_FUSE=1 turns it on.
 POOL_FUSE_GRADS = os.environ.get("HRP_POOL_FUSE", "0") not in ("0", "")
+# external images are converted (NCHW fp32 / bytes -> NHWC) in the lane of their first reader (PlanBuilder.image_input)
+LAZY_INPUTS = os.environ.get("HRP_LAZY_INPUTS", "1") not in ("0", "")
+ARENA_ZERO_EARLY = True
 BATCHING = True      # False (tests): merged mode without batching = the same launches one by one
 # lanes of DIFFERENT launch sequences (the paths of a fuse layer) merge by their heads - the largest group of equal merge key first -
 # instead of by position: 646 -> 628 conv launches, 34.12 -> 33.87 ms per step (A/B/A/B on one box)
@@ -530,6 +540,7 @@ class Plan:
         self.linear_grad_written = set()
         self.grad_owner = {}       # gradient buffer address -> TensorH root (every producer registers through take_grad_slot)
         self.reg_chains = []       # PlanBuilder.regressors: mask buffer and saved operands of every fused regressor chain
+        self.pending_inputs = []       # external images whose conversion launch waits for the first reader (TensorH.materialize)
         self.pending_block_ends = []   # block outputs whose forward pass waits for a consumer (TensorH.materialize)
         self.row_last_writer = {}  # gradient buffer address -> (row-strip conv descriptor that completes it, lane path, producers of the gradient so far)
 
@@ -648,9 +659,16 @@ class Plan:
                     tab[i].dst_t = (arena.data_ptr() + w.bwd_off * esz) if w.need_t else None
                     tab[i].Cout, tab[i].Cin, tab[i].ntaps, tab[i].pad_t = w.cout, w.cin, w.ntaps, w.pad_t
                 tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
-                self.keep.append(tdev)
-                dest.append((tdev, len(group), _cdt(self, dtype), max(w.max_elems for w in group)))
+                # compact grid: entry i owns the workgroups first[i] .. first[i + 1] - 1 (hrp_pack_weights_compact)
+                cdt = _cdt(self, dtype)
+                first = [0]
+                for w in group:
+                    first.append(first[-1] + nv.lib().hrp_pack_blocks(w.cout, w.cin, w.ntaps, cdt, 1, 1 if w.need_t else 0))
+                fdev = torch.tensor(first, dtype=torch.int32, device=dev)
+                self.keep += [tdev, fdev]
+                dest.append((tdev, fdev, len(group), first[-1], cdt))
         self._pack_stream = None
+        self._arena_clean = False      # the gradient arena was zeroed by this forward's run_prep (side stream)
         if self._pack_tables_late:
             self._pack_stream = torch.cuda.Stream(device=dev)
             list.insert(self.fwd, cut, Entry(None, (), _PackJoin(self)))
@@ -853,10 +871,16 @@ class Plan:
         if self._pack_stream is not None and not SERIAL_LANES:   # (serial runs skip the join entry of the forward list)
             self._pack_stream.wait_stream(torch.cuda.current_stream(self.device))
             late_s = self._pack_stream.cuda_stream
-        for tdev, n, dt, maxel in self._pack_tables_late:
-            nv.call("hrp_pack_weights", tdev.data_ptr(), n, dt, maxel, late_s)
-        for tdev, n, dt, maxel in self._pack_tables:
-            nv.call("hrp_pack_weights", tdev.data_ptr(), n, dt, maxel, s)
+        for tdev, fdev, n, nblk, dt in self._pack_tables_late:
+            nv.call("hrp_pack_weights_compact", tdev.data_ptr(), fdev.data_ptr(), n, nblk, dt, late_s)
+        if late_s != s and self.need_grad and self.grad_arena is not None and ARENA_ZERO_EARLY:
+            # the gradient arena's memset (228 MB for the two-trunk network, 40 us) rides on the side stream under the stems instead of
+            # standing between the loss and the backward, where nothing overlaps it; run_backward zeroes itself when this did not run
+            with torch.cuda.stream(self._pack_stream):
+                self.grad_arena.zero_()
+            self._arena_clean = True
+        for tdev, fdev, n, nblk, dt in self._pack_tables:
+            nv.call("hrp_pack_weights_compact", tdev.data_ptr(), fdev.data_ptr(), n, nblk, dt, s)
         if self._fold_tab:
             nv.call("hrp_bn_fold", self._fold_tab[0].data_ptr(), self._fold_tab[1], s)
 
@@ -925,8 +949,9 @@ class Plan:
             part = ("seg", 1)
         j = None if part is None else part[1]
         if j in (None, 0):
-            if self.grad_arena is not None:
+            if self.grad_arena is not None and not self._arena_clean:
                 self.grad_arena.zero_()   # one memset; every weight / bias gradient kernel then accumulates
+            self._arena_clean = False
             if self.bsums_floats:
                 self.bsums.zero_()
         ops = self.bwd_ops()
@@ -1010,7 +1035,13 @@ class PlanBuilder(BlockOps, HeadOps):
                 nv.call("hrp_u8_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, 255.0, 0, s)
             else:
                 nv.call("hrp_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
-        p.fwd.append(op)
+        if LAZY_INPUTS:
+            # the conversion is emitted in front of the first reader, in ITS lane: the images of two trunks are converted side by side
+            # inside the trunks' lanes instead of one after the other in front of the fork
+            t.pending_input = op
+            p.pending_inputs.append(t)
+        else:
+            p.fwd.append(op)
         t.external = name
         return t
 
@@ -1236,10 +1267,15 @@ class PlanBuilder(BlockOps, HeadOps):
         p = self.plan
         t = p.new(N, 1, 1, Cc, torch.float32, pitch=Cc if dense else None)
 
-        def op(s):
-            x = p.dyn[name]
-            nv.call("hrp_copy_cols", x.data_ptr(), Cc, t.ptr(), t.pitch, N, Cc, 0, s)
-        p.fwd.append(op)
+        # the vector inputs of a plan are declared next to each other (full_net._build: k_value, K, init_pose, init_rot): ONE launch
+        # copies all that were declared since the last other forward op
+        grp = getattr(self, "_vec_group", None)
+        if grp is None or grp["at"] != len(p.fwd) or grp["lane"] != p.lane_path or len(grp["items"]) >= nv.COPY_MAX:
+            grp = self._vec_group = dict(items=[], lane=p.lane_path)
+            items = grp["items"]
+            p.fwd.append(lambda s: nv.copy_cols_batch([(p.dyn[n_].data_ptr(), c_, t_.ptr(), t_.pitch, r_, c_, 0) for n_, r_, c_, t_ in items], s))
+            grp["at"] = len(p.fwd)
+        grp["items"].append((name, N, Cc, t))
         return t
 
     def nchw_output(self, t):
@@ -1768,6 +1804,8 @@ class PlanBuilder(BlockOps, HeadOps):
         """Emit the backward list (reverse forward order) and resolve pointers."""
         p = self.plan
         assert p.cur_lane == 0 and p.lane_path == ()
+        for t in list(p.pending_inputs):          # (an input nothing read)
+            t.materialize()
         for t in list(p.pending_block_ends):      # block outputs nobody read in the forward (plan outputs are handled in output())
             t.materialize()
         for lane, path, emit in reversed(self.bwd_stack):

@@ -51,12 +51,27 @@ class Runner:
         p.run_forward()
 
     def _results(self):
-        res = []
-        for kind, h, shape in self.outs:
+        """Fresh tensors for the caller (the plan's buffers are overwritten by the next call).  The [B, C] fp32 outputs - all eight of
+        RootNetwithRegInt - leave through ONE launch into one allocation and come back as views of it (eight device copies, each a
+        node of its own in a captured step, sat between the forward and the loss where nothing overlaps them)."""
+        p = self.plan
+        res = [None] * len(self.outs)
+        dense = [(i, h, shape) for i, (kind, h, shape) in enumerate(self.outs) if kind != "nchw" and h.dtype == torch.float32]
+        if len(dense) > 1:
+            flat = torch.empty(sum(h.N * h.C for _, h, _ in dense), dtype=torch.float32, device=p.device)
+            items, off = [], 0
+            for i, h, shape in dense:
+                items.append((h.ptr(), h.pitch, flat.data_ptr() + 4 * off, h.C, h.N, h.C, 0))
+                res[i] = flat[off:off + h.N * h.C].view(shape)
+                off += h.N * h.C
+            nv.copy_cols_batch(items, torch.cuda.current_stream(p.device).cuda_stream)
+        for i, (kind, h, shape) in enumerate(self.outs):
+            if res[i] is not None:
+                continue
             if kind == "nchw":
-                res.append(h["out"].clone() if self.g_fwd is not None else h["out"])   # (graph pool memory is reused)
+                res[i] = h["out"].clone() if self.g_fwd is not None else h["out"]   # (graph pool memory is reused)
             else:
-                res.append(h.buf.view(-1)[: h.N * h.pitch].view(h.N, h.pitch)[:, : h.C].reshape(shape).clone())
+                res[i] = h.buf.view(-1)[h.offset: h.offset + h.N * h.pitch].view(h.N, h.pitch)[:, : h.C].reshape(shape).clone()
         return tuple(res)
 
     def _graphs_allowed(self):
@@ -113,18 +128,29 @@ class Runner:
     def backward(self, grads):
         p = self.plan
         s = torch.cuda.current_stream(p.device).cuda_stream
+        items, keep = [], []
         for (kind, h, shape), g in zip(self.outs, grads):
             t = h["handle"] if kind == "nchw" else h
             if not (t.requires_grad and t.grad_written):
                 continue
             gb = t.grad_buf()
-            if g is None:
+            if kind != "nchw" and t.dtype == torch.float32:
+                # the [B, C] gradients coming back from the loss: one launch for all of them (None: zero fill)
+                if g is not None:
+                    g = g.reshape(t.N, t.C)
+                    if g.dtype != torch.float32 or not g.is_contiguous():
+                        g = g.contiguous().float()
+                    keep.append(g)
+                items.append((None if g is None else g.data_ptr(), t.C, t.gptr(), t.pitch, t.N, t.C, 0))
+            elif g is None:
                 gb.zero_()
             elif kind == "nchw":
                 g = g.contiguous().float()
                 nv.call("hrp_nchw_to_nhwc", g.data_ptr(), t.gptr(), _dt(t.dtype), t.N, t.C, t.H, t.W, t.pitch, s)
             else:
                 gb.view(t.N, t.pitch)[:, : t.C].copy_(g.reshape(t.N, t.C))
+        if items:
+            nv.copy_cols_batch(items, s)
         self.bwd_calls += 1
         if self.g_bwd is not None and self._graphs_allowed():
             self.g_bwd.replay()

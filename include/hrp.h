@@ -350,6 +350,12 @@ int hrp_nchw_grad_from_nhwc(const void* src, float* dst, int dtype, int N, int C
 int hrp_u8_nchw_to_nhwc(const uint8_t* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch,
                         float divisor, int s2d, void* stream);
 int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int max_elems, void* stream);
+/* The same packing for a whole network's table with a compact grid: entry i is packed by the workgroups first_block[i] ..
+ * first_block[i + 1] - 1 (first_block_dev: count + 1 int32 on the device, hrp_pack_blocks() workgroups per entry or more;
+ * total_blocks = first_block[count]).  hrp_pack_weights gives every entry the workgroups of the largest one. */
+int hrp_pack_blocks(int Cout, int Cin, int ntaps, int dtype, int has_dst, int has_dst_t);   /* host only */
+int hrp_pack_weights_compact(const hrp_pack_entry* table_dev, const int32_t* first_block_dev, int count, int total_blocks,
+                             int dtype, void* stream);
 /* ResNet stem (lib/models/backbones/Resnet.py:21-25): the 7x7 stride-2 convolution runs as a 4x4 stride-1
  * convolution over the 2x2 space-to-depth image.  dst[n, y, x, (dy*2+dx)*C + c] = src[n, c, 2y+dy, 2x+dx]. */
 int hrp_nchw_to_nhwc_s2d(const float* src, void* dst, int dtype, int N, int C, int H, int W, int dst_pitch, void* stream);
@@ -604,6 +610,17 @@ int hrp_fk_project_rot_bwd(const hrp_fk_chain* chain_dev, const float* q, const 
 
 /* small fp32 helpers used by the regression heads */
 int hrp_copy_cols(const float* src, int src_pitch, float* dst, int dst_pitch, int rows, int cols, int accumulate, void* stream);
+/* n <= HRP_COPY_MAX such copies in ONE launch (the [B, C] vectors at the plan boundary: the external inputs of
+ * RootNetwithRegInt.forward - k_value, K, init_pose, init_rot, full_net.py:236-248 -, its eight outputs :392-395 and their gradients
+ * coming back from the loss); src == NULL: the block is zero-filled (an output the loss does not use). */
+#define HRP_COPY_MAX 16
+typedef struct hrp_copy_desc {
+  const float* src;
+  float* dst;
+  int src_pitch, dst_pitch, rows, cols;
+  int accumulate, reserved;
+} hrp_copy_desc;
+int hrp_copy_cols_batch(const hrp_copy_desc* descs, int n, void* stream);
 int hrp_scale_rows(float* x, int pitch, int rows, int cols, const float* row_scale, float s, void* stream);
 /* y (+)= x * m element-wise on [rows, cols] fp32 (dropout masks of the regression heads, full_net.py:98-99) */
 int hrp_mul_f32(const float* x, int x_pitch, const float* m, int m_pitch, float* y, int y_pitch, int rows, int cols,

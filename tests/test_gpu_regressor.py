@@ -301,3 +301,31 @@ def test_fused_chain_launch_count():
     # have an identically zero gradient and no launch (PlanBuilder._conv_bwd)
     assert head["hrp_colsum"] <= 1
     assert sum(head.values()) <= 20, head
+
+
+def test_copy_cols_batch_copies_accumulates_and_zero_fills():
+    """hrp_copy_cols_batch: 18 problems (two launches) of different shapes and pitches - plain copies, accumulating copies, zero fills -
+    against torch indexing; the columns beyond every block keep their contents."""
+    from hrpe_amd import _native as nv
+    g = torch.Generator(device="cpu").manual_seed(5)
+    items, checks, keep = [], [], []
+    for i in range(18):
+        rows, cols = 1 + (7 * i) % 64, 1 + (5 * i) % 23
+        sp, dp = cols + i % 3, cols + (i + 1) % 4
+        src = torch.randn(rows, sp, generator=g).to(DEV)
+        dst = torch.randn(rows, dp, generator=g).to(DEV)
+        want = dst.clone()
+        mode = i % 3
+        if mode == 0:
+            want[:, :cols] = src[:, :cols]
+        elif mode == 1:
+            want[:, :cols] += src[:, :cols]
+        else:
+            want[:, :cols] = 0
+        items.append((None if mode == 2 else src.data_ptr(), sp, dst.data_ptr(), dp, rows, cols, 1 if mode == 1 else 0))
+        checks.append((dst, want))
+        keep.append(src)
+    nv.copy_cols_batch(items, None)
+    torch.cuda.synchronize()
+    for dst, want in checks:
+        assert torch.equal(dst, want)

@@ -676,3 +676,48 @@ def test_block_stack_with_block_end_forward_in_the_next_conv1(Cc):
         ef, eu, ab = err(res[True][k], want[k]), err(res[False][k], want[k]), err(res[True][k], res[False][k])
         assert ef <= 1.15 * eu + 2e-3, (k, ef, eu)
         assert ab < 4e-2, (k, ab)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f32x3"])
+def test_compact_weight_packing_equals_the_rectangular_launch(dtype):
+    """hrp_pack_weights_compact (a network's table, hrp_pack_blocks workgroups per entry) writes what hrp_pack_weights writes, byte
+    for byte: 1x1 / 3x3 / 16-tap layers, channel counts that are no multiple of a chunk, entries without a transposed packing, padded tap
+    slots (which stay what the caller put there)."""
+    nv = nvmod()
+    code = {"bf16": nv.HRP_BF16, "f32": nv.HRP_F32, "f32x3": nv.HRP_F32X3}[dtype]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    ck = 16 if dtype == "bf16" else 8
+    shapes = [(32, 32, 9, True, 0), (64, 3, 9, False, 0), (256, 64, 1, True, 0), (24, 40, 9, True, 0), (64, 12, 16, False, 0),
+              (128, 64, 9, True, 1), (7, 2048, 1, True, 0), (512, 256, 9, True, 0), (1024, 512, 9, True, 0)]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    outs = []
+    for compact in (False, True):
+        tab = (nv.PackEntry * len(shapes))()
+        keep, first, most = [], [0], 0
+        for i, (cout, cin, nt, need_t, pad_t) in enumerate(shapes):
+            w = torch.randn(cout, cin, nt, generator=torch.Generator(device="cpu").manual_seed(100 + i)).to(DEV)
+            nf = -(-cin // ck) * nt * rup(cout, 32) * ck
+            nb = -(-cout // ck) * (nt + pad_t) * rup(cin, 32) * ck
+            dst = torch.full((nf,), 7.0, dtype=tdt, device=DEV)
+            dst_t = torch.full((nb,), 7.0, dtype=tdt, device=DEV) if need_t else None
+            tab[i].src, tab[i].dst, tab[i].dst_t = w.data_ptr(), dst.data_ptr(), dst_t.data_ptr() if need_t else None
+            tab[i].Cout, tab[i].Cin, tab[i].ntaps, tab[i].pad_t = cout, cin, nt, pad_t
+            keep += [w, dst, dst_t]
+            first.append(first[-1] + nv.lib().hrp_pack_blocks(cout, cin, nt, code, 1, 1 if need_t else 0))
+            most = max(most, nf, nb)
+        tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(DEV)
+        if compact:
+            fdev = torch.tensor(first, dtype=torch.int32, device=DEV)
+            nv.call("hrp_pack_weights_compact", tdev.data_ptr(), fdev.data_ptr(), len(shapes), first[-1], code, None)
+        else:
+            nv.call("hrp_pack_weights", tdev.data_ptr(), len(shapes), code, most, None)
+        torch.cuda.synchronize()
+        outs.append(keep)
+    assert first[-1] < 2000          # (the rectangular grid of this table: 9 x 256 workgroups of which most find no row)
+    for a, b in zip(*outs):
+        if a is not None:
+            assert torch.equal(a, b)
+    # the padded tap slots of the transposed packing were not touched
+    cout, cin, nt, _, pad_t = shapes[5]
+    dst_t = outs[1][3 * 5 + 2].view(-(-cout // ck), nt + pad_t, rup(cin, 32), ck)
+    assert bool((dst_t[:, nt:] == 7.0).all()) and not bool((dst_t[:, :nt] == 7.0).all())

@@ -46,10 +46,10 @@ def test_ctypes_struct_sizes_match_c():
 #include <stdio.h>
 #include "hrp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrp_conv_desc), sizeof(hrp_wgrad_desc), sizeof(hrp_pack_entry),
          sizeof(hrp_ew_input), sizeof(hrp_ew_desc), sizeof(hrp_ew_bwd_desc), sizeof(hrp_bn_entry), sizeof(hrp_fk_chain),
          sizeof(hrp_opt_tensor), sizeof(hrp_opt_chunk), sizeof(hrp_batch_info), sizeof(hrp_pose_loss_desc), sizeof(hrp_wgrad_fold_desc),
-         sizeof(hrp_block_desc), sizeof(hrp_block_info), sizeof(hrp_regressor_step_desc), sizeof(hrp_linear_wgrad_desc));
+         sizeof(hrp_block_desc), sizeof(hrp_block_info), sizeof(hrp_regressor_step_desc), sizeof(hrp_linear_wgrad_desc), sizeof(hrp_copy_desc));
   return 0;
 }'''
     import tempfile
@@ -61,9 +61,9 @@ int main(void) {
     sizes = [int(v) for v in out]
     mirrors = [nv.ConvDesc, nv.WgradDesc, nv.PackEntry, nv.EwInput, nv.EwDesc, nv.EwBwdDesc, nv.BnEntry, nv.FkChain,
                nv.OptTensor, nv.OptChunk, nv.BatchInfo, nv.PoseLossDesc, nv.WgradFoldDesc,
-               nv.BlockDesc, nv.BlockInfo, nv.RegStepDesc, nv.LinWgradDesc]
+               nv.BlockDesc, nv.BlockInfo, nv.RegStepDesc, nv.LinWgradDesc, nv.CopyDesc]
     assert sizes == [C.sizeof(m) for m in mirrors]
-    assert (nv.REG_MAX_P, nv.REG_MAX_PROBLEMS, nv.LIN_WGRAD_MAX) == (16, 4, 8)      # HRP_REG_MAX_P, HRP_REG_MAX_PROBLEMS, HRP_LIN_WGRAD_MAX
+    assert (nv.REG_MAX_P, nv.REG_MAX_PROBLEMS, nv.LIN_WGRAD_MAX, nv.COPY_MAX) == (16, 4, 8, 16)      # HRP_REG_MAX_P, HRP_REG_MAX_PROBLEMS, HRP_LIN_WGRAD_MAX
 
 
 def test_regressor_entry_points_reject_bad_descriptors_without_a_gpu():
@@ -82,6 +82,11 @@ def test_regressor_entry_points_reject_bad_descriptors_without_a_gpu():
     g = nv.LinWgradDesc()
     assert nv.lib().hrp_linear_wgrad_batch((nv.LinWgradDesc * 1)(g), 1, None) == -1
     assert nv.lib().hrp_dropout_masks(None, 16, 0.5, None, 0, None) == -1
+    c = nv.CopyDesc()
+    assert nv.lib().hrp_copy_cols_batch((nv.CopyDesc * 1)(c), 1, None) == -1                  # no destination
+    assert nv.lib().hrp_copy_cols_batch((nv.CopyDesc * 1)(c), 17, None) == -1 and b"problems" in nv.lib().hrp_last_error()
+    c.dst, c.rows, c.cols, c.dst_pitch, c.accumulate = 16, 2, 3, 3, 1
+    assert nv.lib().hrp_copy_cols_batch((nv.CopyDesc * 1)(c), 1, None) == -1 and b"accumulates nothing" in nv.lib().hrp_last_error()
 
 
 def test_bad_descriptor_is_rejected_without_a_gpu():

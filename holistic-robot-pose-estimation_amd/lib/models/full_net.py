@@ -287,13 +287,16 @@ class RootNetwithRegInt(PlannedModule):
         J, root = self.num_joints, self.reference_keypoint_id
         resnet_reg = self.backbone_name in _RESNETS
         resnet_root = self.rootnet_backbone_name not in _HRNETS
-        xr = (pb.image_input_s2d if resnet_reg else pb.image_input)("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3], u8=x_reg.dtype == torch.uint8)
+        lazy = lambda resnet: {} if resnet else {"lazy": True}      # noqa: E731  (HRNet stems read the image with pb.conv)
+        xr = (pb.image_input_s2d if resnet_reg else pb.image_input)("x_reg", N, 3, x_reg.shape[2], x_reg.shape[3], u8=x_reg.dtype == torch.uint8,
+                                                                    **lazy(resnet_reg))
         if not resnet_root and HRnet.TRUNK_FP32_FROM == "1":
             # the WHOLE DepthNet in fp32 inside a bf16 plan (measurement mode, DESIGN 4: the cheapest mode that keeps every
             # key-point of the fixture within 0.5 px - bf16 operands anywhere in this trunk do not)
-            xo = pb.image_input("x_root", N, 3, x_root.shape[2], x_root.shape[3], u8=x_root.dtype == torch.uint8, dtype=torch.float32)
+            xo = pb.image_input("x_root", N, 3, x_root.shape[2], x_root.shape[3], u8=x_root.dtype == torch.uint8, dtype=torch.float32, lazy=True)
         else:
-            xo = (pb.image_input_s2d if resnet_root else pb.image_input)("x_root", N, 3, x_root.shape[2], x_root.shape[3], u8=x_root.dtype == torch.uint8)
+            xo = (pb.image_input_s2d if resnet_root else pb.image_input)("x_root", N, 3, x_root.shape[2], x_root.shape[3], u8=x_root.dtype == torch.uint8,
+                                                                         **lazy(resnet_root))
         kv = pb.vector_input("k_value", N, 1, dense=True)
         Km = pb.vector_input("K", N, 9, dense=True)
         ip = None if self.reg_joint_map else pb.vector_input("init_pose", N, self.init_pose.shape[1], dense=True)

@@ -1020,7 +1020,7 @@ class PlanBuilder(BlockOps, HeadOps):
         self.fuse_inference = (not plan.training) and (not plan.need_grad)
 
     # ---- inputs / outputs ---------------------------------------------------------------------------
-    def image_input(self, name, N, Cc, H, W, u8=False, dtype=None):
+    def image_input(self, name, N, Cc, H, W, u8=False, dtype=None, lazy=False):
         """NCHW fp32 external tensor -> NHWC plan tensor (channel-padded to 8).  u8: the external tensor holds the
         dataset's bytes and is divided by 255 on the way in (reference lib/core/function.py:26,29).  dtype: element type of
         the plan tensor when it is not the plan's (a trunk that computes in fp32 inside a bf16 plan)."""
@@ -1035,7 +1035,8 @@ class PlanBuilder(BlockOps, HeadOps):
                 nv.call("hrp_u8_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, 255.0, 0, s)
             else:
                 nv.call("hrp_nchw_to_nhwc", x.data_ptr(), t.ptr(), dt, N, Cc, H, W, t.pitch, s)
-        if LAZY_INPUTS:
+        if lazy and LAZY_INPUTS:
+            # (lazy: the caller's first reader is a convolution - an op that announces its reads with check_readable)
             # the conversion is emitted in front of the first reader, in ITS lane: the images of two trunks are converted side by side
             # inside the trunks' lanes instead of one after the other in front of the fork
             t.pending_input = op

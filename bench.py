@@ -723,6 +723,32 @@ def main():
                 traffic = by / dom[1][0]      # per launch of the family as bench.py counts launches
                 traffic_source = ("profiles/" + os.path.basename(tpath) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
                                   "tools/one_step.py (same network, batch and library sources), not collected in this run")
+    # ... and the family's time inside the step as rocprofv3 saw it (kernel trace of this command, committed next to the counter passes
+    # by tools/collect_profiles.sh): the cross-check of the one-by-one figure below
+    profiled = None
+    if traffic is not None:
+        spath = tpath.replace("_traffic.json", "_bench_kernel_stats.csv")
+        if os.path.exists(spath):
+            import csv
+            import re
+            pat = re.compile(r"hrp::(" + "|".join(fam_kernels) + r")[<(]")
+            steps_seen = fam_ns = fam_calls = 0
+            with open(spath) as fh:
+                for row in csv.DictReader(fh):
+                    if "softargmax_bwd_kernel" in row["Name"]:
+                        steps_seen += int(row["Calls"])
+                    # (the tails' backward forms are BatchNorm-backward launches, as launch_descs attributes them; the fp32 / fp32x3
+                    # instantiations in the trace belong to the run's pixel-error passes, not to the bf16 step)
+                    if (pat.search(row["Name"]) and not re.search(r"conv_pw_tail_kernel<\d+, [34]>", row["Name"])
+                            and "<float" not in row["Name"] and "f32x3_t" not in row["Name"]):
+                        fam_ns += int(row["TotalDurationNs"])
+                        fam_calls += int(row["Calls"])
+            if steps_seen and fam_calls:
+                pms = fam_ns / steps_seen * 1e-6
+                profiled = {"family_ms_per_step": round(pms, 3), "kernel_launches_per_step": round(fam_calls / steps_seen, 1),
+                            "achieved": round(dom[1][3] / (pms * 1e-3) / 1e9, 2), "frac": round(dom[1][3] / (pms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                            "source": "profiles/" + os.path.basename(spath) + ": rocprofv3 --kernel-trace --stats of bench.py (graph replays, "
+                                      "both trunk lanes running) on the same library sources; per step = per soft-argmax backward launch"}
     roofline = {"kernel": dom[0], "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(ach_gb if hbm_bound else ach_tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -733,6 +759,8 @@ def main():
                 "bytes_incl_fused_operands_per_launch": round(dom[1][4] / dom[1][0]),
                 "achieved_incl_fused_operands": round(dom[1][4] / (dom[1][1] * 1e-3) / 1e9, 2), "flop_per_byte": round(intensity, 1),
                 "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4)}
+    if profiled:
+        roofline["profiled"] = profiled
     gf_img = FWD_GFLOP_PER_IMAGE["depthnet" if hrnet else "full"] * (1 if fwd_only else 3)
     step_tflops = gf_img * 1e9 * B * world / (ms_per_step * 1e-3) / 1e12 / world     # per GPU
     passes = 1 if hrnet else 2

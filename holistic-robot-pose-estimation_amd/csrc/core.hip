@@ -251,6 +251,77 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const hrp_pack_entry*
   pack_entry<T>(e, blockIdx.x, gridDim.x);
 }
 
+// One read of the source for both packings: a workgroup takes a tile of 32 output x 32 input channels x all taps through LDS
+// (32 contiguous spans of 32 * taps floats), then writes the tile's rows of the forward packing (thread = (chunk, tap, co), co
+// fastest: consecutive 32-byte rows) and of the transposed one (thread = (chunk, tap, ci)).  The row-per-thread body above reads the
+// source once per packing, the transposed gather with 2.7 x over-fetch: 607 MB of fetches for the 228 MB of an HRNet pair's
+// parameters.  Layers of up to PACK_TILE_TAPS taps (1 x 1, 3 x 3); the 16-tap stem forms keep the body above.
+constexpr int PACK_TILE_TAPS = 9;
+template <typename T>
+__device__ __forceinline__ void pack_store_row(void* dst, const size_t row, const float (&v)[32 / Elem<T>::SZ]) {
+  constexpr int CK = 32 / Elem<T>::SZ;
+  uint4* q = (uint4*)((char*)dst + row * 32);
+  if constexpr (std::is_same<T, f32x3_t>::value) {
+    split_bf16x8(v, q[0], q[1]);
+  } else {
+    float a[CK / 2], b[CK / 2];
+#pragma unroll
+    for (int k = 0; k < CK / 2; ++k) { a[k] = v[k]; b[k] = v[CK / 2 + k]; }
+    q[0] = Elem<T>::pack(a);
+    q[1] = Elem<T>::pack(b);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_entry_tile(const hrp_pack_entry& e, const unsigned tile_id, float* __restrict__ lds) {
+  constexpr int CK = 32 / Elem<T>::SZ, NC = 32 / CK;       // chunks of a 32-channel tile side
+  const unsigned Cout = e.Cout, Cin = e.Cin, nt = e.ntaps;
+  const unsigned cout_pad = (Cout + 31) / 32 * 32, cin_pad = (Cin + 31) / 32 * 32;
+  const unsigned n_cit = cin_pad / 32;
+  const unsigned co0 = (tile_id / n_cit) * 32, ci0 = (tile_id % n_cit) * 32;
+  const unsigned span = 32 * nt, pitch = span + 1;         // LDS row = one output channel: [ci local][tap], odd pitch
+  // wave w takes the rows w, w + 4, ..: a row is ONE contiguous span of the source, read lane-linear; four rows' loads in flight
+  {
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned valid = Cin > ci0 ? (Cin - ci0 < 32 ? (Cin - ci0) * nt : span) : 0;      // floats of a row inside the tensor
+    for (unsigned r0 = wave; r0 < 32; r0 += 16) {
+      for (unsigned j = lane; j < span; j += 64) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned co = co0 + r0 + 4 * u;
+          v[u] = (co < Cout && j < valid) ? e.src[((size_t)co * Cin + ci0) * nt + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lds[(r0 + 4 * u) * pitch + j] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (e.dst) {
+    const unsigned nch = (Cin + CK - 1) / CK;
+    for (unsigned r = threadIdx.x; r < NC * nt * 32; r += 256) {
+      const unsigned co = r & 31, q = r >> 5, tap = q % nt, c = q / nt, ch = ci0 / CK + c;
+      if (ch >= nch) continue;
+      float v[CK];
+#pragma unroll
+      for (int k = 0; k < CK; ++k) v[k] = lds[co * pitch + (c * CK + k) * nt + tap];
+      pack_store_row<T>(e.dst, (size_t)(ch * nt + tap) * cout_pad + co0 + co, v);
+    }
+  }
+  if (e.dst_t) {
+    const unsigned nch = (Cout + CK - 1) / CK;
+    for (unsigned r = threadIdx.x; r < NC * nt * 32; r += 256) {
+      const unsigned ci = r & 31, q = r >> 5, tap = q % nt, c = q / nt, ch = co0 / CK + c;
+      if (ch >= nch) continue;
+      float v[CK];
+#pragma unroll
+      for (int k = 0; k < CK; ++k) v[k] = lds[(c * CK + k) * pitch + ci * nt + tap];
+      pack_store_row<T>(e.dst_t, (size_t)(ch * (nt + e.pad_t) + tap) * cin_pad + ci0 + ci, v);
+    }
+  }
+}
+
 // A network's table: entry i owns the workgroups first[i] .. first[i + 1] - 1 (hrp_pack_blocks each).  The rectangular grid above
 // launched 256 x 650 workgroups for the benchmark network, nearly all of them empty: 0.4 ms of workgroup dispatch that the trunks'
 // first kernels on the other streams queued behind (the step lost 0.8 ms to a 0.9 GB side-stream copy).
@@ -264,6 +335,11 @@ __global__ __launch_bounds__(256) void pack_weights_compact_kernel(const hrp_pac
     if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
   const hrp_pack_entry e = table[lo];
+  if (e.ntaps <= PACK_TILE_TAPS) {            // (workgroup-uniform) hrp_pack_blocks gave this entry one workgroup per tile
+    __shared__ float lds[32 * (32 * PACK_TILE_TAPS + 1)];
+    pack_entry_tile<T>(e, blockIdx.x - first[lo], lds);
+    return;
+  }
   pack_entry<T>(e, blockIdx.x - first[lo], first[lo + 1] - first[lo]);
 }
 
@@ -587,6 +663,7 @@ extern "C" int hrp_pack_blocks(int Cout, int Cin, int ntaps, int dtype, int has_
   if (Cout <= 0 || Cin <= 0 || ntaps <= 0) return 0;
   const int CK = dtype == HRP_BF16 ? 16 : 8;
   const long cout_pad = (Cout + 31) / 32 * 32, cin_pad = (Cin + 31) / 32 * 32;
+  if (ntaps <= PACK_TILE_TAPS) return (int)((cout_pad / 32) * (cin_pad / 32));      // pack_entry_tile: one workgroup per 32 x 32 tile
   const long rf = has_dst ? (long)cdiv(Cin, CK) * ntaps * cout_pad : 0, rt = has_dst_t ? (long)cdiv(Cout, CK) * ntaps * cin_pad : 0;
   const long rows = rf > rt ? rf : rt;      // (a workgroup walks its share of the forward rows, then of the transposed rows)
   const long b = (rows + PACK_ROWS_PER_BLOCK - 1) / PACK_ROWS_PER_BLOCK;

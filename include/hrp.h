@@ -351,7 +351,7 @@ int hrp_u8_nchw_to_nhwc(const uint8_t* src, void* dst, int dtype, int N, int C, 
                         float divisor, int s2d, void* stream);
 int hrp_pack_weights(const hrp_pack_entry* table_dev, int count, int dtype, int max_elems, void* stream);
 /* The same packing for a whole network's table with a compact grid: entry i is packed by the workgroups first_block[i] ..
- * first_block[i + 1] - 1 (first_block_dev: count + 1 int32 on the device, hrp_pack_blocks() workgroups per entry or more;
+ * first_block[i + 1] - 1 (first_block_dev: count + 1 int32 on the device, EXACTLY hrp_pack_blocks() workgroups per entry;
  * total_blocks = first_block[count]).  hrp_pack_weights gives every entry the workgroups of the largest one. */
 int hrp_pack_blocks(int Cout, int Cin, int ntaps, int dtype, int has_dst, int has_dst_t);   /* host only */
 int hrp_pack_weights_compact(const hrp_pack_entry* table_dev, const int32_t* first_block_dev, int count, int total_blocks,

@@ -278,6 +278,7 @@ __device__ __forceinline__ void pack_entry_tile(const hrp_pack_entry& e, const u
   const unsigned Cout = e.Cout, Cin = e.Cin, nt = e.ntaps;
   const unsigned cout_pad = (Cout + 31) / 32 * 32, cin_pad = (Cin + 31) / 32 * 32;
   const unsigned n_cit = cin_pad / 32;
+  if (tile_id >= (cout_pad / 32) * n_cit) return;          // (a table built with more workgroups than hrp_pack_blocks asked for)
   const unsigned co0 = (tile_id / n_cit) * 32, ci0 = (tile_id % n_cit) * 32;
   const unsigned span = 32 * nt, pitch = span + 1;         // LDS row = one output channel: [ci local][tap], odd pitch
   // wave w takes the rows w, w + 4, ..: a row is ONE contiguous span of the source, read lane-linear; four rows' loads in flight

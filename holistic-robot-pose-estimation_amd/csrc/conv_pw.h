@@ -78,6 +78,7 @@ static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
 // LDS: [4 waves][2 blocks][64 lanes] statistic partials (waves that share channels are added up before the atomics), then rows
 // 6 .. 9 of conv_row.h's constant table (epilogue reduce only)
 constexpr int PW_STAT_BYTES = 4 * 2 * 64 * 4;
+constexpr int PW_TAIL_XP_BYTES = 4 * 2 * 32 * 144;      // conv_pw_tail_kernel: two transpose tiles per wave (stores of modes 2 / 4)
 static inline int pw_lds_bytes(const hrp_conv_desc& d) { return PW_STAT_BYTES + (d.bnb_x ? 10 * d.Cout * 4 : 0); }
 
 template <int KS, int MW, bool EXT>
@@ -287,6 +288,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
   // per-channel constants: a table in LDS (one thread per channel derives them from the statistic slots), then the lane's
   // channels cl(mi) .. + 15 into registers - a lane's channels are the same in every tile
   float* ctab = (float*)(smem + PW_STAT_BYTES);          // [3][Cout]: sc, sh | sc, c0, c1
+  // Stores through a transpose (MODE 2 / 4): a lane holds 2 x 32 bytes of ONE pixel's row, so a store instruction of the direct form
+  // scatters 64 pieces of 16 bytes over 64 lines and relies on L2 to merge eight such pieces per 128-byte line before it evicts
+  // them - it does at 128 output channels (5.5 TB/s) and does not at 256 (3.6).  Each wave drops its 32 pixels x 128 bytes into a
+  // private LDS tile ([pixel][144 B]) and stores them back out as whole 128-byte rows, eight lanes per row.
+  constexpr int XP_PITCH = 144, XP_BYTES = 32 * XP_PITCH;
+  char* xp_y = smem + PW_STAT_BYTES + 3 * Cout * 4 + wave * (2 * XP_BYTES);
+  char* xp_s = xp_y + XP_BYTES;                              // (MODE 4: the rider)
+  const int xp_mine = l31 * XP_PITCH + half * 32;          // + mi * 64 + hh * 16: the lane's pieces inside its pixel's 128 bytes
+  const int xp_row = lane >> 3, xp_pc = (lane & 7) * 16;   // read-back: pixel xp_row + 8 k, piece lane & 7
   float k_sc[MODE == 2 || MODE == 4 ? MW : 1][16], k_sh[MODE == 2 ? MW : 1][16];
   if constexpr (MODE == 2 || MODE == 4) {
     for (int c = tid; c < Cout; c += 256) {
@@ -372,6 +382,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
     }
   };
 
+  auto flush = [&](const char* xp, void* dst, int t) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long px = (long)t * 32 + xp_row + 8 * k;
+      if (t < p.ntiles && px < M)
+        *(uint4*)((char*)dst + (size_t)px * (Cout * 2) + cbase * 2 + xp_pc) = *(const uint4*)(xp + (xp_row + 8 * k) * XP_PITCH + xp_pc);
+    }
+  };
   auto compute = [&](int t, const bf16x8 (&xb)[KS], const Epi& e) {
     const long pix = (long)t * 32 + l31;
     const bool ok = t < p.ntiles && pix < M;
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
               v[i] = fmaxf(fmaf(acc[8 * hh + i], k_sc[mi][8 * hh + i], k_sh[mi][8 * hh + i]) + r[i], 0.f);
               bits |= (v[i] > 0.f ? 1u : 0u) << (8 * hh + i);
             }
-            if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
+            *(uint4*)(xp_y + xp_mine + mi * 64 + hh * 16) = Elem<bf16_t>::pack(v);
           }
           if (ok) *(unsigned short*)(d.tail_mask + (off >> 4)) = (unsigned short)bits;
         } else {
@@ -419,8 +437,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
 #pragma unroll
               for (int i = 0; i < 8; ++i) { s1[mi][8 * hh + i] += g[i]; s2[mi][8 * hh + i] = fmaf(g[i], acc[8 * hh + i], s2[mi][8 * hh + i]); }
             } else {
-              if (d.tail_side && ok) {
-                char* q = (char*)d.tail_side + off + 16 * hh;
+              if (d.tail_side) {
+                char* q = xp_s + xp_mine + mi * 64 + hh * 16;
                 if (side_acc) {
                   float o[8];
                   Elem<bf16_t>::unpack(e.sd[mi][hh], o);
@@ -440,10 +458,16 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
                 v[i + 2] = fmaf(k_sc[mi][8 * hh + i + 2], g[i + 2], fmaf(c1.z, acc[8 * hh + i + 2], c0.z));
                 v[i + 3] = fmaf(k_sc[mi][8 * hh + i + 3], g[i + 3], fmaf(c1.w, acc[8 * hh + i + 3], c0.w));
               }
-              if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
+              *(uint4*)(xp_y + xp_mine + mi * 64 + hh * 16) = Elem<bf16_t>::pack(v);
             }
           }
         }
+      }
+    }
+    if constexpr (MODE == 2 || MODE == 4) {
+      flush(xp_y, d.y, t);
+      if constexpr (MODE == 4) {
+        if (d.tail_side) flush(xp_s, d.tail_side, t);
       }
     }
   };
@@ -616,7 +640,7 @@ static inline int pw_tail_occupancy() {
   static int occ = 0;
   if (!occ) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail_kernel<KS, MODE>, 256, PW_STAT_BYTES + 3 * 256 * 4) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail_kernel<KS, MODE>, 256, PW_STAT_BYTES + 3 * 256 * 4 + PW_TAIL_XP_BYTES) != hipSuccess || nb < 1) nb = 1;
     occ = nb;
   }
   return occ;
@@ -650,7 +674,7 @@ static inline int launch_conv_pw(const hrp_conv_desc& d, const PwPlan& p0, hipSt
   const dim3 blk(256);
   const int lds = pw_lds_bytes(d);
   if (d.tail_mode) {
-#define HRP_PWT_CASE(K, MD) if (p.ks == K && d.tail_mode == MD) { pw_fill_grid(p, pw_tail_occupancy<K, MD>()); hipLaunchKernelGGL((conv_pw_tail_kernel<K, MD>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p); return check_launch("conv_pw_tail_kernel"); }
+#define HRP_PWT_CASE(K, MD) if (p.ks == K && d.tail_mode == MD) { pw_fill_grid(p, pw_tail_occupancy<K, MD>()); hipLaunchKernelGGL((conv_pw_tail_kernel<K, MD>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4 + PW_TAIL_XP_BYTES, s, d, p); return check_launch("conv_pw_tail_kernel"); }
     HRP_PWT_CASE(2, 1) HRP_PWT_CASE(2, 2) HRP_PWT_CASE(2, 3) HRP_PWT_CASE(2, 4) HRP_PWT_CASE(4, 1) HRP_PWT_CASE(4, 2) HRP_PWT_CASE(4, 3) HRP_PWT_CASE(4, 4)
 #undef HRP_PWT_CASE
     if (d.tail_mode == 5) {

@@ -356,30 +356,41 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
   // that uses them they were one exposed HBM latency per tile (mode 2: 99 us for 310 MB; the element-wise pass it replaces streams
   // the same tensors at 4.6 TB/s)
   struct Epi {
-    uint4 v[MW][2];
-    uint4 sd[MODE == 4 ? MW : 1][2];
+    uint4 raw[4];                       // the wave's 32 pixels x 128 bytes as whole rows: pixel xp_row + 8 k, piece lane & 7
+    uint4 sraw[MODE == 4 ? 4 : 1];
     int bits[MW];
   };
   const bool side_acc = MODE == 4 && d.tail_side && d.tail_side_acc;
   auto load_epi = [&](int t, Epi& e) {
     if constexpr (MODE != 1) {
-      const long pix = (long)t * 32 + l31;
-      const bool ok = t < p.ntiles && pix < M;
       const char* src = (const char*)(MODE == 2 ? d.res : d.tail_g);
 #pragma unroll
-      for (int mi = 0; mi < MW; ++mi) {
-        const unsigned off = (unsigned)(pix * Cout + cbase + mi * 32 + 16 * half) * 2u;
-        e.v[mi][0] = e.v[mi][1] = make_uint4(0, 0, 0, 0);
-        e.bits[mi] = 0;
-        if (ok) {
-          e.v[mi][0] = *(const uint4*)(src + off); e.v[mi][1] = *(const uint4*)(src + off + 16);
-          if constexpr (MODE >= 3) e.bits[mi] = *(const unsigned short*)(d.tail_mask + (off >> 4));
+      for (int k = 0; k < 4; ++k) {
+        const long px = (long)t * 32 + xp_row + 8 * k;
+        const size_t off = (size_t)px * (Cout * 2) + cbase * 2 + xp_pc;
+        e.raw[k] = make_uint4(0, 0, 0, 0);
+        if (t < p.ntiles && px < M) {
+          e.raw[k] = *(const uint4*)(src + off);
           if constexpr (MODE == 4) {
-            if (side_acc) { e.sd[mi][0] = *(const uint4*)((const char*)d.tail_side + off); e.sd[mi][1] = *(const uint4*)((const char*)d.tail_side + off + 16); }
+            if (side_acc) e.sraw[k] = *(const uint4*)((const char*)d.tail_side + off);
           }
         }
       }
+      if constexpr (MODE >= 3) {
+        const long pix = (long)t * 32 + l31;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+          e.bits[mi] = 0;
+          if (t < p.ntiles && pix < M) e.bits[mi] = *(const unsigned short*)(d.tail_mask + (((size_t)pix * Cout + cbase + mi * 32 + 16 * half) >> 3));
+        }
+      }
     }
+  };
+  // ... and back into the MFMA's lane order (pixel l31, 16 channels per half) through the same LDS tiles the stores use: the rows go
+  // in here, every lane reads ITS pieces where it needs them (and later writes its results to the same places)
+  auto stage_epi = [&](const uint4 (&raw)[4], char* xp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(uint4*)(xp + (xp_row + 8 * k) * XP_PITCH + xp_pc) = raw[k];
   };
 
   auto flush = [&](const char* xp, void* dst, int t) {
@@ -393,6 +404,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
   auto compute = [&](int t, const bf16x8 (&xb)[KS], const Epi& e) {
     const long pix = (long)t * 32 + l31;
     const bool ok = t < p.ntiles && pix < M;
+    if constexpr (MODE != 1) stage_epi(e.raw, xp_y);
+    if constexpr (MODE == 4) {
+      if (side_acc) stage_epi(e.sraw, xp_s);
+    }
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
       if constexpr (MODE == 1) {
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             float v[8], r[8];
-            Elem<bf16_t>::unpack(e.v[mi][hh], r);
+            Elem<bf16_t>::unpack(*(const uint4*)(xp_y + xp_mine + mi * 64 + hh * 16), r);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               v[i] = fmaxf(fmaf(acc[8 * hh + i], k_sc[mi][8 * hh + i], k_sh[mi][8 * hh + i]) + r[i], 0.f);
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             float g[8];
-            Elem<bf16_t>::unpack(e.v[mi][hh], g);
+            Elem<bf16_t>::unpack(*(const uint4*)(xp_y + xp_mine + mi * 64 + hh * 16), g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = row_keep_if_bit(g[i], bits, 8 * hh + i);
             if constexpr (MODE == 3) {
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
                 char* q = xp_s + xp_mine + mi * 64 + hh * 16;
                 if (side_acc) {
                   float o[8];
-                  Elem<bf16_t>::unpack(e.sd[mi][hh], o);
+                  Elem<bf16_t>::unpack(*(const uint4*)q, o);
 #pragma unroll
                   for (int i = 0; i < 8; ++i) o[i] += g[i];
                   *(uint4*)q = Elem<bf16_t>::pack(o);
@@ -576,6 +591,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail2_kernel(const hrp_conv_de
   __syncthreads();
   const long M = (long)d.N * d.Ho * d.Wo;
   const int tile0 = wg * (p.tpw * p.wp) + wpi, tstep = p.wp;
+  // stores as whole 128-byte rows through a per-wave LDS tile (as conv_pw_tail_kernel)
+  constexpr int XP_PITCH = 144, XP_BYTES = 32 * XP_PITCH;
+  char* xp_y = smem + PW_STAT_BYTES + 3 * Cout * 4 + wave * XP_BYTES;
+  const int xp_mine = l31 * XP_PITCH + half * 32, xp_row = lane >> 3, xp_pc = (lane & 7) * 16;
   auto load_tile = [&](int t, bf16x8 (&xb)[KS], bf16x8 (&xc)[KS]) {
     const long pix = (long)t * 32 + l31;
     if (t < p.ntiles && pix < M) {
@@ -620,9 +639,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail2_kernel(const hrp_conv_de
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) bits |= (v[i] > 0.f ? 1u : 0u) << (8 * hh + i);
-        if (ok) *(uint4*)((char*)d.y + off + 16 * hh) = Elem<bf16_t>::pack(v);
+        *(uint4*)(xp_y + xp_mine + mi * 64 + hh * 16) = Elem<bf16_t>::pack(v);
       }
       if (ok) *(unsigned short*)(d.tail_mask + (off >> 4)) = (unsigned short)bits;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long px = (long)t * 32 + xp_row + 8 * k;
+      if (t < p.ntiles && px < M)
+        *(uint4*)((char*)d.y + (size_t)px * (Cout * 2) + cbase * 2 + xp_pc) = *(const uint4*)(xp_y + (xp_row + 8 * k) * XP_PITCH + xp_pc);
     }
   };
   bf16x8 xa[KS], xa2[KS], xb[KS], xb2[KS];
@@ -682,13 +707,13 @@ static inline int launch_conv_pw(const hrp_conv_desc& d, const PwPlan& p0, hipSt
       const int which = p.ks == 2 ? 0 : 1;
       if (!occ2[which]) {
         int nb = 0;
-        const hipError_t e = p.ks == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail2_kernel<2>, 256, PW_STAT_BYTES + 3 * 256 * 4)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail2_kernel<4>, 256, PW_STAT_BYTES + 3 * 256 * 4);
+        const hipError_t e = p.ks == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail2_kernel<2>, 256, PW_STAT_BYTES + 3 * 256 * 4 + PW_TAIL_XP_BYTES)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_tail2_kernel<4>, 256, PW_STAT_BYTES + 3 * 256 * 4 + PW_TAIL_XP_BYTES);
         occ2[which] = (e != hipSuccess || nb < 1) ? 1 : nb;
       }
       pw_fill_grid(p, occ2[which]);
-      if (p.ks == 2) hipLaunchKernelGGL((conv_pw_tail2_kernel<2>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p);
-      else hipLaunchKernelGGL((conv_pw_tail2_kernel<4>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4, s, d, p);
+      if (p.ks == 2) hipLaunchKernelGGL((conv_pw_tail2_kernel<2>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4 + PW_TAIL_XP_BYTES, s, d, p);
+      else hipLaunchKernelGGL((conv_pw_tail2_kernel<4>), dim3(p.wgs * p.groups), blk, PW_STAT_BYTES + 3 * d.Cout * 4 + PW_TAIL_XP_BYTES, s, d, p);
       return check_launch("conv_pw_tail2_kernel");
     }
     set_error("conv: no Bottleneck-tail instantiation for Cin=%d mode %d", d.Cin, d.tail_mode);

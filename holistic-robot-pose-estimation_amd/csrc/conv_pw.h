@@ -325,19 +325,23 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
 
   const long M = (long)d.N * d.Ho * d.Wo;
   const int tile0 = wg * (p.tpw * p.wp) + wpi, tstep = p.wp;
-  const char* xg = (const char*)d.x + half * 16;
-  auto load_tile = [&](int t, bf16x8 (&xb)[KS]) {
-    const long pix = (long)t * 32 + l31;
-    if (t < p.ntiles && pix < M) {
-      const char* q = xg + (size_t)pix * (Cin * 2);
+  // x as whole rows (Cin * 2 bytes = 2 KS pieces per pixel): lane -> (pixel lane / (2 KS) + (32 / KS) k, piece lane % (2 KS)), KS vectors
+  // per lane and tile - the same registers as the MFMA-ordered form (pixel l31, half) needed, but a load instruction touches 8 lines
+  // instead of 32.  stage_x puts a tile's rows into the wave's LDS tile and reads the B fragments back.
+  using XRaw = uint4[KS];
+  const int xr_px = lane / (2 * KS), xr_pc = (lane % (2 * KS)) * 16;
+  auto load_tile = [&](int t, uint4 (&raw)[KS]) {
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) xb[kk] = *(const bf16x8*)(q + kk * 32);
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xb[kk][i] = (__bf16)0.f;
+    for (int k = 0; k < KS; ++k) {
+      const long pix = (long)t * 32 + xr_px + (32 / KS) * k;
+      raw[k] = (t < p.ntiles && pix < M) ? *(const uint4*)((const char*)d.x + (size_t)pix * (Cin * 2) + xr_pc) : make_uint4(0, 0, 0, 0);
     }
+  };
+  auto stage_x = [&](const uint4 (&raw)[KS], bf16x8 (&xb)[KS]) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) *(uint4*)(xp_y + (xr_px + (32 / KS) * k) * XP_PITCH + xr_pc) = raw[k];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xb[kk] = *(const bf16x8*)(xp_y + l31 * XP_PITCH + kk * 32 + half * 16);
   };
 
   float vt[MW], vq[MW];                      // MODE 1: per lane (channel co_lane) sum / sum of squares
@@ -401,9 +405,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
         *(uint4*)((char*)dst + (size_t)px * (Cout * 2) + cbase * 2 + xp_pc) = *(const uint4*)(xp + (xp_row + 8 * k) * XP_PITCH + xp_pc);
     }
   };
-  auto compute = [&](int t, const bf16x8 (&xb)[KS], const Epi& e) {
+  auto compute = [&](int t, const uint4 (&xraw)[KS], const Epi& e) {
     const long pix = (long)t * 32 + l31;
     const bool ok = t < p.ntiles && pix < M;
+    bf16x8 xb[KS];
+    stage_x(xraw, xb);
     if constexpr (MODE != 1) stage_epi(e.raw, xp_y);
     if constexpr (MODE == 4) {
       if (side_acc) stage_epi(e.sraw, xp_s);
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
   if constexpr (MODE == 1) {
     // statistics only: nothing but x is read - four tiles of loads in flight per wave (two left the pass latency bound: 24 us for
     // 33 MB at 64 -> 256 channels)
-    bf16x8 xq[4][KS];
+    uint4 xq[4][KS];
     Epi e0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) load_tile(tile0 + j * tstep, xq[j]);
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_tail_kernel(const hrp_conv_des
       }
     }
   } else {
-    bf16x8 xa[KS], xb[KS];
+    uint4 xa[KS], xb[KS];
     Epi ea, eb;
     load_tile(tile0, xa);
     load_epi(tile0, ea);

@@ -79,11 +79,13 @@ static inline int pw_plan(const hrp_conv_desc& d, PwPlan& p) {
 // 6 .. 9 of conv_row.h's constant table (epilogue reduce only)
 constexpr int PW_STAT_BYTES = 4 * 2 * 64 * 4;
 constexpr int PW_TAIL_XP_BYTES = 4 * 2 * 32 * 144;      // conv_pw_tail_kernel: two transpose tiles per wave (stores of modes 2 / 4)
-static inline int pw_lds_bytes(const hrp_conv_desc& d) { return PW_STAT_BYTES + (d.bnb_x ? 10 * d.Cout * 4 : 0); }
+// ... then one input tile per wave: 32 pixels x (Cin * 2 + 16) bytes (conv_pw_body_t: x arrives as whole rows)
+static inline int pw_xtile_bytes(int Cin) { return 32 * (Cin * 2 + 16); }
+static inline int pw_lds_bytes(const hrp_conv_desc& d) { return PW_STAT_BYTES + (d.bnb_x ? 10 * d.Cout * 4 : 0) + 4 * pw_xtile_bytes(d.Cin); }
 
 template <int KS, int MW, bool EXT>
 __device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwPlan& p, const int bid, const int stat_slot) {
-  constexpr bool PF = KS <= 8;                       // next tile's operand in flight under this tile's MFMAs (registers allow)
+  constexpr bool PF = KS <= 8 && !(KS == 8 && MW == 2);      // next tile's operand in flight under this tile's MFMAs (where the registers allow)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* stat_lds = (float*)smem;
   float* ctab = (float*)(smem + PW_STAT_BYTES);      // rows 6 .. 9 of conv_row.h's constant table (epilogue reduce)
@@ -125,19 +127,24 @@ __device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwP
   // ---- the wave's tiles: t0, t0 + wp, ...   (the workgroup's run is contiguous in memory)
   const long M = (long)d.N * d.Ho * d.Wo;
   const int tile0 = wg * (p.tpw * p.wp) + wpi, tstep = p.wp;
-  const char* xg = (const char*)d.x + half * 16;
-  auto load_tile = [&](int t, bf16x8 (&xb)[KS]) {
-    const long pix = (long)t * 32 + l31;
-    if (t < p.ntiles && pix < M) {
-      const char* q = xg + (size_t)pix * (Cin * 2);
+  // x as whole rows (Cin * 2 bytes = 2 KS pieces of 16 bytes per pixel): lane -> (pixel lane / (2 KS) + (32 / KS) k, piece lane % (2 KS)), KS
+  // vectors per lane and tile, re-read as MFMA B fragments (pixel l31, k half) from the wave's LDS tile.  In MFMA order a load
+  // instruction touched 32 lines for 1 KB (two pieces of every pixel's row); at 512-byte rows (Cin = 256) the pass ran at 3.3 TB/s.
+  constexpr int XPITCH = KS * 32 + 16;
+  char* xt = smem + PW_STAT_BYTES + (bnb ? 10 * Cout * 4 : 0) + wave * (32 * XPITCH);
+  const int xr_px = lane / (2 * KS), xr_pc = (lane % (2 * KS)) * 16;
+  auto load_tile = [&](int t, uint4 (&raw)[KS]) {
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) xb[kk] = *(const bf16x8*)(q + kk * 32);
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xb[kk][i] = (__bf16)0.f;
+    for (int k = 0; k < KS; ++k) {
+      const long pix = (long)t * 32 + xr_px + (32 / KS) * k;
+      raw[k] = (t < p.ntiles && pix < M) ? *(const uint4*)((const char*)d.x + (size_t)pix * (Cin * 2) + xr_pc) : make_uint4(0, 0, 0, 0);
     }
+  };
+  auto stage_x = [&](const uint4 (&raw)[KS], bf16x8 (&xb)[KS]) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) *(uint4*)(xt + (xr_px + (32 / KS) * k) * XPITCH + xr_pc) = raw[k];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xb[kk] = *(const bf16x8*)(xt + l31 * XPITCH + kk * 32 + half * 16);
   };
 
   // Statistics.  Plain sum / sum of squares (train-mode forward layers): a SECOND product per tile with the operands swapped -
@@ -152,9 +159,11 @@ __device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwP
 #pragma unroll
   for (int mi = 0; mi < MW; ++mi) vt[mi] = vq[mi] = 0.f;
 
-  auto compute = [&](int t, const bf16x8 (&xb)[KS]) {
+  auto compute = [&](int t, const uint4 (&xraw)[KS]) {
     const long pix = (long)t * 32 + l31;
     const unsigned ok = (t < p.ntiles && pix < M) ? 1u : 0u;
+    bf16x8 xb[KS];
+    stage_x(xraw, xb);
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
       f32x16 acc[1];
@@ -193,7 +202,7 @@ __device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwP
   };
 
   if constexpr (PF) {
-    bf16x8 xa[KS], xb[KS];
+    uint4 xa[KS], xb[KS];
     load_tile(tile0, xa);
     for (int it = 0; it < p.tpw; it += 2) {
       load_tile(tile0 + (it + 1) * tstep, xb);
@@ -203,7 +212,7 @@ __device__ __forceinline__ void conv_pw_body_t(const hrp_conv_desc& d, const PwP
     }
   } else {
     for (int it = 0; it < p.tpw; ++it) {
-      bf16x8 xa[KS];
+      uint4 xa[KS];
       load_tile(tile0 + it * tstep, xa);
       compute(tile0 + it * tstep, xa);
     }
@@ -694,7 +703,8 @@ static inline int pw_occupancy() {
   static int occ = 0;
   if (!occ) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_kernel<KS, MW>, 256, 16) != hipSuccess || nb < 1) nb = 2;
+    (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pw_kernel<KS, MW>, 256, PW_STAT_BYTES + 4 * pw_xtile_bytes(KS * 16)) != hipSuccess || nb < 1) nb = 2;
     occ = nb;
   }
   return occ;

@@ -22,6 +22,7 @@ HEAD_FP32 = os.environ.get("HRP_HEAD_FP32", "0") not in ("0", "")
 # measurement switch (DESIGN 4, bf16 key-point 0): from which stage on a FEATURE-ONLY trunk (the DepthNet) computes in fp32 - "" (bf16
 # throughout), "4" or "3": the branch tensors entering that stage are cast and everything behind runs on the fp32 kernels; "1": the
 # whole trunk from its input image on (full_net.py creates that input as an fp32 tensor)
+HEAD_INCRE_LANES = os.environ.get("HRP_HEAD_INCRE_LANES", "1") not in ("0", "")      # emit_heads: the incre modules in virtual lanes
 TRUNK_FP32_FROM = ""      # (a module constant: measurement tools set it before the plan is built)
 logger = logging.getLogger(__name__)
 
@@ -537,10 +538,19 @@ class PoseHighResolutionNet(PlannedModule):
                 # the classification head of a feature-only trunk (the DepthNet) in fp32: its pooled feature sets the root depth,
                 # where 1 mm is 3 px for a key-point 0.13 m in front of the camera
                 ys = [pb.cast(y, torch.float32) for y in ys]
-            y = self.incre_modules[0][0].emit(pb, ys[0])
+            # HRnet.py:535-541 interleaves incre_modules[i + 1] with the down-sampling chain; the four incre modules depend on the
+            # trunk's outputs only, so they are emitted side by side in virtual lanes: the 1 x 1 / 3 x 3 / 1 x 1 + projection launches
+            # of the three low-resolution Bottlenecks batch position by position (each ran alone for 15-25 us at < 1 TB/s)
+            incs = [None] * len(self.incre_modules)
+            if HEAD_INCRE_LANES:
+                with pb.parallel(len(incs), virtual=True) as par:
+                    for i in range(len(incs)):
+                        with par.lane(i):
+                            incs[i] = self.incre_modules[i][0].emit(pb, ys[i])
+            y = incs[0] if incs[0] is not None else self.incre_modules[0][0].emit(pb, ys[0])
             for i, dm in enumerate(self.downsamp_modules):
                 d = pb.act([conv_bn(pb, y, dm[0], dm[1])], relu=True)
-                inc = self.incre_modules[i + 1][0].emit(pb, ys[i + 1])
+                inc = incs[i + 1] if incs[i + 1] is not None else self.incre_modules[i + 1][0].emit(pb, ys[i + 1])
                 y = pb.act([Term(inc), Term(d)], relu=False)
             y = pb.act([conv_bn(pb, y, self.final_feat_layer[0], self.final_feat_layer[1])], relu=True)
             feat = pb.avgpool(y, out=feat_out)

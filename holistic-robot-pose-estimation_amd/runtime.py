@@ -90,6 +90,9 @@ class Runner:
                 if what == "fwd":
                     self._forward_launches(prep=False)
                 else:
+                    # a backward graph of its own always zeroes the gradient arena itself: replayed twice behind one forward
+                    # (retain_graph) it must not rely on the forward's early memset (Plan.run_prep)
+                    p._arena_clean = False
                     p.run_backward(None)
             return g
         except Exception as e:   # a capture-unsafe op somewhere: stay eager for this plan

@@ -1305,6 +1305,10 @@ static int launch_conv_row(const hrp_conv_desc& d, hipStream_t s) {
   if (!C) return -100;
   RowPlan rp;
   row_plan(d, rp);
+  // a 128-channel layer launched ALONE (inference plans: the third branch's convolutions have no batch partner) takes the
+  // half-image variant: 2 N workgroups instead of N - at B = 64 the whole-image kernel occupies a quarter of the chip
+  // (forward_only 7.255 -> 7.17 ms).  Inside a batch the whole-image form stays (the other problems fill the chip).
+  if (rp.img && C == 128) { rp.img = 0; rp.nstrips = d.N * rp.spi; }
   if (C == 32) hipLaunchKernelGGL(conv_row_kernel<32>, dim3(row_grid(rp, 32)), dim3(256), RowCfg<32>::LDS_BYTES, s, d, rp);
   else if (C == 64) hipLaunchKernelGGL(conv_row_kernel<64>, dim3(row_grid(rp, 64)), dim3(256), RowCfg<64>::LDS_BYTES, s, d, rp);
   else if (rp.img) {
